@@ -1,0 +1,250 @@
+"""ctypes binding of libgraphgibbs.so (include/graphgibbs.h).
+
+This is the only bridge between the Python classes and the HIP engine.  There is
+no fallback: if the shared library is missing or no HIP device is present the
+calls raise (EngineError) instead of silently computing on the CPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libgraphgibbs.so")
+
+# enums of include/graphgibbs.h
+SBM_ADJ, BB_ADJ, BERN_ADJ, SBM_GAUSS_W, NIW_W, FIXED_W, LOGISTIC_EIG = 1, 2, 3, 4, 5, 6, 7
+(ST_C, ST_M, ST_PI, ST_P, ST_P_SELF, ST_MU, ST_SIGMA, ST_MU_SELF, ST_SIGMA_SELF, ST_NIW, ST_NIW_SELF, ST_SWEEP, ST_F,
+ ST_LMBDA, ST_MU0, ST_MU_LMBDA) = range(1, 17)
+PART_PARAMS, PART_C, PART_M, PART_OMEGA, PART_F, PART_MU0, PART_LMBDA, PART_ALL = 1, 2, 4, 8, 16, 32, 64, 127
+ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NUMERIC = -1, -2, -3, -4, -5
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("graphgibbs error %d: %s" % (code, text))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("B", C.c_int32), ("D", C.c_int32),
+                ("allow_self_connections", C.c_int32), ("special_case_self_conns", C.c_int32), ("device", C.c_int32),
+                ("seed", C.c_uint64), ("tau1", C.c_double), ("tau0", C.c_double), ("sigma_mu0", C.c_double),
+                ("sigma_F", C.c_double), ("sigma_lmbda", C.c_double), ("mu_mu_0", C.c_double),
+                ("lmbda_given", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("sweeps", C.c_uint64), ("label_changes", C.c_uint64), ("resolve_rounds", C.c_uint64),
+                ("bulk_bytes", C.c_double), ("bulk_ms", C.c_double), ("bulk_launches", C.c_uint64),
+                ("total_ms", C.c_double)]
+
+
+EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
+           "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_log_likelihood", "gg_node_lp", "gg_last_stats",
+           "gg_set_timing", "gg_selftest_math", "gg_selftest_draws"]
+
+
+def build(force=False):
+    """Compile the engine for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        cmd = ["make", "-C", os.path.join(_HERE, "csrc")] + (["-B"] if force else [])
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the engine.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(ERR_NO_DEVICE, "%s not found: build it with `python -c 'import __graft_entry__ as g; "
+                                              "g.build()'` or `make -C graphistician_amd/csrc`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.gg_last_error.restype = C.c_char_p
+        L.gg_version.restype = C.c_char_p
+        vp = C.c_void_p
+        L.gg_data_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32]
+        L.gg_data_destroy.argtypes = [vp]
+        L.gg_data_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int64)]
+        L.gg_data_create_sbm.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp, C.c_double,
+                                         C.c_double, C.c_uint64, C.c_int32]
+        L.gg_data_download.argtypes = [vp, vp, vp]
+        L.gg_model_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+        L.gg_model_destroy.argtypes = [vp]
+        L.gg_set_state.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+        L.gg_get_state.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+        L.gg_resample.argtypes = [vp, vp, C.c_int32, C.c_double]
+        L.gg_resample_part.argtypes = [vp, vp, C.c_int32, C.c_double]
+        L.gg_log_likelihood.argtypes = [vp, vp, C.POINTER(C.c_double)]
+        L.gg_node_lp.argtypes = [vp, vp, C.c_int32, vp]
+        L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.gg_set_timing.argtypes = [vp, C.c_int32]
+        L.gg_selftest_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, C.c_int64]
+        L.gg_selftest_draws.argtypes = [C.c_int32, C.c_int32, C.c_uint64, vp, C.c_int32, vp, C.c_int64, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EngineError(rc, lib().gg_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().gg_device_count(C.byref(n))
+    return n.value
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceData(object):
+    """Device-resident (A, W): replaces the ndarray pair of networks.py:28,69."""
+
+    def __init__(self, A=None, W=None, device=0, handle=None, N=None, B=None):
+        self._h = C.c_void_p()
+        if handle is not None:
+            self._h = handle
+        else:
+            A = np.ascontiguousarray(np.asarray(A) != 0, dtype=np.uint8)
+            assert A.ndim == 2 and A.shape[0] == A.shape[1]
+            N = A.shape[0]
+            if W is not None:
+                W = np.ascontiguousarray(W, dtype=np.float64)
+                if W.ndim == 2:
+                    W = W[:, :, None].copy()
+                assert W.shape[:2] == (N, N)
+                B = W.shape[2]
+                check(lib().gg_data_create(C.byref(self._h), N, B, _ptr(A), _ptr(W), device))
+            else:
+                B = 1
+                check(lib().gg_data_create(C.byref(self._h), N, 1, _ptr(A), None, device))
+        self.N, self.B, self.device = N, B, device
+        self.has_w = W is not None or handle is not None
+
+    @classmethod
+    def synthetic_sbm(cls, N, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device=0):
+        """Planted Gaussian SBM (B = 1) generated on the device."""
+        c = np.ascontiguousarray(c, dtype=np.int32)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+        K = p.shape[0]
+        h = C.c_void_p()
+        check(lib().gg_data_create_sbm(C.byref(h), N, K, _ptr(c), _ptr(p), float(p_self), _ptr(mu), _ptr(sigma),
+                                       float(mu_self), float(sigma_self), C.c_uint64(seed), device))
+        return cls(handle=h, N=N, B=1, device=device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        N, B, sh, ne = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        check(lib().gg_data_info(self._h, C.byref(N), C.byref(B), C.byref(sh), C.byref(ne)))
+        return dict(N=N.value, B=B.value, shift=sh.value, n_edges=ne.value)
+
+    def download(self, with_weights=True):
+        A = np.zeros((self.N, self.N), dtype=np.uint8)
+        W = np.zeros((self.N, self.N, self.B)) if (with_weights and self.has_w) else None
+        check(lib().gg_data_download(self._h, _ptr(A), _ptr(W) if W is not None else None))
+        return A, W
+
+    def close(self):
+        if self._h:
+            lib().gg_data_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Model(object):
+    """Thin owner of one gg_model handle."""
+
+    def __init__(self, **cfg):
+        c = Config()
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p()
+        check(lib().gg_model_create(C.byref(self._h), C.byref(c)))
+
+    def set(self, sid, arr, dtype=np.float64):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        check(lib().gg_set_state(self._h, sid, _ptr(a), a.nbytes))
+
+    def get(self, sid, shape, dtype=np.float64):
+        a = np.zeros(shape, dtype=dtype)
+        check(lib().gg_get_state(self._h, sid, _ptr(a), a.nbytes))
+        return a
+
+    def resample(self, data, n_sweeps=1, beta=1.0):
+        check(lib().gg_resample(self._h, data.handle, n_sweeps, beta))
+
+    def resample_part(self, data, parts, beta=1.0):
+        check(lib().gg_resample_part(self._h, data.handle, parts, beta))
+
+    def log_likelihood(self, data):
+        out = C.c_double(0)
+        check(lib().gg_log_likelihood(self._h, data.handle, C.byref(out)))
+        return out.value
+
+    def node_lp(self, data, n, K):
+        lp = np.zeros(K)
+        check(lib().gg_node_lp(self._h, data.handle, n, _ptr(lp)))
+        return lp
+
+    def stats(self):
+        s = Stats()
+        check(lib().gg_last_stats(self._h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def set_timing(self, on=True):
+        check(lib().gg_set_timing(self._h, 1 if on else 0))
+
+    @property
+    def sweep(self):
+        return int(self.get(ST_SWEEP, (1,), np.uint32)[0])
+
+    @sweep.setter
+    def sweep(self, v):
+        self.set(ST_SWEEP, np.array([v], dtype=np.uint32), np.uint32)
+
+    def close(self):
+        if self._h:
+            lib().gg_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def selftest_math(op, x, y=None, device=0):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    yy = np.ascontiguousarray(y, dtype=np.float64) if y is not None else None
+    check(lib().gg_selftest_math(device, op, _ptr(x), _ptr(yy) if yy is not None else None, _ptr(out), x.size))
+    return out
+
+
+def selftest_draws(what, seed, params, n, stride=1, device=0):
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    out = np.empty((n, stride) if stride > 1 else (n,))
+    check(lib().gg_selftest_draws(device, what, C.c_uint64(seed), _ptr(params), params.size, _ptr(out), n, stride))
+    return out

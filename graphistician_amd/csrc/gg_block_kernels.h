@@ -1,0 +1,545 @@
+// gg_block_kernels.h — HIP kernels of the block-model half-sweep (SBM adjacency,
+// SBM Gaussian weights and their K = 1 special cases Beta-Bernoulli / NIW).
+//
+// One half-sweep (adjacency.py:615-618 or weights.py:394-397) is
+//   sort labels -> BULK statistics -> pair tables -> draw parameters -> tables
+//   -> speculate -> resolve [-> apply_L -> speculate -> resolve]* -> draw m
+// BULK is the only kernel that touches the N x N data and is HBM-bound; every
+// other kernel works on O(N K) statistics.
+//
+// Statistics G[dir][k][n] (dir 0 = out-edges of n, 1 = in-edges of n) are block
+// histograms of node n's row/column: exact integers, so any summation order
+// gives the same bits and the sequential scan of the reference can be resolved
+// speculatively (kernel k_resolve) without changing a single draw.
+#pragma once
+#include "gg_common.h"
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ long long gg_shfl_down_ll(long long v, int delta) {
+  int lo = __shfl_down((int)(v & 0xffffffffll), delta);
+  int hi = __shfl_down((int)(v >> 32), delta);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+__device__ __forceinline__ long long gg_wave_sum_ll(long long v) {
+  for (int d = 32; d >= 1; d >>= 1) v += gg_shfl_down_ll(v, d);
+  return v;
+}
+
+// ------------------------------------------------------------------ label sort
+// Counting sort of the labels: perm groups node indices by block, lab_start[k]
+// is the first position of block k, cnt[k] its size.  One workgroup.
+__global__ __launch_bounds__(1024) void k_sort_labels(const int32_t* __restrict__ c, int N, int K,
+                                                      int32_t* __restrict__ perm, int32_t* __restrict__ lab_start,
+                                                      int32_t* __restrict__ cnt) {
+  extern __shared__ int s_hist[];  // [K] counts, [K] cursors
+  int* s_cur = s_hist + K;
+  for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) s_hist[k] = 0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) atomicAdd(&s_hist[c[n]], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int k = 0; k < K; ++k) {
+      lab_start[k] = acc;
+      cnt[k] = s_hist[k];
+      s_cur[k] = acc;
+      acc += s_hist[k];
+    }
+    lab_start[K] = acc;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    int pos = atomicAdd(&s_cur[c[n]], 1);
+    perm[pos] = n;
+  }
+}
+
+// ------------------------------------------------------------------ BULK kernels
+// G[k][n] = sum over rows i with label k of X[i][n]  (column sums grouped by the
+// row's label).  Run on X it yields the in-edge histograms of every node, run on
+// the stored transpose the out-edge histograms.  Rows are visited grouped by
+// label (perm), so a wave accumulates in registers only; a workgroup covers one
+// (label, row sub-chunk, column strip) and adds its partial sums to G with
+// integer atomics (order independent).  Row reads are whole 1 KiB wave
+// transactions of a contiguous row segment: coalesced regardless of perm.
+//
+// slot -> (label k, sub-chunk): labels with more than RW rows span several slots.
+__device__ __forceinline__ bool gg_find_slot(const int32_t* __restrict__ lab_start, int K, int RW, int slot,
+                                             int* k_out, int* row0, int* nrows) {
+  for (int k = 0; k < K; ++k) {
+    int s0 = lab_start[k], n = lab_start[k + 1] - s0;
+    int ns = (n + RW - 1) / RW;
+    if (slot < ns) {
+      *k_out = k;
+      *row0 = s0 + slot * RW;
+      int rem = n - slot * RW;
+      *nrows = rem < RW ? rem : RW;
+      return true;
+    }
+    slot -= ns;
+  }
+  return false;
+}
+
+// Adjacency: 16 uint8 per lane per row, SWAR byte counters (<= 255 rows per wave).
+__global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ X, int Np,
+                                                  const int32_t* __restrict__ perm,
+                                                  const int32_t* __restrict__ lab_start, int K, int RW,
+                                                  int32_t* __restrict__ G) {
+  __shared__ unsigned int s_bins[1024];
+  int k, row0, nrows;
+  if (!gg_find_slot(lab_start, K, RW, blockIdx.y, &k, &row0, &nrows)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col0 = blockIdx.x * 1024 + lane * 16;
+  for (int i = tid; i < 1024; i += 256) s_bins[i] = 0;
+  __syncthreads();
+  unsigned int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (col0 < Np) {
+    int r = wave;
+    for (; r + 12 < nrows; r += 16) {  // 4 rows in flight per wave
+      int i0 = perm[row0 + r], i1 = perm[row0 + r + 4], i2 = perm[row0 + r + 8], i3 = perm[row0 + r + 12];
+      uint4 v0 = *reinterpret_cast<const uint4*>(X + (size_t)i0 * Np + col0);
+      uint4 v1 = *reinterpret_cast<const uint4*>(X + (size_t)i1 * Np + col0);
+      uint4 v2 = *reinterpret_cast<const uint4*>(X + (size_t)i2 * Np + col0);
+      uint4 v3 = *reinterpret_cast<const uint4*>(X + (size_t)i3 * Np + col0);
+      a0 += v0.x + v1.x + v2.x + v3.x;
+      a1 += v0.y + v1.y + v2.y + v3.y;
+      a2 += v0.z + v1.z + v2.z + v3.z;
+      a3 += v0.w + v1.w + v2.w + v3.w;
+    }
+    for (; r < nrows; r += 4) {
+      int i0 = perm[row0 + r];
+      uint4 v0 = *reinterpret_cast<const uint4*>(X + (size_t)i0 * Np + col0);
+      a0 += v0.x; a1 += v0.y; a2 += v0.z; a3 += v0.w;
+    }
+    unsigned int acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        unsigned int v = (acc[w] >> (8 * b)) & 255u;
+        if (v) atomicAdd(&s_bins[lane * 16 + w * 4 + b], v);
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < 1024; i += 256) {
+    unsigned int v = s_bins[i];
+    int col = blockIdx.x * 1024 + i;
+    if (v && col < Np) atomicAdd(&G[(size_t)k * Np + col], (int)v);
+  }
+}
+
+// Weights: 4 int32 per lane per row = 4 / B elements; per element edge count,
+// sum q_r, sum q_r q_s in 64-bit integers.
+template <int B>
+__global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ X, int Np,
+                                                const int32_t* __restrict__ perm,
+                                                const int32_t* __restrict__ lab_start, int K, int RW,
+                                                int32_t* __restrict__ Gcnt, long long* __restrict__ GS) {
+  constexpr int EPL = 4 / B;               // elements per lane
+  constexpr int NSI = B + B * (B + 1) / 2; // integer statistics per element
+  constexpr int SC = 64 * EPL;             // strip columns
+  __shared__ int s_cnt[SC];
+  __shared__ unsigned long long s_s[SC * NSI];
+  int k, row0, nrows;
+  if (!gg_find_slot(lab_start, K, RW, blockIdx.y, &k, &row0, &nrows)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col0 = blockIdx.x * SC + lane * EPL;
+  for (int i = tid; i < SC; i += 256) s_cnt[i] = 0;
+  for (int i = tid; i < SC * NSI; i += 256) s_s[i] = 0ull;
+  __syncthreads();
+  if (col0 < Np) {
+    int cnt[EPL];
+    long long st[EPL][NSI];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      cnt[e] = 0;
+#pragma unroll
+      for (int s = 0; s < NSI; ++s) st[e][s] = 0;
+    }
+    auto accumulate = [&](const int4& v) {
+      const int q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const bool valid = q[e * B] != GG_NO_EDGE;
+        cnt[e] += valid ? 1 : 0;
+        long long x[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) x[r] = valid ? (long long)q[e * B + r] : 0ll;
+#pragma unroll
+        for (int r = 0; r < B; ++r) st[e][r] += x[r];
+        int t = B;
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+          for (int s = r; s < B; ++s) st[e][t++] += x[r] * x[s];
+      }
+    };
+    int r = wave;
+    for (; r + 12 < nrows; r += 16) {
+      int i0 = perm[row0 + r], i1 = perm[row0 + r + 4], i2 = perm[row0 + r + 8], i3 = perm[row0 + r + 12];
+      int4 v0 = *reinterpret_cast<const int4*>(X + ((size_t)i0 * Np + col0) * B);
+      int4 v1 = *reinterpret_cast<const int4*>(X + ((size_t)i1 * Np + col0) * B);
+      int4 v2 = *reinterpret_cast<const int4*>(X + ((size_t)i2 * Np + col0) * B);
+      int4 v3 = *reinterpret_cast<const int4*>(X + ((size_t)i3 * Np + col0) * B);
+      accumulate(v0); accumulate(v1); accumulate(v2); accumulate(v3);
+    }
+    for (; r < nrows; r += 4) {
+      int i0 = perm[row0 + r];
+      int4 v0 = *reinterpret_cast<const int4*>(X + ((size_t)i0 * Np + col0) * B);
+      accumulate(v0);
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      if (cnt[e]) {
+        atomicAdd(&s_cnt[lane * EPL + e], cnt[e]);
+#pragma unroll
+        for (int s = 0; s < NSI; ++s) atomicAdd(&s_s[(lane * EPL + e) * NSI + s], (unsigned long long)st[e][s]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < SC; i += 256) {
+    int col = blockIdx.x * SC + i;
+    int v = s_cnt[i];
+    if (v && col < Np) {
+      atomicAdd(&Gcnt[(size_t)k * Np + col], v);
+      for (int s = 0; s < NSI; ++s)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&GS[((size_t)k * Np + col) * NSI + s]), s_s[i * NSI + s]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ pair tables
+// tab[a][b][.] = sum over nodes n of block a of the out-statistics G[0][b][n]:
+// the K x K masked sums of adjacency.py:630-634 / weights.py:405-408 in one
+// pass over O(N K) numbers.  Weight sums are kept as (hi, lo) 32-bit halves so
+// that N^2 terms of 46 bits cannot overflow (gg_hilo_to_double rounds once).
+// Layout: adjacency NTAB = 1 {ones}; weights NTAB = 1 + 2 NSI {cnt, hi_s, lo_s ...}.
+// When the diagonal is not special-cased it belongs to pair (c_i, c_i).
+__global__ __launch_bounds__(256) void k_pair_tables(const int32_t* __restrict__ Gcnt0,
+                                                     const long long* __restrict__ GS0, int Np, int K, int NSI,
+                                                     const int32_t* __restrict__ perm,
+                                                     const int32_t* __restrict__ lab_start, int add_diag,
+                                                     const uint8_t* __restrict__ dA,
+                                                     const int32_t* __restrict__ dWq, int B,
+                                                     long long* __restrict__ tab) {
+  const int a = blockIdx.x / K, b = blockIdx.x % K;
+  const int NTAB = GS0 ? 1 + 2 * NSI : 1;
+  const int s0 = lab_start[a], s1 = lab_start[a + 1];
+  long long acc[1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+  for (int t = 0; t < NTAB; ++t) acc[t] = 0;
+  for (int r = s0 + threadIdx.x; r < s1; r += blockDim.x) {
+    int n = perm[r];
+    acc[0] += Gcnt0[(size_t)b * Np + n];
+    if (GS0)
+      for (int s = 0; s < NSI; ++s) {
+        long long v = GS0[((size_t)b * Np + n) * NSI + s];
+        acc[1 + 2 * s] += (v >> 32);
+        acc[2 + 2 * s] += (v & 0xffffffffll);
+      }
+    if (add_diag && a == b && dA[n]) {
+      acc[0] += 1;
+      if (GS0) {
+        const int32_t* q = dWq + (size_t)n * B;
+        int t = 0;
+        for (int r1 = 0; r1 < B; ++r1, ++t) {
+          long long v = q[r1];
+          acc[1 + 2 * t] += (v >> 32);
+          acc[2 + 2 * t] += (v & 0xffffffffll);
+        }
+        for (int r1 = 0; r1 < B; ++r1)
+          for (int r2 = r1; r2 < B; ++r2, ++t) {
+            long long v = (long long)q[r1] * (long long)q[r2];
+            acc[1 + 2 * t] += (v >> 32);
+            acc[2 + 2 * t] += (v & 0xffffffffll);
+          }
+      }
+    }
+  }
+  __shared__ long long s_red[4][1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = 0; t < NTAB; ++t) {
+    long long v = gg_wave_sum_ll(acc[t]);
+    if (lane == 0) s_red[wave][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NTAB) {
+    long long v = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_red[w][threadIdx.x];
+    tab[(size_t)blockIdx.x * NTAB + threadIdx.x] = v;
+  }
+}
+
+// ------------------------------------------------------------------ parameter draws
+struct gg_adj_hyp {
+  double tau1, tau0;
+  int special;       // special_case_self_conns (BB: self_connection)
+  int bb;            // Beta-Bernoulli semantics (adjacency.py:153-181)
+  long long d1, d0;  // diagonal edge / non-edge counts
+};
+
+// adjacency.py:620-648 (SBM) and :153-181 (Beta-Bernoulli): one thread per block pair.
+__global__ void k_draw_p(const long long* __restrict__ tab, const int32_t* __restrict__ cnt, int K, gg_adj_hyp h,
+                         uint64_t seed, uint32_t sweep, double* __restrict__ p, double* __restrict__ p_self) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < K * K) {
+    int a = t / K, b = t % K;
+    long long n1 = tab[t];
+    long long pairs = (long long)cnt[a] * (long long)cnt[b];
+    if (a == b && h.special) pairs -= cnt[a];
+    if (h.bb && !h.special) { /* all entries incl. diagonal: tab already holds the diagonal */ }
+    long long n0 = pairs - n1;
+    gg_stream s;
+    gg_stream_init(&s, seed, h.bb ? GG_SITE_BB_P : GG_SITE_ADJ_P, sweep, (uint32_t)t);
+    p[t] = gg_beta(&s, h.tau1 + (double)n1, h.tau0 + (double)n0);
+  } else if (t == K * K && h.special) {
+    gg_stream s;
+    gg_stream_init(&s, seed, h.bb ? GG_SITE_BB_PSELF : GG_SITE_ADJ_PSELF, sweep, 0u);
+    *p_self = gg_beta(&s, h.tau1 + (double)h.d1, h.tau0 + (double)h.d0);
+  }
+}
+
+struct gg_w_hyp {
+  gg_niw niw, niw_self;
+  int special;
+  int shift;
+  long long d1;
+  long long dS[GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];
+};
+
+__device__ inline void gg_unpack_wstats(const long long* hl /* hi,lo pairs */, int B, int shift, double* s1, double* s2) {
+  const double sc1 = gg_pow2i(-shift), sc2 = gg_pow2i(-2 * shift);
+  int t = 0;
+  for (int r = 0; r < B; ++r, ++t) s1[r] = gg_hilo_to_double(hl[2 * t], hl[2 * t + 1]) * sc1;
+  for (int r = 0; r < B; ++r)
+    for (int s = r; s < B; ++s, ++t) {
+      double v = gg_hilo_to_double(hl[2 * t], hl[2 * t + 1]) * sc2;
+      s2[r * B + s] = v;
+      s2[s * B + r] = v;
+    }
+}
+
+// weights.py:399-413 resample_mu_and_Sig (and :154-162 for the NIW kind, K = 1).
+__global__ void k_draw_niw(const long long* __restrict__ tab, int K, int B, gg_w_hyp h, uint64_t seed,
+                           uint32_t sweep, double* __restrict__ mu, double* __restrict__ sigma,
+                           double* __restrict__ mu_self, double* __restrict__ sigma_self) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NSI = B + B * (B + 1) / 2;
+  double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB], mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
+  if (t < K * K) {
+    const long long* e = tab + (size_t)t * (1 + 2 * NSI);
+    gg_unpack_wstats(e + 1, B, h.shift, s1, s2);
+    gg_stream s;
+    gg_stream_init(&s, seed, GG_SITE_W_NIW, sweep, (uint32_t)t);
+    gg_niw_posterior_draw(&s, &h.niw, B, (double)e[0], s1, s2, mo, so);
+    for (int i = 0; i < B; ++i) mu[(size_t)t * B + i] = mo[i];
+    for (int i = 0; i < B * B; ++i) sigma[(size_t)t * B * B + i] = so[i];
+  } else if (t == K * K && h.special) {
+    long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+    for (int i = 0; i < NSI; ++i) { hl[2 * i] = h.dS[i] >> 32; hl[2 * i + 1] = h.dS[i] & 0xffffffffll; }
+    gg_unpack_wstats(hl, B, h.shift, s1, s2);
+    gg_stream s;
+    gg_stream_init(&s, seed, GG_SITE_W_NIW_SELF, sweep, 0u);
+    gg_niw_posterior_draw(&s, &h.niw_self, B, (double)h.d1, s1, s2, mo, so);
+    for (int i = 0; i < B; ++i) mu_self[i] = mo[i];
+    for (int i = 0; i < B * B; ++i) sigma_self[i] = so[i];
+  }
+}
+
+// Coefficient tables of the conditional (gg_lp.h): T[a][b][t]; Tout[j][t][k] = T[k][j][t];
+// Tin[j][t][k] = T[j][k][t] (k padded to Kp) so that lane k reads consecutive words.
+__global__ void k_prep_tables(int is_adj, int K, int Kp, int B, const double* __restrict__ m,
+                              const double* __restrict__ p, const double* __restrict__ mu,
+                              const double* __restrict__ sigma, double* __restrict__ logm, double* __restrict__ T,
+                              double* __restrict__ Tout, double* __restrict__ Tin, int* __restrict__ status) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NT = is_adj ? 2 : (1 + B + B * (B + 1) / 2);
+  if (t < K * K) {
+    int a = t / K, b = t % K;
+    double e[GG_MAXNT];
+    if (is_adj) {
+      e[0] = gg_log(p[t]);
+      e[1] = gg_log(1.0 - p[t]);
+    } else {
+      if (gg_gauss_table(mu + (size_t)t * B, sigma + (size_t)t * B * B, B, e)) {
+        atomicOr(status, 1);
+        for (int i = 0; i < NT; ++i) e[i] = gg_nan();
+      }
+    }
+    for (int i = 0; i < NT; ++i) {
+      T[(size_t)t * NT + i] = e[i];
+      Tout[((size_t)b * NT + i) * Kp + a] = e[i];  // T[k=a][j=b]
+      Tin[((size_t)a * NT + i) * Kp + b] = e[i];   // T[j=a][k=b]
+    }
+  } else if (t < K * K + K) {
+    int k = t - K * K;
+    logm[k] = gg_log(m[k]);
+  }
+}
+
+// adjacency.py:697-702 / weights.py:493-498 resample_m.
+__global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restrict__ pi, int K, uint64_t seed,
+                         uint32_t site, uint32_t sweep, double* __restrict__ m) {
+  extern __shared__ double s_g[];
+  int k = threadIdx.x;
+  if (k < K) s_g[k] = gg_dirichlet_gamma_at(seed, site, sweep, k, pi[k] + (double)cnt[k]);
+  __syncthreads();
+  if (k < K) {
+    double tot = 0.0;
+    for (int j = 0; j < K; ++j) tot += s_g[j];
+    m[k] = s_g[k] / tot;
+  }
+}
+
+// ------------------------------------------------------------------ per-node conditional
+struct gg_node_ctx {
+  int N, Np, K, Kp, B, shift;
+  int special;     // special_case_self_conns
+  const int32_t* c;
+  const int32_t* cnt;
+  const double* logm;
+  const double* T;
+  const double* Tout;
+  const double* Tin;
+  const int32_t* Gcnt[2];
+  const long long* GS[2];
+  const uint8_t* dA;
+  const int32_t* dWq;
+};
+
+// Statistics -> double, spec order {n | ones, zeros}, {s1_r}, {s2_rs}.
+template <int NT>
+struct gg_statvec { double v[NT]; };
+
+// The categorical draw of gg_lp.h::gg_categorical executed by a group of Kp lanes
+// (lane k holds lp[k]; lanes k >= K hold -inf).  Returns the label on every lane.
+__device__ __forceinline__ int gg_group_categorical(double lp, int k, int K, int Kp, double u) {
+  double mx = lp;
+  for (int s = Kp >> 1; s >= 1; s >>= 1) {
+    double o = __shfl_xor(mx, s, Kp);
+    mx = o > mx ? o : mx;
+  }
+  double x = (k < K) ? gg_exp(lp - mx) : 0.0;
+  for (int s = 1; s < Kp; s <<= 1) {
+    double o = __shfl_up(x, s, Kp);
+    if (k >= s) x = x + o;
+  }
+  double tot = __shfl(x, K - 1, Kp);
+  double thr = u * tot;
+  bool flag = (k < K) && (thr > x);
+  unsigned long long bal = __ballot(flag);
+  int lane = threadIdx.x & 63;
+  int g0 = lane & ~(Kp - 1);
+  unsigned long long mask = (Kp >= 64) ? ~0ull : (((1ull << Kp) - 1ull) << g0);
+  int idx = __popcll(bal & mask);
+  return idx > K - 1 ? K - 1 : idx;
+}
+
+// lp[k] of one node (gg_lp.h::gg_block_lp order).  `ld(j, so, si)` supplies the
+// node's out / in statistics towards block j as doubles in spec order.
+template <int NT, bool ADJ, class Loader>
+__device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld) {
+  if (k >= x.K) return -gg_inf();
+  const int K = x.K, Kp = x.Kp;
+  double acc_o[NT], acc_i[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc_o[t] = 0.0; acc_i[t] = 0.0; }
+  for (int j = 0; j < K; ++j) {
+    double so[NT], si[NT];
+    ld(j, so, si);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc_o[t] = gg_fma(x.Tout[((size_t)j * NT + t) * Kp + k], so[t], acc_o[t]);
+      acc_i[t] = gg_fma(x.Tin[((size_t)j * NT + t) * Kp + k], si[t], acc_i[t]);
+    }
+  }
+  double lp = x.logm[k];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) lp += acc_o[t];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) lp += acc_i[t];
+  if (!x.special) {
+    constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+    const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+    double self[NT];
+    if (ADJ) {
+      double a = x.dA[n] ? 1.0 : 0.0;
+      self[0] = a; self[1] = 1.0 - a;
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) self[t] = 0.0;
+      if (x.dA[n]) {
+        const int32_t* q = x.dWq + (size_t)n * B;
+        self[0] = 1.0;
+        int t = 1;
+        for (int r = 0; r < B; ++r) self[t++] = (double)q[r] * sc1;
+        for (int r = 0; r < B; ++r)
+          for (int s = r; s < B; ++s) self[t++] = (double)((long long)q[r] * (long long)q[s]) * sc2;
+      }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc = gg_fma(x.T[((size_t)k * K + k) * NT + t], self[t], acc);
+    lp += acc;
+  }
+  return lp;
+}
+
+// Integer statistics -> spec-order doubles.
+template <int NT, bool ADJ>
+__device__ __forceinline__ void gg_stats_to_double(int cnt_o, int cnt_i, const long long* so_i, const long long* si_i,
+                                                   int cx, double sc1, double sc2, double* so, double* si) {
+  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+  constexpr int NSI = NT - 1;
+  if (ADJ) {
+    so[0] = (double)cnt_o; so[1] = (double)(cx - cnt_o);
+    si[0] = (double)cnt_i; si[1] = (double)(cx - cnt_i);
+  } else {
+    so[0] = (double)cnt_o;
+    si[0] = (double)cnt_i;
+#pragma unroll
+    for (int s = 0; s < NSI; ++s) {
+      double sc = s < B ? sc1 : sc2;
+      so[1 + s] = (double)so_i[s] * sc;
+      si[1 + s] = (double)si_i[s] * sc;
+    }
+  }
+}
+
+template <int NT, bool ADJ>
+__device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n, int k) {
+  const int cn = x.c[n];
+  const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  constexpr int NSI = NT - 1;
+  auto ld = [&](int j, double* so, double* si) {
+    const size_t gi = (size_t)j * x.Np + n;
+    int cx = ADJ ? (x.cnt[j] - (cn == j ? 1 : 0)) : 0;
+    long long a[NSI > 0 ? NSI : 1], b[NSI > 0 ? NSI : 1];
+    if (!ADJ) {
+#pragma unroll
+      for (int s = 0; s < NSI; ++s) { a[s] = x.GS[0][gi * NSI + s]; b[s] = x.GS[1][gi * NSI + s]; }
+    }
+    gg_stats_to_double<NT, ADJ>(x.Gcnt[0][gi], x.Gcnt[1][gi], a, b, cx, sc1, sc2, so, si);
+  };
+  return gg_node_lp_core<NT, ADJ>(x, n, k, ld);
+}
+
+// Speculative evaluation: every node n >= n_begin draws its label as if no
+// earlier node of this scan changed.  Lane = (node, k): Kp lanes per node.
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
+                                                   uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
+                                                   double* __restrict__ lp_out) {
+  const int per = 256 / x.Kp;
+  const int n = n_begin + blockIdx.x * per + threadIdx.x / x.Kp;
+  const int k = threadIdx.x % x.Kp;
+  const bool live = n < x.N;
+  const int nn = live ? n : x.N - 1;
+  double lp = gg_node_lp_global<NT, ADJ>(x, nn, k);
+  if (lp_out && nn == lp_node && live && k < x.K) lp_out[k] = lp;
+  double u = gg_uniform_at(seed, site, sweep, (uint32_t)nn);
+  int lab = gg_group_categorical(lp, k, x.K, x.Kp, u);
+  if (live && k == 0) cand[n] = lab;
+}

@@ -1,0 +1,331 @@
+// gg_data.hip — device-resident network: upload, fixed-point quantisation,
+// stored transposes, synthetic generation.
+//
+// Replaces the (A, W) ndarray pair the reference hands to every call
+// (networks.py:28,69; data conventions SURVEY.md §8b).  The Gibbs scan needs row
+// n and column n of the data for every node, so both the matrix and its
+// transpose are kept resident: every access in the sweep is then a contiguous
+// row read.
+#include <math.h>
+#include <stdarg.h>
+
+#include "gg_common.h"
+
+thread_local std::string gg_err_text;
+
+int gg_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  gg_err_text = buf;
+  return code;
+}
+
+int gg_ensure_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return gg_fail(GG_ERR_NO_DEVICE, "no HIP device available (%s); the engine has no CPU fallback",
+                   e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return gg_fail(GG_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  GG_HIP(hipSetDevice(device));
+  return GG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <typename T, int B>
+__global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int N, int Np) {
+  __shared__ T tile[32][33 * B];
+  int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    int i = by + r, j = bx + tx;
+    for (int b = 0; b < B; ++b) {
+      T v = (T)0;
+      if (i < N && j < N) v = src[((size_t)i * Np + j) * B + b];
+      tile[r][tx * B + b] = v;
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int i = bx + r, j = by + tx;  // dst[i][j] = src[j][i]
+    if (i < N && j < N)
+      for (int b = 0; b < B; ++b) dst[((size_t)i * Np + j) * B + b] = tile[tx][r * B + b];
+  }
+}
+
+__global__ void k_fill_i32(int32_t* p, size_t n, int B, int32_t v0) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = (i % B == 0) ? v0 : 0;
+}
+
+// Synthetic planted SBM (B = 1): A_ij ~ Bern(p[c_i,c_j]) (diag: p_self), W_ij ~ N(mu, sigma)
+// for edges; one Philox block per (i, j).  Mirrors adjacency.py:558-560 and weights.py:360-373.
+__global__ void k_generate_sbm(uint8_t* A, int32_t* Wq, uint8_t* dA, int32_t* dWq, int N, int Np, int K,
+                               const int32_t* __restrict__ c, const double* __restrict__ p, double p_self,
+                               const double* __restrict__ mu, const double* __restrict__ sd, double mu_self,
+                               double sd_self, uint64_t seed, double scale, int qmax) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.y;
+  if (j >= N) return;
+  gg_u32x4 r = gg_philox4x32_10((uint32_t)j, (uint32_t)i, 0u, GG_SITE_DATA, (uint32_t)seed, (uint32_t)(seed >> 32));
+  int ab = c[i] * K + c[j];
+  double pe = (i == j) ? p_self : p[ab];
+  double u = gg_u53(r.v[0], r.v[1]);
+  int a = u < pe;
+  // one normal by inversion-free Box-Muller-less route: polar needs a loop; use a second block if rejected
+  gg_stream s;
+  gg_stream_init(&s, seed, GG_SITE_DATA, 1u + (uint32_t)i, (uint32_t)j);
+  double z = gg_normal(&s);
+  double w = (i == j) ? (mu_self + sd_self * z) : (mu[ab] + sd[ab] * z);
+  double qd = __builtin_rint(w * scale);
+  if (qd > (double)qmax) qd = (double)qmax;
+  if (qd < -(double)qmax) qd = -(double)qmax;
+  int32_t q = a ? (int32_t)qd : GG_NO_EDGE;
+  if (i == j) {
+    dA[i] = (uint8_t)a;
+    dWq[i] = q;
+    A[(size_t)i * Np + j] = 0;
+    Wq[(size_t)i * Np + j] = GG_NO_EDGE;
+  } else {
+    A[(size_t)i * Np + j] = (uint8_t)a;
+    Wq[(size_t)i * Np + j] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------
+static int alloc_data(gg_data* d) {
+  size_t nA = (size_t)d->N * d->Np;
+  GG_HIP(hipMalloc(&d->A, nA));
+  GG_HIP(hipMalloc(&d->AT, nA));
+  GG_HIP(hipMalloc(&d->dA, (size_t)d->N));
+  GG_HIP(hipMemsetAsync(d->A, 0, nA, d->stream));
+  GG_HIP(hipMemsetAsync(d->AT, 0, nA, d->stream));
+  if (d->has_w) {
+    size_t nW = nA * d->B;
+    GG_HIP(hipMalloc(&d->Wq, nW * sizeof(int32_t)));
+    GG_HIP(hipMalloc(&d->WqT, nW * sizeof(int32_t)));
+    GG_HIP(hipMalloc(&d->dWq, (size_t)d->N * d->B * sizeof(int32_t)));
+    k_fill_i32<<<2048, 256, 0, d->stream>>>(d->Wq, nW, d->B, GG_NO_EDGE);
+    k_fill_i32<<<2048, 256, 0, d->stream>>>(d->WqT, nW, d->B, GG_NO_EDGE);
+  }
+  return GG_OK;
+}
+
+static int make_transposes(gg_data* d) {
+  dim3 blk(32, 8), grd((d->N + 31) / 32, (d->N + 31) / 32);
+  k_transpose<uint8_t, 1><<<grd, blk, 0, d->stream>>>(d->A, d->AT, d->N, d->Np);
+  if (d->has_w) {
+    switch (d->B) {
+      case 1: k_transpose<int32_t, 1><<<grd, blk, 0, d->stream>>>(d->Wq, d->WqT, d->N, d->Np); break;
+      case 2: k_transpose<int32_t, 2><<<grd, blk, 0, d->stream>>>(d->Wq, d->WqT, d->N, d->Np); break;
+      case 3: k_transpose<int32_t, 3><<<grd, blk, 0, d->stream>>>(d->Wq, d->WqT, d->N, d->Np); break;
+      case 4: k_transpose<int32_t, 4><<<grd, blk, 0, d->stream>>>(d->Wq, d->WqT, d->N, d->Np); break;
+    }
+  }
+  GG_HIP(hipGetLastError());
+  return GG_OK;
+}
+
+static void diag_stats_host(gg_data* d, const uint8_t* dA, const int32_t* dWq) {
+  d->d1 = 0;
+  for (int s = 0; s < gg_nsi(GG_MAXB); ++s) d->dS[s] = 0;
+  int B = d->B;
+  for (int i = 0; i < d->N; ++i) {
+    if (!dA[i]) continue;
+    d->d1 += 1;
+    if (!d->has_w) continue;
+    const int32_t* q = dWq + (size_t)i * B;
+    for (int r = 0; r < B; ++r) d->dS[r] += q[r];
+    int t = B;
+    for (int r = 0; r < B; ++r)
+      for (int s = r; s < B; ++s) d->dS[t++] += (long long)q[r] * (long long)q[s];
+  }
+}
+
+extern "C" {
+
+int gg_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  *count = n;
+  return GG_OK;
+}
+
+const char* gg_last_error(void) { return gg_err_text.c_str(); }
+const char* gg_version(void) { return "graphgibbs-mi355x 0.1 (gfx950)"; }
+
+int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t device) {
+  if (!out || !A || N <= 0) return gg_fail(GG_ERR_INVALID, "gg_data_create: bad arguments");
+  if (W && (B < 1 || B > GG_MAXB)) return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d not in 1..%d", B, GG_MAXB);
+  int rc = gg_ensure_device(device);
+  if (rc) return rc;
+  gg_data* d = new gg_data();
+  memset(d, 0, sizeof(*d));
+  d->device = device;
+  d->N = N;
+  d->B = W ? B : 1;
+  d->Np = gg_round_up(N, 64);
+  d->has_w = W ? 1 : 0;
+  GG_HIP(hipStreamCreate(&d->stream));
+  rc = alloc_data(d);
+  if (rc) return rc;
+
+  // host staging: off-diagonal copy, diagonal, quantisation (same arithmetic as the
+  // oracle's orc_quantise: shift = qbits - frexp-exponent of max |w| over edges).
+  size_t nA = (size_t)N * d->Np;
+  std::vector<uint8_t> hA(nA, 0), hdA(N, 0);
+  long long nedges = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      uint8_t a = A[(size_t)i * N + j] ? 1 : 0;
+      nedges += a;
+      if (i == j) hdA[i] = a; else hA[(size_t)i * d->Np + j] = a;
+    }
+  d->n_edges = nedges;
+  GG_HIP(hipMemcpyAsync(d->A, hA.data(), nA, hipMemcpyHostToDevice, d->stream));
+  GG_HIP(hipMemcpyAsync(d->dA, hdA.data(), N, hipMemcpyHostToDevice, d->stream));
+  std::vector<int32_t> hW, hdW;
+  if (W) {
+    double wmax = 0.0;
+    for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
+      if (!A[ij]) continue;
+      for (int b = 0; b < B; ++b) {
+        double a = fabs(W[ij * B + b]);
+        if (!(a <= 1.7e308)) { gg_data_destroy(d); return gg_fail(GG_ERR_NUMERIC, "non-finite weight on an edge"); }
+        if (a > wmax) wmax = a;
+      }
+    }
+    if (wmax == 0.0) wmax = 1.0;
+    int e;
+    frexp(wmax, &e);
+    d->shift = gg_qbits(N) - e;
+    hW.assign(nA * B, 0);
+    hdW.assign((size_t)N * B, 0);
+    for (size_t x = 0; x < nA; ++x) hW[x * B] = GG_NO_EDGE;
+    for (int i = 0; i < N; ++i) {
+      hdW[(size_t)i * B] = GG_NO_EDGE;
+      for (int j = 0; j < N; ++j) {
+        size_t ij = (size_t)i * N + j;
+        if (!A[ij]) continue;
+        int32_t* dst = (i == j) ? &hdW[(size_t)i * B] : &hW[((size_t)i * d->Np + j) * B];
+        for (int b = 0; b < B; ++b) dst[b] = (int32_t)llrint(ldexp(W[ij * B + b], d->shift));
+      }
+    }
+    GG_HIP(hipMemcpyAsync(d->Wq, hW.data(), hW.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    GG_HIP(hipMemcpyAsync(d->dWq, hdW.data(), hdW.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+  }
+  diag_stats_host(d, hdA.data(), W ? hdW.data() : nullptr);
+  rc = make_transposes(d);
+  if (rc) { gg_data_destroy(d); return rc; }
+  GG_HIP(hipStreamSynchronize(d->stream));
+  *out = d;
+  return GG_OK;
+}
+
+int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                       const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                       int32_t device) {
+  if (!out || N <= 0 || K <= 0 || !c || !p || !mu || !sigma) return gg_fail(GG_ERR_INVALID, "gg_data_create_sbm: bad arguments");
+  int rc = gg_ensure_device(device);
+  if (rc) return rc;
+  gg_data* d = new gg_data();
+  memset(d, 0, sizeof(*d));
+  d->device = device; d->N = N; d->B = 1; d->Np = gg_round_up(N, 64); d->has_w = 1;
+  GG_HIP(hipStreamCreate(&d->stream));
+  rc = alloc_data(d);
+  if (rc) return rc;
+  // fixed-point scale from a bound on |w|: max |mu| + 8 sd (values beyond are clamped; probability < 1e-15 per edge)
+  double wb = fabs(mu_self) + 8.0 * sqrt(sigma_self);
+  std::vector<double> sd((size_t)K * K);
+  for (int ab = 0; ab < K * K; ++ab) {
+    sd[ab] = sqrt(sigma[ab]);
+    double v = fabs(mu[ab]) + 8.0 * sd[ab];
+    if (v > wb) wb = v;
+  }
+  int e;
+  frexp(wb, &e);
+  int qb = gg_qbits(N);
+  d->shift = qb - e;
+  int32_t* dc; double *dp, *dmu, *dsd;
+  GG_HIP(hipMalloc(&dc, (size_t)N * 4));
+  GG_HIP(hipMalloc(&dp, (size_t)K * K * 8));
+  GG_HIP(hipMalloc(&dmu, (size_t)K * K * 8));
+  GG_HIP(hipMalloc(&dsd, (size_t)K * K * 8));
+  GG_HIP(hipMemcpyAsync(dc, c, (size_t)N * 4, hipMemcpyHostToDevice, d->stream));
+  GG_HIP(hipMemcpyAsync(dp, p, (size_t)K * K * 8, hipMemcpyHostToDevice, d->stream));
+  GG_HIP(hipMemcpyAsync(dmu, mu, (size_t)K * K * 8, hipMemcpyHostToDevice, d->stream));
+  GG_HIP(hipMemcpyAsync(dsd, sd.data(), (size_t)K * K * 8, hipMemcpyHostToDevice, d->stream));
+  dim3 grd((N + 255) / 256, N);
+  k_generate_sbm<<<grd, 256, 0, d->stream>>>(d->A, d->Wq, d->dA, d->dWq, N, d->Np, K, dc, dp, p_self, dmu, dsd, mu_self,
+                                             sqrt(sigma_self), seed, ldexp(1.0, d->shift), 1 << qb);
+  GG_HIP(hipGetLastError());
+  rc = make_transposes(d);
+  if (rc) return rc;
+  std::vector<uint8_t> hdA(N);
+  std::vector<int32_t> hdW(N);
+  GG_HIP(hipMemcpyAsync(hdA.data(), d->dA, N, hipMemcpyDeviceToHost, d->stream));
+  GG_HIP(hipMemcpyAsync(hdW.data(), d->dWq, (size_t)N * 4, hipMemcpyDeviceToHost, d->stream));
+  GG_HIP(hipStreamSynchronize(d->stream));
+  diag_stats_host(d, hdA.data(), hdW.data());
+  d->n_edges = -1;
+  hipFree(dc); hipFree(dp); hipFree(dmu); hipFree(dsd);
+  *out = d;
+  return GG_OK;
+}
+
+int gg_data_destroy(gg_data* d) {
+  if (!d) return GG_OK;
+  hipSetDevice(d->device);
+  if (d->A) hipFree(d->A);
+  if (d->AT) hipFree(d->AT);
+  if (d->dA) hipFree(d->dA);
+  if (d->Wq) hipFree(d->Wq);
+  if (d->WqT) hipFree(d->WqT);
+  if (d->dWq) hipFree(d->dWq);
+  if (d->stream) hipStreamDestroy(d->stream);
+  delete d;
+  return GG_OK;
+}
+
+int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64_t* n_edges) {
+  if (!d) return gg_fail(GG_ERR_INVALID, "null data");
+  if (N) *N = d->N;
+  if (B) *B = d->B;
+  if (shift) *shift = d->shift;
+  if (n_edges) *n_edges = d->n_edges;
+  return GG_OK;
+}
+
+int gg_data_download(const gg_data* d, uint8_t* A, double* W) {
+  if (!d || !A) return gg_fail(GG_ERR_INVALID, "gg_data_download: bad arguments");
+  GG_HIP(hipSetDevice(d->device));
+  int N = d->N, Np = d->Np, B = d->B;
+  std::vector<uint8_t> hA((size_t)N * Np), hdA(N);
+  GG_HIP(hipMemcpy(hA.data(), d->A, hA.size(), hipMemcpyDeviceToHost));
+  GG_HIP(hipMemcpy(hdA.data(), d->dA, N, hipMemcpyDeviceToHost));
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) A[(size_t)i * N + j] = (i == j) ? hdA[i] : hA[(size_t)i * Np + j];
+  if (W && d->has_w) {
+    std::vector<int32_t> hW((size_t)N * Np * B), hdW((size_t)N * B);
+    GG_HIP(hipMemcpy(hW.data(), d->Wq, hW.size() * 4, hipMemcpyDeviceToHost));
+    GG_HIP(hipMemcpy(hdW.data(), d->dWq, hdW.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const int32_t* q = (i == j) ? &hdW[(size_t)i * B] : &hW[((size_t)i * Np + j) * B];
+        for (int b = 0; b < B; ++b)
+          W[((size_t)i * N + j) * B + b] = (q[0] == GG_NO_EDGE) ? 0.0 : ldexp((double)q[b], -d->shift);
+      }
+  }
+  return GG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+/* graphgibbs.h — C ABI of the MI355X Gibbs engine (libgraphgibbs.so).
+ *
+ * Drop-in boundary for graphistician's Aldous-Hoover Gibbs hot path.  The
+ * reference is pure Python; the binding a maintainer adds is a ctypes stub
+ * (INTEGRATION.md).  Each entry point names the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions: every function returns 0 on success or a negative gg_status;
+ * nothing throws across the ABI; gg_last_error() gives the text of the last
+ * failure on the calling thread.  Plain pointers and sizes only.  A handle is
+ * not re-entrant; distinct handles are independent.  There is NO CPU fallback:
+ * without a HIP device every call that needs one fails with GG_ERR_NO_DEVICE.
+ */
+#ifndef GRAPHGIBBS_H
+#define GRAPHGIBBS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gg_data gg_data;   /* device-resident network (A, A^T, W, W^T, diagonals) */
+typedef struct gg_model gg_model; /* one component distribution with device-resident state */
+
+enum gg_status {
+  GG_OK = 0,
+  GG_ERR_NO_DEVICE = -1,
+  GG_ERR_INVALID = -2,
+  GG_ERR_HIP = -3,
+  GG_ERR_UNSUPPORTED = -4,
+  GG_ERR_NUMERIC = -5
+};
+
+/* Component kinds.  Reference classes:
+ *  GG_SBM_ADJ       adjacency.py:440-702  SBMAdjacencyDistribution
+ *  GG_BB_ADJ        adjacency.py:110-188  BetaBernoulliAdjacencyDistribution
+ *  GG_BERN_ADJ      adjacency.py:65-107   BernoulliAdjacencyDistribution (scalar p, p_self)
+ *  GG_SBM_GAUSS_W   weights.py:172-498    SBMGaussianWeightDistribution
+ *  GG_NIW_W         weights.py:68-162     NIWGaussianWeightDistribution
+ *  GG_FIXED_W       weights.py:9-65       FixedGaussianWeightDistribution
+ *  GG_LOGISTIC_EIG  eigenmodel.py:822-965 _GibbsLogisticEigenmodel
+ */
+enum gg_kind {
+  GG_SBM_ADJ = 1,
+  GG_BB_ADJ = 2,
+  GG_BERN_ADJ = 3,
+  GG_SBM_GAUSS_W = 4,
+  GG_NIW_W = 5,
+  GG_FIXED_W = 6,
+  GG_LOGISTIC_EIG = 7
+};
+
+typedef struct gg_config {
+  int32_t kind;                   /* gg_kind */
+  int32_t N;                      /* nodes */
+  int32_t K;                      /* blocks C (1 for non-SBM kinds) */
+  int32_t B;                      /* weight dimension (weights kinds), 1..4 */
+  int32_t D;                      /* latent dimension (eigenmodel) */
+  int32_t allow_self_connections; /* adjacency.py:461 */
+  int32_t special_case_self_conns;/* adjacency.py:462, weights.py:189; BB: self_connection (adjacency.py:119-125) */
+  int32_t device;                 /* HIP device ordinal */
+  uint64_t seed;                  /* Philox key */
+  double tau1, tau0;              /* Beta prior (adjacency.py:460) */
+  double sigma_mu0, sigma_F, sigma_lmbda, mu_mu_0; /* eigenmodel.py:41-56 */
+  int32_t lmbda_given;            /* eigenmodel.py:65-67 */
+  int32_t reserved;
+} gg_config;
+
+/* State ids for gg_get_state / gg_set_state.  Shapes in comments, C order. */
+enum gg_state_id {
+  GG_ST_C = 1,          /* int32  (N)        block labels                 adjacency.py:496, weights.py:206 */
+  GG_ST_M = 2,          /* double (K)        block probabilities          adjacency.py:486, weights.py:205 */
+  GG_ST_PI = 3,         /* double (K)        Dirichlet prior              adjacency.py:469-473 */
+  GG_ST_P = 4,          /* double (K,K)      connection probabilities     adjacency.py:507 */
+  GG_ST_P_SELF = 5,     /* double (1)                                     adjacency.py:512 */
+  GG_ST_MU = 6,         /* double (K,K,B)    Gaussian means               weights.py:231-235 */
+  GG_ST_SIGMA = 7,      /* double (K,K,B,B)  Gaussian covariances         weights.py:237-241 */
+  GG_ST_MU_SELF = 8,    /* double (B)                                     weights.py:226-228 */
+  GG_ST_SIGMA_SELF = 9, /* double (B,B) */
+  GG_ST_NIW = 10,       /* double (B + B*B + 2) = mu_0, Sigma_0, nu_0, kappa_0   weights.py:208-222 */
+  GG_ST_NIW_SELF = 11,  /* same layout, prior of the self Gaussian */
+  GG_ST_SWEEP = 12,     /* uint32 (1)        sweep counter = Philox counter word */
+  GG_ST_F = 13,         /* double (N,D)      latent features              eigenmodel.py:62 */
+  GG_ST_LMBDA = 14,     /* double (D)                                     eigenmodel.py:64-73 */
+  GG_ST_MU0 = 15,       /* double (1)                                     eigenmodel.py:57 */
+  GG_ST_MU_LMBDA = 16   /* double (D)        prior mean of lambda         eigenmodel.py:71 */
+};
+
+/* Parts of a sweep, for step-wise parity tests (gg_resample_part). */
+enum gg_part {
+  GG_PART_PARAMS = 1, /* resample_p (adjacency.py:620) / resample_mu_and_Sig (weights.py:399) */
+  GG_PART_C = 2,      /* resample_c (adjacency.py:650, weights.py:415) */
+  GG_PART_M = 4,      /* resample_m (adjacency.py:697, weights.py:493) */
+  GG_PART_OMEGA = 8,  /* _resample_Omega (eigenmodel.py:859) */
+  GG_PART_F = 16,     /* _resample_F     (eigenmodel.py:876) */
+  GG_PART_MU0 = 32,   /* _resample_mu_0  (eigenmodel.py:910) */
+  GG_PART_LMBDA = 64, /* _resample_lmbda (eigenmodel.py:934) */
+  GG_PART_ALL = 127
+};
+
+typedef struct gg_stats {
+  uint64_t sweeps;              /* sweeps run on this handle */
+  uint64_t label_changes;       /* labels changed by resample_c since creation */
+  uint64_t resolve_rounds;      /* speculate/resolve rounds (1 per half-sweep when nothing changes) */
+  double bulk_bytes;            /* algorithmic bytes streamed by the bulk statistics kernels, last call */
+  double bulk_ms;               /* HIP-event time of those kernels, last call */
+  uint64_t bulk_launches;       /* number of bulk kernel launches, last call */
+  double total_ms;              /* HIP-event time of the whole last call */
+} gg_stats;
+
+/* ---- library ------------------------------------------------------------- */
+int gg_device_count(int* count);
+const char* gg_last_error(void);
+const char* gg_version(void);
+
+/* ---- data: replaces the (A, W) ndarray pair the reference passes to every
+ * resample / log_likelihood call (networks.py:28,69).  A is (N,N) C-order,
+ * A[i][j] != 0 means an edge i -> j (adjacency.py:686-692); W is (N,N,B) C-order
+ * float64 or NULL for adjacency-only use.  The engine copies; the caller keeps
+ * ownership.  Weights are stored as fixed point. */
+int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t device);
+int gg_data_destroy(gg_data* d);
+int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64_t* n_edges);
+/* Synthetic planted-SBM network generated on the device (bench / large N):
+ * mirrors SBMAdjacencyDistribution.rvs (adjacency.py:558-560) and
+ * SBMGaussianWeightDistribution.rvs (weights.py:360-373) for B = 1. */
+int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                       const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                       int32_t device);
+/* Copy the stored network back (de-quantised weights); W may be NULL. */
+int gg_data_download(const gg_data* d, uint8_t* A, double* W);
+
+/* ---- models ---------------------------------------------------------------- */
+int gg_model_create(gg_model** out, const gg_config* cfg);
+int gg_model_destroy(gg_model* m);
+int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes);
+int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes);
+
+/* n_sweeps x resample(data): adjacency.py:615-618 / weights.py:394-397 /
+ * adjacency.py:153-181 / weights.py:154-162 / eigenmodel.py:836-857.
+ * beta is the AIS inverse temperature (graph_models.py:50-64); 1.0 = plain Gibbs. */
+int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta);
+int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta);
+
+/* abstractions.py:111-115 (adjacency kinds), weights.py:316-331 /
+ * abstractions.py:257-274 (weight kinds), eigenmodel.py:110-129. */
+int gg_log_likelihood(gg_model* m, const gg_data* d, double* out);
+
+/* Conditional log-probabilities lp[K] of node n under the current state
+ * (the vector handed to sample_discrete_from_log at adjacency.py:695 /
+ * weights.py:488) — for parity tests. */
+int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp);
+
+int gg_last_stats(gg_model* m, gg_stats* out);
+/* Record HIP events around the bulk kernels (on the engine stream) so that gg_last_stats reports their device time. */
+int gg_set_timing(gg_model* m, int32_t on);
+
+/* Device self-test of the shared arithmetic spec: evaluates exp/log/sqrt/div
+ * on the device for n inputs (parity tests compare with the host build). */
+int gg_selftest_math(int32_t device, int32_t op, const double* x, const double* y, double* out, int64_t n);
+/* Conjugate draws executed on the device (same streams as the host spec). */
+int gg_selftest_draws(int32_t device, int32_t what, uint64_t seed, const double* params, int32_t nparams,
+                      double* out, int64_t n, int32_t stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHGIBBS_H */

@@ -1,0 +1,242 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY — see the header of oracle_sbm.cpp.  Imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package graphistician_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+PART_PARAMS, PART_C, PART_M = 1, 2, 4
+PART_ALL = 7
+
+
+def build(force=False):
+    """Compile the oracle with g++ (no GPU needed)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_sbm_adj_loglik.restype = C.c_double
+        _lib.orc_const_adj_loglik.restype = C.c_double
+        _lib.orc_sbm_w_loglik.restype = C.c_double
+        _lib.orc_uniform_at.restype = C.c_double
+        for name in ("orc_eig_loglik",):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_double
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, _p(a, C.c_uint8)
+
+
+def _i32(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return _p(a, C.c_int32)
+
+
+def _f64(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous, (a.dtype, a.flags)
+    return _p(a, C.c_double)
+
+
+def pack_niw(mu_0, sigma_0, nu_0, kappa_0):
+    mu_0 = np.asarray(mu_0, dtype=np.float64).ravel()
+    sigma_0 = np.asarray(sigma_0, dtype=np.float64).ravel()
+    return np.ascontiguousarray(np.concatenate([mu_0, sigma_0, [float(nu_0), float(kappa_0)]]))
+
+
+def quantise(A, W):
+    """Fixed-point weight storage: returns (q int32 (N,N,B), shift)."""
+    N = A.shape[0]
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    B = W.shape[2]
+    A8, pA = _u8(A != 0)
+    q = np.empty((N, N, B), dtype=np.int32)
+    shift = C.c_int(0)
+    rc = lib().orc_quantise(N, B, pA, _f64(W), _i32(q), C.byref(shift))
+    if rc:
+        raise ValueError("non-finite weight on an edge")
+    return q, shift.value
+
+
+def dequantise(q, shift):
+    return np.ldexp(q.astype(np.float64), -shift)
+
+
+# ---------------------------------------------------------------- SBM adjacency
+def sbm_adj_sweep(A, c, m, p, p_self, pi, tau1, tau0, special, seed, sweep, parts=PART_ALL):
+    """In-place sweep of (c, m, p); returns new p_self."""
+    N, K = A.shape[0], m.shape[0]
+    A8, pA = _u8(A != 0)
+    ps = C.c_double(float(p_self))
+    lib().orc_sbm_adj_sweep(N, K, pA, _i32(c), _f64(m), _f64(p), C.byref(ps), _f64(np.ascontiguousarray(pi, dtype=np.float64)),
+                            C.c_double(tau1), C.c_double(tau0), int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts))
+    return ps.value
+
+
+def sbm_adj_node_lp(A, c, m, p, special, n1, literal=False):
+    N, K = A.shape[0], m.shape[0]
+    A8, pA = _u8(A != 0)
+    lp = np.zeros(K)
+    f = lib().orc_sbm_adj_node_lp_literal if literal else lib().orc_sbm_adj_node_lp
+    f(N, K, pA, _i32(c), _f64(m), _f64(p), int(special), int(n1), _f64(lp))
+    return lp
+
+
+def categorical(lp, u):
+    lp = np.ascontiguousarray(lp, dtype=np.float64)
+    return lib().orc_categorical(_f64(lp), lp.shape[0], C.c_double(u))
+
+
+def sbm_adj_loglik(A, c, p, p_self, allow_self=True, special=True):
+    N, K = A.shape[0], p.shape[0]
+    A8, pA = _u8(A != 0)
+    return lib().orc_sbm_adj_loglik(N, K, pA, _i32(c), _f64(p), C.c_double(p_self), int(allow_self), int(special))
+
+
+def bb_adj_sweep(A, tau1, tau0, self_connection, seed, sweep):
+    N = A.shape[0]
+    A8, pA = _u8(A != 0)
+    p, ps = C.c_double(0), C.c_double(0)
+    lib().orc_bb_adj_sweep(N, pA, C.byref(p), C.byref(ps), C.c_double(tau1), C.c_double(tau0), int(self_connection),
+                           C.c_uint64(seed), C.c_uint32(sweep))
+    return p.value, ps.value
+
+
+def const_adj_loglik(A, p, p_self):
+    N = A.shape[0]
+    A8, pA = _u8(A != 0)
+    return lib().orc_const_adj_loglik(N, pA, C.c_double(p), C.c_double(p_self))
+
+
+# ---------------------------------------------------------------- Gaussian weights
+def sbm_w_sweep(A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, niw, niw_self, special, seed, sweep,
+                parts=PART_ALL):
+    N, K, B = A.shape[0], m.shape[0], q.shape[2]
+    A8, pA = _u8(A != 0)
+    rc = lib().orc_sbm_w_sweep(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma),
+                               _f64(mu_self), _f64(sigma_self), _f64(np.ascontiguousarray(pi, dtype=np.float64)),
+                               _f64(niw), _f64(niw_self), int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts))
+    if rc:
+        raise RuntimeError("oracle sbm_w_sweep failed rc=%d" % rc)
+
+
+def sbm_w_node_lp(A, q, shift, c, m, mu, sigma, special, n1, literal=False):
+    N, K, B = A.shape[0], m.shape[0], q.shape[2]
+    A8, pA = _u8(A != 0)
+    lp = np.zeros(K)
+    f = lib().orc_sbm_w_node_lp_literal if literal else lib().orc_sbm_w_node_lp
+    rc = f(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma), int(special), int(n1), _f64(lp))
+    if rc:
+        raise RuntimeError("oracle sbm_w_node_lp failed rc=%d" % rc)
+    return lp
+
+
+def sbm_w_loglik(A, q, shift, c, mu, sigma, mu_self, sigma_self, special=True):
+    N, B = A.shape[0], q.shape[2]
+    K = mu.shape[0]
+    A8, pA = _u8(A != 0)
+    return lib().orc_sbm_w_loglik(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(mu), _f64(sigma), _f64(mu_self),
+                                  _f64(sigma_self), int(special))
+
+
+def niw_w_sweep(A, q, shift, mu, sigma, mu_self, sigma_self, niw, niw_self, seed, sweep):
+    N, B = A.shape[0], q.shape[2]
+    A8, pA = _u8(A != 0)
+    rc = lib().orc_niw_w_sweep(N, B, pA, _i32(q), int(shift), _f64(mu), _f64(sigma), _f64(mu_self), _f64(sigma_self),
+                               _f64(niw), _f64(niw_self), C.c_uint64(seed), C.c_uint32(sweep))
+    if rc:
+        raise RuntimeError("oracle niw_w_sweep failed rc=%d" % rc)
+
+
+# ---------------------------------------------------------------- spec primitives
+def philox(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox(*[C.c_uint32(x) for x in ctr], *[C.c_uint32(x) for x in key], out)
+    return [int(x) for x in out]
+
+
+def uniform_at(seed, site, sweep, index):
+    return lib().orc_uniform_at(C.c_uint64(seed), C.c_uint32(site), C.c_uint32(sweep), C.c_uint32(index))
+
+
+def exp_vec(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().orc_exp_vec(_f64(x), _f64(y), C.c_longlong(x.size))
+    return y
+
+
+def log_vec(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().orc_log_vec(_f64(x), _f64(y), C.c_longlong(x.size))
+    return y
+
+
+def normal_vec(seed, n):
+    y = np.empty(n)
+    lib().orc_normal_vec(C.c_uint64(seed), _f64(y), C.c_longlong(n))
+    return y
+
+
+def gamma_vec(seed, a, n):
+    y = np.empty(n)
+    lib().orc_gamma_vec(C.c_uint64(seed), C.c_double(a), _f64(y), C.c_longlong(n))
+    return y
+
+
+def beta_vec(seed, a, b, n):
+    y = np.empty(n)
+    lib().orc_beta_vec(C.c_uint64(seed), C.c_double(a), C.c_double(b), _f64(y), C.c_longlong(n))
+    return y
+
+
+def dirichlet_vec(seed, alpha, n):
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    y = np.empty((n, alpha.shape[0]))
+    lib().orc_dirichlet_vec(C.c_uint64(seed), _f64(alpha), alpha.shape[0], _f64(y), C.c_longlong(n))
+    return y
+
+
+def niw_vec(seed, niw, B, n_obs, s1, s2, n):
+    s1 = np.ascontiguousarray(s1, dtype=np.float64)
+    s2 = np.ascontiguousarray(s2, dtype=np.float64)
+    mu = np.empty((n, B))
+    sig = np.empty((n, B, B))
+    lib().orc_niw_vec(C.c_uint64(seed), _f64(niw), B, C.c_double(n_obs), _f64(s1), _f64(s2), _f64(mu), _f64(sig),
+                      C.c_longlong(n))
+    return mu, sig
+
+
+def gauss_table(mu, sigma):
+    mu = np.ascontiguousarray(mu, dtype=np.float64)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    B = mu.shape[0]
+    out = np.zeros(1 + B + B * (B + 1) // 2)
+    rc = lib().orc_gauss_table(_f64(mu), _f64(sigma), B, _f64(out))
+    if rc:
+        raise ValueError("sigma not SPD")
+    return out

@@ -1,0 +1,206 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bit-exact for labels, counts and — because statistics are
+exact integers and the arithmetic spec is shared — also for the drawn parameters."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import planted_sbm, er_network, AdjState, WState
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from graphistician_amd import _abi
+    if _abi.device_count() < 1:
+        pytest.fail("no HIP device: the engine has no CPU fallback")
+    return _abi
+
+
+def make_adj(abi, st, seed, special=1, allow=1):
+    m = abi.Model(kind=abi.SBM_ADJ, N=st.N, K=st.K, B=1, seed=seed, tau1=st.tau1, tau0=st.tau0,
+                  allow_self_connections=allow, special_case_self_conns=special)
+    m.set(abi.ST_C, st.c, np.int32)
+    m.set(abi.ST_M, st.m)
+    m.set(abi.ST_PI, st.pi)
+    m.set(abi.ST_P, st.p)
+    m.set(abi.ST_P_SELF, np.array([st.p_self]))
+    return m
+
+
+def make_w(abi, st, seed, special=1):
+    m = abi.Model(kind=abi.SBM_GAUSS_W, N=st.N, K=st.K, B=st.B, seed=seed, special_case_self_conns=special)
+    m.set(abi.ST_C, st.c, np.int32)
+    m.set(abi.ST_M, st.m)
+    m.set(abi.ST_PI, st.pi)
+    m.set(abi.ST_MU, st.mu)
+    m.set(abi.ST_SIGMA, st.sigma)
+    m.set(abi.ST_MU_SELF, st.mu_self)
+    m.set(abi.ST_SIGMA_SELF, st.sigma_self)
+    m.set(abi.ST_NIW, st.niw)
+    m.set(abi.ST_NIW_SELF, st.niw_self)
+    return m
+
+
+# ------------------------------------------------------------------ arithmetic spec on the device
+def test_device_math_bitexact(abi):
+    rng = np.random.RandomState(1)
+    x = np.concatenate([rng.uniform(-745, 709, 200000), rng.uniform(-2, 2, 200000), rng.uniform(-60, 0, 100000)])
+    assert np.array_equal(abi.selftest_math(0, x), O.exp_vec(x))
+    y = np.exp(rng.uniform(-700, 700, 300000))
+    y = np.concatenate([y, rng.uniform(0.4, 2.5, 200000)])
+    assert np.array_equal(abi.selftest_math(1, y), O.log_vec(y))
+    assert np.array_equal(abi.selftest_math(2, y), np.sqrt(y))
+    a = rng.randn(300000) * 10 ** rng.uniform(-5, 5, 300000)
+    b = rng.randn(300000) * 10 ** rng.uniform(-5, 5, 300000)
+    assert np.array_equal(abi.selftest_math(3, a, b), a / b)
+    big = np.round(rng.uniform(-2 ** 62, 2 ** 62, 100000))
+    assert np.array_equal(abi.selftest_math(5, big), big.astype(np.int64).astype(np.float64))
+
+
+def test_device_draws_bitexact(abi):
+    for a in [0.3, 1.0, 4.5, 2000.0]:
+        assert np.array_equal(abi.selftest_draws(1, 7, [a], 20000), O.gamma_vec(7, a, 20000))
+    assert np.array_equal(abi.selftest_draws(2, 9, [3.0, 40.5], 20000), O.beta_vec(9, 3.0, 40.5, 20000))
+    alpha = np.array([0.5, 1.0, 7.0, 100.0, 3.0])
+    assert np.array_equal(abi.selftest_draws(3, 11, alpha, 5000, stride=5), O.dirichlet_vec(11, alpha, 5000))
+    for B in [1, 2, 4]:
+        rng = np.random.RandomState(B)
+        X = rng.randn(50, B) + 1.0
+        niw = O.pack_niw(rng.randn(B), np.eye(B) * 1.5, B + 2, 0.7)
+        s1, s2 = X.sum(0), X.T.dot(X)
+        prm = np.concatenate([[B], niw, [50.0], s1, s2.ravel()])
+        out = abi.selftest_draws(4, 13, prm, 4000, stride=B + B * B)
+        mu, sig = O.niw_vec(13, niw, B, 50.0, s1, s2, 4000)
+        assert np.array_equal(out[:, :B], mu)
+        assert np.array_equal(out[:, B:].reshape(-1, B, B), sig)
+
+
+# ------------------------------------------------------------------ SBM adjacency
+@pytest.mark.parametrize("N,K,special", [(50, 3, 1), (193, 7, 1), (128, 16, 0), (300, 64, 1)])
+def test_adj_node_lp_bitexact(abi, N, K, special):
+    A, W, _ = planted_sbm(N, K, seed=N)
+    st = AdjState(N, K, seed=K)
+    d = abi.DeviceData(A, None)
+    m = make_adj(abi, st, seed=5, special=special)
+    for n in [0, 1, N // 2, N - 1]:
+        lp_g = m.node_lp(d, n, K)
+        lp_o = O.sbm_adj_node_lp(A, st.c, st.m, st.p, special, n)
+        assert np.array_equal(lp_g, lp_o), (n, lp_g - lp_o)
+
+
+@pytest.mark.parametrize("N,K,special", [(50, 3, 1), (193, 7, 0), (257, 16, 1)])
+def test_adj_sweep_parts_bitexact(abi, N, K, special):
+    A, W, _ = planted_sbm(N, K, seed=3 * N)
+    st = AdjState(N, K, seed=K + 1)
+    d = abi.DeviceData(A, None)
+    m = make_adj(abi, st, seed=77, special=special)
+    # p
+    m.resample_part(d, abi.PART_PARAMS)
+    ps = O.sbm_adj_sweep(A, st.c, st.m, st.p, st.p_self, st.pi, st.tau1, st.tau0, special, 77, 0, O.PART_PARAMS)
+    assert np.array_equal(m.get(abi.ST_P, (K, K)), st.p)
+    if special:
+        assert m.get(abi.ST_P_SELF, (1,))[0] == ps
+    # c
+    m.resample_part(d, abi.PART_C)
+    O.sbm_adj_sweep(A, st.c, st.m, st.p, ps, st.pi, st.tau1, st.tau0, special, 77, 0, O.PART_C)
+    assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c)
+    # m
+    m.resample_part(d, abi.PART_M)
+    O.sbm_adj_sweep(A, st.c, st.m, st.p, ps, st.pi, st.tau1, st.tau0, special, 77, 0, O.PART_M)
+    assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+
+
+@pytest.mark.parametrize("N,K", [(120, 4), (400, 16)])
+def test_adj_chain_bitexact(abi, N, K):
+    """Several full sweeps from a random start: burn-in (many label changes per scan) then steady state."""
+    A, W, _ = planted_sbm(N, K, seed=11)
+    st = AdjState(N, K, seed=2)
+    d = abi.DeviceData(A, None)
+    m = make_adj(abi, st, seed=1234)
+    ps = st.p_self
+    nsweeps = 6
+    m.resample(d, nsweeps)
+    for s in range(nsweeps):
+        ps = O.sbm_adj_sweep(A, st.c, st.m, st.p, ps, st.pi, st.tau1, st.tau0, 1, 1234, s)
+    assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c)
+    assert np.array_equal(m.get(abi.ST_P, (K, K)), st.p)
+    assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+    assert m.get(abi.ST_P_SELF, (1,))[0] == ps
+    assert m.stats()["label_changes"] > 0
+    ll_g = m.log_likelihood(d)
+    ll_o = O.sbm_adj_loglik(A, st.c, st.p, ps)
+    assert abs(ll_g - ll_o) <= 1e-10 * abs(ll_o)
+
+
+# ------------------------------------------------------------------ SBM Gaussian weights
+@pytest.mark.parametrize("N,K,B,special", [(50, 3, 1, 1), (130, 5, 2, 1), (96, 16, 1, 0), (70, 4, 4, 1), (200, 64, 1, 1)])
+def test_w_node_lp_bitexact(abi, N, K, B, special):
+    A, W, _ = planted_sbm(N, K, B=B, seed=N + B)
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=K)
+    d = abi.DeviceData(A, W)
+    assert d.info()["shift"] == shift
+    m = make_w(abi, st, seed=5, special=special)
+    for n in [0, N // 3, N - 1]:
+        lp_g = m.node_lp(d, n, K)
+        lp_o = O.sbm_w_node_lp(A, q, shift, st.c, st.m, st.mu, st.sigma, special, n)
+        assert np.array_equal(lp_g, lp_o), (n, lp_g - lp_o)
+
+
+@pytest.mark.parametrize("N,K,B,special", [(60, 3, 1, 1), (150, 6, 2, 0), (260, 16, 1, 1)])
+def test_w_chain_bitexact(abi, N, K, B, special):
+    A, W, _ = planted_sbm(N, K, B=B, seed=5 * N)
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=K + 3)
+    d = abi.DeviceData(A, W)
+    m = make_w(abi, st, seed=4321, special=special)
+    nsweeps = 5
+    m.resample(d, nsweeps)
+    for s in range(nsweeps):
+        O.sbm_w_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, st.niw, st.niw_self,
+                      special, 4321, s)
+    assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c)
+    assert np.array_equal(m.get(abi.ST_MU, (K, K, B)), st.mu)
+    assert np.array_equal(m.get(abi.ST_SIGMA, (K, K, B, B)), st.sigma)
+    assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+    if special:
+        assert np.array_equal(m.get(abi.ST_MU_SELF, (B,)), st.mu_self)
+    ll_g = m.log_likelihood(d)
+    ll_o = O.sbm_w_loglik(A, q, shift, st.c, st.mu, st.sigma, st.mu_self, st.sigma_self, special)
+    assert abs(ll_g - ll_o) <= 1e-9 * abs(ll_o)
+
+
+def test_bb_and_niw_config1(abi):
+    """Config 1 shape: Beta-Bernoulli adjacency + NIW weights, N=50, B=2."""
+    A, W = er_network(50, B=2, seed=1)
+    q, shift = O.quantise(A, W)
+    d = abi.DeviceData(A, W)
+    for selfc in [0, 1]:
+        m = abi.Model(kind=abi.BB_ADJ, N=50, K=1, B=1, seed=99, tau1=1.0, tau0=1.0, special_case_self_conns=selfc,
+                      allow_self_connections=1)
+        for s in range(3):
+            m.resample(d, 1)
+            p, ps = O.bb_adj_sweep(A, 1.0, 1.0, selfc, 99, s)
+            assert m.get(abi.ST_P, (1, 1))[0, 0] == p
+            if selfc:
+                assert m.get(abi.ST_P_SELF, (1,))[0] == ps
+        ll = m.log_likelihood(d)
+        assert abs(ll - O.const_adj_loglik(A, p, ps if selfc else p)) <= 1e-10 * abs(ll)
+    B = 2
+    w = abi.Model(kind=abi.NIW_W, N=50, K=1, B=B, seed=5)
+    niw = O.pack_niw(np.zeros(B), np.eye(B), B + 2, 1.0)
+    w.set(abi.ST_NIW, niw)
+    w.set(abi.ST_NIW_SELF, niw)
+    mu, sig, mus, sigs = np.zeros((1, 1, B)), np.zeros((1, 1, B, B)), np.zeros(B), np.zeros((B, B))
+    for s in range(3):
+        w.resample(d, 1)
+        O.niw_w_sweep(A, q, shift, mu, sig, mus, sigs, niw, niw, 5, s)
+        assert np.array_equal(w.get(abi.ST_MU, (1, 1, B)), mu)
+        assert np.array_equal(w.get(abi.ST_SIGMA, (1, 1, B, B)), sig)
+        assert np.array_equal(w.get(abi.ST_MU_SELF, (B,)), mus)
+        assert np.array_equal(w.get(abi.ST_SIGMA_SELF, (B, B)), sigs)
+    ll = w.log_likelihood(d)
+    ll_o = O.sbm_w_loglik(A, q, shift, np.zeros(50, np.int32), mu, sig, mus, sigs, 1)
+    assert abs(ll - ll_o) <= 1e-9 * abs(ll_o)
