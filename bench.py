@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — full Gibbs sweeps/sec on the Gaussian-SBM configuration of BASELINE.json.
+
+One *step* = one full sweep = FactorizedNetworkDistribution.resample((A,W))
+(reference networks.py:69-71): the SBM adjacency half (adjacency.py:615-618)
+followed by the SBM Gaussian-weight half (weights.py:394-397), on a synthetic
+planted Gaussian SBM resident in HBM.  N=1 runs BASELINE.json configs[1]
+(N=4096, K=16, B=1, dense).  With --gpus G (one process per GPU, launched by
+torch.distributed.run) every rank runs an independent chain on its own copy of
+the workload (north_star: "otherwise independent chains map one-per-GPU"), no
+data-path collective; value = total sweeps / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  torch is used only for the multi-process
+rendezvous / barrier; the engine itself is ctypes -> libgraphgibbs.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
+
+
+def planted_truth(N, K, seed):
+    """Planted Gaussian SBM parameters (SURVEY.md §8d cfg 2 recipe)."""
+    rng = np.random.RandomState(seed)
+    m = rng.dirichlet(np.ones(K) * 10.0)
+    c = rng.choice(K, p=m, size=N).astype(np.int32)
+    p = rng.beta(1.0, 1.0, size=(K, K))
+    p_self = float(rng.beta(1.0, 1.0))
+    sigma = 1.0 / rng.gamma(1.5, 1.0 / 0.5, size=(K, K))   # IW(1, nu=3) in one dimension: 1/Gamma(nu/2, rate 1/2)
+    mu = rng.randn(K, K) * np.sqrt(sigma)
+    return dict(m=m, c=c, p=p, p_self=p_self, mu=mu, sigma=sigma, mu_self=0.0, sigma_self=1.0)
+
+
+def build_models(abi, N, K, chain_seed, device):
+    rng = np.random.RandomState(chain_seed)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=chain_seed * 2 + 1, tau1=1.0, tau0=1.0,
+                    allow_self_connections=1, special_case_self_conns=1, device=device)
+    pi_a = np.ones(K)
+    m_a = rng.dirichlet(pi_a)
+    adj.set(abi.ST_PI, pi_a)
+    adj.set(abi.ST_M, m_a)
+    adj.set(abi.ST_C, rng.choice(K, p=m_a, size=N).astype(np.int32), np.int32)
+    adj.set(abi.ST_P, rng.beta(1.0, 1.0, size=(K, K)))
+    adj.set(abi.ST_P_SELF, np.array([rng.beta(1.0, 1.0)]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=chain_seed * 2 + 2, special_case_self_conns=1, device=device)
+    pi_w = np.ones(K) * 10.0
+    m_w = rng.dirichlet(pi_w)
+    w.set(abi.ST_PI, pi_w)
+    w.set(abi.ST_M, m_w)
+    w.set(abi.ST_C, rng.choice(K, p=m_w, size=N).astype(np.int32), np.int32)
+    w.set(abi.ST_MU, rng.randn(K, K, 1))
+    w.set(abi.ST_SIGMA, np.ones((K, K, 1, 1)))
+    niw = np.array([0.0, 1.0, 3.0, 1.0])
+    w.set(abi.ST_NIW, niw)
+    w.set(abi.ST_NIW_SELF, niw)
+    return adj, w
+
+
+def cpu_baseline(abi, data, N, K, budget_s):
+    """Time the CPU oracle (single-threaded C++ restatement, kind "port") on the same workload."""
+    from oracle import oracle as O
+    A, W = data.download()
+    q, shift = O.quantise(A, W)
+    rng = np.random.RandomState(7)
+    c_a = rng.choice(K, size=N).astype(np.int32)
+    m_a = np.ones(K) / K
+    p = np.ascontiguousarray(rng.beta(1, 1, size=(K, K)))
+    ps = 0.5
+    c_w = rng.choice(K, size=N).astype(np.int32)
+    m_w = np.ones(K) / K
+    mu, sig = np.zeros((K, K, 1)), np.ones((K, K, 1, 1))
+    mus, sigs = np.zeros(1), np.ones((1, 1))
+    niw = O.pack_niw([0.0], [[1.0]], 3.0, 1.0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ps = O.sbm_adj_sweep(A, c_a, m_a, p, ps, np.ones(K), 1.0, 1.0, 1, 11, n)
+        O.sbm_w_sweep(A, q, shift, c_w, m_w, mu, sig, mus, sigs, np.ones(K) * 10, niw, niw, 1, 12, n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return dict(value=n / el, unit="sweeps/s", cores=1, kind="port",
+                sample="%d full sweeps (adjacency + weights) of the same N=%d K=%d network, oracle/ C++ -O2, 1 thread" % (n, N, K))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nodes", type=int, default=4096)
+    ap.add_argument("--blocks", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from graphistician_amd import _abi as abi
+    N, K = args.nodes, args.blocks
+    device = local_rank
+    truth = planted_truth(N, K, seed=1234)
+    data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                        truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
+    adj, w = build_models(abi, N, K, chain_seed=1 + rank, device=device)
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        adj.resample(data, 1)
+        w.resample(data, 1)
+    chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
+    adj.set_timing(True)
+    w.set_timing(True)
+    bulk = dict(adj_ms=0.0, adj_n=0, w_ms=0.0, w_n=0, adj_bytes=0.0, w_bytes=0.0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        adj.resample(data, 1)   # gg_resample synchronises its stream before returning
+        s = adj.stats()
+        bulk["adj_ms"] += s["bulk_ms"]; bulk["adj_n"] += s["bulk_launches"]; bulk["adj_bytes"] += s["bulk_bytes"]
+        w.resample(data, 1)
+        s = w.stats()
+        bulk["w_ms"] += s["bulk_ms"]; bulk["w_n"] += s["bulk_launches"]; bulk["w_bytes"] += s["bulk_bytes"]
+    barrier()
+    el = time.perf_counter() - t0
+    chg = adj.stats()["label_changes"] + w.stats()["label_changes"] - chg0
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        # dominant kernel: k_bulk_w<1> — one launch streams the N x N int32 weight matrix (or its transpose) once
+        per_launch_ms = bulk["w_ms"] / max(bulk["w_n"], 1)
+        alg_bytes = float(N) * N * 4.0
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        sweep_bytes = 2.0 * N * N * (1.0 + 4.0)
+        out = {
+            "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak",
+            "value": world * args.steps / el,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64 statistics / f64 conditionals (u8 adjacency, 24-bit fixed-point weights in int32)",
+            "data": "synthetic",
+            "config": {
+                "workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1, dense adjacency (BASELINE.json configs[1])" % (N, K),
+                "parallelism": "independent chain per GPU" if world > 1 else "single GPU",
+                "label_changes_in_timed_region": int(chg),
+                "sweep_algorithmic_bytes": sweep_bytes,
+                "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_bulk_w<1>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launch_ms": per_launch_ms,
+                "launch_bytes": alg_bytes,
+                "adj_kernel": {"kernel": "k_bulk_adj", "launch_ms": bulk["adj_ms"] / max(bulk["adj_n"], 1),
+                               "launch_bytes": float(N) * N},
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(abi, data, N, K, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,7 +195,7 @@ class Model(object):
         check(lib().gg_resample(self._h, data.handle, n_sweeps, beta))
 
     def resample_part(self, data, parts, beta=1.0):
-        check(lib().gg_resample_part(self._h, data.handle, parts, beta))
+        check(lib().gg_resample_part(self._h, data.handle if data is not None else None, parts, beta))
 
     def log_likelihood(self, data):
         out = C.c_double(0)

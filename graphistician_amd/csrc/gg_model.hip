@@ -563,7 +563,8 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   GG_HIP(hipSetDevice(m->cfg.device));
   if (beta != 1.0) return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals (beta != 1) are not implemented yet");
   if (m->eig) return gg_eigen_resample(m->eig, d, parts);
-  int rc = check_data(m, d);
+  int rc = GG_OK;
+  if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
   if (rc) return rc;
   begin_call(m);
   rc = resample_parts(m, d, parts);

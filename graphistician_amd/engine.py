@@ -1,0 +1,112 @@
+"""Host-side plumbing between the distribution classes and the HIP engine.
+
+* `as_device_data` turns the (A, W) ndarray pair the reference passes to every
+  call (networks.py:28,69) into a device-resident `DeviceData`, cached by array
+  identity so that a sweep loop written against the reference
+  (examples/demo_model_comparison.py:69-72) uploads its data once.
+* `EngineBacked` keeps a host copy of a component's state (numpy, so that `rvs`,
+  `P`, `log_prior` work anywhere) in step with the engine handle: host edits are
+  pushed before the next engine call, engine results are pulled on first read.
+
+There is no CPU implementation of resample / log_likelihood here: they need the
+engine and raise `_abi.EngineError` without a HIP device.
+"""
+import collections
+
+import numpy as np
+
+from . import _abi
+
+_DATA_CACHE = collections.OrderedDict()
+_DATA_CACHE_SIZE = 4
+
+
+def _fingerprint(a):
+    if a is None:
+        return None
+    return (id(a), a.shape, a.dtype.str, a.__array_interface__["data"][0])
+
+
+def as_device_data(A, W=None, device=0):
+    """Device-resident network for (A, W); accepts an existing DeviceData."""
+    if isinstance(A, _abi.DeviceData):
+        return A
+    if isinstance(A, tuple) and W is None:
+        A, W = A
+    A = np.asarray(A)
+    Wn = None if W is None else np.asarray(W)
+    key = (_fingerprint(A), _fingerprint(Wn), device)
+    hit = _DATA_CACHE.get(key)
+    if hit is not None:
+        _DATA_CACHE.move_to_end(key)
+        return hit[0]
+    d = _abi.DeviceData(A, Wn, device=device)
+    _DATA_CACHE[key] = (d, A, Wn)  # keep the arrays alive so ids are not reused
+    while len(_DATA_CACHE) > _DATA_CACHE_SIZE:
+        _DATA_CACHE.popitem(last=False)
+    return d
+
+
+def clear_data_cache():
+    _DATA_CACHE.clear()
+
+
+def draw_seed():
+    """Engine seed from numpy's global stream, so np.random.seed(...) fixes the chain."""
+    return int(np.random.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(np.random.randint(0, 2 ** 31 - 1))
+
+
+class EngineBacked(object):
+    """Mixin: state fields mirrored between host numpy arrays and a gg_model handle."""
+
+    # name -> (state id, dtype, shape function(self))
+    _fields = {}
+
+    def _init_engine(self, device=0, seed=None, **cfg):
+        self._device = device
+        self._seed = draw_seed() if seed is None else int(seed)
+        self._cfg = dict(cfg, device=device, seed=self._seed)
+        self._model = None
+        self._host = {}
+        self._dirty = set()
+        self._stale = set()
+
+    # -- host <-> device -------------------------------------------------------
+    def _hget(self, name):
+        if name in self._stale:
+            sid, dtype, shape = self._fields[name]
+            self._host[name] = self._model.get(sid, shape(self), dtype)
+            self._stale.discard(name)
+        return self._host[name]
+
+    def _hset(self, name, value):
+        sid, dtype, shape = self._fields[name]
+        v = np.ascontiguousarray(value, dtype=dtype).reshape(shape(self)).copy()
+        self._host[name] = v
+        self._stale.discard(name)
+        self._dirty.add(name)
+
+    def _engine(self):
+        if self._model is None:
+            self._model = _abi.Model(**self._cfg)   # raises without a HIP device
+            self._dirty = set(self._host.keys())
+        for name in sorted(self._dirty):
+            sid, dtype, shape = self._fields[name]
+            self._model.set(sid, self._host[name], dtype)
+        self._dirty.clear()
+        return self._model
+
+    def _mark_stale(self, *names):
+        for n in names:
+            self._stale.add(n)
+
+    def _data(self, data):
+        if isinstance(data, _abi.DeviceData):
+            return data
+        if isinstance(data, (tuple, list)):
+            return as_device_data(data[0], data[1], device=self._device)
+        return as_device_data(data, None, device=self._device)
+
+    @property
+    def engine_stats(self):
+        return self._engine().stats()

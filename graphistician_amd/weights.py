@@ -1,0 +1,431 @@
+"""Gaussian weight distributions with the interface of graphistician/weights.py.
+
+resample / log_likelihood of the fixed, NIW and SBM Gaussian models run on the
+MI355X engine; the reference delegates the NIW arithmetic to pybasicbayes
+`Gaussian` objects (not vendored) — here `_gaussian`,
+`_self_gaussian` and `_gaussians[c1][c2]` are light views onto the engine state
+that expose the attributes the reference reads (`mu`, `sigma`, `sigma_chol`,
+`mu_0`, `sigma_0`, `nu_0`, `kappa_0`).
+"""
+import numpy as np
+from scipy.stats import dirichlet as _dirichlet, invwishart as _invwishart, multivariate_normal as _mvn
+
+from . import _abi
+from .abstractions import GaussianWeightDistribution, GibbsSampling
+from .engine import EngineBacked
+
+
+def _pack_niw(mu_0, sigma_0, nu_0, kappa_0):
+    return np.concatenate([np.asarray(mu_0, dtype=np.float64).ravel(), np.asarray(sigma_0, dtype=np.float64).ravel(),
+                           [float(nu_0), float(kappa_0)]])
+
+
+def _niw_prior_draw(mu_0, sigma_0, nu_0, kappa_0):
+    """(mu, Sigma) ~ NIW: what pybasicbayes Gaussian.resample() with no data returns (weights.py:118-119)."""
+    B = len(mu_0)
+    sigma = np.atleast_2d(_invwishart.rvs(df=nu_0, scale=np.asarray(sigma_0).reshape(B, B)))
+    mu = np.random.multivariate_normal(mu_0, sigma / kappa_0)
+    return mu, sigma
+
+
+def niw_log_prob(mu, sigma, mu_0, sigma_0, nu_0, kappa_0):
+    """internals/utils.py:34-51 normal_inverse_wishart_log_prob."""
+    lp = _invwishart.logpdf(sigma, nu_0, sigma_0)
+    lp += _mvn.logpdf(mu, mu_0, sigma / kappa_0)
+    return lp
+
+
+class _GaussianView(object):
+    """The slice of a pybasicbayes `Gaussian` the reference touches, backed by the owner's state arrays."""
+
+    def __init__(self, owner, mu_name, sigma_name, niw_name, index=None):
+        self._o, self._mu, self._sg, self._niw, self._ix = owner, mu_name, sigma_name, niw_name, index
+
+    def _get(self, name):
+        a = self._o._hget(name)
+        return a[self._ix] if self._ix is not None else a
+
+    @property
+    def mu(self):
+        return self._get(self._mu).copy()
+
+    @mu.setter
+    def mu(self, v):
+        a = self._o._hget(self._mu).copy()
+        if self._ix is not None:
+            a[self._ix] = v
+        else:
+            a[...] = v
+        self._o._hset(self._mu, a)
+
+    @property
+    def sigma(self):
+        return self._get(self._sg).copy()
+
+    @sigma.setter
+    def sigma(self, v):
+        a = self._o._hget(self._sg).copy()
+        if self._ix is not None:
+            a[self._ix] = v
+        else:
+            a[...] = v
+        self._o._hset(self._sg, a)
+
+    @property
+    def sigma_chol(self):
+        return np.linalg.cholesky(self.sigma)
+
+    def _hyp(self):
+        B = self._o.B
+        h = self._o._hget(self._niw)
+        return h[:B].copy(), h[B:B + B * B].reshape(B, B).copy(), h[B + B * B], h[B + B * B + 1]
+
+    def _set_hyp(self, pos, v):
+        B = self._o.B
+        h = self._o._hget(self._niw).copy()
+        if pos == 0:
+            h[:B] = np.asarray(v).ravel()
+        elif pos == 1:
+            h[B:B + B * B] = np.asarray(v).ravel()
+        else:
+            h[B + B * B + (pos - 2)] = v
+        self._o._hset(self._niw, h)
+
+    mu_0 = property(lambda s: s._hyp()[0], lambda s, v: s._set_hyp(0, v))
+    sigma_0 = property(lambda s: s._hyp()[1], lambda s, v: s._set_hyp(1, v))
+    nu_0 = property(lambda s: s._hyp()[2], lambda s, v: s._set_hyp(2, v))
+    kappa_0 = property(lambda s: s._hyp()[3], lambda s, v: s._set_hyp(3, v))
+
+    def resample(self, data=[]):
+        """Prior draw (pybasicbayes Gaussian.resample() without data), host numpy."""
+        assert len(data) == 0, "posterior draws happen inside the engine sweep"
+        mu, sigma = _niw_prior_draw(*self._hyp())
+        self.mu, self.sigma = mu, sigma
+
+    def rvs(self, size=None):
+        return np.random.multivariate_normal(self.mu, self.sigma, size=size)
+
+    def log_likelihood(self, x):
+        x = np.atleast_2d(x)
+        if x.shape[0] == 0:
+            return np.zeros(0)
+        return np.atleast_1d(_mvn.logpdf(x, self.mu, self.sigma))
+
+
+class _WeightsBase(GaussianWeightDistribution, GibbsSampling, EngineBacked):
+    def log_likelihood(self, data):
+        d = self._data(data)
+        assert d.N == self.N and d.B == self.B
+        return self._engine().log_likelihood(d)
+
+
+class FixedGaussianWeightDistribution(_WeightsBase):
+    """weights.py:9-65."""
+
+    _fields = {"_mu": (_abi.ST_MU, np.float64, lambda s: (1, 1, s.B)),
+               "_sigma": (_abi.ST_SIGMA, np.float64, lambda s: (1, 1, s.B, s.B)),
+               "_mu_self": (_abi.ST_MU_SELF, np.float64, lambda s: (s.B,)),
+               "_sigma_self": (_abi.ST_SIGMA_SELF, np.float64, lambda s: (s.B, s.B)),
+               "_niw": (_abi.ST_NIW, np.float64, lambda s: (s.B + s.B * s.B + 2,)),
+               "_niw_self": (_abi.ST_NIW_SELF, np.float64, lambda s: (s.B + s.B * s.B + 2,))}
+
+    def __init__(self, N, B, mu, sigma, mu_self=None, sigma_self=None, device=0, seed=None):
+        super(FixedGaussianWeightDistribution, self).__init__(N)
+        self.B = B
+        assert mu.shape == (B,)
+        self.mu = mu
+        assert sigma.shape == (B, B)
+        self.sigma = sigma
+        self._init_engine(device=device, seed=seed, kind=_abi.FIXED_W, N=N, K=1, B=B, special_case_self_conns=1)
+        self._hset("_mu", mu)
+        self._hset("_sigma", sigma)
+        if mu_self is not None and sigma_self is not None:
+            self._hset("_mu_self", mu_self)
+            self._hset("_sigma_self", sigma_self)
+        else:
+            self._hset("_mu_self", mu)
+            self._hset("_sigma_self", sigma)
+        hyp = _pack_niw(np.zeros(B), np.eye(B), B + 2, 1.0)
+        self._hset("_niw", hyp)
+        self._hset("_niw_self", hyp)
+        self._gaussian = _GaussianView(self, "_mu", "_sigma", "_niw", (0, 0))
+        self._self_gaussian = _GaussianView(self, "_mu_self", "_sigma_self", "_niw_self")
+
+    @property
+    def Mu(self):
+        Mu = np.tile(self._gaussian.mu[None, None, :], (self.N, self.N, 1))
+        Mu[np.arange(self.N), np.arange(self.N)] = self._self_gaussian.mu
+        return Mu
+
+    @property
+    def Sigma(self):
+        Sig = np.tile(self._gaussian.sigma[None, None, :, :], (self.N, self.N, 1, 1))
+        Sig[np.arange(self.N), np.arange(self.N)] = self._self_gaussian.sigma
+        return Sig
+
+    def initialize_from_prior(self):
+        pass
+
+    def initialize_hypers(self, W=None):
+        pass
+
+    def log_prior(self):
+        return 0
+
+    def sample_predictive_parameters(self):
+        Murow = Mucol = np.tile(self._gaussian.mu[None, :], (self.N + 1, 1))
+        Lrow = Lcol = np.tile(self._gaussian.sigma_chol[None, :, :], (self.N + 1, 1, 1))
+        return Murow, Mucol, Lrow, Lcol
+
+    def resample(self, data=[]):
+        pass
+
+
+class NIWGaussianWeightDistribution(_WeightsBase):
+    """weights.py:68-162: one Gaussian for off-diagonal edges, one for self edges, NIW priors."""
+
+    _fields = FixedGaussianWeightDistribution._fields
+
+    def __init__(self, N, B=1, mu_0=None, Sigma_0=None, nu_0=None, kappa_0=None, device=0, seed=None):
+        super(NIWGaussianWeightDistribution, self).__init__(N)
+        self.B = B
+        if mu_0 is None:
+            mu_0 = np.zeros(B)
+        if Sigma_0 is None:
+            Sigma_0 = np.eye(B)
+        if nu_0 is None:
+            nu_0 = B + 2
+        if kappa_0 is None:
+            kappa_0 = 1.0
+        self._init_engine(device=device, seed=seed, kind=_abi.NIW_W, N=N, K=1, B=B, special_case_self_conns=1)
+        hyp = _pack_niw(mu_0, Sigma_0, nu_0, kappa_0)
+        self._hset("_niw", hyp)
+        self._hset("_niw_self", hyp)
+        self._hset("_mu", np.zeros((1, 1, B)))
+        self._hset("_sigma", np.eye(B).reshape(1, 1, B, B))
+        self._hset("_mu_self", np.zeros(B))
+        self._hset("_sigma_self", np.eye(B))
+        self._gaussian = _GaussianView(self, "_mu", "_sigma", "_niw", (0, 0))
+        self._self_gaussian = _GaussianView(self, "_mu_self", "_sigma_self", "_niw_self")
+        # pybasicbayes Gaussian(mu_0=..) initialises itself with a prior draw
+        self._gaussian.resample()
+        self._self_gaussian.resample()
+
+    Mu = FixedGaussianWeightDistribution.Mu
+    Sigma = FixedGaussianWeightDistribution.Sigma
+
+    def initialize_from_prior(self):
+        self._gaussian.resample()
+        self._self_gaussian.resample()
+
+    def initialize_hypers(self, W):
+        # weights.py:121-134
+        self._gaussian.mu_0 = W.mean(axis=(0, 1))
+        self._gaussian.sigma_0 = np.diag(W.var(axis=(0, 1)))
+        self._gaussian.resample()
+        W_self = W[np.arange(self.N), np.arange(self.N)]
+        self._self_gaussian.mu_0 = W_self.mean(axis=0)
+        self._self_gaussian.sigma_0 = np.diag(W_self.var(axis=0))
+        self._self_gaussian.resample()
+
+    def log_prior(self):
+        # weights.py:136-142
+        lp = 0
+        for g in (self._gaussian, self._self_gaussian):
+            lp += niw_log_prob(g.mu, g.sigma, g.mu_0, g.sigma_0, g.nu_0, g.kappa_0)
+        return lp
+
+    def sample_predictive_parameters(self):
+        # weights.py:144-152
+        Murow = np.tile(self._gaussian.mu[None, :], (self.N + 1, 1))
+        Mucol = Murow.copy()
+        Lrow = np.tile(self._gaussian.sigma_chol[None, :, :], (self.N + 1, 1, 1))
+        Lcol = Lrow.copy()
+        Murow[-1, :] = Mucol[-1, :] = self._self_gaussian.mu
+        Lrow[-1, :, :] = Lcol[-1, :, :] = self._self_gaussian.sigma_chol
+        return Murow, Mucol, Lrow, Lcol
+
+    def resample(self, data):
+        """weights.py:154-162."""
+        d = self._data(data)
+        assert d.N == self.N and d.B == self.B
+        self._engine().resample(d, 1)
+        self._mark_stale("_mu", "_sigma", "_mu_self", "_sigma_self")
+
+
+class LowRankGaussianWeightDistribution(GaussianWeightDistribution, GibbsSampling):
+    """weights.py:165-170."""
+
+    def __init__(self, N, dim):
+        raise NotImplementedError
+
+
+class SBMGaussianWeightDistribution(_WeightsBase):
+    """weights.py:172-498: K x K Gaussians indexed by the blocks of the two endpoints."""
+
+    _fields = {"c": (_abi.ST_C, np.int32, lambda s: (s.N,)),
+               "m": (_abi.ST_M, np.float64, lambda s: (s.C,)),
+               "pi": (_abi.ST_PI, np.float64, lambda s: (s.C,)),
+               "_mu": (_abi.ST_MU, np.float64, lambda s: (s.C, s.C, s.B)),
+               "_sigma": (_abi.ST_SIGMA, np.float64, lambda s: (s.C, s.C, s.B, s.B)),
+               "_mu_self": (_abi.ST_MU_SELF, np.float64, lambda s: (s.B,)),
+               "_sigma_self": (_abi.ST_SIGMA_SELF, np.float64, lambda s: (s.B, s.B)),
+               "_niw": (_abi.ST_NIW, np.float64, lambda s: (s.B + s.B * s.B + 2,)),
+               "_niw_self": (_abi.ST_NIW_SELF, np.float64, lambda s: (s.B + s.B * s.B + 2,))}
+
+    def __init__(self, N, B=1, C=2, pi=10.0, mu_0=None, Sigma_0=None, nu_0=None, kappa_0=None,
+                 special_case_self_conns=True, device=0, seed=None):
+        super(SBMGaussianWeightDistribution, self).__init__(N)
+        self.B = B
+        assert isinstance(C, (int, np.integer)) and C >= 1, "C must be a positive integer number of blocks"
+        self.C = int(C)
+        if isinstance(pi, (int, float)):
+            pi = pi * np.ones(C)
+        else:
+            assert isinstance(pi, np.ndarray) and pi.shape == (C,), "pi must be a sclar or a C-vector"
+        self.special_case_self_conns = special_case_self_conns
+        self._init_engine(device=device, seed=seed, kind=_abi.SBM_GAUSS_W, N=N, K=self.C, B=B,
+                          special_case_self_conns=1 if special_case_self_conns else 0)
+        self.pi = pi
+        self.m = np.random.dirichlet(self.pi)
+        self.c = np.random.choice(self.C, p=self.m, size=(self.N))
+        if mu_0 is None:
+            mu_0 = np.zeros(B)
+        if Sigma_0 is None:
+            Sigma_0 = np.eye(B)
+        if nu_0 is None:
+            nu_0 = B + 2
+        if kappa_0 is None:
+            kappa_0 = 1.0
+        hyp = _pack_niw(mu_0, Sigma_0, nu_0, kappa_0)
+        self._hset("_niw", hyp)
+        self._hset("_niw_self", hyp)
+        self._hset("_mu", np.zeros((C, C, B)))
+        self._hset("_sigma", np.tile(np.eye(B), (C, C, 1, 1)))
+        self._hset("_mu_self", np.zeros(B))
+        self._hset("_sigma_self", np.eye(B))
+        self._gaussians = [[_GaussianView(self, "_mu", "_sigma", "_niw", (c1, c2)) for c2 in range(C)]
+                           for c1 in range(C)]
+        for row in self._gaussians:
+            for g in row:
+                g.resample()
+        if special_case_self_conns:
+            self._self_gaussian = _GaussianView(self, "_mu_self", "_sigma_self", "_niw_self")
+            self._self_gaussian.resample()
+
+    c = property(lambda s: s._hget("c"), lambda s, v: s._hset("c", v))
+    m = property(lambda s: s._hget("m"), lambda s, v: s._hset("m", v))
+    pi = property(lambda s: s._hget("pi"), lambda s, v: s._hset("pi", v))
+
+    @property
+    def _Mu(self):
+        return self._hget("_mu").copy()
+
+    @property
+    def _Sigma(self):
+        return self._hget("_sigma").copy()
+
+    @property
+    def Mu(self):
+        # weights.py:243-256
+        c = self.c
+        Mu = self._Mu[np.ix_(c, c)]
+        if self.special_case_self_conns:
+            Mu[np.arange(self.N), np.arange(self.N)] = self._self_gaussian.mu
+        return Mu
+
+    @property
+    def Sigma(self):
+        # weights.py:258-271
+        c = self.c
+        Sigma = self._Sigma[np.ix_(c, c)]
+        if self.special_case_self_conns:
+            Sigma[np.arange(self.N), np.arange(self.N)] = self._self_gaussian.sigma
+        return Sigma
+
+    def initialize_from_prior(self):
+        # weights.py:273-281
+        self.m = np.random.dirichlet(self.pi)
+        self.c = np.random.choice(self.C, p=self.m, size=(self.N))
+        for row in self._gaussians:
+            for g in row:
+                g.resample()
+        if self.special_case_self_conns:
+            self._self_gaussian.resample()
+
+    def initialize_hypers(self, W):
+        # weights.py:283-306 (all block pairs share one prior here, as they do after this call in the reference)
+        g00 = self._gaussians[0][0]
+        nu_0 = g00.nu_0
+        g00.mu_0 = W.mean(axis=(0, 1))
+        g00.sigma_0 = np.diag(W.var(axis=(0, 1))) * (nu_0 - self.B - 1) / self.C
+        for row in self._gaussians:
+            for g in row:
+                g.resample()
+        if self.special_case_self_conns:
+            W_self = W[np.arange(self.N), np.arange(self.N)]
+            self._self_gaussian.mu_0 = W_self.mean(axis=0)
+            self._self_gaussian.sigma_0 = np.diag(W_self.var(axis=0))
+            self._self_gaussian.resample()
+        from sklearn.cluster import KMeans
+        features = np.hstack((W[:, :, 0], W[:, :, 0].T))
+        km = KMeans(n_clusters=self.C, n_init=10)
+        km.fit(features)
+        self.c = km.labels_.astype(np.int32)
+
+    def log_prior(self):
+        # weights.py:333-357
+        lp = 0
+        lp += _dirichlet(self.pi).logpdf(self.m)
+        for row in self._gaussians:
+            for g in row:
+                lp += niw_log_prob(g.mu, g.sigma, g.mu_0, g.sigma_0, g.nu_0, g.kappa_0)
+        if self.special_case_self_conns:
+            g = self._self_gaussian
+            lp += niw_log_prob(g.mu, g.sigma, g.mu_0, g.sigma_0, g.nu_0, g.kappa_0)
+        lp += (np.log(self.m)[self.c]).sum()
+        return lp
+
+    def rvs(self, size=[]):
+        # weights.py:360-373 (same law: W_ij ~ N(mu[c_i,c_j], Sigma[c_i,c_j]); self Gaussian on the diagonal)
+        return GaussianWeightDistribution.rvs(self)
+
+    def sample_predictive_parameters(self):
+        # weights.py:375-389
+        c2 = np.random.choice(self.C, p=self.m)
+        cext = np.concatenate((self.c, [c2]))
+        mu, sig = self._Mu, self._Sigma
+        chol = np.linalg.cholesky(sig)
+        Murow, Lrow = mu[c2, cext], chol[c2, cext]
+        Mucol, Lcol = mu[cext, c2], chol[cext, c2]
+        if self.special_case_self_conns:
+            Murow[-1] = Mucol[-1] = self._self_gaussian.mu
+            Lrow[-1] = Lcol[-1] = self._self_gaussian.sigma_chol
+        return Murow, Mucol, Lrow, Lcol
+
+    # -- Gibbs (weights.py:394-498): on the device ---------------------------------
+    def _run(self, data, parts):
+        d = self._data(data) if data is not None else None
+        assert d is None or (d.N == self.N and d.B == self.B)
+        eng = self._engine()
+        if parts == _abi.PART_ALL:
+            eng.resample(d, 1)
+        else:
+            eng.resample_part(d, parts)
+            if parts == _abi.PART_M:
+                eng.sweep = eng.sweep + 1
+        self._mark_stale("c", "m", "_mu", "_sigma", "_mu_self", "_sigma_self")
+
+    def resample(self, data):
+        self._run(data, _abi.PART_ALL)
+
+    def resample_mu_and_Sig(self, A, W):
+        self._run((A, W), _abi.PART_PARAMS)
+
+    def resample_c(self, A, W):
+        if self.C == 1:
+            return
+        self._run((A, W), _abi.PART_C)
+
+    def resample_m(self):
+        self._run(None, _abi.PART_M)

@@ -1,0 +1,64 @@
+"""Generates the golden fixtures in this directory from the CPU oracle (fixed Philox
+seeds).  The reference holds no fixtures for this path and cannot be run
+(SURVEY.md §8c), so these are REGRESSION vectors: they pin the oracle (and through
+it the HIP engine) across rounds; evidence of reference parity is in
+tests/test_spec_and_oracle.py.   Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as O  # noqa: E402
+from tests.helpers import planted_sbm, er_network, AdjState, WState  # noqa: E402
+
+
+def sbm_case(N, K, B, seed, nsweeps, special):
+    A, W, _ = planted_sbm(N, K, B=B, seed=seed)
+    q, shift = O.quantise(A, W)
+    a, w = AdjState(N, K, seed=seed + 1), WState(N, K, B, seed=seed + 2)
+    init = dict(a_c=a.c.copy(), a_m=a.m.copy(), a_p=a.p.copy(), a_p_self=a.p_self, a_pi=a.pi,
+                w_c=w.c.copy(), w_m=w.m.copy(), w_mu=w.mu.copy(), w_sigma=w.sigma.copy(), w_mu_self=w.mu_self.copy(),
+                w_sigma_self=w.sigma_self.copy(), w_pi=w.pi, w_niw=w.niw, w_niw_self=w.niw_self)
+    ps = a.p_self
+    trace_c = []
+    for s in range(nsweeps):
+        ps = O.sbm_adj_sweep(A, a.c, a.m, a.p, ps, a.pi, 1.0, 1.0, special, 1000 + seed, s)
+        O.sbm_w_sweep(A, q, shift, w.c, w.m, w.mu, w.sigma, w.mu_self, w.sigma_self, w.pi, w.niw, w.niw_self, special,
+                      2000 + seed, s)
+        trace_c.append(np.concatenate([a.c, w.c]))
+    ll_a = O.sbm_adj_loglik(A, a.c, a.p, ps, 1, special)
+    ll_w = O.sbm_w_loglik(A, q, shift, w.c, w.mu, w.sigma, w.mu_self, w.sigma_self, special)
+    out = dict(N=N, K=K, B=B, nsweeps=nsweeps, special=special, seed_a=1000 + seed, seed_w=2000 + seed, A=A, W=W,
+               shift=shift, out_a_c=a.c, out_a_m=a.m, out_a_p=a.p, out_a_p_self=ps, out_w_c=w.c, out_w_m=w.m,
+               out_w_mu=w.mu, out_w_sigma=w.sigma, out_w_mu_self=w.mu_self, out_w_sigma_self=w.sigma_self,
+               trace_c=np.array(trace_c), ll_a=ll_a, ll_w=ll_w)
+    out.update({"init_" + k: v for k, v in init.items()})
+    return out
+
+
+def er_case(N, B, seed, nsweeps):
+    """Config 1: Beta-Bernoulli adjacency + NIW weights (plumbing case, N=50)."""
+    A, W = er_network(N, B=B, seed=seed)
+    q, shift = O.quantise(A, W)
+    niw = O.pack_niw(np.zeros(B), np.eye(B), B + 2, 1.0)
+    mu, sig, mus, sigs = np.zeros((1, 1, B)), np.zeros((1, 1, B, B)), np.zeros(B), np.zeros((B, B))
+    ps_trace = []
+    for s in range(nsweeps):
+        p, ps = O.bb_adj_sweep(A, 1.0, 1.0, 1, 3000 + seed, s)
+        O.niw_w_sweep(A, q, shift, mu, sig, mus, sigs, niw, niw, 4000 + seed, s)
+        ps_trace.append([p, ps])
+    ll_a = O.const_adj_loglik(A, p, ps)
+    ll_w = O.sbm_w_loglik(A, q, shift, np.zeros(N, np.int32), mu, sig, mus, sigs, 1)
+    return dict(N=N, B=B, nsweeps=nsweeps, seed_a=3000 + seed, seed_w=4000 + seed, A=A, W=W, shift=shift, niw=niw,
+                out_p=p, out_p_self=ps, p_trace=np.array(ps_trace), out_mu=mu, out_sigma=sig, out_mu_self=mus,
+                out_sigma_self=sigs, ll_a=ll_a, ll_w=ll_w)
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "sbm_n64_k4_b1.npz"), **sbm_case(64, 4, 1, 7, 6, 1))
+    np.savez_compressed(os.path.join(HERE, "sbm_n48_k3_b2_nospecial.npz"), **sbm_case(48, 3, 2, 9, 4, 0))
+    np.savez_compressed(os.path.join(HERE, "er_n50_b2.npz"), **er_case(50, 2, 1234, 5))
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,148 @@
+"""CPU tests: the C-ABI library loads and exports every symbol declared in
+include/graphgibbs.h, fails loudly without a device, and the host-side logic of the
+reference-shaped classes (construction, P, rvs, priors, data cache)."""
+import os
+import re
+
+import numpy as np
+import pytest
+from scipy import stats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from graphistician_amd import _abi
+    hdr = open(os.path.join(ROOT, "include", "graphgibbs.h")).read()
+    declared = sorted(set(re.findall(r"\b(gg_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    L = _abi.lib()
+    for name in declared:
+        assert hasattr(L, name), "libgraphgibbs.so does not export %s" % name
+    assert sorted(_abi.EXPORTS) == declared
+    assert b"gfx950" in L.gg_version()
+
+
+def test_no_cpu_fallback():
+    from graphistician_amd import _abi
+    if _abi.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(_abi.EngineError) as e:
+        _abi.Model(kind=_abi.SBM_ADJ, N=8, K=2, B=1)
+    assert e.value.code == _abi.ERR_NO_DEVICE
+    with pytest.raises(_abi.EngineError):
+        _abi.DeviceData(np.zeros((4, 4), np.uint8), None)
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    m = SBMAdjacencyDistribution(8, C=2)
+    with pytest.raises(_abi.EngineError):
+        m.resample(np.zeros((8, 8)))
+    with pytest.raises(_abi.EngineError):
+        m.log_likelihood(np.zeros((8, 8)))
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "graphistician_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle/", r"liboracle", r"oracle\.py", r"orc_[a-z_]+\("):
+                    assert not re.search(pat, src), "%s references the oracle (%s)" % (f, pat)
+
+
+def test_sbm_adjacency_host_logic():
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    np.random.seed(0)
+    m = SBMAdjacencyDistribution(20, C=3, pi=2.0, tau0=2.0, tau1=3.0)
+    assert m.c.shape == (20,) and m.c.min() >= 0 and m.c.max() <= 2
+    assert m.p.shape == (3, 3) and abs(m.m.sum() - 1) < 1e-12
+    P = m.P
+    assert P.shape == (20, 20) and np.all(np.diag(P) == m.p_self) and P[0, 1] == m.p[m.c[0], m.c[1]]
+    lp = stats.dirichlet(m.pi).logpdf(m.m) + stats.beta(3.0, 2.0).logpdf(m.p).sum() + stats.beta(3.0, 2.0).logpdf(m.p_self) \
+        + np.log(m.m)[m.c].sum()
+    assert abs(m.log_prior() - lp) < 1e-10
+    A = m.rvs()
+    assert A.shape == (20, 20) and A.dtype == bool
+    m2 = SBMAdjacencyDistribution(20, C=3, allow_self_connections=False)
+    assert np.all(np.diag(m2.P) == 0)
+    with pytest.raises(AssertionError):
+        SBMAdjacencyDistribution(20, C=0)
+    with pytest.raises(AssertionError):
+        SBMAdjacencyDistribution(20, C=2, m=np.array([0.9, 0.3]))
+    with pytest.raises(AssertionError):
+        SBMAdjacencyDistribution(20, C=2, c=np.zeros(19, dtype=int))
+    m.c = np.zeros(20, dtype=np.int64)
+    assert m.c.dtype == np.int32 and m.P[0, 1] == m.p[0, 0]
+    prow, pcol = m.sample_predictive_parameters()
+    assert prow.shape == (21,) and pcol.shape == (21,)
+    assert sorted(m.invariant_sbm_order()) == list(range(20))
+
+
+def test_weights_host_logic():
+    from graphistician_amd.weights import SBMGaussianWeightDistribution, NIWGaussianWeightDistribution, \
+        FixedGaussianWeightDistribution, LowRankGaussianWeightDistribution, niw_log_prob
+    np.random.seed(1)
+    w = SBMGaussianWeightDistribution(15, B=2, C=3)
+    assert w.Mu.shape == (15, 15, 2) and w.Sigma.shape == (15, 15, 2, 2)
+    g = w._gaussians[1][2]
+    assert np.array_equal(w.Mu[np.where(w.c == 1)[0][:1], np.where(w.c == 2)[0][:1]].ravel(), g.mu) or \
+        not ((w.c == 1).any() and (w.c == 2).any())
+    assert np.allclose(g.sigma_chol.dot(g.sigma_chol.T), g.sigma)
+    assert g.nu_0 == 4 and g.kappa_0 == 1.0 and np.array_equal(g.mu_0, np.zeros(2))
+    lp = stats.dirichlet(w.pi).logpdf(w.m) + np.log(w.m)[w.c].sum()
+    for r in w._gaussians:
+        for gg in r:
+            lp += niw_log_prob(gg.mu, gg.sigma, gg.mu_0, gg.sigma_0, gg.nu_0, gg.kappa_0)
+    sg = w._self_gaussian
+    lp += niw_log_prob(sg.mu, sg.sigma, sg.mu_0, sg.sigma_0, sg.nu_0, sg.kappa_0)
+    assert abs(w.log_prior() - lp) < 1e-9
+    W = w.rvs()
+    assert W.shape == (15, 15, 2)
+    n = NIWGaussianWeightDistribution(10, B=1)
+    assert n.Mu.shape == (10, 10, 1) and np.isfinite(n.log_prior())
+    Mr, Mc, Lr, Lc = n.sample_predictive_parameters()
+    assert Mr.shape == (11, 1) and Lc.shape == (11, 1, 1)
+    f = FixedGaussianWeightDistribution(6, 2, np.zeros(2), np.eye(2))
+    assert f.log_prior() == 0 and f.Sigma.shape == (6, 6, 2, 2)
+    with pytest.raises(NotImplementedError):
+        LowRankGaussianWeightDistribution(5, 2)
+
+
+def test_rvs_statistics_follow_the_model():
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution
+    np.random.seed(3)
+    net = FactorizedNetworkDistribution(200, SBMAdjacencyDistribution, {"C": 2}, SBMGaussianWeightDistribution, {"C": 2})
+    A, W = net.rvs()
+    a, w = net.adjacency, net.weights
+    for k1 in range(2):
+        for k2 in range(2):
+            blk = (a.c == k1)[:, None] & (a.c == k2)[None, :] & ~np.eye(200, dtype=bool)
+            if blk.sum() > 500:
+                assert abs(A[blk].mean() - a.p[k1, k2]) < 5 * np.sqrt(0.25 / blk.sum())
+            blk = (w.c == k1)[:, None] & (w.c == k2)[None, :] & ~np.eye(200, dtype=bool)
+            if blk.sum() > 500:
+                sd = np.sqrt(w._Sigma[k1, k2, 0, 0])
+                assert abs(W[blk, 0].mean() - w._Mu[k1, k2, 0]) < 5 * sd / np.sqrt(blk.sum())
+
+
+def test_network_composition_and_errors():
+    from graphistician_amd.networks import FactorizedNetworkDistribution, GaussianBernoulliNetwork
+    from graphistician_amd.adjacency import BetaBernoulliAdjacencyDistribution, LatentDistanceAdjacencyDistribution, \
+        CompleteAdjacencyDistribution, EmptyAdjacencyDistribution
+    from graphistician_amd.weights import NIWGaussianWeightDistribution
+    np.random.seed(2)
+    with pytest.raises(AssertionError):
+        FactorizedNetworkDistribution(5, NIWGaussianWeightDistribution, {}, NIWGaussianWeightDistribution, {})
+    net = FactorizedNetworkDistribution(9, BetaBernoulliAdjacencyDistribution, {}, NIWGaussianWeightDistribution, {"B": 2})
+    assert net.adjacency.N == 9 and net.weights.B == 2
+    assert abs(net.log_prior() - (net.adjacency.log_prior() + net.weights.log_prior())) < 1e-12
+    g = GaussianBernoulliNetwork(7, 3, p=0.25)
+    assert g.adjacency.p == 0.25 and g.adjacency.P[0, 0] == 0.25 and g.weights.Mu.shape == (7, 7, 3)
+    with pytest.raises(NotImplementedError):
+        LatentDistanceAdjacencyDistribution(5)
+    assert CompleteAdjacencyDistribution(4).log_likelihood(np.ones((4, 4))) == 0
+    assert EmptyAdjacencyDistribution(4).log_likelihood(np.ones((4, 4))) == -np.inf
+    Arow, Acol, Wrow, Wcol = net.sample_predictive_distribution()
+    assert np.isfinite(net.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=4))

@@ -1,0 +1,104 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py):
+the CPU oracle must reproduce them (no GPU), and the HIP engine must reproduce
+them through the Python surface (gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SBM_CASES = ["sbm_n64_k4_b1.npz", "sbm_n48_k3_b2_nospecial.npz"]
+
+
+def load(name):
+    z = np.load(os.path.join(G, name))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", SBM_CASES)
+def test_oracle_reproduces_sbm_golden(name):
+    g = load(name)
+    A, W = g["A"], g["W"]
+    special = int(g["special"])
+    q, shift = O.quantise(A, W)
+    assert shift == int(g["shift"])
+    c, m, p, ps = g["init_a_c"].copy(), g["init_a_m"].copy(), g["init_a_p"].copy(), float(g["init_a_p_self"])
+    wc, wm, mu, sig = g["init_w_c"].copy(), g["init_w_m"].copy(), g["init_w_mu"].copy(), g["init_w_sigma"].copy()
+    mus, sigs = g["init_w_mu_self"].copy(), g["init_w_sigma_self"].copy()
+    for s in range(int(g["nsweeps"])):
+        ps = O.sbm_adj_sweep(A, c, m, p, ps, g["init_a_pi"], 1.0, 1.0, special, int(g["seed_a"]), s)
+        O.sbm_w_sweep(A, q, shift, wc, wm, mu, sig, mus, sigs, g["init_w_pi"], g["init_w_niw"], g["init_w_niw_self"],
+                      special, int(g["seed_w"]), s)
+        assert np.array_equal(np.concatenate([c, wc]), g["trace_c"][s])
+    assert np.array_equal(p, g["out_a_p"]) and np.array_equal(m, g["out_a_m"])
+    assert np.array_equal(mu, g["out_w_mu"]) and np.array_equal(sig, g["out_w_sigma"])
+    assert O.sbm_adj_loglik(A, c, p, ps, 1, special) == float(g["ll_a"])
+
+
+def test_oracle_reproduces_er_golden():
+    g = load("er_n50_b2.npz")
+    A, W, B = g["A"], g["W"], int(g["B"])
+    q, shift = O.quantise(A, W)
+    mu, sig, mus, sigs = np.zeros((1, 1, B)), np.zeros((1, 1, B, B)), np.zeros(B), np.zeros((B, B))
+    for s in range(int(g["nsweeps"])):
+        p, ps = O.bb_adj_sweep(A, 1.0, 1.0, 1, int(g["seed_a"]), s)
+        O.niw_w_sweep(A, q, shift, mu, sig, mus, sigs, g["niw"], g["niw"], int(g["seed_w"]), s)
+        assert [p, ps] == list(g["p_trace"][s])
+    assert np.array_equal(mu, g["out_mu"]) and np.array_equal(sigs, g["out_sigma_self"])
+
+
+# ------------------------------------------------------------------ engine, through the reference-shaped classes
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SBM_CASES)
+def test_engine_reproduces_sbm_golden(name):
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution
+    g = load(name)
+    N, K, B, special = int(g["N"]), int(g["K"]), int(g["B"]), bool(g["special"])
+    net = FactorizedNetworkDistribution(
+        N, SBMAdjacencyDistribution, dict(C=K, special_case_self_conns=special, seed=int(g["seed_a"])),
+        SBMGaussianWeightDistribution, dict(C=K, B=B, special_case_self_conns=special, seed=int(g["seed_w"])))
+    a, w = net.adjacency, net.weights
+    a.c, a.m, a.p, a.pi = g["init_a_c"], g["init_a_m"], g["init_a_p"], g["init_a_pi"]
+    a.p_self = float(g["init_a_p_self"])
+    w.c, w.m, w.pi = g["init_w_c"], g["init_w_m"], g["init_w_pi"]
+    w._hset("_mu", g["init_w_mu"]); w._hset("_sigma", g["init_w_sigma"])
+    w._hset("_mu_self", g["init_w_mu_self"]); w._hset("_sigma_self", g["init_w_sigma_self"])
+    w._hset("_niw", g["init_w_niw"]); w._hset("_niw_self", g["init_w_niw_self"])
+    data = (g["A"], g["W"])
+    for s in range(int(g["nsweeps"])):
+        net.resample(data)
+        assert np.array_equal(np.concatenate([a.c, w.c]), g["trace_c"][s]), "sweep %d" % s
+    assert np.array_equal(a.p, g["out_a_p"]) and np.array_equal(a.m, g["out_a_m"])
+    assert np.array_equal(w._Mu, g["out_w_mu"]) and np.array_equal(w._Sigma, g["out_w_sigma"])
+    assert np.array_equal(w.m, g["out_w_m"])
+    ll = net.log_likelihood(data)
+    ref = float(g["ll_a"]) + float(g["ll_w"])
+    assert abs(ll - ref) <= 1e-9 * abs(ref)
+    assert np.isfinite(net.log_probability(data))
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_er_golden():
+    """Config 1 (BASELINE.json configs[0] shape): Beta-Bernoulli + NIW, N=50, B=2."""
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import BetaBernoulliAdjacencyDistribution
+    from graphistician_amd.weights import NIWGaussianWeightDistribution
+    g = load("er_n50_b2.npz")
+    N, B = int(g["N"]), int(g["B"])
+    net = FactorizedNetworkDistribution(
+        N, BetaBernoulliAdjacencyDistribution, dict(tau1_self=1.0, tau0_self=1.0, seed=int(g["seed_a"])),
+        NIWGaussianWeightDistribution, dict(B=B, seed=int(g["seed_w"])))
+    data = (g["A"], g["W"])
+    for s in range(int(g["nsweeps"])):
+        net.resample(data)
+        assert [net.adjacency.p, net.adjacency.p_self] == list(g["p_trace"][s])
+    assert np.array_equal(net.weights._gaussian.mu, g["out_mu"][0, 0])
+    assert np.array_equal(net.weights._gaussian.sigma, g["out_sigma"][0, 0])
+    assert np.array_equal(net.weights._self_gaussian.sigma, g["out_sigma_self"])
+    ll = net.log_likelihood(data)
+    ref = float(g["ll_a"]) + float(g["ll_w"])
+    assert abs(ll - ref) <= 1e-9 * abs(ref)
