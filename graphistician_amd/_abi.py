@@ -43,7 +43,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_log_likelihood", "gg_node_lp", "gg_last_stats",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats",
            "gg_set_timing", "gg_selftest_math", "gg_selftest_draws"]
 
 
@@ -82,6 +82,8 @@ def lib():
         L.gg_get_state.argtypes = [vp, C.c_int32, vp, C.c_size_t]
         L.gg_resample.argtypes = [vp, vp, C.c_int32, C.c_double]
         L.gg_resample_part.argtypes = [vp, vp, C.c_int32, C.c_double]
+        L.gg_resample_async.argtypes = [vp, vp, C.c_int32, C.c_double]
+        L.gg_sync.argtypes = [vp]
         L.gg_log_likelihood.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gg_node_lp.argtypes = [vp, vp, C.c_int32, vp]
         L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -193,6 +195,12 @@ class Model(object):
 
     def resample(self, data, n_sweeps=1, beta=1.0):
         check(lib().gg_resample(self._h, data.handle, n_sweeps, beta))
+
+    def resample_async(self, data, n_sweeps=1, beta=1.0):
+        check(lib().gg_resample_async(self._h, data.handle, n_sweeps, beta))
+
+    def sync(self):
+        check(lib().gg_sync(self._h))
 
     def resample_part(self, data, parts, beta=1.0):
         check(lib().gg_resample_part(self._h, data.handle if data is not None else None, parts, beta))

@@ -198,7 +198,7 @@ class BetaBernoulliAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, E
         reference does at :175)."""
         d = self._data(A)
         assert d.N == self.N
-        self._engine().resample(d, 1)
+        self._engine().resample_async(d, 1)
         self._mark_stale("p", "p_self")
 
     def sample_predictive_parameters(self):
@@ -341,7 +341,7 @@ class SBMAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacke
         assert d is None or d.N == self.N
         eng = self._engine()
         if parts == _abi.PART_ALL:
-            eng.resample(d, 1)
+            eng.resample_async(d, 1)    # stream-ordered: the next state read (or log_likelihood) waits for it
         else:
             eng.resample_part(d, parts)
             if parts == _abi.PART_M:

@@ -83,11 +83,17 @@ __device__ __forceinline__ bool gg_find_slot(const int32_t* __restrict__ lab_sta
 }
 
 // Adjacency: 16 uint8 per lane per row, SWAR byte counters (<= 255 rows per wave).
-__global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ X, int Np,
-                                                  const int32_t* __restrict__ perm,
+// blockIdx.z selects the direction: 0 = out-statistics (reads X^T), 1 = in-statistics (reads X).
+__global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ XT, const uint8_t* __restrict__ X1,
+                                                  int Np, const int32_t* __restrict__ perm,
                                                   const int32_t* __restrict__ lab_start, int K, int RW,
-                                                  int32_t* __restrict__ G) {
+                                                  int32_t* __restrict__ G0, int32_t* __restrict__ G1, int dir0,
+                                                  const int32_t* __restrict__ ctl) {
   __shared__ unsigned int s_bins[1024];
+  if (ctl && ctl[4]) return;  // pipeline stalled by an earlier scan: leave everything untouched
+  const int dir = dir0 + blockIdx.z;
+  const uint8_t* __restrict__ X = dir == 0 ? XT : X1;
+  int32_t* __restrict__ G = dir == 0 ? G0 : G1;
   int k, row0, nrows;
   if (!gg_find_slot(lab_start, K, RW, blockIdx.y, &k, &row0, &nrows)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,15 +139,22 @@ __global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ X,
 // Weights: 4 int32 per lane per row = 4 / B elements; per element edge count,
 // sum q_r, sum q_r q_s in 64-bit integers.
 template <int B>
-__global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ X, int Np,
-                                                const int32_t* __restrict__ perm,
+__global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
+                                                int Np, const int32_t* __restrict__ perm,
                                                 const int32_t* __restrict__ lab_start, int K, int RW,
-                                                int32_t* __restrict__ Gcnt, long long* __restrict__ GS) {
+                                                int32_t* __restrict__ Gc0, int32_t* __restrict__ Gc1,
+                                                long long* __restrict__ Gs0, long long* __restrict__ Gs1, int dir0,
+                                                const int32_t* __restrict__ ctl) {
   constexpr int EPL = 4 / B;               // elements per lane
   constexpr int NSI = B + B * (B + 1) / 2; // integer statistics per element
   constexpr int SC = 64 * EPL;             // strip columns
   __shared__ int s_cnt[SC];
   __shared__ unsigned long long s_s[SC * NSI];
+  if (ctl && ctl[4]) return;
+  const int dir = dir0 + blockIdx.z;
+  const int32_t* __restrict__ X = dir == 0 ? XT : X1;
+  int32_t* __restrict__ Gcnt = dir == 0 ? Gc0 : Gc1;
+  long long* __restrict__ GS = dir == 0 ? Gs0 : Gs1;
   int k, row0, nrows;
   if (!gg_find_slot(lab_start, K, RW, blockIdx.y, &k, &row0, &nrows)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -393,6 +406,165 @@ __global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restri
   }
 }
 
+// ------------------------------------------------------------------ fused parameter step
+// One workgroup per block pair (a, b) (+ one for the self parameter and log m):
+//   1. reduce the pair's sufficient statistics from the out-histograms (k_pair_tables),
+//   2. thread 0 draws the parameter (k_draw_p / k_draw_niw),
+//   3. and writes the pair's coefficient-table entries (k_prep_tables);
+// every thread also zeroes a slice of the *other* statistics buffer, which the
+// next half-sweep's bulk kernel accumulates into.
+struct gg_params_args {
+  int is_adj, K, Kp, B, NSI, Np, N;
+  int do_tables, do_draw, do_prep;
+  int add_diag;
+  const int32_t* Gcnt0;
+  const long long* GS0;
+  const int32_t* perm;
+  const int32_t* lab_start;
+  const int32_t* cnt;
+  const uint8_t* dA;
+  const int32_t* dWq;
+  long long* tab;
+  gg_adj_hyp ah;
+  gg_w_hyp wh;
+  uint64_t seed;
+  uint32_t sweep;
+  double *m, *logm, *p, *p_self, *mu, *sigma, *mu_self, *sigma_self, *T, *Tout, *Tin;
+  int32_t* ctl;
+  unsigned long long* zero_ptr;   // other statistics buffer (8-byte words) or null
+  size_t zero_words;
+};
+
+__global__ __launch_bounds__(256) void k_params(gg_params_args g) {
+  if (g.ctl[4]) return;
+  const int K = g.K, B = g.B, NSI = g.NSI;
+  const int NTAB = g.is_adj ? 1 : 1 + 2 * NSI;
+  const int NT = g.is_adj ? 2 : (1 + B + B * (B + 1) / 2);
+  if (g.zero_ptr) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < g.zero_words; i += stride) g.zero_ptr[i] = 0ull;
+  }
+  __shared__ long long s_red[4][1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+  __shared__ long long s_tab[1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+  const int t = blockIdx.x;
+  if (t < K * K) {
+    const int a = t / K, b = t % K;
+    if (g.do_tables) {
+      const int s0 = g.lab_start[a], s1 = g.lab_start[a + 1];
+      long long acc[1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+      for (int q = 0; q < NTAB; ++q) acc[q] = 0;
+      for (int r = s0 + threadIdx.x; r < s1; r += blockDim.x) {
+        int n = g.perm[r];
+        acc[0] += g.Gcnt0[(size_t)b * g.Np + n];
+        if (!g.is_adj)
+          for (int s = 0; s < NSI; ++s) {
+            long long v = g.GS0[((size_t)b * g.Np + n) * NSI + s];
+            acc[1 + 2 * s] += (v >> 32);
+            acc[2 + 2 * s] += (v & 0xffffffffll);
+          }
+        if (g.add_diag && a == b && g.dA[n]) {
+          acc[0] += 1;
+          if (!g.is_adj) {
+            const int32_t* q = g.dWq + (size_t)n * B;
+            int tt = 0;
+            for (int r1 = 0; r1 < B; ++r1, ++tt) {
+              long long v = q[r1];
+              acc[1 + 2 * tt] += (v >> 32);
+              acc[2 + 2 * tt] += (v & 0xffffffffll);
+            }
+            for (int r1 = 0; r1 < B; ++r1)
+              for (int r2 = r1; r2 < B; ++r2, ++tt) {
+                long long v = (long long)q[r1] * (long long)q[r2];
+                acc[1 + 2 * tt] += (v >> 32);
+                acc[2 + 2 * tt] += (v & 0xffffffffll);
+              }
+          }
+        }
+      }
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      for (int q = 0; q < NTAB; ++q) {
+        long long v = gg_wave_sum_ll(acc[q]);
+        if (lane == 0) s_red[wave][q] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < NTAB) {
+        long long v = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_red[w][threadIdx.x];
+        s_tab[threadIdx.x] = v;
+        g.tab[(size_t)t * NTAB + threadIdx.x] = v;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      double e[GG_MAXNT];
+      if (g.is_adj) {
+        double pv;
+        if (g.do_draw) {
+          long long n1 = s_tab[0];
+          long long pairs = (long long)g.cnt[a] * (long long)g.cnt[b];
+          if (a == b && g.ah.special) pairs -= g.cnt[a];
+          long long n0 = pairs - n1;
+          gg_stream s;
+          gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_P : GG_SITE_ADJ_P, g.sweep, (uint32_t)t);
+          pv = gg_beta(&s, g.ah.tau1 + (double)n1, g.ah.tau0 + (double)n0);
+          g.p[t] = pv;
+        } else {
+          pv = g.p[t];
+        }
+        e[0] = gg_log(pv);
+        e[1] = gg_log(1.0 - pv);
+      } else {
+        double mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
+        if (g.do_draw) {
+          double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB];
+          gg_unpack_wstats(s_tab + 1, B, g.wh.shift, s1, s2);
+          gg_stream s;
+          gg_stream_init(&s, g.seed, GG_SITE_W_NIW, g.sweep, (uint32_t)t);
+          gg_niw_posterior_draw(&s, &g.wh.niw, B, (double)s_tab[0], s1, s2, mo, so);
+          for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
+          for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
+        } else {
+          for (int i = 0; i < B; ++i) mo[i] = g.mu[(size_t)t * B + i];
+          for (int i = 0; i < B * B; ++i) so[i] = g.sigma[(size_t)t * B * B + i];
+        }
+        if (g.do_prep && gg_gauss_table(mo, so, B, e)) {
+          atomicOr(&g.ctl[3], 1);
+          for (int i = 0; i < NT; ++i) e[i] = gg_nan();
+        }
+      }
+      if (g.do_prep)
+        for (int i = 0; i < NT; ++i) {
+          g.T[(size_t)t * NT + i] = e[i];
+          g.Tout[((size_t)b * NT + i) * g.Kp + a] = e[i];
+          g.Tin[((size_t)a * NT + i) * g.Kp + b] = e[i];
+        }
+    }
+  } else {
+    // last workgroup: the self parameter and log m
+    if (threadIdx.x == 0 && g.do_draw) {
+      if (g.is_adj) {
+        if (g.ah.special) {
+          gg_stream s;
+          gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_PSELF : GG_SITE_ADJ_PSELF, g.sweep, 0u);
+          *g.p_self = gg_beta(&s, g.ah.tau1 + (double)g.ah.d1, g.ah.tau0 + (double)g.ah.d0);
+        }
+      } else if (g.wh.special) {
+        long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+        for (int i = 0; i < NSI; ++i) { hl[2 * i] = g.wh.dS[i] >> 32; hl[2 * i + 1] = g.wh.dS[i] & 0xffffffffll; }
+        double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB], mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
+        gg_unpack_wstats(hl, B, g.wh.shift, s1, s2);
+        gg_stream s;
+        gg_stream_init(&s, g.seed, GG_SITE_W_NIW_SELF, g.sweep, 0u);
+        gg_niw_posterior_draw(&s, &g.wh.niw_self, B, (double)g.wh.d1, s1, s2, mo, so);
+        for (int i = 0; i < B; ++i) g.mu_self[i] = mo[i];
+        for (int i = 0; i < B * B; ++i) g.sigma_self[i] = so[i];
+      }
+    }
+    if (g.do_prep && threadIdx.x >= 64 && threadIdx.x < 64 + K) g.logm[threadIdx.x - 64] = gg_log(g.m[threadIdx.x - 64]);
+  }
+}
+
 // ------------------------------------------------------------------ per-node conditional
 struct gg_node_ctx {
   int N, Np, K, Kp, B, shift;
@@ -531,7 +703,8 @@ __device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n,
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
                                                    uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
-                                                   double* __restrict__ lp_out) {
+                                                   double* __restrict__ lp_out, const int32_t* __restrict__ ctl) {
+  if (ctl && ctl[4]) return;
   const int per = 256 / x.Kp;
   const int n = n_begin + blockIdx.x * per + threadIdx.x / x.Kp;
   const int k = threadIdx.x % x.Kp;

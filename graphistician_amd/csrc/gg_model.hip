@@ -32,20 +32,25 @@ struct gg_model {
   double *p, *p_self;
   double *mu, *sigma, *mu_self, *sigma_self;
   double *T, *Tout, *Tin;
-  int32_t* Gcnt[2];
-  long long* GS[2];
+  // statistics: two buffers [Gcnt out | Gcnt in | GS out | GS in]; the pipeline alternates between
+  // them so that the next half-sweep's buffer is zeroed inside the current one (k_params)
+  unsigned char* Gbuf[2];
+  size_t Gbytes;
+  int cur;
+  bool zeroed[2];
+  bool perm_valid;
   long long* tab;
-  int32_t *rs, *L;
-  int* status;
+  int32_t *rs, *L;   // rs = control block (gg_resolve_kernels.h)
   double* lp_out;
+  int pending;                 // optimistic sweeps enqueued and not yet confirmed
+  const gg_data* pend_data;
   // host mirrors / hypers
   gg_niw niw, niw_self;
-  int32_t* h_rs;  // pinned
+  int32_t* h_rs;  // pinned copy of the control block
   hipStream_t stream;
   uint32_t sweep;
   int Lmax, CH, max_idle;
   size_t resolve_lds;
-  bool g_valid;  // G consistent with the labels for the bound data
   // timing
   bool timing;
   std::vector<hipEvent_t> ev;
@@ -121,12 +126,12 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
       (rc = dmalloc(&m->perm, N)) || (rc = dmalloc(&m->lab_start, K + 1)) || (rc = dmalloc(&m->m, K)) ||
       (rc = dmalloc(&m->logm, K)) || (rc = dmalloc(&m->pi, K)) || (rc = dmalloc(&m->T, KK * NT)) ||
       (rc = dmalloc(&m->Tout, (size_t)K * NT * m->Kp)) || (rc = dmalloc(&m->Tin, (size_t)K * NT * m->Kp)) ||
-      (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 8)) || (rc = dmalloc(&m->status, 1)) ||
-      (rc = dmalloc(&m->lp_out, K)))
+      (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 8)) || (rc = dmalloc(&m->lp_out, K)))
     return rc;
-  for (int d = 0; d < 2; ++d) {
-    if ((rc = dmalloc(&m->Gcnt[d], (size_t)K * m->Np))) return rc;
-    if (!m->is_adj && (rc = dmalloc(&m->GS[d], (size_t)K * m->Np * m->NSI))) return rc;
+  m->Gbytes = (size_t)2 * K * m->Np * (sizeof(int32_t) + (size_t)m->NSI * sizeof(long long));
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = dmalloc(&m->Gbuf[b], m->Gbytes))) return rc;
+    m->zeroed[b] = true;
   }
   if (m->is_adj) {
     if ((rc = dmalloc(&m->p, KK)) || (rc = dmalloc(&m->p_self, 1))) return rc;
@@ -177,8 +182,8 @@ int gg_model_destroy(gg_model* m) {
   hipSetDevice(m->cfg.device);
   if (m->eig) { gg_eigen_destroy(m->eig); delete m; return GG_OK; }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->perm, m->lab_start, m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
-                  m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gcnt[0], m->Gcnt[1], m->GS[0], m->GS[1], m->tab,
-                  m->rs, m->L, m->status, m->lp_out};
+                  m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
+                  m->rs, m->L, m->lp_out};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   for (hipEvent_t e : m->ev) hipEventDestroy(e);
@@ -207,10 +212,13 @@ static int state_ptr(gg_model* m, int id, void** p, size_t* nbytes) {
   return *p ? GG_OK : GG_ERR_INVALID;
 }
 
+static int model_sync(gg_model* m);
+
 int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
   if (!m || !buf) return gg_fail(GG_ERR_INVALID, "gg_set_state: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return gg_eigen_set_state(m->eig, id, buf, nbytes);
+  { int rc0 = model_sync(m); if (rc0) return rc0; }
   const size_t B = m->B;
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
@@ -237,7 +245,7 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
     const int32_t* c = (const int32_t*)buf;
     for (int n = 0; n < m->N; ++n)
       if (c[n] < 0 || c[n] >= m->K) return gg_fail(GG_ERR_INVALID, "label c[%d]=%d out of range [0,%d)", n, c[n], m->K);
-    m->g_valid = false;
+    m->perm_valid = false;
   }
   GG_HIP(hipMemcpyAsync(p, buf, nbytes, hipMemcpyHostToDevice, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));
@@ -248,6 +256,7 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes) {
   if (!m || !buf) return gg_fail(GG_ERR_INVALID, "gg_get_state: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return gg_eigen_get_state(m->eig, id, buf, nbytes);
+  { int rc0 = model_sync(m); if (rc0) return rc0; }
   const size_t B = m->B;
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
@@ -299,20 +308,29 @@ static hipEvent_t next_event(gg_model* m) {
   return m->ev[m->ev_used++];
 }
 
-static gg_node_ctx node_ctx(const gg_model* m, const gg_data* d) {
+static int32_t* gcnt(const gg_model* m, int buf, int dir) {
+  return reinterpret_cast<int32_t*>(m->Gbuf[buf]) + (size_t)dir * m->K * m->Np;
+}
+static long long* gs(const gg_model* m, int buf, int dir) {
+  if (m->is_adj) return nullptr;
+  unsigned char* base = m->Gbuf[buf] + (size_t)2 * m->K * m->Np * sizeof(int32_t);
+  return reinterpret_cast<long long*>(base) + (size_t)dir * m->K * m->Np * m->NSI;
+}
+
+static gg_node_ctx node_ctx(const gg_model* m, const gg_data* d, int buf) {
   gg_node_ctx x;
   x.N = m->N; x.Np = m->Np; x.K = m->K; x.Kp = m->Kp; x.B = m->B; x.shift = m->is_adj ? 0 : d->shift;
   x.special = m->cfg.special_case_self_conns;
   x.c = m->c; x.cnt = m->cnt; x.logm = m->logm; x.T = m->T; x.Tout = m->Tout; x.Tin = m->Tin;
-  x.Gcnt[0] = m->Gcnt[0]; x.Gcnt[1] = m->Gcnt[1]; x.GS[0] = m->GS[0]; x.GS[1] = m->GS[1];
+  x.Gcnt[0] = gcnt(m, buf, 0); x.Gcnt[1] = gcnt(m, buf, 1); x.GS[0] = gs(m, buf, 0); x.GS[1] = gs(m, buf, 1);
   x.dA = d->dA; x.dWq = d->dWq;
   return x;
 }
 
 // rows per workgroup of the bulk kernel: enough workgroups to fill 256 CUs,
 // at most 1020 rows (SWAR byte counters: 255 rows per wave).
-static int bulk_rw(const gg_model* m, int strips) {
-  long long target_wg = 2048;
+static int bulk_rw(const gg_model* m, int strips, int ndirs) {
+  long long target_wg = 2048 / ndirs;
   long long rows_slots = target_wg / (strips > 0 ? strips : 1);
   if (rows_slots < 1) rows_slots = 1;
   long long rw = (m->N + rows_slots - 1) / rows_slots;
@@ -322,93 +340,110 @@ static int bulk_rw(const gg_model* m, int strips) {
   return (int)rw;
 }
 
-// sort + BULK statistics under the current labels.  dirs: bit 0 = out (reads X^T), bit 1 = in (reads X).
-static int run_bulk(gg_model* m, const gg_data* d, int dirs) {
-  const int N = m->N, K = m->K, Np = m->Np;
-  k_sort_labels<<<1, 1024, 2 * K * sizeof(int), m->stream>>>(m->c, N, K, m->perm, m->lab_start, m->cnt);
-  for (int dir = 0; dir < 2; ++dir) {
-    if (!(dirs & (1 << dir))) continue;
-    GG_HIP(hipMemsetAsync(m->Gcnt[dir], 0, (size_t)K * Np * sizeof(int32_t), m->stream));
-    if (!m->is_adj) GG_HIP(hipMemsetAsync(m->GS[dir], 0, (size_t)K * Np * m->NSI * sizeof(long long), m->stream));
+static int ensure_perm(gg_model* m) {
+  if (!m->perm_valid) {
+    k_sort_labels<<<1, 1024, 2 * m->K * sizeof(int), m->stream>>>(m->c, m->N, m->K, m->perm, m->lab_start, m->cnt);
+    GG_HIP(hipGetLastError());
+    m->perm_valid = true;
   }
+  return GG_OK;
+}
+
+static int ensure_zero(gg_model* m, int buf) {
+  if (!m->zeroed[buf]) {
+    GG_HIP(hipMemsetAsync(m->Gbuf[buf], 0, m->Gbytes, m->stream));
+    m->zeroed[buf] = true;
+  }
+  return GG_OK;
+}
+
+// BULK statistics under the current labels into buffer `buf`.  dirs: bit 0 = out (reads X^T), bit 1 = in (reads X).
+static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined) {
+  const int N = m->N, K = m->K, Np = m->Np;
+  int rc;
+  if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, buf))) return rc;
+  const int dir0 = (dirs & 1) ? 0 : 1;
+  const int ndirs = (dirs == 3) ? 2 : 1;
+  const int32_t* ctl = pipelined ? m->rs : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (m->timing) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
-  for (int dir = 0; dir < 2; ++dir) {
-    if (!(dirs & (1 << dir))) continue;
-    if (m->is_adj) {
-      int strips = (Np + 1023) / 1024;
-      int RW = bulk_rw(m, strips);
-      dim3 grd(strips, (N + RW - 1) / RW + K);
-      const uint8_t* X = dir == 0 ? d->AT : d->A;
-      k_bulk_adj<<<grd, 256, 0, m->stream>>>(X, Np, m->perm, m->lab_start, K, RW, m->Gcnt[dir]);
-      m->st.bulk_bytes += (double)N * (double)N * 1.0;
-    } else {
-      const int32_t* X = dir == 0 ? d->WqT : d->Wq;
-      int SC = 64 * (4 / m->B);
-      int strips = (Np + SC - 1) / SC;
-      int RW = bulk_rw(m, strips);
-      dim3 grd(strips, (N + RW - 1) / RW + K);
-      switch (m->B) {
-        case 1: k_bulk_w<1><<<grd, 256, 0, m->stream>>>(X, Np, m->perm, m->lab_start, K, RW, m->Gcnt[dir], m->GS[dir]); break;
-        case 2: k_bulk_w<2><<<grd, 256, 0, m->stream>>>(X, Np, m->perm, m->lab_start, K, RW, m->Gcnt[dir], m->GS[dir]); break;
-        case 4: k_bulk_w<4><<<grd, 256, 0, m->stream>>>(X, Np, m->perm, m->lab_start, K, RW, m->Gcnt[dir], m->GS[dir]); break;
-      }
-      m->st.bulk_bytes += (double)N * (double)N * 4.0 * m->B;
+  if (m->is_adj) {
+    int strips = (Np + 1023) / 1024;
+    int RW = bulk_rw(m, strips, ndirs);
+    dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
+    k_bulk_adj<<<grd, 256, 0, m->stream>>>(d->AT, d->A, Np, m->perm, m->lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1),
+                                           dir0, ctl);
+    m->st.bulk_bytes += (double)ndirs * N * (double)N;
+  } else {
+    int SC = 64 * (4 / m->B);
+    int strips = (Np + SC - 1) / SC;
+    int RW = bulk_rw(m, strips, ndirs);
+    dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
+#define BULKW(BV)                                                                                                     \
+  k_bulk_w<BV><<<grd, 256, 0, m->stream>>>(d->WqT, d->Wq, Np, m->perm, m->lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), \
+                                           gs(m, buf, 0), gs(m, buf, 1), dir0, ctl)
+    switch (m->B) {
+      case 1: BULKW(1); break;
+      case 2: BULKW(2); break;
+      case 4: BULKW(4); break;
     }
-    m->st.bulk_launches += 1;
+#undef BULKW
+    m->st.bulk_bytes += (double)ndirs * N * (double)N * 4.0 * m->B;
   }
+  m->st.bulk_launches += 1;
   if (m->timing) GG_HIP(hipEventRecord(e1, m->stream));
   GG_HIP(hipGetLastError());
+  m->zeroed[buf] = false;
   return GG_OK;
 }
 
-static int run_pair_tables(gg_model* m, const gg_data* d) {
-  int add_diag = m->cfg.special_case_self_conns ? 0 : 1;
-  k_pair_tables<<<m->K * m->K, 256, 0, m->stream>>>(m->Gcnt[0], m->is_adj ? nullptr : m->GS[0], m->Np, m->K, m->NSI,
-                                                    m->perm, m->lab_start, add_diag, d->dA, d->dWq, m->B, m->tab);
-  GG_HIP(hipGetLastError());
-  return GG_OK;
-}
-
-static int run_draw_params(gg_model* m, const gg_data* d) {
-  const int K = m->K;
-  int nthr = K * K + 1;
-  if (m->is_adj) {
-    gg_adj_hyp h;
-    h.tau1 = m->cfg.tau1; h.tau0 = m->cfg.tau0;
-    h.special = m->cfg.special_case_self_conns;
-    h.bb = (m->kind == GG_BB_ADJ);
-    h.d1 = d->d1; h.d0 = (long long)m->N - d->d1;
-    k_draw_p<<<(nthr + 63) / 64, 64, 0, m->stream>>>(m->tab, m->cnt, K, h, m->cfg.seed, m->sweep, m->p, m->p_self);
-  } else {
-    gg_w_hyp h;
-    h.niw = m->niw; h.niw_self = m->niw_self;
-    h.special = m->cfg.special_case_self_conns;
-    h.shift = d->shift; h.d1 = d->d1;
-    for (int i = 0; i < gg_nsi(GG_MAXB); ++i) h.dS[i] = d->dS[i];
-    k_draw_niw<<<(nthr + 63) / 64, 64, 0, m->stream>>>(m->tab, K, m->B, h, m->cfg.seed, m->sweep, m->mu, m->sigma,
-                                                       m->mu_self, m->sigma_self);
+// fused: pair tables (from buffer `buf`) -> parameter draw -> coefficient tables; optionally zero the other buffer
+static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, bool draw, bool prep, bool zero_other,
+                          uint32_t sweep) {
+  gg_params_args g;
+  memset(&g, 0, sizeof(g));
+  g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.Kp = m->Kp; g.B = m->B; g.NSI = m->NSI; g.Np = m->Np; g.N = m->N;
+  g.do_tables = tables; g.do_draw = draw; g.do_prep = prep;
+  g.add_diag = m->cfg.special_case_self_conns ? 0 : 1;
+  g.Gcnt0 = gcnt(m, buf, 0); g.GS0 = gs(m, buf, 0);
+  g.perm = m->perm; g.lab_start = m->lab_start; g.cnt = m->cnt;
+  g.dA = d ? d->dA : nullptr; g.dWq = d ? d->dWq : nullptr;
+  g.tab = m->tab;
+  g.ah.tau1 = m->cfg.tau1; g.ah.tau0 = m->cfg.tau0;
+  g.ah.special = m->cfg.special_case_self_conns;
+  g.ah.bb = (m->kind == GG_BB_ADJ);
+  if (d) { g.ah.d1 = d->d1; g.ah.d0 = (long long)m->N - d->d1; }
+  if (!m->is_adj) {
+    g.wh.niw = m->niw; g.wh.niw_self = m->niw_self;
+    g.wh.special = m->cfg.special_case_self_conns;
+    if (d) {
+      g.wh.shift = d->shift; g.wh.d1 = d->d1;
+      for (int i = 0; i < gg_nsi(GG_MAXB); ++i) g.wh.dS[i] = d->dS[i];
+    }
   }
+  g.seed = m->cfg.seed; g.sweep = sweep;
+  g.m = m->m; g.logm = m->logm; g.p = m->p; g.p_self = m->p_self; g.mu = m->mu; g.sigma = m->sigma;
+  g.mu_self = m->mu_self; g.sigma_self = m->sigma_self; g.T = m->T; g.Tout = m->Tout; g.Tin = m->Tin;
+  g.ctl = m->rs;
+  if (zero_other && !m->zeroed[1 - buf]) {
+    g.zero_ptr = reinterpret_cast<unsigned long long*>(m->Gbuf[1 - buf]);
+    g.zero_words = m->Gbytes / 8;
+    m->zeroed[1 - buf] = true;
+  }
+  k_params<<<m->K * m->K + 1, 256, 0, m->stream>>>(g);
   GG_HIP(hipGetLastError());
   return GG_OK;
 }
 
-static int run_prep_tables(gg_model* m) {
-  int nthr = m->K * m->K + m->K;
-  k_prep_tables<<<(nthr + 63) / 64, 64, 0, m->stream>>>(m->is_adj ? 1 : 0, m->K, m->Kp, m->B, m->m, m->p, m->mu, m->sigma,
-                                                        m->logm, m->T, m->Tout, m->Tin, m->status);
-  GG_HIP(hipGetLastError());
-  return GG_OK;
-}
-
-static int launch_speculate(gg_model* m, const gg_data* d, int n_begin, int lp_node) {
-  gg_node_ctx x = node_ctx(m, d);
+static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined) {
+  gg_node_ctx x = node_ctx(m, d, buf);
   int per = 256 / m->Kp;
   int nb = (m->N - n_begin + per - 1) / per;
   if (nb < 1) nb = 1;
   uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
   double* lpo = lp_node >= 0 ? m->lp_out : nullptr;
-#define SPEC(NTV, ADJV) k_speculate<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, n_begin, m->cfg.seed, site, m->sweep, m->cand, lp_node, lpo)
+  const int32_t* ctl = pipelined ? m->rs : nullptr;
+#define SPEC(NTV, ADJV) k_speculate<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl)
   if (m->is_adj) SPEC(2, true);
   else if (m->B == 1) SPEC(3, false);
   else if (m->B == 2) SPEC(6, false);
@@ -418,13 +453,16 @@ static int launch_speculate(gg_model* m, const gg_data* d, int n_begin, int lp_n
   return GG_OK;
 }
 
-static int launch_resolve(gg_model* m, const gg_data* d, int fresh) {
+static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort) {
   gg_resolve_args g;
-  g.x = node_ctx(m, d);
+  g.x = node_ctx(m, d, buf);
   g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
-  g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = fresh;
+  g.tail_m = tail_m ? 1 : 0; g.tail_sort = tail_sort ? 1 : 0;
+  g.m = m->m; g.pi = m->pi; g.perm = m->perm; g.lab_start = m->lab_start;
+  g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
+  g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
-  g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = m->sweep;
+  g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   size_t lds = m->resolve_lds;
 #define RES(NTV, ADJV)                                                                                           \
   do {                                                                                                           \
@@ -444,12 +482,12 @@ static int launch_resolve(gg_model* m, const gg_data* d, int fresh) {
   return GG_OK;
 }
 
-static int launch_apply_L(gg_model* m, const gg_data* d) {
-  gg_node_ctx x = node_ctx(m, d);
+static int launch_apply_L(gg_model* m, const gg_data* d, int buf) {
+  gg_node_ctx x = node_ctx(m, d, buf);
   int nb = (m->N + 255) / 256;
 #define APL(NTV, ADJV)                                                                                             \
-  k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, m->Gcnt[0], m->Gcnt[1], m->GS[0], m->GS[1], d->A, d->AT, \
-                                                  d->Wq, d->WqT)
+  k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0),   \
+                                                  gs(m, buf, 1), d->A, d->AT, d->Wq, d->WqT)
   if (m->is_adj) APL(2, true);
   else if (m->B == 1) APL(3, false);
   else if (m->B == 2) APL(6, false);
@@ -459,74 +497,57 @@ static int launch_apply_L(gg_model* m, const gg_data* d) {
   return GG_OK;
 }
 
-// resample_c: speculate, then resolve rounds until the scan is complete.
-static int run_resample_c(gg_model* m, const gg_data* d) {
-  if (m->K == 1) return GG_OK;  // adjacency.py:657-658, weights.py:421-422
+static int read_ctl(gg_model* m) {
+  GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipStreamSynchronize(m->stream));
+  return GG_OK;
+}
+
+static int write_ctl_word(gg_model* m, int idx, int32_t v) {
+  GG_HIP(hipMemcpyAsync(m->rs + idx, &v, sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+  GG_HIP(hipStreamSynchronize(m->stream));
+  return GG_OK;
+}
+
+// Finish a scan the pipeline left unfinished: rounds of (apply L, re-speculate the
+// remainder, resolve) with a host check after each, until the last node is done.
+static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort) {
   int rc;
-  int32_t init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  GG_HIP(hipMemcpyAsync(m->rs, init, sizeof(init), hipMemcpyHostToDevice, m->stream));
-  int pos = 0;
-  for (int round = 0; pos < m->N; ++round) {
-    if (round > 0) {
-      if ((rc = launch_apply_L(m, d))) return rc;
-    }
-    if ((rc = launch_speculate(m, d, pos, -1))) return rc;
-    if ((rc = launch_resolve(m, d, 1))) return rc;
-    GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-    GG_HIP(hipStreamSynchronize(m->stream));
-    pos = m->h_rs[0];
+  for (int round = 0;; ++round) {
+    if ((rc = read_ctl(m))) return rc;
+    if (!m->h_rs[4]) return GG_OK;  // scan complete
+    int pos = m->h_rs[0];
+    if ((rc = launch_apply_L(m, d, buf))) return rc;
+    if ((rc = write_ctl_word(m, 4, 0))) return rc;
+    if ((rc = launch_speculate(m, d, buf, pos, -1, sweep, false))) return rc;
+    if ((rc = launch_resolve(m, d, buf, sweep, tail_m, tail_sort))) return rc;
     m->st.resolve_rounds += 1;
     if (round > 2 * m->N + 8) return gg_fail(GG_ERR_HIP, "resolve did not make progress (pos=%d)", pos);
   }
-  m->st.label_changes += (uint64_t)m->h_rs[2];
-  if (m->h_rs[2] > 0) m->g_valid = false;
-  return GG_OK;
 }
 
-static int run_draw_m(gg_model* m) {
-  uint32_t site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
-  k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed, site, m->sweep, m->m);
-  GG_HIP(hipGetLastError());
-  return GG_OK;
-}
-
-static int check_status(gg_model* m) {
-  int st = 0;
-  GG_HIP(hipMemcpyAsync(&st, m->status, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipStreamSynchronize(m->stream));
-  if (st) {
-    int z = 0;
-    hipMemcpy(m->status, &z, sizeof(int), hipMemcpyHostToDevice);
-    return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
-  }
-  return GG_OK;
-}
-
-static int resample_parts(gg_model* m, const gg_data* d, int parts) {
+// One full sweep enqueued optimistically on the model's stream (no host sync):
+//   bulk -> params (+ zero the other buffer) -> speculate -> resolve (+ draw m, re-sort)
+// K = 1 kinds (Beta-Bernoulli, NIW) have no scan: bulk (out only) -> params.
+static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
   int rc;
   const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
-  const bool do_params = (parts & GG_PART_PARAMS) && learn_params;
-  const bool do_c = (parts & GG_PART_C) && m->sbm && m->K > 1;
-  const bool do_m = (parts & GG_PART_M) && m->sbm;
-  if (do_params || do_c) {
-    // out-statistics feed the pair tables; the scan needs both directions
-    if ((rc = run_bulk(m, d, do_c ? 3 : 1))) return rc;
+  if (!learn_params) return GG_OK;
+  const bool scan = m->sbm && m->K > 1;
+  const int buf = m->cur;
+  if ((rc = enqueue_bulk(m, d, buf, scan ? 3 : 1, true))) return rc;
+  if ((rc = enqueue_params(m, d, buf, true, true, scan, true, sweep))) return rc;
+  if (scan) {
+    if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
+    if ((rc = launch_resolve(m, d, buf, sweep, true, true))) return rc;
+    m->st.resolve_rounds += 1;
+  } else if (m->sbm) {
+    // K == 1 SBM: resample_c returns early (adjacency.py:657-658) but m is still drawn
+    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+                                                        m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, sweep, m->m);
+    GG_HIP(hipGetLastError());
   }
-  if (do_params) {
-    if ((rc = run_pair_tables(m, d))) return rc;
-    if ((rc = run_draw_params(m, d))) return rc;
-  }
-  if (do_c) {
-    if ((rc = run_prep_tables(m))) return rc;
-    if ((rc = run_resample_c(m, d))) return rc;
-  }
-  if (do_m) {
-    if (!do_c && !do_params) {
-      // block sizes under the current labels
-      k_sort_labels<<<1, 1024, 2 * m->K * sizeof(int), m->stream>>>(m->c, m->N, m->K, m->perm, m->lab_start, m->cnt);
-    }
-    if ((rc = run_draw_m(m))) return rc;
-  }
+  m->cur = 1 - buf;
   return GG_OK;
 }
 
@@ -536,9 +557,7 @@ static void begin_call(gg_model* m) {
   hipEventRecord(m->ev_call0, m->stream);
 }
 
-static int end_call(gg_model* m) {
-  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
-  GG_HIP(hipStreamSynchronize(m->stream));
+static int collect_timing(gg_model* m) {
   float ms = 0;
   GG_HIP(hipEventElapsedTime(&ms, m->ev_call0, m->ev_call1));
   m->st.total_ms = ms;
@@ -550,6 +569,57 @@ static int end_call(gg_model* m) {
   return GG_OK;
 }
 
+// Confirm the optimistic sweeps: if a scan stalled, finish it on the slow path and
+// re-enqueue the sweeps that became no-ops behind it.
+static int model_sync(gg_model* m) {
+  if (m->eig || m->pending == 0) return GG_OK;
+  int rc;
+  const gg_data* d = m->pend_data;
+  const bool scan = m->sbm && m->K > 1;
+  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  for (;;) {
+    if ((rc = read_ctl(m))) return rc;
+    if (m->h_rs[3]) {
+      write_ctl_word(m, 3, 0);
+      m->pending = 0;
+      return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
+    }
+    int done = scan ? m->h_rs[5] : m->pending;
+    if (!m->h_rs[4]) {  // nothing stalled: every enqueued sweep completed
+      m->sweep += (uint32_t)m->pending;
+      m->st.sweeps += (uint64_t)m->pending;
+      break;
+    }
+    // sweep number `done` (0-based among the pending ones) stalled inside its scan
+    int remaining = m->pending - done - 1;
+    // the pipeline advanced m->cur once per enqueued sweep; the stalled sweep used this buffer:
+    int buf_stalled = (m->cur + m->pending - done) & 1;   // cur - (pending - done) mod 2
+    uint32_t sw = m->sweep + (uint32_t)done;
+    if ((rc = finish_scan(m, d, buf_stalled, sw, true, true))) return rc;
+    m->sweep += (uint32_t)(done + 1);
+    m->st.sweeps += (uint64_t)(done + 1);
+    m->pending = 0;
+    if ((rc = write_ctl_word(m, 5, 0))) return rc;
+    // buffers after the stalled sweep: its own buffer is dirty, the other one was zeroed by its k_params
+    m->cur = 1 - buf_stalled;
+    m->zeroed[buf_stalled] = false;
+    m->zeroed[1 - buf_stalled] = true;
+    for (int i = 0; i < remaining; ++i)
+      if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i))) return rc;
+    m->pending = remaining;
+    if (remaining == 0) break;
+    GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  }
+  m->pending = 0;
+  if (scan) {
+    if ((rc = write_ctl_word(m, 5, 0))) return rc;
+    if ((rc = read_ctl(m))) return rc;
+  }
+  m->st.label_changes = (uint64_t)m->h_rs[2];
+  GG_HIP(hipEventSynchronize(m->ev_call1));
+  return collect_timing(m);
+}
+
 extern "C" {
 
 int gg_set_timing(gg_model* m, int32_t on) {
@@ -558,23 +628,8 @@ int gg_set_timing(gg_model* m, int32_t on) {
   return GG_OK;
 }
 
-int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) {
-  if (!m) return gg_fail(GG_ERR_INVALID, "null model");
-  GG_HIP(hipSetDevice(m->cfg.device));
-  if (beta != 1.0) return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals (beta != 1) are not implemented yet");
-  if (m->eig) return gg_eigen_resample(m->eig, d, parts);
-  int rc = GG_OK;
-  if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
-  if (rc) return rc;
-  begin_call(m);
-  rc = resample_parts(m, d, parts);
-  if (rc) return rc;
-  if ((rc = end_call(m))) return rc;
-  if (!m->is_adj && (parts & GG_PART_C) && (rc = check_status(m))) return rc;
-  return GG_OK;
-}
-
-int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
+// Enqueue n sweeps and return without waiting; gg_sync (or any state read) completes them.
+int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (beta != 1.0) return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals (beta != 1) are not implemented yet");
@@ -587,32 +642,93 @@ int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
   }
   int rc = check_data(m, d);
   if (rc) return rc;
-  begin_call(m);
+  if (m->pending && m->pend_data != d && (rc = model_sync(m))) return rc;
+  if (m->pending == 0) begin_call(m);
+  m->pend_data = d;
   for (int s = 0; s < n_sweeps; ++s) {
-    if ((rc = resample_parts(m, d, GG_PART_ALL))) return rc;
-    m->sweep += 1;
-    m->st.sweeps += 1;
+    if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)m->pending))) return rc;
+    m->pending += 1;
   }
-  if ((rc = end_call(m))) return rc;
-  if (!m->is_adj && (rc = check_status(m))) return rc;
   return GG_OK;
+}
+
+int gg_sync(gg_model* m) {
+  if (!m) return gg_fail(GG_ERR_INVALID, "null model");
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (m->eig) return GG_OK;
+  return model_sync(m);
+}
+
+int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
+  int rc = gg_resample_async(m, d, n_sweeps, beta);
+  if (rc) return rc;
+  return gg_sync(m);
+}
+
+// Step-wise parts (parity tests, reference-style resample_p / resample_c / resample_m calls): synchronous.
+int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) {
+  if (!m) return gg_fail(GG_ERR_INVALID, "null model");
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (beta != 1.0) return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals (beta != 1) are not implemented yet");
+  if (m->eig) return gg_eigen_resample(m->eig, d, parts);
+  int rc = model_sync(m);
+  if (rc) return rc;
+  if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
+  if (rc) return rc;
+  begin_call(m);
+  const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
+  const bool do_params = (parts & GG_PART_PARAMS) && learn_params;
+  const bool do_c = (parts & GG_PART_C) && m->sbm && m->K > 1;
+  const bool do_m = (parts & GG_PART_M) && m->sbm;
+  const int buf = m->cur;
+  if (do_params || do_c) {
+    if ((rc = enqueue_bulk(m, d, buf, do_c ? 3 : 1, false))) return rc;
+    if ((rc = enqueue_params(m, d, buf, do_params, do_params, do_c, false, m->sweep))) return rc;
+  }
+  if (do_c) {
+    if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false))) return rc;
+    if ((rc = launch_resolve(m, d, buf, m->sweep, false, true))) return rc;
+    m->st.resolve_rounds += 1;
+    if ((rc = finish_scan(m, d, buf, m->sweep, false, true))) return rc;
+    if ((rc = write_ctl_word(m, 5, 0))) return rc;
+    m->st.label_changes = (uint64_t)m->h_rs[2];
+  }
+  if (do_m) {
+    if ((rc = ensure_perm(m))) return rc;
+    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+                                                        m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
+    GG_HIP(hipGetLastError());
+  }
+  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  if ((rc = read_ctl(m))) return rc;
+  if (m->h_rs[3]) {
+    write_ctl_word(m, 3, 0);
+    return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
+  }
+  return collect_timing(m);
 }
 
 int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (!m || !lp) return gg_fail(GG_ERR_INVALID, "gg_node_lp: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: block models only");
-  int rc = check_data(m, d);
+  int rc = model_sync(m);
   if (rc) return rc;
+  if ((rc = check_data(m, d))) return rc;
   if (n < 0 || n >= m->N) return gg_fail(GG_ERR_INVALID, "node %d out of range", n);
   begin_call(m);
-  if ((rc = run_bulk(m, d, 3))) return rc;
-  if ((rc = run_prep_tables(m))) return rc;
-  if ((rc = launch_speculate(m, d, 0, n))) return rc;
-  if ((rc = end_call(m))) return rc;
-  if (!m->is_adj && (rc = check_status(m))) return rc;
+  const int buf = m->cur;
+  if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;
+  if ((rc = enqueue_params(m, d, buf, false, false, true, false, m->sweep))) return rc;
+  if ((rc = launch_speculate(m, d, buf, 0, n, m->sweep, false))) return rc;
+  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  if ((rc = read_ctl(m))) return rc;
+  if (m->h_rs[3]) {
+    write_ctl_word(m, 3, 0);
+    return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
+  }
   GG_HIP(hipMemcpy(lp, m->lp_out, (size_t)m->K * 8, hipMemcpyDeviceToHost));
-  return GG_OK;
+  return collect_timing(m);
 }
 
 // Closed forms from the K x K tables:
@@ -622,18 +738,22 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
   if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return gg_eigen_log_likelihood(m->eig, d, out);
-  int rc = check_data(m, d);
+  int rc = model_sync(m);
   if (rc) return rc;
+  if ((rc = check_data(m, d))) return rc;
   begin_call(m);
-  if ((rc = run_bulk(m, d, 1))) return rc;
-  if ((rc = run_pair_tables(m, d))) return rc;
+  const int buf = m->cur;
+  if ((rc = enqueue_bulk(m, d, buf, 1, false))) return rc;
+  if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
   const int K = m->K, B = m->B;
   const size_t KK = (size_t)K * K;
   std::vector<long long> tab(KK * m->NTAB);
   std::vector<int32_t> cnt(K);
   GG_HIP(hipMemcpyAsync(tab.data(), m->tab, tab.size() * 8, hipMemcpyDeviceToHost, m->stream));
   GG_HIP(hipMemcpyAsync(cnt.data(), m->cnt, K * 4, hipMemcpyDeviceToHost, m->stream));
-  if ((rc = end_call(m))) return rc;
+  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  GG_HIP(hipStreamSynchronize(m->stream));
+  if ((rc = collect_timing(m))) return rc;
   const int special = m->cfg.special_case_self_conns;
   double ll = 0.0;
   if (m->is_adj) {
@@ -652,7 +772,6 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
       for (int b = 0; b < K; ++b) {
         long long n1 = tab[(size_t)a * K + b];
         long long pairs = (long long)cnt[a] * cnt[b] - ((a == b && special) ? cnt[a] : 0);
-        // with the diagonal forced to zero probability the (a,a) table must not hold it
         ll += term(p[(size_t)a * K + b], n1, pairs - n1);
       }
     long long d1 = d->d1, d0 = (long long)m->N - d->d1;
@@ -671,7 +790,7 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
       ll += term(p_self, d1, d0);
     }
   } else {
-    const int NT = m->NT, NSI = m->NSI;
+    const int NSI = m->NSI;
     std::vector<double> mu(KK * B), sigma(KK * B * B), mus(B), sigs((size_t)B * B);
     GG_HIP(hipMemcpy(mu.data(), m->mu, mu.size() * 8, hipMemcpyDeviceToHost));
     GG_HIP(hipMemcpy(sigma.data(), m->sigma, sigma.size() * 8, hipMemcpyDeviceToHost));
@@ -689,7 +808,6 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
       }
       return v;
     };
-    (void)NT;
     for (size_t ab = 0; ab < KK; ++ab) {
       const long long* e = &tab[ab * m->NTAB];
       ll += ll_of(&mu[ab * B], &sigma[ab * B * B], (double)e[0], e + 1);
@@ -707,6 +825,8 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
 int gg_last_stats(gg_model* m, gg_stats* out) {
   if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_last_stats: null argument");
   if (m->eig) return gg_eigen_stats(m->eig, out);
+  int rc = model_sync(m);
+  if (rc) return rc;
   *out = m->st;
   return GG_OK;
 }

@@ -26,8 +26,17 @@ struct gg_resolve_args {
   int32_t* c;
   int32_t* cnt;
   const int32_t* cand;
-  int32_t* rs;   // [0] pos, [1] nL, [2] label changes (accumulated), [3] status
+  int32_t* rs;   // control block: [0] pos, [1] nL, [2] label changes (accumulated), [3] status,
+                 //                [4] stalled (scan left unfinished: later pipeline kernels do nothing), [5] completed scans
   int32_t* L;    // [Lcap][3] = (node, old, new)
+  // tail, run when the scan completes: resample_m (adjacency.py:697-702 / weights.py:493-498)
+  // and the label sort the next half-sweep's bulk kernel needs
+  int tail_m, tail_sort;
+  double* m;
+  const double* pi;
+  int32_t* perm;
+  int32_t* lab_start;
+  uint32_t site_m;
   int Lmax;
   int max_idle;
   int CH;
@@ -83,9 +92,11 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
   int32_t* s_blkw = reinterpret_cast<int32_t*>(s_raw + off);           // [CH][CH][B] (weights)
   uint8_t* s_blka = reinterpret_cast<uint8_t*>(s_raw + off);           // [CH][CH]    (adjacency)
 
+  if (g.rs[4]) return;  // an earlier scan of this pipeline is unfinished
   int pos = g.rs[0];
   int nL = g.fresh ? 0 : g.rs[1];
   int nchg = 0;
+  bool finished = false;
   for (int k = tid; k < K; k += nth) s_cnt[k] = g.cnt[k];
   if (tid == 0) s_ctl[0] = N;
   __syncthreads();
@@ -99,24 +110,25 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
     __syncthreads();
     int ns = s_ctl[0];
     if (ns >= N) {
-      if (tid == 0) { g.rs[0] = N; g.rs[1] = 0; }
-      return;
+      pos = N;
+      finished = true;
+    } else {
+      int a = g.c[ns], b = g.cand[ns];
+      __syncthreads();
+      if (tid == 0) {
+        g.c[ns] = b;
+        s_cnt[a] -= 1; s_cnt[b] += 1;
+        g.L[0] = ns; g.L[1] = a; g.L[2] = b;
+      }
+      nL = 1; nchg = 1; pos = ns + 1;
+      __syncthreads();
     }
-    int a = g.c[ns], b = g.cand[ns];
-    __syncthreads();
-    if (tid == 0) {
-      g.c[ns] = b;
-      s_cnt[a] -= 1; s_cnt[b] += 1;
-      g.L[0] = ns; g.L[1] = a; g.L[2] = b;
-    }
-    nL = 1; nchg = 1; pos = ns + 1;
-    __syncthreads();
   }
 
   // ---------------------------------------------------------------- phase B
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
   int idle = 0;
-  while (pos < N && nL < g.Lmax && idle < g.max_idle) {
+  while (!finished && pos < N && nL < g.Lmax && idle < g.max_idle) {
     const int pos0 = pos;
     const int nch = (N - pos0) < CH ? (N - pos0) : CH;
     // load chunk labels, statistics (coalesced over the node index) and the diagonal block
@@ -216,12 +228,40 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
     idle = changed ? 0 : idle + 1;
     __syncthreads();
   }
-  if (tid == 0) {
-    g.rs[0] = pos;
-    g.rs[1] = nL;
-    g.rs[2] += nchg;
-  }
   for (int k = tid; k < K; k += nth) g.cnt[k] = s_cnt[k];
+  const bool done = pos >= N;
+  __syncthreads();
+  if (done) {
+    double* s_gam = reinterpret_cast<double*>(s_raw);        // [K]   (chunk statistics are dead now)
+    int* s_cur = reinterpret_cast<int*>(s_raw + 64 * sizeof(double));  // [K]
+    if (g.tail_m) {
+      if (tid < K) s_gam[tid] = gg_dirichlet_gamma_at(g.seed, g.site_m, g.sweep, tid, g.pi[tid] + (double)s_cnt[tid]);
+      __syncthreads();
+      if (tid < K) {
+        double tot = 0.0;
+        for (int j = 0; j < K; ++j) tot += s_gam[j];
+        g.m[tid] = s_gam[tid] / tot;
+      }
+    }
+    if (g.tail_sort) {
+      if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < K; ++k) { g.lab_start[k] = acc; s_cur[k] = acc; acc += s_cnt[k]; }
+        g.lab_start[K] = acc;
+      }
+      __syncthreads();
+      for (int n = tid; n < N; n += nth) {
+        int at = atomicAdd(&s_cur[g.c[n]], 1);
+        g.perm[at] = n;
+      }
+    }
+  }
+  if (tid == 0) {
+    g.rs[0] = done ? 0 : pos;
+    g.rs[1] = done ? 0 : nL;
+    g.rs[2] += nchg;
+    if (done) g.rs[5] += 1; else g.rs[4] = 1;
+  }
 }
 
 // Apply the change list to the resident statistics of every node (chip-wide):

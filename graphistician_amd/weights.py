@@ -249,7 +249,7 @@ class NIWGaussianWeightDistribution(_WeightsBase):
         """weights.py:154-162."""
         d = self._data(data)
         assert d.N == self.N and d.B == self.B
-        self._engine().resample(d, 1)
+        self._engine().resample_async(d, 1)
         self._mark_stale("_mu", "_sigma", "_mu_self", "_sigma_self")
 
 
@@ -409,7 +409,7 @@ class SBMGaussianWeightDistribution(_WeightsBase):
         assert d is None or (d.N == self.N and d.B == self.B)
         eng = self._engine()
         if parts == _abi.PART_ALL:
-            eng.resample(d, 1)
+            eng.resample_async(d, 1)    # stream-ordered: the next state read (or log_likelihood) waits for it
         else:
             eng.resample_part(d, parts)
             if parts == _abi.PART_M:

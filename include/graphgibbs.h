@@ -143,6 +143,12 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes);
  * beta is the AIS inverse temperature (graph_models.py:50-64); 1.0 = plain Gibbs. */
 int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta);
 int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta);
+/* Stream-ordered form: gg_resample_async enqueues n_sweeps sweeps on the model's HIP stream and
+ * returns; gg_sync (and every call that reads state) waits for them.  gg_resample = async + sync.
+ * Distinct models run on distinct streams, so the adjacency and weight halves of
+ * FactorizedNetworkDistribution.resample (networks.py:69-71), which share only the data, overlap. */
+int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta);
+int gg_sync(gg_model* m);
 
 /* abstractions.py:111-115 (adjacency kinds), weights.py:316-331 /
  * abstractions.py:257-274 (weight kinds), eigenmodel.py:110-129. */
