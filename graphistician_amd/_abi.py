@@ -43,7 +43,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk",
            "gg_set_timing", "gg_selftest_math", "gg_selftest_draws"]
 
 
@@ -88,6 +88,7 @@ def lib():
         L.gg_node_lp.argtypes = [vp, vp, C.c_int32, vp]
         L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gg_set_timing.argtypes = [vp, C.c_int32]
+        L.gg_bench_bulk.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.gg_selftest_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, C.c_int64]
         L.gg_selftest_draws.argtypes = [C.c_int32, C.c_int32, C.c_uint64, vp, C.c_int32, vp, C.c_int64, C.c_int32]
         _lib = L
@@ -220,8 +221,14 @@ class Model(object):
         check(lib().gg_last_stats(self._h, C.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
 
-    def set_timing(self, on=True):
-        check(lib().gg_set_timing(self._h, 1 if on else 0))
+    def bench_bulk(self, data, reps=20):
+        ms, nb = C.c_double(0), C.c_double(0)
+        check(lib().gg_bench_bulk(self._h, data.handle, reps, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
+
+    def set_timing(self, every=1):
+        """HIP-event timing of the bulk kernel on every `every`-th sweep (0/False = off)."""
+        check(lib().gg_set_timing(self._h, int(every)))
 
     @property
     def sweep(self):

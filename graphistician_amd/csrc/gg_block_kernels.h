@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ XT
 
 // Weights: 4 int32 per lane per row = 4 / B elements; per element edge count,
 // sum q_r, sum q_r q_s in 64-bit integers.
-template <int B>
+template <int B, int U>
 __global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
                                                 int Np, const int32_t* __restrict__ perm,
                                                 const int32_t* __restrict__ lab_start, int K, int RW,
@@ -190,13 +190,15 @@ __global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, 
       }
     };
     int r = wave;
-    for (; r + 12 < nrows; r += 16) {
-      int i0 = perm[row0 + r], i1 = perm[row0 + r + 4], i2 = perm[row0 + r + 8], i3 = perm[row0 + r + 12];
-      int4 v0 = *reinterpret_cast<const int4*>(X + ((size_t)i0 * Np + col0) * B);
-      int4 v1 = *reinterpret_cast<const int4*>(X + ((size_t)i1 * Np + col0) * B);
-      int4 v2 = *reinterpret_cast<const int4*>(X + ((size_t)i2 * Np + col0) * B);
-      int4 v3 = *reinterpret_cast<const int4*>(X + ((size_t)i3 * Np + col0) * B);
-      accumulate(v0); accumulate(v1); accumulate(v2); accumulate(v3);
+    for (; r + 4 * (U - 1) < nrows; r += 4 * U) {   // U rows in flight per wave
+      int4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int iu = perm[row0 + r + 4 * u];
+        v[u] = *reinterpret_cast<const int4*>(X + ((size_t)iu * Np + col0) * B);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(v[u]);
     }
     for (; r < nrows; r += 4) {
       int i0 = perm[row0 + r];
@@ -433,31 +435,40 @@ struct gg_params_args {
   int32_t* ctl;
   unsigned long long* zero_ptr;   // other statistics buffer (8-byte words) or null
   size_t zero_words;
+  // deferred resample_m of the PREVIOUS sweep (adjacency.py:697-702): drawn here, off the scan's
+  // critical path, before log m is formed
+  int draw_m;
+  uint32_t m_site, m_sweep;
+  const double* pi;
 };
 
+template <bool ADJ, int B>
 __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
   if (g.ctl[4]) return;
-  const int K = g.K, B = g.B, NSI = g.NSI;
-  const int NTAB = g.is_adj ? 1 : 1 + 2 * NSI;
-  const int NT = g.is_adj ? 2 : (1 + B + B * (B + 1) / 2);
+  const int K = g.K;
+  constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
+  constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;
+  constexpr int NT = ADJ ? 2 : (1 + B + B * (B + 1) / 2);
   if (g.zero_ptr) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < g.zero_words; i += stride) g.zero_ptr[i] = 0ull;
   }
-  __shared__ long long s_red[4][1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
-  __shared__ long long s_tab[1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+  __shared__ long long s_red[4][NTAB];
+  __shared__ long long s_tab[NTAB];
   const int t = blockIdx.x;
   if (t < K * K) {
     const int a = t / K, b = t % K;
     if (g.do_tables) {
       const int s0 = g.lab_start[a], s1 = g.lab_start[a + 1];
-      long long acc[1 + 2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+      long long acc[NTAB];
+#pragma unroll
       for (int q = 0; q < NTAB; ++q) acc[q] = 0;
       for (int r = s0 + threadIdx.x; r < s1; r += blockDim.x) {
         int n = g.perm[r];
         acc[0] += g.Gcnt0[(size_t)b * g.Np + n];
-        if (!g.is_adj)
+        if (!ADJ)
+#pragma unroll
           for (int s = 0; s < NSI; ++s) {
             long long v = g.GS0[((size_t)b * g.Np + n) * NSI + s];
             acc[1 + 2 * s] += (v >> 32);
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
           }
         if (g.add_diag && a == b && g.dA[n]) {
           acc[0] += 1;
-          if (!g.is_adj) {
+          if (!ADJ) {
             const int32_t* q = g.dWq + (size_t)n * B;
             int tt = 0;
             for (int r1 = 0; r1 < B; ++r1, ++tt) {
@@ -483,6 +494,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         }
       }
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
       for (int q = 0; q < NTAB; ++q) {
         long long v = gg_wave_sum_ll(acc[q]);
         if (lane == 0) s_red[wave][q] = v;
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
     }
     if (threadIdx.x == 0) {
       double e[GG_MAXNT];
-      if (g.is_adj) {
+      if (ADJ) {
         double pv;
         if (g.do_draw) {
           long long n1 = s_tab[0];
@@ -543,7 +555,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
   } else {
     // last workgroup: the self parameter and log m
     if (threadIdx.x == 0 && g.do_draw) {
-      if (g.is_adj) {
+      if (ADJ) {
         if (g.ah.special) {
           gg_stream s;
           gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_PSELF : GG_SITE_ADJ_PSELF, g.sweep, 0u);
@@ -561,7 +573,24 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         for (int i = 0; i < B * B; ++i) g.sigma_self[i] = so[i];
       }
     }
-    if (g.do_prep && threadIdx.x >= 64 && threadIdx.x < 64 + K) g.logm[threadIdx.x - 64] = gg_log(g.m[threadIdx.x - 64]);
+    __shared__ double s_gam[64];
+    const int kk = (int)threadIdx.x - 64;   // wave 1 handles m, wave 0 the self parameter
+    if (g.draw_m) {
+      if (kk >= 0 && kk < K) s_gam[kk] = gg_dirichlet_gamma_at(g.seed, g.m_site, g.m_sweep, kk, g.pi[kk] + (double)g.cnt[kk]);
+    }
+    __syncthreads();
+    if (kk >= 0 && kk < K) {
+      double mk;
+      if (g.draw_m) {
+        double tot = 0.0;
+        for (int j = 0; j < K; ++j) tot += s_gam[j];
+        mk = s_gam[kk] / tot;
+        g.m[kk] = mk;
+      } else {
+        mk = g.m[kk];
+      }
+      if (g.do_prep) g.logm[kk] = gg_log(mk);
+    }
   }
 }
 
@@ -612,7 +641,8 @@ __device__ __forceinline__ int gg_group_categorical(double lp, int k, int K, int
 // lp[k] of one node (gg_lp.h::gg_block_lp order).  `ld(j, so, si)` supplies the
 // node's out / in statistics towards block j as doubles in spec order.
 template <int NT, bool ADJ, class Loader>
-__device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld) {
+__device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld,
+                                                  const double* __restrict__ Tout, const double* __restrict__ Tin) {
   if (k >= x.K) return -gg_inf();
   const int K = x.K, Kp = x.Kp;
   double acc_o[NT], acc_i[NT];
@@ -623,8 +653,8 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
     ld(j, so, si);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      acc_o[t] = gg_fma(x.Tout[((size_t)j * NT + t) * Kp + k], so[t], acc_o[t]);
-      acc_i[t] = gg_fma(x.Tin[((size_t)j * NT + t) * Kp + k], si[t], acc_i[t]);
+      acc_o[t] = gg_fma(Tout[((size_t)j * NT + t) * Kp + k], so[t], acc_o[t]);
+      acc_i[t] = gg_fma(Tin[((size_t)j * NT + t) * Kp + k], si[t], acc_i[t]);
     }
   }
   double lp = x.logm[k];
@@ -695,24 +725,70 @@ __device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n,
     }
     gg_stats_to_double<NT, ADJ>(x.Gcnt[0][gi], x.Gcnt[1][gi], a, b, cx, sc1, sc2, so, si);
   };
-  return gg_node_lp_core<NT, ADJ>(x, n, k, ld);
+  return gg_node_lp_core<NT, ADJ>(x, n, k, ld, x.Tout, x.Tin);
 }
 
 // Speculative evaluation: every node n >= n_begin draws its label as if no
-// earlier node of this scan changed.  Lane = (node, k): Kp lanes per node.
+// earlier node of this scan changed.  Lane = (node, k): Kp lanes per node, 256 / Kp
+// nodes per workgroup.  The workgroup first stages its nodes' statistics (one
+// coalesced round of loads) and, when they fit, the coefficient tables in LDS:
+// the per-j loop then never waits on global memory.
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
                                                    uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
-                                                   double* __restrict__ lp_out, const int32_t* __restrict__ ctl) {
+                                                   double* __restrict__ lp_out, const int32_t* __restrict__ ctl,
+                                                   int stage_tables) {
   if (ctl && ctl[4]) return;
-  const int per = 256 / x.Kp;
-  const int n = n_begin + blockIdx.x * per + threadIdx.x / x.Kp;
-  const int k = threadIdx.x % x.Kp;
+  constexpr int NSI = ADJ ? 0 : NT - 1;
+  extern __shared__ __align__(16) unsigned char s_spec[];
+  const int K = x.K, Kp = x.Kp;
+  const int per = 256 / Kp;
+  // statistics of the workgroup's nodes, already converted to spec-order doubles: [dir][j][node][NT]
+  double* s_st = reinterpret_cast<double*>(s_spec);
+  double* s_T = s_st + (size_t)2 * K * per * NT;   // Tout | Tin (when staged)
+  const int n0 = n_begin + blockIdx.x * per;
+  const int tid = threadIdx.x;
+  const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  for (int idx = tid; idx < 2 * K * per; idx += 256) {
+    const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
+    const int n = (n0 + i < x.N) ? n0 + i : x.N - 1;
+    const size_t gi = (size_t)j * x.Np + n;
+    const int gc = x.Gcnt[d][gi];
+    double* dst = s_st + (size_t)idx * NT;
+    if (ADJ) {
+      const int cx = x.cnt[j] - (x.c[n] == j ? 1 : 0);
+      dst[0] = (double)gc;
+      dst[1] = (double)(cx - gc);
+    } else {
+      constexpr int B = (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+      dst[0] = (double)gc;
+#pragma unroll
+      for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)x.GS[d][gi * NSI + s] * (s < B ? sc1 : sc2);
+    }
+  }
+  const int ntab = K * NT * Kp;
+  if (stage_tables) {
+    for (int idx = tid; idx < ntab; idx += 256) {
+      s_T[idx] = x.Tout[idx];
+      s_T[ntab + idx] = x.Tin[idx];
+    }
+  }
+  __syncthreads();
+  const int i = tid / Kp, k = tid % Kp;
+  const int n = n0 + i;
   const bool live = n < x.N;
   const int nn = live ? n : x.N - 1;
-  double lp = gg_node_lp_global<NT, ADJ>(x, nn, k);
-  if (lp_out && nn == lp_node && live && k < x.K) lp_out[k] = lp;
+  auto ld = [&](int j, double* so, double* si) {
+    const double* a = s_st + (size_t)((0 * K + j) * per + i) * NT;
+    const double* b = s_st + (size_t)((1 * K + j) * per + i) * NT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { so[t] = a[t]; si[t] = b[t]; }
+  };
+  const double* To = stage_tables ? s_T : x.Tout;
+  const double* Ti = stage_tables ? s_T + ntab : x.Tin;
+  double lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, To, Ti);
+  if (lp_out && nn == lp_node && live && k < K) lp_out[k] = lp;
   double u = gg_uniform_at(seed, site, sweep, (uint32_t)nn);
-  int lab = gg_group_categorical(lp, k, x.K, x.Kp, u);
+  int lab = gg_group_categorical(lp, k, K, Kp, u);
   if (live && k == 0) cand[n] = lab;
 }

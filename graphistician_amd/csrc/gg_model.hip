@@ -6,6 +6,7 @@
 // State lives on the device between calls; the Python classes read it through
 // gg_get_state.  No CPU fallback: every entry point needs a HIP device.
 #include <math.h>
+#include <stdlib.h>
 
 #include "gg_common.h"
 #include "gg_block_kernels.h"
@@ -42,6 +43,8 @@ struct gg_model {
   long long* tab;
   int32_t *rs, *L;   // rs = control block (gg_resolve_kernels.h)
   double* lp_out;
+  bool m_pending;              // resample_m of sweep m_sweep not drawn yet (done by the next k_params or at sync)
+  uint32_t m_sweep;
   int pending;                 // optimistic sweeps enqueued and not yet confirmed
   const gg_data* pend_data;
   // host mirrors / hypers
@@ -52,7 +55,7 @@ struct gg_model {
   int Lmax, CH, max_idle;
   size_t resolve_lds;
   // timing
-  bool timing;
+  int timing;        // 0 = off; n > 0: HIP events around the bulk kernel of every n-th sweep
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   hipEvent_t ev_call0, ev_call1;
@@ -330,10 +333,13 @@ static gg_node_ctx node_ctx(const gg_model* m, const gg_data* d, int buf) {
 // rows per workgroup of the bulk kernel: enough workgroups to fill 256 CUs,
 // at most 1020 rows (SWAR byte counters: 255 rows per wave).
 static int bulk_rw(const gg_model* m, int strips, int ndirs) {
-  long long target_wg = 2048 / ndirs;
-  long long rows_slots = target_wg / (strips > 0 ? strips : 1);
-  if (rows_slots < 1) rows_slots = 1;
-  long long rw = (m->N + rows_slots - 1) / rows_slots;
+  static int override_rw = -1;
+  if (override_rw < 0) { const char* e = getenv("GG_BULK_RW"); override_rw = e ? atoi(e) : 0; }
+  if (override_rw > 0) return override_rw > 1020 ? 1020 : (override_rw + 3) / 4 * 4;
+  (void)strips; (void)ndirs;
+  // measured on MI355X at N=4096 (tools/tune_bulk.py): weights best at 128 rows per workgroup,
+  // adjacency at 64; larger N keeps the same number of row slots per label
+  long long rw = m->is_adj ? m->N / 64 : m->N / 32;
   rw = (rw + 3) / 4 * 4;
   if (rw < 16) rw = 16;
   if (rw > 1020) rw = 1020;
@@ -358,7 +364,7 @@ static int ensure_zero(gg_model* m, int buf) {
 }
 
 // BULK statistics under the current labels into buffer `buf`.  dirs: bit 0 = out (reads X^T), bit 1 = in (reads X).
-static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined) {
+static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined, uint32_t sweep = 0) {
   const int N = m->N, K = m->K, Np = m->Np;
   int rc;
   if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, buf))) return rc;
@@ -366,32 +372,37 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   const int ndirs = (dirs == 3) ? 2 : 1;
   const int32_t* ctl = pipelined ? m->rs : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (m->timing) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
+  const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+  if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
   if (m->is_adj) {
     int strips = (Np + 1023) / 1024;
     int RW = bulk_rw(m, strips, ndirs);
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
     k_bulk_adj<<<grd, 256, 0, m->stream>>>(d->AT, d->A, Np, m->perm, m->lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1),
                                            dir0, ctl);
-    m->st.bulk_bytes += (double)ndirs * N * (double)N;
+    if (timed) m->st.bulk_bytes += (double)ndirs * N * (double)N;
   } else {
     int SC = 64 * (4 / m->B);
     int strips = (Np + SC - 1) / SC;
     int RW = bulk_rw(m, strips, ndirs);
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
-#define BULKW(BV)                                                                                                     \
-  k_bulk_w<BV><<<grd, 256, 0, m->stream>>>(d->WqT, d->Wq, Np, m->perm, m->lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), \
-                                           gs(m, buf, 0), gs(m, buf, 1), dir0, ctl)
+    static int unroll = -1;
+    if (unroll < 0) { const char* e = getenv("GG_BULK_UNROLL"); unroll = e ? atoi(e) : 4; }
+#define BULKW(BV, UV)                                                                                                 \
+  k_bulk_w<BV, UV><<<grd, 256, 0, m->stream>>>(d->WqT, d->Wq, Np, m->perm, m->lab_start, K, RW, gcnt(m, buf, 0),         \
+                                               gcnt(m, buf, 1), gs(m, buf, 0), gs(m, buf, 1), dir0, ctl)
     switch (m->B) {
-      case 1: BULKW(1); break;
-      case 2: BULKW(2); break;
-      case 4: BULKW(4); break;
+      case 1: if (unroll >= 8) BULKW(1, 8); else if (unroll >= 4) BULKW(1, 4); else BULKW(1, 2); break;
+      case 2: BULKW(2, 4); break;
+      case 4: BULKW(4, 4); break;
     }
 #undef BULKW
-    m->st.bulk_bytes += (double)ndirs * N * (double)N * 4.0 * m->B;
+    if (timed) m->st.bulk_bytes += (double)ndirs * N * (double)N * 4.0 * m->B;
   }
-  m->st.bulk_launches += 1;
-  if (m->timing) GG_HIP(hipEventRecord(e1, m->stream));
+  if (timed) {
+    m->st.bulk_launches += 1;
+    GG_HIP(hipEventRecord(e1, m->stream));
+  }
   GG_HIP(hipGetLastError());
   m->zeroed[buf] = false;
   return GG_OK;
@@ -425,25 +436,39 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   g.m = m->m; g.logm = m->logm; g.p = m->p; g.p_self = m->p_self; g.mu = m->mu; g.sigma = m->sigma;
   g.mu_self = m->mu_self; g.sigma_self = m->sigma_self; g.T = m->T; g.Tout = m->Tout; g.Tin = m->Tin;
   g.ctl = m->rs;
+  g.pi = m->pi;
+  if (m->m_pending && prep) {
+    g.draw_m = 1; g.m_site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M; g.m_sweep = m->m_sweep;
+    m->m_pending = false;
+  }
   if (zero_other && !m->zeroed[1 - buf]) {
     g.zero_ptr = reinterpret_cast<unsigned long long*>(m->Gbuf[1 - buf]);
     g.zero_words = m->Gbytes / 8;
     m->zeroed[1 - buf] = true;
   }
-  k_params<<<m->K * m->K + 1, 256, 0, m->stream>>>(g);
+  const int nwg = m->K * m->K + 1;
+  if (m->is_adj) k_params<true, 1><<<nwg, 256, 0, m->stream>>>(g);
+  else if (m->B == 1) k_params<false, 1><<<nwg, 256, 0, m->stream>>>(g);
+  else if (m->B == 2) k_params<false, 2><<<nwg, 256, 0, m->stream>>>(g);
+  else k_params<false, 4><<<nwg, 256, 0, m->stream>>>(g);
   GG_HIP(hipGetLastError());
   return GG_OK;
 }
 
 static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined) {
   gg_node_ctx x = node_ctx(m, d, buf);
-  int per = 256 / m->Kp;
+  const int K = m->K, per = 256 / m->Kp;
   int nb = (m->N - n_begin + per - 1) / per;
   if (nb < 1) nb = 1;
   uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
   double* lpo = lp_node >= 0 ? m->lp_out : nullptr;
   const int32_t* ctl = pipelined ? m->rs : nullptr;
-#define SPEC(NTV, ADJV) k_speculate<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl)
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
+  const size_t tab_bytes = (size_t)2 * K * m->NT * m->Kp * sizeof(double);
+  const int stage = (lds + tab_bytes <= 48 * 1024) ? 1 : 0;
+  if (stage) lds += tab_bytes;
+#define SPEC(NTV, ADJV) \
+  k_speculate<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl, stage)
   if (m->is_adj) SPEC(2, true);
   else if (m->B == 1) SPEC(3, false);
   else if (m->B == 2) SPEC(6, false);
@@ -535,12 +560,14 @@ static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
   if (!learn_params) return GG_OK;
   const bool scan = m->sbm && m->K > 1;
   const int buf = m->cur;
-  if ((rc = enqueue_bulk(m, d, buf, scan ? 3 : 1, true))) return rc;
+  if ((rc = enqueue_bulk(m, d, buf, scan ? 3 : 1, true, sweep))) return rc;
   if ((rc = enqueue_params(m, d, buf, true, true, scan, true, sweep))) return rc;
   if (scan) {
     if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
-    if ((rc = launch_resolve(m, d, buf, sweep, true, true))) return rc;
+    if ((rc = launch_resolve(m, d, buf, sweep, false, true))) return rc;
     m->st.resolve_rounds += 1;
+    m->m_pending = true;   // drawn by the next sweep's k_params (or by flush_m at the next sync)
+    m->m_sweep = sweep;
   } else if (m->sbm) {
     // K == 1 SBM: resample_c returns early (adjacency.py:657-658) but m is still drawn
     k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
@@ -595,7 +622,9 @@ static int model_sync(gg_model* m) {
     // the pipeline advanced m->cur once per enqueued sweep; the stalled sweep used this buffer:
     int buf_stalled = (m->cur + m->pending - done) & 1;   // cur - (pending - done) mod 2
     uint32_t sw = m->sweep + (uint32_t)done;
-    if ((rc = finish_scan(m, d, buf_stalled, sw, true, true))) return rc;
+    if ((rc = finish_scan(m, d, buf_stalled, sw, false, true))) return rc;
+    m->m_pending = true;
+    m->m_sweep = sw;
     m->sweep += (uint32_t)(done + 1);
     m->st.sweeps += (uint64_t)(done + 1);
     m->pending = 0;
@@ -611,6 +640,12 @@ static int model_sync(gg_model* m) {
     GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   }
   m->pending = 0;
+  if (m->m_pending) {
+    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+                                                        m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m);
+    GG_HIP(hipGetLastError());
+    m->m_pending = false;
+  }
   if (scan) {
     if ((rc = write_ctl_word(m, 5, 0))) return rc;
     if ((rc = read_ctl(m))) return rc;
@@ -624,7 +659,7 @@ extern "C" {
 
 int gg_set_timing(gg_model* m, int32_t on) {
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
-  m->timing = on != 0;
+  m->timing = on < 0 ? 0 : on;
   return GG_OK;
 }
 
@@ -819,6 +854,36 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
     }
   }
   *out = ll;
+  return GG_OK;
+}
+
+// Microbenchmark of the bulk statistics kernel alone (both directions, current labels): average
+// device time per launch over `reps` launches, measured with HIP events on the model's stream.
+int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_launch, double* bytes_per_launch) {
+  if (!m || !ms_per_launch) return gg_fail(GG_ERR_INVALID, "gg_bench_bulk: null argument");
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "gg_bench_bulk: block models only");
+  int rc = model_sync(m);
+  if (rc) return rc;
+  if ((rc = check_data(m, d))) return rc;
+  const int t0 = m->timing;
+  m->timing = 0;
+  const int buf = m->cur;
+  if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;  // warm-up
+  GG_HIP(hipEventRecord(m->ev_call0, m->stream));
+  for (int r = 0; r < reps; ++r) {
+    m->zeroed[buf] = true;  // accumulate on top: contents are irrelevant here
+    if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;
+  }
+  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  GG_HIP(hipEventSynchronize(m->ev_call1));
+  float ms = 0;
+  GG_HIP(hipEventElapsedTime(&ms, m->ev_call0, m->ev_call1));
+  *ms_per_launch = ms / (reps > 0 ? reps : 1);
+  if (bytes_per_launch) *bytes_per_launch = 2.0 * m->N * (double)m->N * (m->is_adj ? 1.0 : 4.0 * m->B);
+  m->zeroed[buf] = false;
+  m->timing = t0;
+  m->st.bulk_bytes = 0; m->st.bulk_launches = 0;
   return GG_OK;
 }
 

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
         const long long* b = ADJ ? nullptr : &s_gs[((size_t)(1 * CH + ii) * K + j) * NSI];
         gg_stats_to_double<NT, ADJ>(s_gc[(0 * CH + ii) * K + j], s_gc[(1 * CH + ii) * K + j], a, b, cx, sc1, sc2, so, si);
       };
-      double lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld);
+      double lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, x.Tout, x.Tin);
       double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)n);
       int lab = gg_group_categorical(lp, k, K, Kp, u);
       if (active && k == 0 && lab != cn) {

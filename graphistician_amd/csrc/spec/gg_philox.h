@@ -82,8 +82,8 @@ GG_HD double gg_uniform_at(uint64_t seed, uint32_t site, uint32_t sweep, uint32_
 struct gg_stream {
   uint32_t k0, k1;
   uint32_t c0, c1, c2, c3;
-  uint32_t buf[4];
-  int have;
+  uint32_t w2, w3;   // second half of the last Philox block
+  int have;          // 1: (w2, w3) not consumed yet
 };
 
 GG_HD void gg_stream_init(gg_stream* s, uint64_t seed, uint32_t site, uint32_t sweep, uint32_t index) {
@@ -91,25 +91,20 @@ GG_HD void gg_stream_init(gg_stream* s, uint64_t seed, uint32_t site, uint32_t s
   s->k1 = (uint32_t)(seed >> 32);
   s->c0 = 0u; s->c1 = index; s->c2 = sweep; s->c3 = site;
   s->have = 0;
-  s->buf[0] = s->buf[1] = s->buf[2] = s->buf[3] = 0u;
+  s->w2 = s->w3 = 0u;
 }
 
-GG_HD uint32_t gg_stream_u32(gg_stream* s) {
-  if (s->have == 0) {
-    gg_u32x4 r = gg_philox4x32_10(s->c0, s->c1, s->c2, s->c3, s->k0, s->k1);
-    s->buf[0] = r.v[0]; s->buf[1] = r.v[1]; s->buf[2] = r.v[2]; s->buf[3] = r.v[3];
-    s->c0 += 1u;
-    s->have = 4;
-  }
-  uint32_t w = s->buf[4 - s->have];
-  s->have -= 1;
-  return w;
-}
-
+// Words are consumed in pairs: block b yields uniforms (w0,w1) then (w2,w3).
 GG_HD double gg_stream_uniform(gg_stream* s) {
-  uint32_t a = gg_stream_u32(s);
-  uint32_t b = gg_stream_u32(s);
-  return gg_u53(a, b);
+  if (s->have) {
+    s->have = 0;
+    return gg_u53(s->w2, s->w3);
+  }
+  gg_u32x4 r = gg_philox4x32_10(s->c0, s->c1, s->c2, s->c3, s->k0, s->k1);
+  s->c0 += 1u;
+  s->w2 = r.v[2]; s->w3 = r.v[3];
+  s->have = 1;
+  return gg_u53(r.v[0], r.v[1]);
 }
 
 // Uniform in (0,1): never returns 0 (safe under log).

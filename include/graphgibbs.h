@@ -160,7 +160,10 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out);
 int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp);
 
 int gg_last_stats(gg_model* m, gg_stats* out);
-/* Record HIP events around the bulk kernels (on the engine stream) so that gg_last_stats reports their device time. */
+/* Device time of the bulk statistics kernel alone (HIP events on the engine stream), for the roofline line. */
+int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_launch, double* bytes_per_launch);
+/* on = n > 0: record HIP events (on the engine stream) around the bulk kernel of every n-th sweep, so that
+ * gg_last_stats reports bulk_ms / bulk_launches / bulk_bytes for the sampled launches; 0 = off. */
 int gg_set_timing(gg_model* m, int32_t on);
 
 /* Device self-test of the shared arithmetic spec: evaluates exp/log/sqrt/div

@@ -1,0 +1,32 @@
+"""World-size-2 gloo test (CPU) of bench.py's N>1 protocol: one process per rank launched by
+torch.distributed.run, rendezvous on 127.0.0.1, barrier on both sides of the timed region,
+MAX over ranks of the elapsed time, whole-job value on rank 0 only."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_gloo():
+    env = dict(os.environ, GG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--dry-run"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0: %r" % out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "weak"
+    assert r["elapsed_s"] >= 0.04            # rank 1 sleeps 40 ms: the max over ranks, not rank 0's 20 ms
+    assert abs(r["value"] - 2 * 4 / r["elapsed_s"]) < 1e-6 * r["value"]
+
+
+def test_bench_single_process_dry_run():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["steps"] == 3
