@@ -1,17 +1,588 @@
-// gg_eigen.hip — logistic eigenmodel Gibbs (eigenmodel.py:822-965).  Placeholder
-// until the PG(1,z) / latent-feature kernels land: every entry point reports
-// GG_ERR_UNSUPPORTED (no CPU fallback).
-#include "gg_common.h"
+// gg_eigen.hip — logistic eigenmodel Gibbs sweep on gfx950
+// (reference graphistician/eigenmodel.py:822-965).
+//
+//   resample = _resample_Omega -> _resample_F -> _resample_mu_0 -> _resample_lmbda  (eigenmodel.py:836-857)
+//
+// Design:
+//  * Omega enters every conditional only through S = Omega + Omega^T (off-diagonal)
+//    and its diagonal: eigenmodel.py:898-901 uses O[n,nn] + O[nn,n] and
+//    O zcent = kappa - O mu_0; :948-958 likewise; :918-925 sums.  The engine
+//    therefore draws omega_ij and omega_ji in the same thread and stores only the
+//    symmetric S (fp64, N x Np) plus the diagonal: one N^2 write, row reads only.
+//  * The latent-feature scan is sequential in n (eigenmodel.py:884,908).  It is
+//    tiled: for a tile of T nodes the Gram statistics against F at tile start are
+//    computed chip-wide (k_eig_tile_stats), then one workgroup walks the tile,
+//    correcting each node's statistics by the rank-one changes of the tile's
+//    earlier nodes (LDS-resident T x T sub-block of S) and drawing F[n] by a D x D
+//    Cholesky.  Floating-point sums are ordered differently from the reference's
+//    double loop: parity is a float tolerance (north_star), not bit-exact.
+//  * All normals of a sweep are pre-drawn in parallel (counter-based RNG).
+#include <math.h>
 
-struct gg_eigen { int dummy; };
+#include "gg_common.h"
+#include "spec/gg_pg.h"
+
+#define EIG_T 64          // nodes per tile of the F scan
+#define EIG_CHN 1024      // neighbours per workgroup in k_eig_tile_stats
+
+struct gg_eigen {
+  gg_config cfg;
+  int N, D, Np, DM;
+  int NEG, NE, NG;        // D(D+1)/2, NEG + D, 2 + 2D + NEG
+  int NCH;
+  double *F, *lmbda, *mu0, *mu_lmbda;
+  double *S, *dO, *Z;
+  double *part, *gpart, *llpart;
+  int* status;
+  hipStream_t stream;
+  uint32_t sweep;
+  bool have_omega;
+  hipEvent_t e0, e1;
+  gg_stats st;
+};
+
+// ------------------------------------------------------------------ kernels
+__global__ void k_eig_normals(double* Z, int n, uint64_t seed, uint32_t site, uint32_t sweep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) Z[i] = gg_normal_at(seed, site, sweep, (uint32_t)i);
+}
+
+__device__ __forceinline__ void eig_tile_pair(int b, int nt, int* I, int* J) {
+  // b-th pair (I <= J) in row-major order of the upper triangle
+  int i = 0, rem = b;
+  while (rem >= nt - i) { rem -= nt - i; ++i; }
+  *I = i; *J = i + rem;
+}
+
+// eigenmodel.py:859-874: omega_ij ~ PG(1, psi_ij), psi = mu_0 + (F lambda) F^T, diag psi = mu_0 (:81-82).
+template <int DM>
+__global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const double* __restrict__ F,
+                                                   const double* __restrict__ lmbda, const double* __restrict__ mu0p,
+                                                   uint64_t seed, uint32_t sweep, double* __restrict__ S,
+                                                   double* __restrict__ dO) {
+  __shared__ double s_fi[32][DM], s_fj[32][DM];
+  __shared__ double s_t[32][33];
+  const int nt = (N + 31) / 32;
+  int I, J;
+  eig_tile_pair(blockIdx.x, nt, &I, &J);
+  const int tid = threadIdx.x;
+  const double mu0 = *mu0p;
+  for (int e = tid; e < 32 * DM; e += 256) {
+    int r = e / DM, d = e % DM;
+    int gi = I * 32 + r, gj = J * 32 + r;
+    s_fi[r][d] = (d < D && gi < N) ? F[(size_t)gi * D + d] * lmbda[d] : 0.0;
+    s_fj[r][d] = (d < D && gj < N) ? F[(size_t)gj * D + d] : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256) {
+    const int li = e >> 5, lj = e & 31;
+    const int gi = I * 32 + li, gj = J * 32 + lj;
+    double val = 0.0;
+    if (gi < N && gj < N) {
+      if (I == J && li == lj) {
+        dO[gi] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gi, mu0);
+      } else if (I < J || li < lj) {
+        double psi = mu0;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) psi += s_fi[li][d] * s_fj[lj][d];
+        double o1 = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gj, psi);
+        double o2 = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gj, (uint32_t)gi, psi);
+        val = o1 + o2;
+      }
+    }
+    if (I < J || li <= lj) s_t[li][lj] = val;
+  }
+  __syncthreads();
+  if (I == J) {
+    for (int e = tid; e < 1024; e += 256) {
+      const int li = e >> 5, lj = e & 31;
+      if (li > lj) s_t[li][lj] = s_t[lj][li];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 1024; e += 256) {
+    const int li = e >> 5, lj = e & 31;
+    const int gi = I * 32 + li, gj = J * 32 + lj;
+    if (gi < N && gj < N) S[(size_t)gi * Np + gj] = s_t[li][lj];
+  }
+  if (I < J) {
+    for (int e = tid; e < 1024; e += 256) {
+      const int lj = e >> 5, li = e & 31;   // transposed tile, coalesced over li
+      const int gi = I * 32 + li, gj = J * 32 + lj;
+      if (gi < N && gj < N) S[(size_t)gj * Np + gi] = s_t[li][lj];
+    }
+  }
+}
+
+// Gram statistics of the tile's nodes against the current F (eigenmodel.py:894-901):
+//   G_n[a,b] = sum_{nn != n} S[n,nn] ft_a ft_b,  h_n[a] = sum_{nn != n} ((A[n,nn]+A[nn,n]-1) - mu_0 S[n,nn]) ft_a,
+// ft = F[nn] * lambda.  One workgroup per (node, chunk of EIG_CHN neighbours).
+template <int DM>
+__global__ __launch_bounds__(256) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
+                                                        const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                        const double* __restrict__ F, const double* __restrict__ lmbda,
+                                                        const double* __restrict__ mu0p, int NCH,
+                                                        double* __restrict__ part) {
+  constexpr int NEGM = DM * (DM + 1) / 2;
+  const int n = t0 + blockIdx.x;
+  if (n >= N) return;
+  const int c = blockIdx.y;
+  const double mu0 = *mu0p;
+  double g[NEGM], h[DM], lam[DM];
+#pragma unroll
+  for (int e = 0; e < NEGM; ++e) g[e] = 0.0;
+#pragma unroll
+  for (int d = 0; d < DM; ++d) { h[d] = 0.0; lam[d] = d < D ? lmbda[d] : 0.0; }
+  const int lo = c * EIG_CHN, hi = (lo + EIG_CHN < N) ? lo + EIG_CHN : N;
+  for (int nn = lo + threadIdx.x; nn < hi; nn += 256) {
+    if (nn == n) continue;
+    const double s = S[(size_t)n * Np + nn];
+    const double a = (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
+    const double v = a - mu0 * s;
+    double ft[DM];
+#pragma unroll
+    for (int d = 0; d < DM; ++d) ft[d] = d < D ? F[(size_t)nn * D + d] * lam[d] : 0.0;
+    int e = 0;
+#pragma unroll
+    for (int a1 = 0; a1 < DM; ++a1) {
+      const double sa = s * ft[a1];
+#pragma unroll
+      for (int b1 = a1; b1 < DM; ++b1) g[e++] += sa * ft[b1];
+      h[a1] += v * ft[a1];
+    }
+  }
+  __shared__ double s_red[4][NEGM + DM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < NEGM + DM; ++e) {
+    double v = e < NEGM ? g[e] : h[e - NEGM];
+    for (int dl = 32; dl >= 1; dl >>= 1) v += __shfl_down(v, dl);
+    if (lane == 0) s_red[wave][e] = v;
+  }
+  __syncthreads();
+  // compact layout: entries of the D x D upper triangle then h, D-dependent
+  const int NEG = D * (D + 1) / 2;
+  if (threadIdx.x < NEGM + DM) {
+    const int e = threadIdx.x;
+    double v = (s_red[0][e] + s_red[1][e]) + (s_red[2][e] + s_red[3][e]);
+    // map padded index -> compact index
+    int out = -1;
+    if (e < NEGM) {
+      int a1 = 0, rem = e;
+      while (rem >= DM - a1) { rem -= DM - a1; ++a1; }
+      int b1 = a1 + rem;
+      if (b1 < D) out = a1 * D - a1 * (a1 - 1) / 2 + (b1 - a1);
+    } else if (e - NEGM < D) {
+      out = NEG + (e - NEGM);
+    }
+    if (out >= 0) part[((size_t)blockIdx.x * NCH + c) * (NEG + D) + out] = v;
+  }
+}
+
+// The sequential part of _resample_F for one tile (eigenmodel.py:884-908), one workgroup.
+template <int DM>
+__global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0, const double* __restrict__ S,
+                                                   const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                   double* __restrict__ F, const double* __restrict__ lmbda,
+                                                   const double* __restrict__ mu0p, double sigma_F, int NCH,
+                                                   const double* __restrict__ part, const double* __restrict__ Z,
+                                                   int* __restrict__ status) {
+  constexpr int NEGM = DM * (DM + 1) / 2;
+  __shared__ double s_S[EIG_T][EIG_T + 1];
+  __shared__ signed char s_a[EIG_T][EIG_T];
+  __shared__ double s_dP[EIG_T][NEGM];
+  __shared__ double s_dF[EIG_T][DM];
+  __shared__ double s_stat[NEGM + DM];
+  const int tid = threadIdx.x;
+  const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
+  const int NEG = D * (D + 1) / 2, NE = NEG + D;
+  const double mu0 = *mu0p;
+  for (int e = tid; e < T * T; e += 256) {
+    int i = e / T, j = e % T;
+    s_S[i][j] = S[(size_t)(t0 + i) * Np + t0 + j];
+    s_a[i][j] = (signed char)((int)A[(size_t)(t0 + i) * Np + t0 + j] + (int)AT[(size_t)(t0 + i) * Np + t0 + j] - 1);
+  }
+  __syncthreads();
+  for (int nl = 0; nl < T; ++nl) {
+    const int n = t0 + nl;
+    if (tid < NE) {
+      double acc = 0.0;
+      for (int c = 0; c < NCH; ++c) acc += part[((size_t)nl * NCH + c) * NE + tid];
+      if (tid < NEG) {
+        for (int n2 = 0; n2 < nl; ++n2) acc += s_S[nl][n2] * s_dP[n2][tid];
+      } else {
+        const int a1 = tid - NEG;
+        for (int n2 = 0; n2 < nl; ++n2) acc += ((double)s_a[nl][n2] - mu0 * s_S[nl][n2]) * s_dF[n2][a1];
+      }
+      s_stat[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double prec[GG_MAXD * GG_MAXD], h[GG_MAXD], z[GG_MAXD], x[GG_MAXD];
+      int e = 0;
+      for (int a1 = 0; a1 < D; ++a1)
+        for (int b1 = a1; b1 < D; ++b1) {
+          double v = s_stat[e++];
+          if (a1 == b1) v += 1.0 / sigma_F;
+          prec[a1 * D + b1] = v;
+          prec[b1 * D + a1] = v;
+        }
+      for (int a1 = 0; a1 < D; ++a1) { h[a1] = s_stat[NEG + a1]; z[a1] = Z[(size_t)n * D + a1]; }
+      if (gg_gauss_from_precision(prec, h, z, D, x)) {
+        atomicOr(status, 1);
+        for (int a1 = 0; a1 < D; ++a1) x[a1] = F[(size_t)n * D + a1];
+      }
+      // rank-one change of this node's outer product, seen by the later nodes of the tile
+      e = 0;
+      for (int a1 = 0; a1 < D; ++a1) {
+        const double fo = F[(size_t)n * D + a1] * lmbda[a1], fn = x[a1] * lmbda[a1];
+        s_dF[nl][a1] = fn - fo;
+        for (int b1 = a1; b1 < D; ++b1) {
+          const double go = F[(size_t)n * D + b1] * lmbda[b1], gn = x[b1] * lmbda[b1];
+          s_dP[nl][e++] = fn * gn - fo * go;
+        }
+      }
+      for (int a1 = 0; a1 < D; ++a1) F[(size_t)n * D + a1] = x[a1];
+    }
+    __syncthreads();
+  }
+}
+
+// Statistics of _resample_mu_0 (eigenmodel.py:914-925) and _resample_lmbda (:938-958) over pairs i < j:
+//   [0] sum S_ij   [1] sum (A_ij + A_ji - 1)   [2..2+D) sum S g   [2+D..2+2D) sum a g   then upper triangle of sum S g g^T,
+// g = F_i * F_j (elementwise).  One workgroup per row i; partials reduced in k_eig_draw_globals.
+template <int DM>
+__global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const double* __restrict__ S,
+                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                    const double* __restrict__ F, double* __restrict__ gpart) {
+  constexpr int NEGM = DM * (DM + 1) / 2;
+  constexpr int NGM = 2 + 2 * DM + NEGM;
+  const int i = blockIdx.x;
+  double acc[NGM];
+#pragma unroll
+  for (int e = 0; e < NGM; ++e) acc[e] = 0.0;
+  double fi[DM];
+#pragma unroll
+  for (int d = 0; d < DM; ++d) fi[d] = d < D ? F[(size_t)i * D + d] : 0.0;
+  for (int j = i + 1 + threadIdx.x; j < N; j += 256) {
+    const double s = S[(size_t)i * Np + j];
+    const double a = (double)((int)A[(size_t)i * Np + j] + (int)AT[(size_t)i * Np + j] - 1);
+    double g[DM];
+#pragma unroll
+    for (int d = 0; d < DM; ++d) g[d] = d < D ? fi[d] * F[(size_t)j * D + d] : 0.0;
+    acc[0] += s;
+    acc[1] += a;
+    int e = 2 + 2 * DM;
+#pragma unroll
+    for (int a1 = 0; a1 < DM; ++a1) {
+      const double sg = s * g[a1];
+      acc[2 + a1] += sg;
+      acc[2 + DM + a1] += a * g[a1];
+#pragma unroll
+      for (int b1 = a1; b1 < DM; ++b1) acc[e++] += sg * g[b1];
+    }
+  }
+  __shared__ double s_red[4][NGM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < NGM; ++e) {
+    double v = acc[e];
+    for (int dl = 32; dl >= 1; dl >>= 1) v += __shfl_down(v, dl);
+    if (lane == 0) s_red[wave][e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NGM) {
+    const int e = threadIdx.x;
+    gpart[(size_t)i * NGM + e] = (s_red[0][e] + s_red[1][e]) + (s_red[2][e] + s_red[3][e]);
+  }
+}
+
+template <int DM>
+__global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int D, const double* __restrict__ gpart,
+                                                          const double* __restrict__ dO, const uint8_t* __restrict__ dA,
+                                                          double* __restrict__ lmbda, double* __restrict__ mu0p,
+                                                          const double* __restrict__ mu_lmbda, double mu_mu_0,
+                                                          double sigma_mu0, double sigma_lmbda, int do_mu0, int do_lmbda,
+                                                          uint64_t seed, uint32_t sweep, int* __restrict__ status) {
+  constexpr int NEGM = DM * (DM + 1) / 2;
+  constexpr int NGM = 2 + 2 * DM + NEGM;
+  __shared__ double s_tot[NGM + 2];
+  __shared__ double s_w[4][2];
+  const int tid = threadIdx.x;
+  if (tid < NGM) {
+    double v = 0.0;
+    for (int i = 0; i < N; ++i) v += gpart[(size_t)i * NGM + tid];   // fixed order
+    s_tot[tid] = v;
+  }
+  // diagonal: sum omega_ii and sum (A_ii - 1/2)
+  double so = 0.0, sk = 0.0;
+  for (int i = tid; i < N; i += 256) { so += dO[i]; sk += (dA[i] ? 1.0 : 0.0) - 0.5; }
+  for (int dl = 32; dl >= 1; dl >>= 1) { so += __shfl_down(so, dl); sk += __shfl_down(sk, dl); }
+  if ((tid & 63) == 0) { s_w[tid >> 6][0] = so; s_w[tid >> 6][1] = sk; }
+  __syncthreads();
+  if (tid == 0) {
+    const double sumO_diag = (s_w[0][0] + s_w[1][0]) + (s_w[2][0] + s_w[3][0]);
+    const double sumK_diag = (s_w[0][1] + s_w[1][1]) + (s_w[2][1] + s_w[3][1]);
+    double mu0 = *mu0p;
+    if (do_mu0) {
+      // eigenmodel.py:914-932
+      double prec = 1.0 / sigma_mu0 + s_tot[0] + sumO_diag;
+      double spsi = 0.0;
+      for (int d = 0; d < D; ++d) spsi += lmbda[d] * s_tot[2 + d];
+      double h = mu_mu_0 / sigma_mu0 + (s_tot[1] + sumK_diag) - spsi;
+      const double var = 1.0 / prec;
+      mu0 = var * h + gg_sqrt(var) * gg_normal_at(seed, GG_SITE_EIG_MU0, sweep, 0u);
+      *mu0p = mu0;
+    }
+    if (do_lmbda) {
+      // eigenmodel.py:938-965
+      double prec[GG_MAXD * GG_MAXD], h[GG_MAXD], z[GG_MAXD], x[GG_MAXD];
+      int e = 2 + 2 * DM;
+      for (int a1 = 0; a1 < DM; ++a1)
+        for (int b1 = a1; b1 < DM; ++b1) {
+          double v = s_tot[e++];
+          if (a1 < D && b1 < D) {
+            if (a1 == b1) v += 1.0 / sigma_lmbda;
+            prec[a1 * D + b1] = v;
+            prec[b1 * D + a1] = v;
+          }
+        }
+      for (int a1 = 0; a1 < D; ++a1) {
+        h[a1] = mu_lmbda[a1] / sigma_lmbda + s_tot[2 + DM + a1] - mu0 * s_tot[2 + a1];
+        z[a1] = gg_normal_at(seed, GG_SITE_EIG_LMBDA, sweep, (uint32_t)a1);
+      }
+      if (gg_gauss_from_precision(prec, h, z, D, x)) atomicOr(status, 1);
+      else
+        for (int a1 = 0; a1 < D; ++a1) lmbda[a1] = x[a1];
+    }
+  }
+}
+
+// eigenmodel.py:110-129 with P = clip(logistic(Mu), 1e-16, 1-1e-16) (:803-811): one partial per 32 x 32 tile.
+template <int DM>
+__global__ __launch_bounds__(256) void k_eig_loglik(int N, int Np, int D, const uint8_t* __restrict__ A,
+                                                    const uint8_t* __restrict__ dA, const double* __restrict__ F,
+                                                    const double* __restrict__ lmbda, const double* __restrict__ mu0p,
+                                                    double* __restrict__ llpart) {
+  __shared__ double s_fi[32][DM], s_fj[32][DM];
+  __shared__ double s_w[4];
+  const int I = blockIdx.y, J = blockIdx.x, tid = threadIdx.x;
+  const double mu0 = *mu0p;
+  for (int e = tid; e < 32 * DM; e += 256) {
+    int r = e / DM, d = e % DM;
+    int gi = I * 32 + r, gj = J * 32 + r;
+    s_fi[r][d] = (d < D && gi < N) ? F[(size_t)gi * D + d] * lmbda[d] : 0.0;
+    s_fj[r][d] = (d < D && gj < N) ? F[(size_t)gj * D + d] : 0.0;
+  }
+  __syncthreads();
+  double ll = 0.0;
+  for (int e = tid; e < 1024; e += 256) {
+    const int li = e >> 5, lj = e & 31;
+    const int gi = I * 32 + li, gj = J * 32 + lj;
+    if (gi < N && gj < N) {
+      double psi = mu0;
+      int a;
+      if (gi == gj) {
+        a = dA[gi];
+      } else {
+#pragma unroll
+        for (int d = 0; d < DM; ++d) psi += s_fi[li][d] * s_fj[lj][d];
+        a = A[(size_t)gi * Np + gj];
+      }
+      double P = 1.0 / (1.0 + gg_exp(-psi));
+      P = P < 1e-16 ? 1e-16 : (P > 1.0 - 1e-16 ? 1.0 - 1e-16 : P);
+      ll += a ? gg_log(P) : gg_log(1.0 - P);
+    }
+  }
+  for (int dl = 32; dl >= 1; dl >>= 1) ll += __shfl_down(ll, dl);
+  if ((tid & 63) == 0) s_w[tid >> 6] = ll;
+  __syncthreads();
+  if (tid == 0) llpart[(size_t)I * gridDim.x + J] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// ------------------------------------------------------------------ host
+template <typename T>
+static int emalloc(T** p, size_t n) {
+  GG_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  GG_HIP(hipMemset(*p, 0, n * sizeof(T)));
+  return GG_OK;
+}
 
 int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
-  (void)out; (void)cfg;
-  return gg_fail(GG_ERR_UNSUPPORTED, "logistic eigenmodel: not implemented in this build");
+  if (cfg->N <= 0 || cfg->D < 1 || cfg->D > 8)
+    return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: need N > 0 and 1 <= D <= 8 (got N=%d D=%d)", cfg->N, cfg->D);
+  if ((long long)cfg->N * cfg->N >= (1LL << 32) + 1)
+    return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: N*N must fit the 32-bit Philox index");
+  gg_eigen* e = new gg_eigen();
+  e->cfg = *cfg;
+  e->N = cfg->N; e->D = cfg->D; e->Np = gg_round_up(cfg->N, 64);
+  e->DM = cfg->D <= 4 ? 4 : 8;
+  e->NEG = e->D * (e->D + 1) / 2; e->NE = e->NEG + e->D;
+  e->NG = 2 + 2 * e->DM + e->DM * (e->DM + 1) / 2;
+  e->NCH = (e->N + EIG_CHN - 1) / EIG_CHN;
+  int rc;
+  GG_HIP(hipStreamCreate(&e->stream));
+  GG_HIP(hipEventCreate(&e->e0));
+  GG_HIP(hipEventCreate(&e->e1));
+  const size_t N = e->N, D = e->D;
+  if ((rc = emalloc(&e->F, N * D)) || (rc = emalloc(&e->lmbda, D)) || (rc = emalloc(&e->mu0, 1)) ||
+      (rc = emalloc(&e->mu_lmbda, D)) || (rc = emalloc(&e->S, N * e->Np)) || (rc = emalloc(&e->dO, N)) ||
+      (rc = emalloc(&e->Z, N * D)) || (rc = emalloc(&e->part, (size_t)EIG_T * e->NCH * e->NE)) ||
+      (rc = emalloc(&e->gpart, N * e->NG)) || (rc = emalloc(&e->status, 1)))
+    return rc;
+  const size_t nt = (N + 31) / 32;
+  if ((rc = emalloc(&e->llpart, nt * nt))) return rc;
+  *out = e;
+  return GG_OK;
 }
-int gg_eigen_destroy(gg_eigen* e) { delete e; return GG_OK; }
-int gg_eigen_set_state(gg_eigen*, int, const void*, size_t) { return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel"); }
-int gg_eigen_get_state(gg_eigen*, int, void*, size_t) { return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel"); }
-int gg_eigen_resample(gg_eigen*, const gg_data*, int) { return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel"); }
-int gg_eigen_log_likelihood(gg_eigen*, const gg_data*, double*) { return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel"); }
-int gg_eigen_stats(gg_eigen*, gg_stats*) { return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel"); }
+
+int gg_eigen_destroy(gg_eigen* e) {
+  if (!e) return GG_OK;
+  void* ptrs[] = {e->F, e->lmbda, e->mu0, e->mu_lmbda, e->S, e->dO, e->Z, e->part, e->gpart, e->llpart, e->status};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (e->e0) (void)hipEventDestroy(e->e0);
+  if (e->e1) (void)hipEventDestroy(e->e1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return GG_OK;
+}
+
+static int eig_state_ptr(gg_eigen* e, int id, void** p, size_t* nbytes) {
+  *p = nullptr;
+  switch (id) {
+    case GG_ST_F: *p = e->F; *nbytes = (size_t)e->N * e->D * 8; break;
+    case GG_ST_LMBDA: *p = e->lmbda; *nbytes = (size_t)e->D * 8; break;
+    case GG_ST_MU0: *p = e->mu0; *nbytes = 8; break;
+    case GG_ST_MU_LMBDA: *p = e->mu_lmbda; *nbytes = (size_t)e->D * 8; break;
+    default: break;
+  }
+  return *p ? GG_OK : GG_ERR_INVALID;
+}
+
+int gg_eigen_set_state(gg_eigen* e, int id, const void* buf, size_t nbytes) {
+  if (id == GG_ST_SWEEP) {
+    if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
+    e->sweep = *(const uint32_t*)buf;
+    return GG_OK;
+  }
+  void* p; size_t need;
+  if (eig_state_ptr(e, id, &p, &need)) return gg_fail(GG_ERR_INVALID, "state id %d not valid for the eigenmodel", id);
+  if (nbytes != need) return gg_fail(GG_ERR_INVALID, "state id %d: expected %zu bytes, got %zu", id, need, nbytes);
+  GG_HIP(hipMemcpyAsync(p, buf, nbytes, hipMemcpyHostToDevice, e->stream));
+  GG_HIP(hipStreamSynchronize(e->stream));
+  return GG_OK;
+}
+
+int gg_eigen_get_state(gg_eigen* e, int id, void* buf, size_t nbytes) {
+  if (id == GG_ST_SWEEP) {
+    if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
+    *(uint32_t*)buf = e->sweep;
+    return GG_OK;
+  }
+  if (id == GG_ST_OMEGA_S) {
+    // symmetrised auxiliary variables: off-diagonal omega_ij + omega_ji, diagonal omega_ii
+    const size_t N = e->N;
+    if (nbytes != N * N * 8) return gg_fail(GG_ERR_INVALID, "GG_ST_OMEGA_S expects N*N doubles");
+    std::vector<double> hS(N * e->Np), hd(N);
+    GG_HIP(hipMemcpy(hS.data(), e->S, hS.size() * 8, hipMemcpyDeviceToHost));
+    GG_HIP(hipMemcpy(hd.data(), e->dO, N * 8, hipMemcpyDeviceToHost));
+    double* o = (double*)buf;
+    for (size_t i = 0; i < N; ++i)
+      for (size_t j = 0; j < N; ++j) o[i * N + j] = (i == j) ? hd[i] : hS[i * e->Np + j];
+    return GG_OK;
+  }
+  void* p; size_t need;
+  if (eig_state_ptr(e, id, &p, &need)) return gg_fail(GG_ERR_INVALID, "state id %d not valid for the eigenmodel", id);
+  if (nbytes != need) return gg_fail(GG_ERR_INVALID, "state id %d: expected %zu bytes, got %zu", id, need, nbytes);
+  GG_HIP(hipMemcpyAsync(buf, p, nbytes, hipMemcpyDeviceToHost, e->stream));
+  GG_HIP(hipStreamSynchronize(e->stream));
+  return GG_OK;
+}
+
+#define EIG_DISPATCH(CALL)                 \
+  do {                                     \
+    if (e->DM == 4) { CALL(4); }           \
+    else { CALL(8); }                      \
+  } while (0)
+
+int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
+  if (!d) return gg_fail(GG_ERR_INVALID, "null data handle");
+  if (d->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, e->N);
+  const int N = e->N, D = e->D, Np = e->Np;
+  hipStream_t st = e->stream;
+  GG_HIP(hipEventRecord(e->e0, st));
+  const bool full = (parts & (GG_PART_OMEGA | GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) ==
+                    (GG_PART_OMEGA | GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA);
+  if (parts & GG_PART_OMEGA) {
+    const int nt = (N + 31) / 32;
+    const int npairs = nt * (nt + 1) / 2;
+#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO)
+    EIG_DISPATCH(CALL);
+#undef CALL
+    e->have_omega = true;
+  }
+  if ((parts & (GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) && !e->have_omega)
+    return gg_fail(GG_ERR_INVALID, "eigenmodel: resample F / mu_0 / lambda needs the auxiliary variables (GG_PART_OMEGA) first");
+  if (parts & GG_PART_F) {
+    k_eig_normals<<<(N * D + 255) / 256, 256, 0, st>>>(e->Z, N * D, e->cfg.seed, GG_SITE_EIG_F, e->sweep);
+    for (int t0 = 0; t0 < N; t0 += EIG_T) {
+      const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
+      dim3 grd(T, e->NCH);
+#define CALL(DMV)                                                                                                      \
+  k_eig_tile_stats<DMV><<<grd, 256, 0, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part); \
+  k_eig_chain<DMV><<<1, 256, 0, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->cfg.sigma_F, e->NCH,  \
+                                      e->part, e->Z, e->status)
+      EIG_DISPATCH(CALL);
+#undef CALL
+    }
+  }
+  const int do_mu0 = (parts & GG_PART_MU0) ? 1 : 0;
+  const int do_lm = ((parts & GG_PART_LMBDA) && !e->cfg.lmbda_given) ? 1 : 0;
+  if (do_mu0 || do_lm) {
+#define CALL(DMV)                                                                                                   \
+  k_eig_global<DMV><<<N, 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart);                                 \
+  k_eig_draw_globals<DMV><<<1, 256, 0, st>>>(N, D, e->gpart, e->dO, d->dA, e->lmbda, e->mu0, e->mu_lmbda,            \
+                                             e->cfg.mu_mu_0, e->cfg.sigma_mu0, e->cfg.sigma_lmbda, do_mu0, do_lm,   \
+                                             e->cfg.seed, e->sweep, e->status)
+    EIG_DISPATCH(CALL);
+#undef CALL
+  }
+  GG_HIP(hipGetLastError());
+  GG_HIP(hipEventRecord(e->e1, st));
+  int stv = 0;
+  GG_HIP(hipMemcpyAsync(&stv, e->status, sizeof(int), hipMemcpyDeviceToHost, st));
+  GG_HIP(hipStreamSynchronize(st));
+  float ms = 0;
+  GG_HIP(hipEventElapsedTime(&ms, e->e0, e->e1));
+  e->st.total_ms = ms;
+  if (stv) {
+    int z = 0;
+    (void)hipMemcpy(e->status, &z, sizeof(int), hipMemcpyHostToDevice);
+    return gg_fail(GG_ERR_NUMERIC, "eigenmodel: a posterior precision is not positive definite");
+  }
+  if (full) { e->sweep += 1; e->st.sweeps += 1; }
+  return GG_OK;
+}
+
+int gg_eigen_log_likelihood(gg_eigen* e, const gg_data* d, double* out) {
+  if (!d || !out) return gg_fail(GG_ERR_INVALID, "null argument");
+  if (d->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, e->N);
+  const int N = e->N, nt = (N + 31) / 32;
+  dim3 grd(nt, nt);
+#define CALL(DMV) k_eig_loglik<DMV><<<grd, 256, 0, e->stream>>>(N, e->Np, e->D, d->A, d->dA, e->F, e->lmbda, e->mu0, e->llpart)
+  EIG_DISPATCH(CALL);
+#undef CALL
+  GG_HIP(hipGetLastError());
+  std::vector<double> h((size_t)nt * nt);
+  GG_HIP(hipMemcpyAsync(h.data(), e->llpart, h.size() * 8, hipMemcpyDeviceToHost, e->stream));
+  GG_HIP(hipStreamSynchronize(e->stream));
+  double ll = 0.0;
+  for (double v : h) ll += v;
+  *out = ll;
+  return GG_OK;
+}
+
+int gg_eigen_stats(gg_eigen* e, gg_stats* out) {
+  *out = e->st;
+  return GG_OK;
+}

@@ -1,0 +1,160 @@
+// gg_pg.h — Polya-gamma PG(1, z) sampler, host + device.
+//
+// The reference draws the N^2 auxiliary variables of the logistic eigenmodel with
+// pypolyagamma's `pgdrawvpar(ppgs, ones(N^2), Mu.ravel(), out)` (eigenmodel.py:
+// 867-871); pypolyagamma is a third-party C++/Cython package absent from the
+// reference tree, so the sampler is restated from its published
+// algorithm: Polson, Scott & Windle (2013), "Bayesian inference for logistic
+// models using Polya-gamma latent variables", §4 / Devroye's alternating-series
+// method for J*(1, z/2), truncation point t = 0.64:
+//   X ~ J*(1, z/2) by rejection from a mixture of a truncated inverse-Gaussian
+//   (left of t) and a truncated exponential (right of t), accepted with the
+//   alternating series S_n = sum (-1)^i a_i(X);  PG(1, z) = X / 4.
+// Only anchor inside the reference: E[omega] = tanh(z/2)/(2z) (eigenmodel.py:1062-1063);
+// tests/ add the variance and a KS test against a series representation.
+//
+// exp/log are the reproducible gg_exp/gg_log; the normal cdf uses the platform
+// erfc (libm on the host, ocml on the device: <= 1 ulp apart), so host and device
+// agree to rounding, not bit for bit — eigenmodel parity is a float tolerance
+// (north_star), unlike the block labels.
+#pragma once
+#include <math.h>
+#include "gg_draws.h"
+
+#define GG_PG_TRUNC 0.64
+#define GG_PI 3.141592653589793238462643383279502884197
+
+GG_HD double gg_norm_cdf(double x) { return 0.5 * erfc(-x * 0.70710678118654752440); }
+
+GG_HD double gg_expon(gg_stream* s) { return -gg_log(gg_stream_uniform_pos(s)); }
+
+// a_n(x): coefficients of the alternating series (Devroye 2009; PSW 2013 eq. 12-13)
+GG_HD double gg_pg_a(int n, double x) {
+  const double K = ((double)n + 0.5) * GG_PI;
+  if (x > GG_PG_TRUNC) return K * gg_exp(-0.5 * K * K * x);
+  if (x > 0.0) {
+    double expnt = -1.5 * (gg_log(0.5 * GG_PI) + gg_log(x)) + gg_log(K) - 2.0 * ((double)n + 0.5) * ((double)n + 0.5) / x;
+    return gg_exp(expnt);
+  }
+  return 0.0;
+}
+
+// probability mass of the truncated-exponential component
+GG_HD double gg_pg_mass_texpon(double Z) {
+  const double t = GG_PG_TRUNC;
+  const double fz = 0.125 * GG_PI * GG_PI + 0.5 * Z * Z;
+  const double b = gg_sqrt(1.0 / t) * (t * Z - 1.0);
+  const double a = -gg_sqrt(1.0 / t) * (t * Z + 1.0);
+  const double x0 = gg_log(fz) + fz * t;
+  const double xb = x0 - Z + gg_log(gg_norm_cdf(b));
+  const double xa = x0 + Z + gg_log(gg_norm_cdf(a));
+  const double qdivp = 4.0 / GG_PI * (gg_exp(xb) + gg_exp(xa));
+  return 1.0 / (1.0 + qdivp);
+}
+
+// inverse Gaussian(mu = 1/Z, lambda = 1) truncated to (0, t]
+GG_HD double gg_pg_rtigauss(gg_stream* s, double Z) {
+  const double t = GG_PG_TRUNC;
+  double X = t + 1.0;
+  if (1.0 / t > Z) {
+    double alpha = 0.0;
+    while (gg_stream_uniform(s) > alpha) {
+      double E1 = gg_expon(s), E2 = gg_expon(s);
+      while (E1 * E1 > 2.0 * E2 / t) { E1 = gg_expon(s); E2 = gg_expon(s); }
+      X = 1.0 + E1 * t;
+      X = t / (X * X);
+      alpha = gg_exp(-0.5 * Z * Z * X);
+    }
+  } else {
+    const double mu = 1.0 / Z;
+    while (X > t) {
+      double Y = gg_normal(s);
+      Y *= Y;
+      const double half_mu = 0.5 * mu;
+      const double mu_Y = mu * Y;
+      X = mu + half_mu * mu_Y - half_mu * gg_sqrt(4.0 * mu_Y + mu_Y * mu_Y);
+      if (gg_stream_uniform(s) > mu / (mu + X)) X = mu * mu / X;
+    }
+  }
+  return X;
+}
+
+// omega ~ PG(1, z)
+GG_HD double gg_pg1(gg_stream* s, double z) {
+  const double Z = 0.5 * gg_fabs(z);
+  const double fz = 0.125 * GG_PI * GG_PI + 0.5 * Z * Z;
+  const double ptex = gg_pg_mass_texpon(Z);
+  for (;;) {
+    double X;
+    if (gg_stream_uniform(s) < ptex) X = GG_PG_TRUNC + gg_expon(s) / fz;
+    else X = gg_pg_rtigauss(s, Z);
+    double S = gg_pg_a(0, X);
+    const double Y = gg_stream_uniform(s) * S;
+    int n = 0;
+    for (;;) {
+      ++n;
+      if (n & 1) {
+        S -= gg_pg_a(n, X);
+        if (Y <= S) return 0.25 * X;
+      } else {
+        S += gg_pg_a(n, X);
+        if (Y > S) break;
+      }
+      if (n > 200) return 0.25 * X;  // numerically converged series
+    }
+  }
+}
+
+// Stream index of omega_ij: one stream per ordered pair.
+GG_HD double gg_pg1_at(uint64_t seed, uint32_t sweep, uint32_t N, uint32_t i, uint32_t j, double psi) {
+  gg_stream s;
+  gg_stream_init(&s, seed, GG_SITE_EIG_OMEGA, sweep, i * N + j);
+  return gg_pg1(&s, psi);
+}
+
+// One standard normal per (site, sweep, index): pre-drawable for a whole sweep.
+GG_HD double gg_normal_at(uint64_t seed, uint32_t site, uint32_t sweep, uint32_t index) {
+  gg_stream s;
+  gg_stream_init(&s, seed, site, sweep, index);
+  return gg_normal(&s);
+}
+
+// ---- dense D x D helpers for the Gaussian conditionals (D <= GG_MAXD) -------
+#define GG_MAXD 16
+
+// In-place lower Cholesky of a symmetric positive-definite matrix (row-major); returns 0 on success.
+GG_HD int gg_chol_d(double* Aq, int D) {
+  for (int j = 0; j < D; ++j) {
+    double d = Aq[j * D + j];
+    for (int k = 0; k < j; ++k) d -= Aq[j * D + k] * Aq[j * D + k];
+    if (!(d > 0.0)) return 1;
+    const double dj = gg_sqrt(d);
+    Aq[j * D + j] = dj;
+    for (int i = j + 1; i < D; ++i) {
+      double v = Aq[i * D + j];
+      for (int k = 0; k < j; ++k) v -= Aq[i * D + k] * Aq[j * D + k];
+      Aq[i * D + j] = v / dj;
+    }
+    for (int i = 0; i < j; ++i) Aq[i * D + j] = 0.0;
+  }
+  return 0;
+}
+
+// x ~ N(prec^{-1} h, prec^{-1}) given standard normals z: with prec = L L^T,
+// mean = L^{-T} L^{-1} h and x = mean + L^{-T} z = L^{-T} (L^{-1} h + z).
+GG_HD int gg_gauss_from_precision(const double* prec, const double* h, const double* z, int D, double* x) {
+  double L[GG_MAXD * GG_MAXD], y[GG_MAXD];
+  for (int i = 0; i < D * D; ++i) L[i] = prec[i];
+  if (gg_chol_d(L, D)) return 1;
+  for (int i = 0; i < D; ++i) {          // y = L^{-1} h + z
+    double v = h[i];
+    for (int k = 0; k < i; ++k) v -= L[i * D + k] * (y[k] - z[k]);
+    y[i] = v / L[i * D + i] + z[i];
+  }
+  for (int i = D - 1; i >= 0; --i) {     // x = L^{-T} y
+    double v = y[i];
+    for (int k = i + 1; k < D; ++k) v -= L[k * D + i] * x[k];
+    x[i] = v / L[i * D + i];
+  }
+  return 0;
+}

@@ -85,7 +85,8 @@ enum gg_state_id {
   GG_ST_F = 13,         /* double (N,D)      latent features              eigenmodel.py:62 */
   GG_ST_LMBDA = 14,     /* double (D)                                     eigenmodel.py:64-73 */
   GG_ST_MU0 = 15,       /* double (1)                                     eigenmodel.py:57 */
-  GG_ST_MU_LMBDA = 16   /* double (D)        prior mean of lambda         eigenmodel.py:71 */
+  GG_ST_MU_LMBDA = 16,  /* double (D)        prior mean of lambda         eigenmodel.py:71 */
+  GG_ST_OMEGA_S = 17    /* double (N,N) read-only: omega_ij + omega_ji off the diagonal, omega_ii on it (eigenmodel.py:859-874) */
 };
 
 /* Parts of a sweep, for step-wise parity tests (gg_resample_part). */

@@ -36,6 +36,7 @@ def lib():
         _lib.orc_const_adj_loglik.restype = C.c_double
         _lib.orc_sbm_w_loglik.restype = C.c_double
         _lib.orc_uniform_at.restype = C.c_double
+        _lib.orc_normal_at.restype = C.c_double
         for name in ("orc_eig_loglik",):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_double
@@ -182,6 +183,10 @@ def uniform_at(seed, site, sweep, index):
     return lib().orc_uniform_at(C.c_uint64(seed), C.c_uint32(site), C.c_uint32(sweep), C.c_uint32(index))
 
 
+def normal_at(seed, site, sweep, index):
+    return lib().orc_normal_at(C.c_uint64(seed), C.c_uint32(site), C.c_uint32(sweep), C.c_uint32(index))
+
+
 def exp_vec(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.empty_like(x)
@@ -239,4 +244,39 @@ def gauss_table(mu, sigma):
     rc = lib().orc_gauss_table(_f64(mu), _f64(sigma), B, _f64(out))
     if rc:
         raise ValueError("sigma not SPD")
+    return out
+
+
+# ---------------------------------------------------------------- logistic eigenmodel
+PART_OMEGA, PART_F, PART_MU0, PART_LMBDA = 8, 16, 32, 64
+PART_EIG_ALL = 120
+
+
+def eig_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given, seed, sweep,
+              parts=PART_EIG_ALL, Omega=None):
+    """In-place sweep of (F, lmbda); returns (mu_0, Omega)."""
+    N, D = F.shape
+    A8, pA = _u8(A != 0)
+    if Omega is None:
+        Omega = np.zeros((N, N))
+    mu = C.c_double(float(mu_0))
+    rc = lib().orc_eig_sweep(N, D, pA, _f64(F), _f64(lmbda), C.byref(mu), _f64(Omega),
+                             _f64(np.ascontiguousarray(mu_lmbda, dtype=np.float64)), C.c_double(mu_mu_0),
+                             C.c_double(sigma_mu0), C.c_double(sigma_F), C.c_double(sigma_lmbda), int(lmbda_given),
+                             C.c_uint64(seed), C.c_uint32(sweep), int(parts))
+    if rc:
+        raise RuntimeError("oracle eig_sweep failed rc=%d" % rc)
+    return mu.value, Omega
+
+
+def eig_loglik(A, F, lmbda, mu_0):
+    N, D = F.shape
+    A8, pA = _u8(A != 0)
+    lib().orc_eig_loglik.restype = C.c_double
+    return lib().orc_eig_loglik(N, D, pA, _f64(F), _f64(lmbda), C.c_double(mu_0))
+
+
+def pg1_vec(seed, z, n):
+    out = np.empty(n)
+    lib().orc_pg1_vec(C.c_uint64(seed), C.c_double(z), _f64(out), C.c_longlong(n))
     return out

@@ -527,6 +527,11 @@ void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
   gg_u32x4 r = gg_philox4x32_10(c0, c1, c2, c3, k0, k1);
   for (int i = 0; i < 4; ++i) out[i] = r.v[i];
 }
+double orc_normal_at(uint64_t seed, uint32_t site, uint32_t sweep, uint32_t index) {
+  gg_stream s;
+  gg_stream_init(&s, seed, site, sweep, index);
+  return gg_normal(&s);
+}
 double orc_uniform_at(uint64_t seed, uint32_t site, uint32_t sweep, uint32_t index) {
   return gg_uniform_at(seed, site, sweep, index);
 }

@@ -1,0 +1,170 @@
+"""Logistic eigenmodel: CPU tests of the oracle (vs the numpy transliteration of
+eigenmodel.py and PG(1,z) theory) and GPU parity of the HIP engine vs the oracle.
+Parity here is a float tolerance (north_star): the engine orders its sums differently
+(symmetrised Omega, tiled scan) and erfc differs by <= 1 ulp between host and device."""
+import numpy as np
+import pytest
+from scipy import stats
+
+from oracle import oracle as O
+from oracle import literal as R
+
+SITE_F, SITE_MU0, SITE_LMBDA = 12, 13, 14
+
+
+def make_case(N, D, seed):
+    rng = np.random.RandomState(seed)
+    F = rng.randn(N, D)
+    lmbda = rng.randn(D)
+    mu_0 = -0.7
+    P = 1.0 / (1.0 + np.exp(-R.eigen_Mu(F, lmbda, mu_0)))
+    A = (rng.rand(N, N) < P).astype(np.uint8)
+    F0 = np.ascontiguousarray(rng.randn(N, D) * 0.8)
+    l0 = np.ascontiguousarray(rng.randn(D))
+    return A, F0, l0, 0.3
+
+
+def gauss_from_precision(prec, h, z):
+    L = np.linalg.cholesky(prec)
+    y = np.linalg.solve(L, h) + z
+    return np.linalg.solve(L.T, y)
+
+
+# ---------------------------------------------------------------- CPU
+def test_pg1_moments_and_law():
+    """E = tanh(z/2)/(2z) (anchor at eigenmodel.py:1062-1063), Var = (sinh z - z)/(4 z^3 cosh^2(z/2));
+    law checked against the sum-of-gammas representation PG(1,z) = (1/2pi^2) sum_k g_k / ((k-1/2)^2 + z^2/(4pi^2))."""
+    rng = np.random.RandomState(0)
+    for z in [0.0, 0.8, 3.0, -5.0, 15.0]:
+        x = O.pg1_vec(7, z, 60000)
+        za = abs(z)
+        mean = 0.25 if za == 0 else np.tanh(za / 2) / (2 * za)
+        var = 1 / 24.0 if za == 0 else (np.sinh(za) - za) / (4 * za ** 3 * np.cosh(za / 2) ** 2)
+        assert abs(x.mean() - mean) < 5 * np.sqrt(var / x.size)
+        assert abs(x.var() - var) < 0.05 * var
+        k = np.arange(1, 301)[None, :]
+        ref = (rng.gamma(1.0, 1.0, size=(60000, 300)) / ((k - 0.5) ** 2 + za ** 2 / (4 * np.pi ** 2))).sum(1) / (2 * np.pi ** 2)
+        assert stats.ks_2samp(x, ref).pvalue > 1e-3
+
+
+def test_oracle_sweep_follows_the_reference_formulas():
+    N, D, seed = 9, 2, 5
+    A, F, lmbda, mu_0 = make_case(N, D, 1)
+    sF, sm, sl, mm, ml = 1.3, 0.9, 1.1, -0.4, np.zeros(D) + 0.2
+    F_in = F.copy()
+    # Omega
+    _, Om = O.eig_sweep(A, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_OMEGA)
+    assert np.all(Om > 0) and Om.shape == (N, N)
+    # F: sequential, in place (eigenmodel.py:884-908)
+    Fo = F.copy()
+    O.eig_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_F, Omega=Om)
+    Fp = F_in.copy()
+    for n in range(N):
+        prec, h = R.eigen_F_conditional(A, Om, Fp, lmbda, mu_0, sF, n)
+        z = np.array([O.normal_at(seed, SITE_F, 3, n * D + d) for d in range(D)])
+        Fp[n] = gauss_from_precision(prec, h, z)
+    assert np.allclose(Fo, Fp, rtol=1e-10, atol=1e-12)
+    # mu_0 (eigenmodel.py:910-932)
+    mu_new, _ = O.eig_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_MU0, Omega=Om)
+    prec, h = R.eigen_mu0_conditional(A, Om, Fo, lmbda, mm, sm)
+    assert abs(mu_new - (h / prec + np.sqrt(1 / prec) * O.normal_at(seed, SITE_MU0, 3, 0))) < 1e-12
+    # lambda (eigenmodel.py:934-965), uses the new mu_0
+    lo = lmbda.copy()
+    O.eig_sweep(A, Fo, lo, mu_new, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_LMBDA, Omega=Om)
+    prec, h = R.eigen_lmbda_conditional(A, Om, Fo, mu_new, ml, sl)
+    z = np.array([O.normal_at(seed, SITE_LMBDA, 3, d) for d in range(D)])
+    assert np.allclose(lo, gauss_from_precision(prec, h, z), rtol=1e-10, atol=1e-12)
+    # log-likelihood (eigenmodel.py:110-129)
+    assert abs(O.eig_loglik(A, Fo, lo, mu_new) - R.eigen_loglik(A, Fo, lo, mu_new)) < 1e-9
+
+
+def test_geweke_eigenmodel_prior_recovery():
+    """Joint-distribution test with assertions (test/test_logistic_eigenmodel_geweke.py:35-52):
+    alternate A ~ p(A | theta) and one oracle sweep; marginals of mu_0, lambda, F must match the priors."""
+    N, D, iters = 6, 2, 3000
+    rng = np.random.RandomState(1)
+    sF, sm, sl, mm, ml = 1.0, 1.0, 1.0, stats.norm.ppf(0.3), np.zeros(D)
+    F = np.ascontiguousarray(rng.randn(N, D))
+    lmbda = np.ascontiguousarray(rng.randn(D))
+    mu_0 = mm + rng.randn()
+    mus, lams, fs = [], [], []
+    for it in range(iters):
+        P = 1.0 / (1.0 + np.exp(-R.eigen_Mu(F, lmbda, mu_0)))
+        A = (rng.rand(N, N) < P).astype(np.uint8)
+        mu_0, _ = O.eig_sweep(A, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, 99, it)
+        mus.append(mu_0); lams.append(lmbda[0]); fs.append(F[0, 0])
+    thin = slice(200, None, 5)
+    assert stats.kstest(np.array(mus)[thin], "norm", args=(mm, 1.0)).pvalue > 1e-3
+    assert stats.kstest(np.array(lams)[thin], "norm").pvalue > 1e-3
+    assert stats.kstest(np.array(fs)[thin], "norm").pvalue > 1e-3
+
+
+def test_eigenmodel_host_logic():
+    from graphistician_amd.eigenmodel import LogisticEigenmodel
+    np.random.seed(4)
+    m = LogisticEigenmodel(12, 3, p=0.2)
+    assert m.F.shape == (12, 3) and m.lmbda.shape == (3,)
+    assert abs(m.mu_mu_0 - stats.norm.ppf(0.2)) < 1e-12
+    assert np.allclose(np.diag(m.Mu), m.mu_0)
+    assert np.allclose(m.Mu, R.eigen_Mu(m.F, m.lmbda, m.mu_0))
+    assert m.P.min() >= 1e-16 and m.P.max() <= 1 - 1e-16
+    lp = -0.5 * (m.F ** 2).sum() - 0.5 * (m.mu_0 - m.mu_mu_0) ** 2 - 0.5 * (m.lmbda ** 2).sum()
+    assert abs(m.log_prior() - lp) < 1e-12
+    assert m.rvs().shape == (12, 12)
+    g = LogisticEigenmodel(5, 2, lmbda=np.array([1.0, -1.0]))
+    assert g.lmbda_given and np.array_equal(g.lmbda, [1.0, -1.0])
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D", [(50, 2), (130, 8), (200, 5)])
+def test_engine_parts_match_oracle(N, D):
+    from graphistician_amd import _abi as abi
+    A, F, lmbda, mu_0 = make_case(N, D, N)
+    sF, sm, sl, mm, ml = 1.2, 0.8, 1.5, -0.3, np.zeros(D) + 0.1
+    seed = 77
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=seed, sigma_mu0=sm, sigma_F=sF, sigma_lmbda=sl,
+                  mu_mu_0=mm, lmbda_given=0)
+    m.set(abi.ST_F, F); m.set(abi.ST_LMBDA, lmbda); m.set(abi.ST_MU0, np.array([mu_0])); m.set(abi.ST_MU_LMBDA, ml)
+    # Omega
+    m.resample_part(d, abi.PART_OMEGA)
+    _, Om = O.eig_sweep(A, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_OMEGA)
+    S = m.get(abi.ST_OMEGA_S, (N, N))
+    ref = Om + Om.T
+    np.fill_diagonal(ref, np.diag(Om))
+    assert np.allclose(S, ref, rtol=1e-9, atol=1e-13)
+    # F
+    m.resample_part(d, abi.PART_F)
+    Fo = F.copy()
+    O.eig_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_F, Omega=Om)
+    assert np.allclose(m.get(abi.ST_F, (N, D)), Fo, rtol=1e-8, atol=1e-10)
+    # mu_0, lambda
+    m.resample_part(d, abi.PART_MU0)
+    mu_new, _ = O.eig_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_MU0, Omega=Om)
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - mu_new) < 1e-9
+    m.resample_part(d, abi.PART_LMBDA)
+    lo = lmbda.copy()
+    O.eig_sweep(A, Fo, lo, mu_new, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_LMBDA, Omega=Om)
+    assert np.allclose(m.get(abi.ST_LMBDA, (D,)), lo, rtol=1e-8, atol=1e-10)
+    ll = m.log_likelihood(d)
+    assert abs(ll - O.eig_loglik(A, Fo, lo, mu_new)) <= 1e-9 * abs(ll)
+
+
+@pytest.mark.gpu
+def test_engine_chain_matches_oracle():
+    """Three full sweeps through the reference-shaped class (tolerance grows with chain length)."""
+    from graphistician_amd.eigenmodel import LogisticEigenmodel
+    N, D = 96, 3
+    A, F, lmbda, mu_0 = make_case(N, D, 3)
+    np.random.seed(0)
+    m = LogisticEigenmodel(N, D, p=0.3, seed=4242)
+    m.F, m.lmbda, m.mu_0 = F, lmbda, mu_0
+    Fo, lo, mo = F.copy(), lmbda.copy(), mu_0
+    for s in range(3):
+        m.resample(A)
+        mo, _ = O.eig_sweep(A, Fo, lo, mo, np.zeros(D), m.mu_mu_0, 1.0, 1.0, 1.0, 0, 4242, s)
+    assert np.allclose(m.F, Fo, rtol=1e-6, atol=1e-8)
+    assert np.allclose(m.lmbda, lo, rtol=1e-6, atol=1e-8) and abs(m.mu_0 - mo) < 1e-7
+    assert abs(m.log_likelihood(A) - O.eig_loglik(A, Fo, lo, mo)) <= 1e-7 * abs(O.eig_loglik(A, Fo, lo, mo))
+    assert np.isfinite(m.log_probability(A))
