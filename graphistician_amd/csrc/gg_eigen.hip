@@ -23,7 +23,7 @@
 #include "spec/gg_pg.h"
 
 #define EIG_T 64          // nodes per tile of the F scan
-#define EIG_CHN 1024      // neighbours per workgroup in k_eig_tile_stats
+#define EIG_CHN 4096      // neighbours per workgroup in k_eig_tile_stats (1024 threads x 4)
 
 struct gg_eigen {
   gg_config cfg;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
 //   G_n[a,b] = sum_{nn != n} S[n,nn] ft_a ft_b,  h_n[a] = sum_{nn != n} ((A[n,nn]+A[nn,n]-1) - mu_0 S[n,nn]) ft_a,
 // ft = F[nn] * lambda.  One workgroup per (node, chunk of EIG_CHN neighbours).
 template <int DM>
-__global__ __launch_bounds__(256) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
+__global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
                                                         const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                         const double* __restrict__ F, const double* __restrict__ lmbda,
                                                         const double* __restrict__ mu0p, int NCH,
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_eig_tile_stats(int N, int Np, int D, in
 #pragma unroll
   for (int d = 0; d < DM; ++d) { h[d] = 0.0; lam[d] = d < D ? lmbda[d] : 0.0; }
   const int lo = c * EIG_CHN, hi = (lo + EIG_CHN < N) ? lo + EIG_CHN : N;
-  for (int nn = lo + threadIdx.x; nn < hi; nn += 256) {
+  for (int nn = lo + threadIdx.x; nn < hi; nn += 1024) {
     if (nn == n) continue;
     const double s = S[(size_t)n * Np + nn];
     const double a = (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_eig_tile_stats(int N, int Np, int D, in
       h[a1] += v * ft[a1];
     }
   }
-  __shared__ double s_red[4][NEGM + DM];
+  __shared__ double s_red[16][NEGM + DM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int e = 0; e < NEGM + DM; ++e) {
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void k_eig_tile_stats(int N, int Np, int D, in
   const int NEG = D * (D + 1) / 2;
   if (threadIdx.x < NEGM + DM) {
     const int e = threadIdx.x;
-    double v = (s_red[0][e] + s_red[1][e]) + (s_red[2][e] + s_red[3][e]);
+    double v = 0.0;
+    for (int w = 0; w < 16; ++w) v += s_red[w][e];
     // map padded index -> compact index
     int out = -1;
     if (e < NEGM) {
@@ -180,6 +181,8 @@ __global__ __launch_bounds__(256) void k_eig_tile_stats(int N, int Np, int D, in
 }
 
 // The sequential part of _resample_F for one tile (eigenmodel.py:884-908), one workgroup.
+// Everything the per-node loop touches is staged in LDS first (T x T block of S and of the
+// symmetrised adjacency, the tile's statistics, normals and old features).
 template <int DM>
 __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0, const double* __restrict__ S,
                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
@@ -188,61 +191,130 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
                                                    const double* __restrict__ part, const double* __restrict__ Z,
                                                    int* __restrict__ status) {
   constexpr int NEGM = DM * (DM + 1) / 2;
-  __shared__ double s_S[EIG_T][EIG_T + 1];
-  __shared__ signed char s_a[EIG_T][EIG_T];
-  __shared__ double s_dP[EIG_T][NEGM];
-  __shared__ double s_dF[EIG_T][DM];
-  __shared__ double s_stat[NEGM + DM];
+  extern __shared__ __align__(16) unsigned char s_chain[];
+  double* s_S = reinterpret_cast<double*>(s_chain);                 // [T][T+1]
+  double* s_dP = s_S + EIG_T * (EIG_T + 1);                         // [T][NEGM]
+  double* s_dF = s_dP + EIG_T * NEGM;                               // [T][DM]
+  double* s_part = s_dF + EIG_T * DM;                               // [T][NEGM+DM] (compact NE used)
+  double* s_Z = s_part + EIG_T * (NEGM + DM);                       // [T][DM]
+  double* s_Fo = s_Z + EIG_T * DM;                                  // [T][DM]
+  double* s_stat = s_Fo + EIG_T * DM;                               // [NEGM+DM]
+  signed char* s_a = reinterpret_cast<signed char*>(s_stat + NEGM + DM);  // [T][T]
   const int tid = threadIdx.x;
   const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
   const int NEG = D * (D + 1) / 2, NE = NEG + D;
   const double mu0 = *mu0p;
   for (int e = tid; e < T * T; e += 256) {
     int i = e / T, j = e % T;
-    s_S[i][j] = S[(size_t)(t0 + i) * Np + t0 + j];
-    s_a[i][j] = (signed char)((int)A[(size_t)(t0 + i) * Np + t0 + j] + (int)AT[(size_t)(t0 + i) * Np + t0 + j] - 1);
+    s_S[i * (EIG_T + 1) + j] = S[(size_t)(t0 + i) * Np + t0 + j];
+    s_a[i * EIG_T + j] = (signed char)((int)A[(size_t)(t0 + i) * Np + t0 + j] + (int)AT[(size_t)(t0 + i) * Np + t0 + j] - 1);
   }
+  for (int e = tid; e < T * NE; e += 256) {
+    int i = e / NE, q = e % NE;
+    double acc = 0.0;
+    for (int c = 0; c < NCH; ++c) acc += part[((size_t)i * NCH + c) * NE + q];
+    s_part[i * (NEGM + DM) + q] = acc;
+  }
+  for (int e = tid; e < T * D; e += 256) {
+    int i = e / D, q = e % D;
+    s_Z[i * DM + q] = Z[(size_t)(t0 + i) * D + q];
+    s_Fo[i * DM + q] = F[(size_t)(t0 + i) * D + q];
+  }
+  double lam[DM];
+#pragma unroll
+  for (int a1 = 0; a1 < DM; ++a1) lam[a1] = a1 < D ? lmbda[a1] : 0.0;
   __syncthreads();
   for (int nl = 0; nl < T; ++nl) {
     const int n = t0 + nl;
-    if (tid < NE) {
-      double acc = 0.0;
-      for (int c = 0; c < NCH; ++c) acc += part[((size_t)nl * NCH + c) * NE + tid];
-      if (tid < NEG) {
-        for (int n2 = 0; n2 < nl; ++n2) acc += s_S[nl][n2] * s_dP[n2][tid];
-      } else {
-        const int a1 = tid - NEG;
-        for (int n2 = 0; n2 < nl; ++n2) acc += ((double)s_a[nl][n2] - mu0 * s_S[nl][n2]) * s_dF[n2][a1];
+    const double* s_stat = s_part + nl * (NEGM + DM);   // this node's statistics, corrections already applied
+    if (tid == 0) {
+      // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
+      double L[DM][DM], hh[DM], x[DM];
+      {
+        int e = 0;
+#pragma unroll
+        for (int a1 = 0; a1 < DM; ++a1)
+#pragma unroll
+          for (int b1 = a1; b1 < DM; ++b1) {
+            double v = 0.0;
+            if (b1 < D) { v = s_stat[e++]; if (a1 == b1) v += 1.0 / sigma_F; }
+            else if (a1 == b1) v = 1.0;
+            L[b1][a1] = v;   // lower triangle holds the precision
+          }
       }
-      s_stat[tid] = acc;
+#pragma unroll
+      for (int a1 = 0; a1 < DM; ++a1) hh[a1] = a1 < D ? s_stat[NEG + a1] : 0.0;
+      bool ok = true;
+      // Cholesky (left-looking, same order as gg_chol_d)
+#pragma unroll
+      for (int j = 0; j < DM; ++j) {
+        double dsum = L[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dsum = gg_fma(-L[j][k], L[j][k], dsum);
+        if (!(dsum > 0.0)) { ok = false; dsum = 1.0; }
+        // one reciprocal square root per column instead of D divisions (float-tolerance path)
+        const double inv = rsqrt(dsum);
+        L[j][j] = inv;           // the diagonal keeps 1 / L_jj: the solves only ever divide by it
+#pragma unroll
+        for (int i = j + 1; i < DM; ++i) {
+          double v = L[i][j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) v = gg_fma(-L[i][k], L[j][k], v);
+          L[i][j] = v * inv;
+        }
+      }
+      // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision)
+      double y[DM], zz[DM];
+#pragma unroll
+      for (int i = 0; i < DM; ++i) zz[i] = i < D ? s_Z[nl * DM + i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < DM; ++i) {
+        double v = hh[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v = gg_fma(-L[i][k], y[k] - zz[k], v);
+        y[i] = gg_fma(v, L[i][i], zz[i]);
+      }
+#pragma unroll
+      for (int i = DM - 1; i >= 0; --i) {
+        double v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < DM; ++k) v = gg_fma(-L[k][i], x[k], v);
+        x[i] = v * L[i][i];
+      }
+      double fo[DM], fn[DM];
+#pragma unroll
+      for (int a1 = 0; a1 < DM; ++a1) {
+        const double old = a1 < D ? s_Fo[nl * DM + a1] : 0.0;
+        if (!ok) x[a1] = old;
+        fo[a1] = old * lam[a1];
+        fn[a1] = x[a1] * lam[a1];
+      }
+      if (!ok) atomicOr(status, 1);
+      // rank-one change of this node's outer product, seen by the later nodes of the tile
+      {
+        int e = 0;
+#pragma unroll
+        for (int a1 = 0; a1 < DM; ++a1) {
+          if (a1 < D) s_dF[nl * DM + a1] = fn[a1] - fo[a1];
+#pragma unroll
+          for (int b1 = a1; b1 < DM; ++b1)
+            if (b1 < D) s_dP[nl * NEGM + (e++)] = fn[a1] * fn[b1] - fo[a1] * fo[b1];
+        }
+      }
+#pragma unroll
+      for (int a1 = 0; a1 < DM; ++a1)
+        if (a1 < D) F[(size_t)n * D + a1] = x[a1];
     }
     __syncthreads();
-    if (tid == 0) {
-      double prec[GG_MAXD * GG_MAXD], h[GG_MAXD], z[GG_MAXD], x[GG_MAXD];
-      int e = 0;
-      for (int a1 = 0; a1 < D; ++a1)
-        for (int b1 = a1; b1 < D; ++b1) {
-          double v = s_stat[e++];
-          if (a1 == b1) v += 1.0 / sigma_F;
-          prec[a1 * D + b1] = v;
-          prec[b1 * D + a1] = v;
-        }
-      for (int a1 = 0; a1 < D; ++a1) { h[a1] = s_stat[NEG + a1]; z[a1] = Z[(size_t)n * D + a1]; }
-      if (gg_gauss_from_precision(prec, h, z, D, x)) {
-        atomicOr(status, 1);
-        for (int a1 = 0; a1 < D; ++a1) x[a1] = F[(size_t)n * D + a1];
-      }
-      // rank-one change of this node's outer product, seen by the later nodes of the tile
-      e = 0;
-      for (int a1 = 0; a1 < D; ++a1) {
-        const double fo = F[(size_t)n * D + a1] * lmbda[a1], fn = x[a1] * lmbda[a1];
-        s_dF[nl][a1] = fn - fo;
-        for (int b1 = a1; b1 < D; ++b1) {
-          const double go = F[(size_t)n * D + b1] * lmbda[b1], gn = x[b1] * lmbda[b1];
-          s_dP[nl][e++] = fn * gn - fo * go;
-        }
-      }
-      for (int a1 = 0; a1 < D; ++a1) F[(size_t)n * D + a1] = x[a1];
+    // right-looking update: push this node's rank-one change into the statistics of the later nodes
+    // (same accumulation order as a per-node loop over the earlier nodes: partial, then n2 ascending)
+    const int rem = T - nl - 1;
+    for (int idx = tid; idx < rem * NE; idx += 256) {
+      const int i = nl + 1 + idx / NE, e = idx % NE;
+      const double sv = s_S[i * (EIG_T + 1) + nl];
+      double* dst = s_part + i * (NEGM + DM) + e;
+      if (e < NEG) *dst = gg_fma(sv, s_dP[nl * NEGM + e], *dst);
+      else *dst = gg_fma(gg_fma(-mu0, sv, (double)s_a[i * EIG_T + nl]), s_dF[nl * DM + (e - NEG)], *dst);
     }
     __syncthreads();
   }
@@ -309,10 +381,18 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int D, const do
   __shared__ double s_tot[NGM + 2];
   __shared__ double s_w[4][2];
   const int tid = threadIdx.x;
-  if (tid < NGM) {
-    double v = 0.0;
-    for (int i = 0; i < N; ++i) v += gpart[(size_t)i * NGM + tid];   // fixed order
-    s_tot[tid] = v;
+  {
+    // fixed-order two-level sum of the per-row partials: 4 row quarters per entry
+    __shared__ double s_q[4][NGM];
+    const int e = tid & 63, q = tid >> 6;
+    if (e < NGM) {
+      const int lo = (int)((long long)N * q / 4), hi = (int)((long long)N * (q + 1) / 4);
+      double v = 0.0;
+      for (int i = lo; i < hi; ++i) v += gpart[(size_t)i * NGM + e];
+      s_q[q][e] = v;
+    }
+    __syncthreads();
+    if (tid < NGM) s_tot[tid] = (s_q[0][tid] + s_q[1][tid]) + (s_q[2][tid] + s_q[3][tid]);
   }
   // diagonal: sum omega_ii and sum (A_ii - 1/2)
   double so = 0.0, sk = 0.0;
@@ -525,13 +605,25 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     return gg_fail(GG_ERR_INVALID, "eigenmodel: resample F / mu_0 / lambda needs the auxiliary variables (GG_PART_OMEGA) first");
   if (parts & GG_PART_F) {
     k_eig_normals<<<(N * D + 255) / 256, 256, 0, st>>>(e->Z, N * D, e->cfg.seed, GG_SITE_EIG_F, e->sweep);
+    const int DMv = e->DM, NEGMv = DMv * (DMv + 1) / 2;
+    const size_t chain_lds = (((size_t)EIG_T * (EIG_T + 1) + (size_t)EIG_T * NEGMv + 3 * (size_t)EIG_T * DMv +
+                               (size_t)EIG_T * (NEGMv + DMv) + (NEGMv + DMv)) * sizeof(double) + (size_t)EIG_T * EIG_T + 15) & ~(size_t)15;
+    static bool attr4 = false, attr8 = false;
+    if (DMv == 4 && !attr4) {
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      attr4 = true;
+    }
+    if (DMv == 8 && !attr8) {
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      attr8 = true;
+    }
     for (int t0 = 0; t0 < N; t0 += EIG_T) {
       const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
       dim3 grd(T, e->NCH);
 #define CALL(DMV)                                                                                                      \
-  k_eig_tile_stats<DMV><<<grd, 256, 0, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part); \
-  k_eig_chain<DMV><<<1, 256, 0, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->cfg.sigma_F, e->NCH,  \
-                                      e->part, e->Z, e->status)
+  k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part); \
+  k_eig_chain<DMV><<<1, 256, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->cfg.sigma_F,  \
+                                              e->NCH, e->part, e->Z, e->status)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
