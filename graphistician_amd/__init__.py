@@ -3,4 +3,4 @@ networks.py surface (resample / log_likelihood).  See DESIGN.md.
 
 Mirrors `graphistician/__init__.py:2`: the four public modules.
 """
-from . import abstractions, adjacency, weights, networks, eigenmodel  # noqa: F401
+from . import abstractions, adjacency, weights, networks, eigenmodel, ais  # noqa: F401

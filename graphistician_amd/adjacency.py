@@ -193,12 +193,12 @@ class BetaBernoulliAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, E
         assert d.N == self.N
         return self._engine().log_likelihood(d)
 
-    def resample(self, A):
+    def resample(self, A, beta=1.0):
         """adjacency.py:153-181 (the self-probability posterior uses tau1, tau0 as the
-        reference does at :175)."""
+        reference does at :175).  beta < 1 tempers the likelihood (graph_models.py:178-182)."""
         d = self._data(A)
         assert d.N == self.N
-        self._engine().resample_async(d, 1)
+        self._engine().resample_async(d, 1, beta)
         self._mark_stale("p", "p_self")
 
     def sample_predictive_parameters(self):
@@ -336,29 +336,30 @@ class SBMAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacke
         return np.argsort(-newc)
 
     # -- Gibbs (adjacency.py:615-702): on the device ------------------------------
-    def _run(self, A, parts):
+    def _run(self, A, parts, beta=1.0):
         d = self._data(A) if A is not None else None
         assert d is None or d.N == self.N
         eng = self._engine()
         if parts == _abi.PART_ALL:
-            eng.resample_async(d, 1)    # stream-ordered: the next state read (or log_likelihood) waits for it
+            eng.resample_async(d, 1, beta)   # stream-ordered: the next state read (or log_likelihood) waits for it
         else:
-            eng.resample_part(d, parts)
+            eng.resample_part(d, parts, beta)
             if parts == _abi.PART_M:
                 eng.sweep = eng.sweep + 1   # resample_m closes a sweep: advance the Philox sweep counter
         self._mark_stale("c", "m", "p", "p_self")
 
-    def resample(self, A):
-        self._run(A, _abi.PART_ALL)
+    def resample(self, A, beta=1.0):
+        """beta < 1: tempered sweep for AIS (likelihood^beta, graph_models.py:278-293,366-367)."""
+        self._run(A, _abi.PART_ALL, beta)
 
-    def resample_p(self, As):
+    def resample_p(self, As, beta=1.0):
         assert len(As) == 1, "one adjacency matrix per model"
-        self._run(As[0], _abi.PART_PARAMS)
+        self._run(As[0], _abi.PART_PARAMS, beta)
 
-    def resample_c(self, A):
+    def resample_c(self, A, beta=1.0):
         if self.C == 1:
             return
-        self._run(A, _abi.PART_C)
+        self._run(A, _abi.PART_C, beta)
 
     def resample_m(self):
         self._run(None, _abi.PART_M)

@@ -440,6 +440,7 @@ struct gg_params_args {
   int draw_m;
   uint32_t m_site, m_sweep;
   const double* pi;
+  double beta;   // tempering of the parameter posterior: counts weighted by beta (graph_models.py:180-181,366-367)
 };
 
 template <bool ADJ, int B>
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
           long long n0 = pairs - n1;
           gg_stream s;
           gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_P : GG_SITE_ADJ_P, g.sweep, (uint32_t)t);
-          pv = gg_beta(&s, g.ah.tau1 + (double)n1, g.ah.tau0 + (double)n0);
+          pv = gg_beta(&s, g.ah.tau1 + g.beta * (double)n1, g.ah.tau0 + g.beta * (double)n0);
           g.p[t] = pv;
         } else {
           pv = g.p[t];
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         if (g.ah.special) {
           gg_stream s;
           gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_PSELF : GG_SITE_ADJ_PSELF, g.sweep, 0u);
-          *g.p_self = gg_beta(&s, g.ah.tau1 + (double)g.ah.d1, g.ah.tau0 + (double)g.ah.d0);
+          *g.p_self = gg_beta(&s, g.ah.tau1 + g.beta * (double)g.ah.d1, g.ah.tau0 + g.beta * (double)g.ah.d0);
         }
       } else if (g.wh.special) {
         long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
 
 // ------------------------------------------------------------------ per-node conditional
 struct gg_node_ctx {
+  double beta;     // AIS inverse temperature (1 = plain Gibbs)
   int N, Np, K, Kp, B, shift;
   int special;     // special_case_self_conns
   const int32_t* c;
@@ -659,9 +661,9 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
   }
   double lp = x.logm[k];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) lp += acc_o[t];
+  for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_o[t], lp);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) lp += acc_i[t];
+  for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_i[t], lp);
   if (!x.special) {
     constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
     const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
@@ -684,7 +686,7 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
     double acc = 0.0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc = gg_fma(x.T[((size_t)k * K + k) * NT + t], self[t], acc);
-    lp += acc;
+    lp = gg_fma(x.beta, acc, lp);
   }
   return lp;
 }

@@ -45,6 +45,7 @@ struct gg_model {
   double* lp_out;
   bool m_pending;              // resample_m of sweep m_sweep not drawn yet (done by the next k_params or at sync)
   uint32_t m_sweep;
+  double beta;                 // inverse temperature of the sweeps being enqueued / pending
   int pending;                 // optimistic sweeps enqueued and not yet confirmed
   const gg_data* pend_data;
   // host mirrors / hypers
@@ -143,6 +144,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
         (rc = dmalloc(&m->sigma_self, (size_t)B * B)))
       return rc;
   }
+  m->beta = 1.0;
   m->Lmax = N < 4096 ? N : 4096;
   if (m->Lmax < 1) m->Lmax = 1;
   if ((rc = dmalloc(&m->L, (size_t)m->Lmax * 3))) return rc;
@@ -322,6 +324,7 @@ static long long* gs(const gg_model* m, int buf, int dir) {
 
 static gg_node_ctx node_ctx(const gg_model* m, const gg_data* d, int buf) {
   gg_node_ctx x;
+  x.beta = m->beta;
   x.N = m->N; x.Np = m->Np; x.K = m->K; x.Kp = m->Kp; x.B = m->B; x.shift = m->is_adj ? 0 : d->shift;
   x.special = m->cfg.special_case_self_conns;
   x.c = m->c; x.cnt = m->cnt; x.logm = m->logm; x.T = m->T; x.Tout = m->Tout; x.Tin = m->Tin;
@@ -437,6 +440,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   g.mu_self = m->mu_self; g.sigma_self = m->sigma_self; g.T = m->T; g.Tout = m->Tout; g.Tin = m->Tin;
   g.ctl = m->rs;
   g.pi = m->pi;
+  g.beta = m->beta;
   if (m->m_pending && prep) {
     g.draw_m = 1; g.m_site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M; g.m_sweep = m->m_sweep;
     m->m_pending = false;
@@ -667,7 +671,9 @@ int gg_set_timing(gg_model* m, int32_t on) {
 int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
-  if (beta != 1.0) return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals (beta != 1) are not implemented yet");
+  if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
+  if (beta != 1.0 && (m->eig || !m->is_adj))
+    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals are defined for the adjacency models only (graph_models.py:168-371)");
   if (m->eig) {
     for (int s = 0; s < n_sweeps; ++s) {
       int rc = gg_eigen_resample(m->eig, d, GG_PART_ALL);
@@ -677,9 +683,10 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   }
   int rc = check_data(m, d);
   if (rc) return rc;
-  if (m->pending && m->pend_data != d && (rc = model_sync(m))) return rc;
+  if (m->pending && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
   if (m->pending == 0) begin_call(m);
   m->pend_data = d;
+  m->beta = beta;
   for (int s = 0; s < n_sweeps; ++s) {
     if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)m->pending))) return rc;
     m->pending += 1;
@@ -704,10 +711,13 @@ int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
 int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) {
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
-  if (beta != 1.0) return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals (beta != 1) are not implemented yet");
+  if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
+  if (beta != 1.0 && (m->eig || !m->is_adj))
+    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals are defined for the adjacency models only (graph_models.py:168-371)");
   if (m->eig) return gg_eigen_resample(m->eig, d, parts);
   int rc = model_sync(m);
   if (rc) return rc;
+  m->beta = beta;
   if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
   if (rc) return rc;
   begin_call(m);
@@ -751,6 +761,7 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (rc) return rc;
   if ((rc = check_data(m, d))) return rc;
   if (n < 0 || n >= m->N) return gg_fail(GG_ERR_INVALID, "node %d out of range", n);
+  m->beta = 1.0;
   begin_call(m);
   const int buf = m->cur;
   if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;

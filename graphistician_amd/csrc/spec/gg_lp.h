@@ -31,23 +31,26 @@
 GG_HD int gg_nt_gauss(int B) { return 1 + B + B * (B + 1) / 2; }
 
 // T: [K][K][NT] row-major; so, si: [K][NT]; self: [NT] or null.
+// beta is the AIS inverse temperature (graph_models.py:50-64,278-293: the likelihood terms are
+// weighted by beta, the prior log m is not); fma(1.0, acc, lp) == lp + acc bit for bit, so
+// beta = 1 is the plain conditional.
 GG_HD double gg_block_lp(int k, int K, int NT, const double* logm, const double* T,
-                         const double* so, const double* si, const double* self) {
+                         const double* so, const double* si, const double* self, double beta = 1.0) {
   double lp = logm[k];
   for (int t = 0; t < NT; ++t) {
     double acc = 0.0;
     for (int j = 0; j < K; ++j) acc = gg_fma(T[(k * K + j) * NT + t], so[j * NT + t], acc);
-    lp += acc;
+    lp = gg_fma(beta, acc, lp);
   }
   for (int t = 0; t < NT; ++t) {
     double acc = 0.0;
     for (int j = 0; j < K; ++j) acc = gg_fma(T[(j * K + k) * NT + t], si[j * NT + t], acc);
-    lp += acc;
+    lp = gg_fma(beta, acc, lp);
   }
   if (self) {
     double acc = 0.0;
     for (int t = 0; t < NT; ++t) acc = gg_fma(T[(k * K + k) * NT + t], self[t], acc);
-    lp += acc;
+    lp = gg_fma(beta, acc, lp);
   }
   return lp;
 }

@@ -87,13 +87,14 @@ def dequantise(q, shift):
 
 
 # ---------------------------------------------------------------- SBM adjacency
-def sbm_adj_sweep(A, c, m, p, p_self, pi, tau1, tau0, special, seed, sweep, parts=PART_ALL):
-    """In-place sweep of (c, m, p); returns new p_self."""
+def sbm_adj_sweep(A, c, m, p, p_self, pi, tau1, tau0, special, seed, sweep, parts=PART_ALL, beta=1.0):
+    """In-place sweep of (c, m, p); returns new p_self.  beta = AIS inverse temperature."""
     N, K = A.shape[0], m.shape[0]
     A8, pA = _u8(A != 0)
     ps = C.c_double(float(p_self))
-    lib().orc_sbm_adj_sweep(N, K, pA, _i32(c), _f64(m), _f64(p), C.byref(ps), _f64(np.ascontiguousarray(pi, dtype=np.float64)),
-                            C.c_double(tau1), C.c_double(tau0), int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts))
+    lib().orc_sbm_adj_sweep_beta(N, K, pA, _i32(c), _f64(m), _f64(p), C.byref(ps),
+                                 _f64(np.ascontiguousarray(pi, dtype=np.float64)), C.c_double(tau1), C.c_double(tau0),
+                                 int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts), C.c_double(beta))
     return ps.value
 
 
@@ -117,12 +118,12 @@ def sbm_adj_loglik(A, c, p, p_self, allow_self=True, special=True):
     return lib().orc_sbm_adj_loglik(N, K, pA, _i32(c), _f64(p), C.c_double(p_self), int(allow_self), int(special))
 
 
-def bb_adj_sweep(A, tau1, tau0, self_connection, seed, sweep):
+def bb_adj_sweep(A, tau1, tau0, self_connection, seed, sweep, beta=1.0):
     N = A.shape[0]
     A8, pA = _u8(A != 0)
     p, ps = C.c_double(0), C.c_double(0)
-    lib().orc_bb_adj_sweep(N, pA, C.byref(p), C.byref(ps), C.c_double(tau1), C.c_double(tau0), int(self_connection),
-                           C.c_uint64(seed), C.c_uint32(sweep))
+    lib().orc_bb_adj_sweep_beta(N, pA, C.byref(p), C.byref(ps), C.c_double(tau1), C.c_double(tau0), int(self_connection),
+                                C.c_uint64(seed), C.c_uint32(sweep), C.c_double(beta))
     return p.value, ps.value
 
 

@@ -82,12 +82,15 @@ int orc_quantise(int N, int B, const uint8_t* A, const double* W, int32_t* q, in
 // SBM adjacency  (adjacency.py:440-702)
 // ---------------------------------------------------------------------------
 
+static void resample_m(int N, int K, const int32_t* c, const double* pi, double* m, uint64_t seed,
+                       uint32_t site, uint32_t sweep);
+
 // adjacency.py:620-648 resample_p: for each (c1,c2) in row-major order, masked
 // edge / non-edge counts (diagonal excluded when special_case_self_conns),
 // p[c1,c2] ~ Beta(tau1 + n1, tau0 + n0); then p_self from the diagonal.
 static void sbm_adj_resample_p(int N, int K, const uint8_t* A, const int32_t* c, double* p,
                                double* p_self, double tau1, double tau0, int special,
-                               uint64_t seed, uint32_t sweep) {
+                               uint64_t seed, uint32_t sweep, double beta) {
   std::vector<long long> n1((size_t)K * K, 0), n0((size_t)K * K, 0);
   long long d1 = 0, d0 = 0;
   for (int i = 0; i < N; ++i)
@@ -104,12 +107,13 @@ static void sbm_adj_resample_p(int N, int K, const uint8_t* A, const int32_t* c,
     for (int c2 = 0; c2 < K; ++c2) {
       gg_stream s;
       gg_stream_init(&s, seed, GG_SITE_ADJ_P, sweep, (uint32_t)(c1 * K + c2));
-      p[c1 * K + c2] = gg_beta(&s, tau1 + (double)n1[c1 * K + c2], tau0 + (double)n0[c1 * K + c2]);
+      // tempered posterior: counts weighted by beta (graph_models.py:366-367)
+      p[c1 * K + c2] = gg_beta(&s, tau1 + beta * (double)n1[c1 * K + c2], tau0 + beta * (double)n0[c1 * K + c2]);
     }
   if (special) {
     gg_stream s;
     gg_stream_init(&s, seed, GG_SITE_ADJ_PSELF, sweep, 0u);
-    *p_self = gg_beta(&s, tau1 + (double)d1, tau0 + (double)d0);
+    *p_self = gg_beta(&s, tau1 + beta * (double)d1, tau0 + beta * (double)d0);
   }
 }
 
@@ -117,7 +121,7 @@ static void sbm_adj_resample_p(int N, int K, const uint8_t* A, const int32_t* c,
 // (SURVEY.md §8a row a6): block histograms of row n1 and column n1, self excluded.
 static void sbm_adj_node_lp(int N, int K, const uint8_t* A, const int32_t* c, const double* logm,
                             const double* T /* [K][K][2] = log p, log(1-p) */, int special, int n1,
-                            double* lp) {
+                            double* lp, double beta = 1.0) {
   std::vector<double> so((size_t)K * 2, 0.0), si((size_t)K * 2, 0.0);
   for (int n2 = 0; n2 < N; ++n2) {
     if (n2 == n1) continue;
@@ -132,7 +136,7 @@ static void sbm_adj_node_lp(int N, int K, const uint8_t* A, const int32_t* c, co
     self[0] = a; self[1] = 1.0 - a;
     selfp = self;
   }
-  for (int k = 0; k < K; ++k) lp[k] = gg_block_lp(k, K, 2, logm, T, so.data(), si.data(), selfp);
+  for (int k = 0; k < K; ++k) lp[k] = gg_block_lp(k, K, 2, logm, T, so.data(), si.data(), selfp, beta);
 }
 
 static void sbm_adj_tables(int K, const double* m, const double* p, double* logm, double* T) {
@@ -145,12 +149,12 @@ static void sbm_adj_tables(int K, const double* m, const double* p, double* logm
 
 // adjacency.py:650-695 resample_c: sequential scan, labels updated in place.
 static void sbm_adj_resample_c(int N, int K, const uint8_t* A, int32_t* c, const double* m,
-                               const double* p, int special, uint64_t seed, uint32_t sweep) {
+                               const double* p, int special, uint64_t seed, uint32_t sweep, double beta) {
   if (K == 1) return;  // adjacency.py:657-658
   std::vector<double> logm(K), T((size_t)K * K * 2), lp(K), scratch(2 * gg_next_pow2(K));
   sbm_adj_tables(K, m, p, logm.data(), T.data());
   for (int n1 = 0; n1 < N; ++n1) {
-    sbm_adj_node_lp(N, K, A, c, logm.data(), T.data(), special, n1, lp.data());
+    sbm_adj_node_lp(N, K, A, c, logm.data(), T.data(), special, n1, lp.data(), beta);
     double u = gg_uniform_at(seed, GG_SITE_ADJ_C, sweep, (uint32_t)n1);
     c[n1] = gg_categorical(lp.data(), K, u, scratch.data());
   }
@@ -166,11 +170,20 @@ static void resample_m(int N, int K, const int32_t* c, const double* pi, double*
 }
 
 // adjacency.py:615-618 resample = resample_p -> resample_c -> resample_m.
+int orc_sbm_adj_sweep_beta(int N, int K, const uint8_t* A, int32_t* c, double* m, double* p,
+                           double* p_self, const double* pi, double tau1, double tau0, int special,
+                           uint64_t seed, uint32_t sweep, int parts, double beta) {
+  if (parts & ORC_PART_PARAMS) sbm_adj_resample_p(N, K, A, c, p, p_self, tau1, tau0, special, seed, sweep, beta);
+  if (parts & ORC_PART_C) sbm_adj_resample_c(N, K, A, c, m, p, special, seed, sweep, beta);
+  if (parts & ORC_PART_M) resample_m(N, K, c, pi, m, seed, GG_SITE_ADJ_M, sweep);
+  return 0;
+}
+
 int orc_sbm_adj_sweep(int N, int K, const uint8_t* A, int32_t* c, double* m, double* p,
                       double* p_self, const double* pi, double tau1, double tau0, int special,
                       uint64_t seed, uint32_t sweep, int parts) {
-  if (parts & ORC_PART_PARAMS) sbm_adj_resample_p(N, K, A, c, p, p_self, tau1, tau0, special, seed, sweep);
-  if (parts & ORC_PART_C) sbm_adj_resample_c(N, K, A, c, m, p, special, seed, sweep);
+  if (parts & ORC_PART_PARAMS) sbm_adj_resample_p(N, K, A, c, p, p_self, tau1, tau0, special, seed, sweep, 1.0);
+  if (parts & ORC_PART_C) sbm_adj_resample_c(N, K, A, c, m, p, special, seed, sweep, 1.0);
   if (parts & ORC_PART_M) resample_m(N, K, c, pi, m, seed, GG_SITE_ADJ_M, sweep);
   return 0;
 }
@@ -240,8 +253,15 @@ double orc_sbm_adj_loglik(int N, int K, const uint8_t* A, const int32_t* c, cons
 // ---------------------------------------------------------------------------
 // adjacency.py:153-181.  NOTE the reference updates p_self with the OFF-diagonal
 // priors tau1,tau0 (adjacency.py:175) — reproduced, not fixed.
+int orc_bb_adj_sweep_beta(int N, const uint8_t* A, double* p, double* p_self, double tau1, double tau0,
+                          int self_connection, uint64_t seed, uint32_t sweep, double beta);
 int orc_bb_adj_sweep(int N, const uint8_t* A, double* p, double* p_self, double tau1, double tau0,
                      int self_connection, uint64_t seed, uint32_t sweep) {
+  return orc_bb_adj_sweep_beta(N, A, p, p_self, tau1, tau0, self_connection, seed, sweep, 1.0);
+}
+// tempered form: graph_models.py:178-182 (a + beta nnz, b + beta (N^2 - nnz))
+int orc_bb_adj_sweep_beta(int N, const uint8_t* A, double* p, double* p_self, double tau1, double tau0,
+                          int self_connection, uint64_t seed, uint32_t sweep, double beta) {
   long long n1 = 0, n0 = 0, d1 = 0, d0 = 0;
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
@@ -251,12 +271,12 @@ int orc_bb_adj_sweep(int N, const uint8_t* A, double* p, double* p_self, double 
   gg_stream s;
   gg_stream_init(&s, seed, GG_SITE_BB_P, sweep, 0u);
   if (self_connection) {
-    *p = gg_beta(&s, tau1 + (double)n1, tau0 + (double)n0);
+    *p = gg_beta(&s, tau1 + beta * (double)n1, tau0 + beta * (double)n0);
     gg_stream s2;
     gg_stream_init(&s2, seed, GG_SITE_BB_PSELF, sweep, 0u);
-    *p_self = gg_beta(&s2, tau1 + (double)d1, tau0 + (double)d0);
+    *p_self = gg_beta(&s2, tau1 + beta * (double)d1, tau0 + beta * (double)d0);
   } else {
-    *p = gg_beta(&s, tau1 + (double)(n1 + d1), tau0 + (double)(n0 + d0));
+    *p = gg_beta(&s, tau1 + beta * (double)(n1 + d1), tau0 + beta * (double)(n0 + d0));
   }
   return 0;
 }

@@ -1,0 +1,108 @@
+"""Tempered conditionals and the AIS driver (examples/demo_ais.py:10-62)."""
+import numpy as np
+import pytest
+from scipy.special import betaln, logsumexp
+
+from oracle import oracle as O
+from tests.helpers import planted_sbm, AdjState
+
+
+def er_log_marginal(A, a, b):
+    n1 = float(A.sum())
+    n0 = A.size - n1
+    return betaln(a + n1, b + n0) - betaln(a, b)
+
+
+def test_oracle_tempered_limits():
+    """beta = 0: the sweep samples the prior (p ~ Beta(tau1, tau0) whatever the data, labels ~ Cat(m));
+    beta = 1: identical to the untempered sweep."""
+    N, K = 30, 3
+    A, _, _ = planted_sbm(N, K, seed=1)
+    st = AdjState(N, K, seed=2)
+    c1, m1, p1 = st.c.copy(), st.m.copy(), st.p.copy()
+    c2, m2, p2 = st.c.copy(), st.m.copy(), st.p.copy()
+    ps1 = O.sbm_adj_sweep(A, c1, m1, p1, st.p_self, st.pi, 1.0, 1.0, 1, 5, 0)
+    ps2 = O.sbm_adj_sweep(A, c2, m2, p2, st.p_self, st.pi, 1.0, 1.0, 1, 5, 0, beta=1.0)
+    assert np.array_equal(c1, c2) and np.array_equal(p1, p2) and ps1 == ps2
+    pa, pb = st.p.copy(), st.p.copy()
+    O.sbm_adj_sweep(A, st.c.copy(), st.m.copy(), pa, st.p_self, st.pi, 1.0, 1.0, 1, 5, 0, O.PART_PARAMS, beta=0.0)
+    O.sbm_adj_sweep(1 - A, st.c.copy(), st.m.copy(), pb, st.p_self, st.pi, 1.0, 1.0, 1, 5, 0, O.PART_PARAMS, beta=0.0)
+    assert np.array_equal(pa, pb)            # data ignored at beta = 0
+
+
+def test_oracle_ais_recovers_er_marginal_likelihood():
+    """AIS with the oracle's tempered Beta-Bernoulli sweep against the closed-form evidence."""
+    rng = np.random.RandomState(0)
+    N, a, b = 10, 1.0, 1.0
+    A = (rng.rand(N, N) < 0.3).astype(np.uint8)
+    betas = np.linspace(0, 1, 40)
+    M, sweep = 200, 0
+    logw, logw_ref = np.zeros(M), np.zeros(M)
+    for m in range(M):
+        p, _ = O.bb_adj_sweep(A, a, b, 0, 77, sweep, beta=0.0)      # prior draw
+        sweep += 1
+        for bb in range(1, len(betas)):
+            logw[m] += (betas[bb] - betas[bb - 1]) * O.const_adj_loglik(A, p, p)      # Neal: before the transition
+            p, _ = O.bb_adj_sweep(A, a, b, 0, 77, sweep, beta=betas[bb])
+            sweep += 1
+            logw_ref[m] += (betas[bb] - betas[bb - 1]) * O.const_adj_loglik(A, p, p)  # demo_ais.py:49-52: after it
+    exact = er_log_marginal(A, a, b)
+    est = -np.log(M) + logsumexp(logw)
+    assert abs(est - exact) < 0.25
+    # the reference ordering is a right-endpoint rule: biased upwards
+    assert (-np.log(M) + logsumexp(logw_ref)) > exact + 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta", [0.0, 0.37, 1.0])
+def test_engine_tempered_sweeps_bitexact(beta):
+    from graphistician_amd import _abi as abi
+    N, K = 150, 5
+    A, _, _ = planted_sbm(N, K, seed=4)
+    st = AdjState(N, K, seed=6)
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=31, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                  special_case_self_conns=1)
+    m.set(abi.ST_C, st.c, np.int32); m.set(abi.ST_M, st.m); m.set(abi.ST_PI, st.pi); m.set(abi.ST_P, st.p)
+    m.set(abi.ST_P_SELF, np.array([st.p_self]))
+    ps = st.p_self
+    for s in range(4):
+        m.resample(d, 1, beta)
+        ps = O.sbm_adj_sweep(A, st.c, st.m, st.p, ps, st.pi, 1.0, 1.0, 1, 31, s, beta=beta)
+        assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c), (beta, s)
+        assert np.array_equal(m.get(abi.ST_P, (K, K)), st.p)
+        assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=1, special_case_self_conns=1)
+    dw = abi.DeviceData(A, np.zeros((N, N, 1)))
+    if beta != 1.0:
+        with pytest.raises(abi.EngineError):
+            w.resample(dw, 1, beta)
+
+
+@pytest.mark.gpu
+def test_engine_ais_er_and_sbm():
+    from graphistician_amd.adjacency import BetaBernoulliAdjacencyDistribution, SBMAdjacencyDistribution
+    from graphistician_amd.ais import estimate_marginal_likelihood, combine_log_weights
+    rng = np.random.RandomState(3)
+    N = 12
+    A = (rng.rand(N, N) < 0.35).astype(np.uint8)
+    np.random.seed(0)
+    er = BetaBernoulliAdjacencyDistribution(N, tau1=1.0, tau0=1.0, seed=5)
+    lz, w = estimate_marginal_likelihood(er, A, N_samples=48, B=30, steps_per_B=1, return_weights=True)
+    assert abs(lz - er_log_marginal(A, 1.0, 1.0)) < 0.3
+    assert abs(combine_log_weights([w[:24], w[24:]]) - lz) < 1e-12
+    # SBM with one block and special-cased diagonal factorises into two Beta-Bernoulli evidences
+    sbm = SBMAdjacencyDistribution(N, C=1, seed=9)
+    lz1 = estimate_marginal_likelihood(sbm, A, N_samples=32, B=30, steps_per_B=1)
+    off = A[~np.eye(N, dtype=bool)]
+    exact = er_log_marginal(off, 1.0, 1.0) + er_log_marginal(np.diag(A), 1.0, 1.0)
+    assert abs(lz1 - exact) < 0.4
+    # a 2-block SBM explains block-structured data better than the Erdos-Renyi model
+    c = np.repeat([0, 1], N // 2)
+    P = np.array([[0.9, 0.05], [0.05, 0.9]])[np.ix_(c, c)]
+    A2 = (rng.rand(N, N) < P).astype(np.uint8)
+    sbm2 = SBMAdjacencyDistribution(N, C=2, pi=10.0, seed=11)
+    lz_sbm = estimate_marginal_likelihood(sbm2, A2, N_samples=24, B=40, steps_per_B=2)
+    er2 = BetaBernoulliAdjacencyDistribution(N, seed=12)
+    lz_er = estimate_marginal_likelihood(er2, A2, N_samples=24, B=40, steps_per_B=1)
+    assert lz_sbm > lz_er + 5.0
