@@ -55,6 +55,14 @@ __global__ __launch_bounds__(1024) void k_sort_labels(const int32_t* __restrict_
   }
 }
 
+// Zero a statistics buffer unless the pipeline is stalled (a stalled scan still needs its buffer).
+__global__ void k_zero_if_live(const int32_t* __restrict__ ctl, unsigned long long* __restrict__ p, size_t words) {
+  if (ctl[4]) return;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < words; i += stride) p[i] = 0ull;
+}
+
 // ------------------------------------------------------------------ BULK kernels
 // G[k][n] = sum over rows i with label k of X[i][n]  (column sums grouped by the
 // row's label).  Run on X it yields the in-edge histograms of every node, run on
@@ -163,11 +171,20 @@ __global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, 
   for (int i = tid; i < SC * NSI; i += 256) s_s[i] = 0ull;
   __syncthreads();
   if (col0 < Np) {
+    // Per-wave partial sums are kept in the cheapest exact type: a wave sees at most RW/4 <= 255
+    // rows and |q| <= 2^23, so sum q fits int32 for <= 127 rows and sum q_r q_s (< 2^46 each) is
+    // exact in fp64 (< 2^53) for <= 127 rows; longer runs flush into the 64-bit accumulators.
     int cnt[EPL];
+    int s1[EPL][B];
+    double s2[EPL][NSI - B];
     long long st[EPL][NSI];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       cnt[e] = 0;
+#pragma unroll
+      for (int r = 0; r < B; ++r) s1[e][r] = 0;
+#pragma unroll
+      for (int t = 0; t < NSI - B; ++t) s2[e][t] = 0.0;
 #pragma unroll
       for (int s = 0; s < NSI; ++s) st[e][s] = 0;
     }
@@ -177,19 +194,30 @@ __global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, 
       for (int e = 0; e < EPL; ++e) {
         const bool valid = q[e * B] != GG_NO_EDGE;
         cnt[e] += valid ? 1 : 0;
-        long long x[B];
+        int x[B];
+        double xd[B];
 #pragma unroll
-        for (int r = 0; r < B; ++r) x[r] = valid ? (long long)q[e * B + r] : 0ll;
+        for (int r = 0; r < B; ++r) { x[r] = valid ? q[e * B + r] : 0; xd[r] = (double)x[r]; }
 #pragma unroll
-        for (int r = 0; r < B; ++r) st[e][r] += x[r];
-        int t = B;
+        for (int r = 0; r < B; ++r) s1[e][r] += x[r];
+        int t = 0;
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
-          for (int s = r; s < B; ++s) st[e][t++] += x[r] * x[s];
+          for (int s = r; s < B; ++s) { s2[e][t] = gg_fma(xd[r], xd[s], s2[e][t]); ++t; }
+      }
+    };
+    auto flush = [&]() {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+        for (int r = 0; r < B; ++r) { st[e][r] += (long long)s1[e][r]; s1[e][r] = 0; }
+#pragma unroll
+        for (int t = 0; t < NSI - B; ++t) { st[e][B + t] += (long long)s2[e][t]; s2[e][t] = 0.0; }
       }
     };
     int r = wave;
+    int since = 0;
     for (; r + 4 * (U - 1) < nrows; r += 4 * U) {   // U rows in flight per wave
       int4 v[U];
 #pragma unroll
@@ -199,12 +227,17 @@ __global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, 
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) accumulate(v[u]);
+      since += U;
+      if (since > 120 - U) { flush(); since = 0; }
     }
     for (; r < nrows; r += 4) {
       int i0 = perm[row0 + r];
       int4 v0 = *reinterpret_cast<const int4*>(X + ((size_t)i0 * Np + col0) * B);
       accumulate(v0);
+      since += 1;
+      if (since > 120) { flush(); since = 0; }
     }
+    flush();
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       if (cnt[e]) {

@@ -28,7 +28,12 @@ struct gg_model {
   int N, K, Kp, B, NT, NSI, Np, NTAB;
   gg_eigen* eig;
   // device state
-  int32_t *c, *cand, *cnt, *perm, *lab_start;
+  int32_t *c, *cand, *cnt;
+  // label sort, double buffered: a completed scan writes the sort of its final labels into the other
+  // buffer, so that the bulk kernel of the following sweep (launched early, see enqueue_sweep_pipe)
+  // can still read the old one
+  int32_t *permb[2], *labb[2];
+  int pcur;
   double *m, *logm, *pi;
   double *p, *p_self;
   double *mu, *sigma, *mu_self, *sigma_self;
@@ -52,6 +57,11 @@ struct gg_model {
   gg_niw niw, niw_self;
   int32_t* h_rs;  // pinned copy of the control block
   hipStream_t stream;
+  hipStream_t sb;               // bulk statistics of the NEXT sweep run here, concurrently with the scan
+  hipEvent_t ev_bulk[2], ev_scan;
+  bool pipe;                    // cross-sweep pipelining enabled (scan models)
+  bool next_bulk;               // Gbuf[cur] already holds (is receiving) the next sweep's statistics
+  int cur0, pcur0;              // buffer indices when the pending batch started
   uint32_t sweep;
   int Lmax, CH, max_idle;
   size_t resolve_lds;
@@ -127,7 +137,8 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   const int N = m->N, K = m->K, B = m->B, NT = m->NT;
   const size_t KK = (size_t)K * K;
   if ((rc = dmalloc(&m->c, N)) || (rc = dmalloc(&m->cand, N)) || (rc = dmalloc(&m->cnt, K)) ||
-      (rc = dmalloc(&m->perm, N)) || (rc = dmalloc(&m->lab_start, K + 1)) || (rc = dmalloc(&m->m, K)) ||
+      (rc = dmalloc(&m->permb[0], N)) || (rc = dmalloc(&m->permb[1], N)) || (rc = dmalloc(&m->labb[0], K + 1)) ||
+      (rc = dmalloc(&m->labb[1], K + 1)) || (rc = dmalloc(&m->m, K)) ||
       (rc = dmalloc(&m->logm, K)) || (rc = dmalloc(&m->pi, K)) || (rc = dmalloc(&m->T, KK * NT)) ||
       (rc = dmalloc(&m->Tout, (size_t)K * NT * m->Kp)) || (rc = dmalloc(&m->Tin, (size_t)K * NT * m->Kp)) ||
       (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 8)) || (rc = dmalloc(&m->lp_out, K)))
@@ -158,6 +169,16 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->max_idle = 2;
   GG_HIP(hipEventCreate(&m->ev_call0));
   GG_HIP(hipEventCreate(&m->ev_call1));
+  GG_HIP(hipStreamCreate(&m->sb));
+  GG_HIP(hipEventCreateWithFlags(&m->ev_bulk[0], hipEventDisableTiming));
+  GG_HIP(hipEventCreateWithFlags(&m->ev_bulk[1], hipEventDisableTiming));
+  GG_HIP(hipEventCreateWithFlags(&m->ev_scan, hipEventDisableTiming));
+  {
+    const char* e = getenv("GG_PIPELINE");
+    // eager cross-sweep pipelining costs more host API time (event records / waits) than it saves on the
+    // device at N = 4096; it is opt-in until the sweep is replayed from a hipGraph
+    m->pipe = m->sbm && m->K > 1 && (e && atoi(e) == 1);
+  }
   // defaults: uniform m, pi = 1, p = 0.5, standard NIW
   std::vector<double> ones(K, 1.0), um(K, 1.0 / K), half(KK, 0.5);
   GG_HIP(hipMemcpy(m->pi, ones.data(), K * 8, hipMemcpyHostToDevice));
@@ -186,7 +207,7 @@ int gg_model_destroy(gg_model* m) {
   if (!m) return GG_OK;
   hipSetDevice(m->cfg.device);
   if (m->eig) { gg_eigen_destroy(m->eig); delete m; return GG_OK; }
-  void* ptrs[] = {m->c, m->cand, m->cnt, m->perm, m->lab_start, m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
+  void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
                   m->rs, m->L, m->lp_out};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -195,6 +216,8 @@ int gg_model_destroy(gg_model* m) {
   if (m->ev_call0) hipEventDestroy(m->ev_call0);
   if (m->ev_call1) hipEventDestroy(m->ev_call1);
   if (m->stream) hipStreamDestroy(m->stream);
+  if (m->sb) hipStreamDestroy(m->sb);
+  for (hipEvent_t e : {m->ev_bulk[0], m->ev_bulk[1], m->ev_scan}) if (e) hipEventDestroy(e);
   delete m;
   return GG_OK;
 }
@@ -218,6 +241,7 @@ static int state_ptr(gg_model* m, int id, void** p, size_t* nbytes) {
 }
 
 static int model_sync(gg_model* m);
+static int drain_pipe(gg_model* m);
 
 int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
   if (!m || !buf) return gg_fail(GG_ERR_INVALID, "gg_set_state: null argument");
@@ -251,6 +275,7 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
     for (int n = 0; n < m->N; ++n)
       if (c[n] < 0 || c[n] >= m->K) return gg_fail(GG_ERR_INVALID, "label c[%d]=%d out of range [0,%d)", n, c[n], m->K);
     m->perm_valid = false;
+    { int rc1 = drain_pipe(m); if (rc1) return rc1; }
   }
   GG_HIP(hipMemcpyAsync(p, buf, nbytes, hipMemcpyHostToDevice, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));
@@ -351,7 +376,7 @@ static int bulk_rw(const gg_model* m, int strips, int ndirs) {
 
 static int ensure_perm(gg_model* m) {
   if (!m->perm_valid) {
-    k_sort_labels<<<1, 1024, 2 * m->K * sizeof(int), m->stream>>>(m->c, m->N, m->K, m->perm, m->lab_start, m->cnt);
+    k_sort_labels<<<1, 1024, 2 * m->K * sizeof(int), m->stream>>>(m->c, m->N, m->K, m->permb[m->pcur], m->labb[m->pcur], m->cnt);
     GG_HIP(hipGetLastError());
     m->perm_valid = true;
   }
@@ -367,21 +392,28 @@ static int ensure_zero(gg_model* m, int buf) {
 }
 
 // BULK statistics under the current labels into buffer `buf`.  dirs: bit 0 = out (reads X^T), bit 1 = in (reads X).
-static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined, uint32_t sweep = 0) {
+static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined, uint32_t sweep = 0,
+                        hipStream_t st = nullptr, int pidx = -1) {
   const int N = m->N, K = m->K, Np = m->Np;
   int rc;
-  if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, buf))) return rc;
+  if (!st) {
+    st = m->stream;
+    if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, buf))) return rc;
+  }
+  if (pidx < 0) pidx = m->pcur;
+  const int32_t* perm = m->permb[pidx];
+  const int32_t* lab_start = m->labb[pidx];
   const int dir0 = (dirs & 1) ? 0 : 1;
   const int ndirs = (dirs == 3) ? 2 : 1;
   const int32_t* ctl = pipelined ? m->rs : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
-  if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
+  if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, st)); }
   if (m->is_adj) {
     int strips = (Np + 1023) / 1024;
     int RW = bulk_rw(m, strips, ndirs);
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
-    k_bulk_adj<<<grd, 256, 0, m->stream>>>(d->AT, d->A, Np, m->perm, m->lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1),
+    k_bulk_adj<<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1),
                                            dir0, ctl);
     if (timed) m->st.bulk_bytes += (double)ndirs * N * (double)N;
   } else {
@@ -392,7 +424,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
     static int unroll = -1;
     if (unroll < 0) { const char* e = getenv("GG_BULK_UNROLL"); unroll = e ? atoi(e) : 4; }
 #define BULKW(BV, UV)                                                                                                 \
-  k_bulk_w<BV, UV><<<grd, 256, 0, m->stream>>>(d->WqT, d->Wq, Np, m->perm, m->lab_start, K, RW, gcnt(m, buf, 0),         \
+  k_bulk_w<BV, UV><<<grd, 256, 0, st>>>(d->WqT, d->Wq, Np, perm, lab_start, K, RW, gcnt(m, buf, 0),         \
                                                gcnt(m, buf, 1), gs(m, buf, 0), gs(m, buf, 1), dir0, ctl)
     switch (m->B) {
       case 1: if (unroll >= 8) BULKW(1, 8); else if (unroll >= 4) BULKW(1, 4); else BULKW(1, 2); break;
@@ -404,7 +436,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   }
   if (timed) {
     m->st.bulk_launches += 1;
-    GG_HIP(hipEventRecord(e1, m->stream));
+    GG_HIP(hipEventRecord(e1, st));
   }
   GG_HIP(hipGetLastError());
   m->zeroed[buf] = false;
@@ -413,14 +445,15 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
 
 // fused: pair tables (from buffer `buf`) -> parameter draw -> coefficient tables; optionally zero the other buffer
 static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, bool draw, bool prep, bool zero_other,
-                          uint32_t sweep) {
+                          uint32_t sweep, int pidx = -1) {
+  if (pidx < 0) pidx = m->pcur;
   gg_params_args g;
   memset(&g, 0, sizeof(g));
   g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.Kp = m->Kp; g.B = m->B; g.NSI = m->NSI; g.Np = m->Np; g.N = m->N;
   g.do_tables = tables; g.do_draw = draw; g.do_prep = prep;
   g.add_diag = m->cfg.special_case_self_conns ? 0 : 1;
   g.Gcnt0 = gcnt(m, buf, 0); g.GS0 = gs(m, buf, 0);
-  g.perm = m->perm; g.lab_start = m->lab_start; g.cnt = m->cnt;
+  g.perm = m->permb[pidx]; g.lab_start = m->labb[pidx]; g.cnt = m->cnt;
   g.dA = d ? d->dA : nullptr; g.dWq = d ? d->dWq : nullptr;
   g.tab = m->tab;
   g.ah.tau1 = m->cfg.tau1; g.ah.tau0 = m->cfg.tau0;
@@ -482,12 +515,16 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
   return GG_OK;
 }
 
-static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort) {
+// The tail of a completed scan sorts the final labels into perm buffer `pw` (default: the other one).
+static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort,
+                          int pw = -1, bool flush_on_change = false) {
+  if (pw < 0) pw = 1 - m->pcur;
   gg_resolve_args g;
   g.x = node_ctx(m, d, buf);
   g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
   g.tail_m = tail_m ? 1 : 0; g.tail_sort = tail_sort ? 1 : 0;
-  g.m = m->m; g.pi = m->pi; g.perm = m->perm; g.lab_start = m->lab_start;
+  g.m = m->m; g.pi = m->pi; g.perm = m->permb[pw]; g.lab_start = m->labb[pw];
+  g.flush_on_change = flush_on_change ? 1 : 0;
   g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
   g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
@@ -540,38 +577,41 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
 
 // Finish a scan the pipeline left unfinished: rounds of (apply L, re-speculate the
 // remainder, resolve) with a host check after each, until the last node is done.
-static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort) {
+// The final resolve sorts the labels into perm buffer `pw`.
+static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort, int pw) {
   int rc;
   for (int round = 0;; ++round) {
     if ((rc = read_ctl(m))) return rc;
-    if (!m->h_rs[4]) return GG_OK;  // scan complete
+    if (!m->h_rs[4] || m->h_rs[0] == 0) {   // scan complete (a set flag with pos == 0 is a pipeline flush, not a stall)
+      if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
+      return GG_OK;
+    }
     int pos = m->h_rs[0];
     if ((rc = launch_apply_L(m, d, buf))) return rc;
     if ((rc = write_ctl_word(m, 4, 0))) return rc;
     if ((rc = launch_speculate(m, d, buf, pos, -1, sweep, false))) return rc;
-    if ((rc = launch_resolve(m, d, buf, sweep, tail_m, tail_sort))) return rc;
+    if ((rc = launch_resolve(m, d, buf, sweep, tail_m, tail_sort, pw, false))) return rc;
     m->st.resolve_rounds += 1;
     if (round > 2 * m->N + 8) return gg_fail(GG_ERR_HIP, "resolve did not make progress (pos=%d)", pos);
   }
 }
 
-// One full sweep enqueued optimistically on the model's stream (no host sync):
-//   bulk -> params (+ zero the other buffer) -> speculate -> resolve (+ draw m, re-sort)
-// K = 1 kinds (Beta-Bernoulli, NIW) have no scan: bulk (out only) -> params.
-static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
+// ---- one full sweep, enqueued optimistically (no host sync) ---------------------------------
+// Serial form (K = 1 kinds, or GG_PIPELINE=0), everything on the scan stream:
+//   bulk -> params (+ zero the other buffer) -> speculate -> resolve (+ re-sort)
+static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
   int rc;
-  const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
-  if (!learn_params) return GG_OK;
   const bool scan = m->sbm && m->K > 1;
-  const int buf = m->cur;
+  const int buf = m->cur, P = m->pcur;
   if ((rc = enqueue_bulk(m, d, buf, scan ? 3 : 1, true, sweep))) return rc;
-  if ((rc = enqueue_params(m, d, buf, true, true, scan, true, sweep))) return rc;
+  if ((rc = enqueue_params(m, d, buf, true, true, scan, true, sweep, P))) return rc;
   if (scan) {
     if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
-    if ((rc = launch_resolve(m, d, buf, sweep, false, true))) return rc;
+    if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
     m->st.resolve_rounds += 1;
-    m->m_pending = true;   // drawn by the next sweep's k_params (or by flush_m at the next sync)
+    m->m_pending = true;   // drawn by the next sweep's k_params (or at the next sync)
     m->m_sweep = sweep;
+    m->pcur = 1 - P;
   } else if (m->sbm) {
     // K == 1 SBM: resample_c returns early (adjacency.py:657-658) but m is still drawn
     k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
@@ -579,6 +619,66 @@ static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
     GG_HIP(hipGetLastError());
   }
   m->cur = 1 - buf;
+  return GG_OK;
+}
+
+// Pipelined form (scan models): the bulk statistics of sweep i+1 are computed on a second stream
+// WHILE sweep i's params -> speculate -> resolve chain runs, under the labels sweep i starts with.
+// They are exactly the statistics sweep i+1 needs iff sweep i's scan changes no label; a scan that
+// changes any label raises the flush flag (k_resolve, flush_on_change), every later pipeline kernel
+// becomes a no-op, and the host restarts from a fresh bulk pass.  Every sweep still streams all of
+// A, A^T, W, W^T once: the work is overlapped, not skipped.
+static int enqueue_sweep_pipe(gg_model* m, const gg_data* d, uint32_t sweep) {
+  int rc;
+  const int g = m->cur, P = m->pcur;
+  if (!m->next_bulk) {
+    // prologue: statistics of THIS sweep (labels final on the scan stream)
+    if ((rc = ensure_perm(m))) return rc;
+    GG_HIP(hipEventRecord(m->ev_scan, m->stream));
+    GG_HIP(hipStreamWaitEvent(m->sb, m->ev_scan, 0));
+    GG_HIP(hipMemsetAsync(m->Gbuf[g], 0, m->Gbytes, m->sb));
+    if ((rc = enqueue_bulk(m, d, g, 3, true, sweep, m->sb, P))) return rc;
+    GG_HIP(hipEventRecord(m->ev_bulk[g], m->sb));
+  }
+  // early bulk of the next sweep, under the same labels
+  GG_HIP(hipStreamWaitEvent(m->sb, m->ev_scan, 0));      // previous scan done: labels final, G[1-g] free
+  {
+    const size_t words = m->Gbytes / 8;
+    int nb = (int)((words + 256 * 8 - 1) / (256 * 8));
+    if (nb > 2048) nb = 2048;
+    k_zero_if_live<<<nb, 256, 0, m->sb>>>(m->rs, reinterpret_cast<unsigned long long*>(m->Gbuf[1 - g]), words);
+  }
+  if ((rc = enqueue_bulk(m, d, 1 - g, 3, true, sweep + 1, m->sb, P))) return rc;
+  GG_HIP(hipEventRecord(m->ev_bulk[1 - g], m->sb));
+  // this sweep's scan chain
+  GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[g], 0));
+  if ((rc = enqueue_params(m, d, g, true, true, true, false, sweep, P))) return rc;
+  if ((rc = launch_speculate(m, d, g, 0, -1, sweep, true))) return rc;
+  if ((rc = launch_resolve(m, d, g, sweep, false, true, 1 - P, true))) return rc;
+  GG_HIP(hipEventRecord(m->ev_scan, m->stream));
+  m->st.resolve_rounds += 1;
+  m->m_pending = true;
+  m->m_sweep = sweep;
+  m->cur = 1 - g;
+  m->pcur = 1 - P;
+  m->next_bulk = true;
+  m->zeroed[0] = m->zeroed[1] = false;
+  return GG_OK;
+}
+
+static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
+  const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
+  if (!learn_params) return GG_OK;
+  return m->pipe ? enqueue_sweep_pipe(m, d, sweep) : enqueue_sweep_serial(m, d, sweep);
+}
+
+// Leave pipelined mode before anything else touches the statistics buffers or the scan stream's state.
+static int drain_pipe(gg_model* m) {
+  if (m->pipe && m->next_bulk) {
+    GG_HIP(hipStreamSynchronize(m->sb));
+    m->next_bulk = false;
+    m->zeroed[0] = m->zeroed[1] = false;
+  }
   return GG_OK;
 }
 
@@ -600,43 +700,55 @@ static int collect_timing(gg_model* m) {
   return GG_OK;
 }
 
-// Confirm the optimistic sweeps: if a scan stalled, finish it on the slow path and
-// re-enqueue the sweeps that became no-ops behind it.
+// Confirm the optimistic sweeps: if a scan stalled (or flushed the pipeline), finish it on the slow
+// path and re-enqueue the sweeps that became no-ops behind it.
 static int model_sync(gg_model* m) {
   if (m->eig || m->pending == 0) return GG_OK;
   int rc;
   const gg_data* d = m->pend_data;
   const bool scan = m->sbm && m->K > 1;
+  bool tainted = false;
   GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   for (;;) {
+    if (m->pipe) GG_HIP(hipStreamSynchronize(m->sb));
     if ((rc = read_ctl(m))) return rc;
     if (m->h_rs[3]) {
       write_ctl_word(m, 3, 0);
       m->pending = 0;
+      m->next_bulk = false;
+      m->zeroed[0] = m->zeroed[1] = false;
       return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
     }
-    int done = scan ? m->h_rs[5] : m->pending;
-    if (!m->h_rs[4]) {  // nothing stalled: every enqueued sweep completed
+    if (!m->h_rs[4]) {  // nothing stalled or flushed: every enqueued sweep completed
       m->sweep += (uint32_t)m->pending;
       m->st.sweeps += (uint64_t)m->pending;
       break;
     }
-    // sweep number `done` (0-based among the pending ones) stalled inside its scan
-    int remaining = m->pending - done - 1;
-    // the pipeline advanced m->cur once per enqueued sweep; the stalled sweep used this buffer:
-    int buf_stalled = (m->cur + m->pending - done) & 1;   // cur - (pending - done) mod 2
-    uint32_t sw = m->sweep + (uint32_t)done;
-    if ((rc = finish_scan(m, d, buf_stalled, sw, false, true))) return rc;
+    tainted = true;
+    // ctl[5] scans completed before the flag went up.  pos != 0: the next one is stuck mid-scan.
+    const int done = scan ? m->h_rs[5] : m->pending;
+    const bool mid = m->h_rs[0] != 0;
+    const int completed = mid ? done + 1 : done;       // after the slow path below
+    if (mid) {
+      const int s_idx = done;                          // index of the stalled sweep within the batch
+      const int buf_s = (m->cur0 + s_idx) & 1, P_s = (m->pcur0 + s_idx) & 1;
+      if ((rc = finish_scan(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
+    } else {
+      if ((rc = write_ctl_word(m, 4, 0))) return rc;
+    }
     m->m_pending = true;
-    m->m_sweep = sw;
-    m->sweep += (uint32_t)(done + 1);
-    m->st.sweeps += (uint64_t)(done + 1);
+    m->m_sweep = m->sweep + (uint32_t)(completed - 1);
+    const int remaining = m->pending - completed;
+    m->sweep += (uint32_t)completed;
+    m->st.sweeps += (uint64_t)completed;
+    m->cur = (m->cur0 + completed) & 1;
+    m->pcur = (m->pcur0 + completed) & 1;
+    m->next_bulk = false;
+    if (m->pipe) m->zeroed[0] = m->zeroed[1] = false;
+    else { m->zeroed[1 - m->cur] = false; m->zeroed[m->cur] = true; }   // serial form: k_params of the last completed sweep zeroed it
     m->pending = 0;
     if ((rc = write_ctl_word(m, 5, 0))) return rc;
-    // buffers after the stalled sweep: its own buffer is dirty, the other one was zeroed by its k_params
-    m->cur = 1 - buf_stalled;
-    m->zeroed[buf_stalled] = false;
-    m->zeroed[1 - buf_stalled] = true;
+    m->cur0 = m->cur; m->pcur0 = m->pcur;
     for (int i = 0; i < remaining; ++i)
       if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i))) return rc;
     m->pending = remaining;
@@ -656,7 +768,9 @@ static int model_sync(gg_model* m) {
   }
   m->st.label_changes = (uint64_t)m->h_rs[2];
   GG_HIP(hipEventSynchronize(m->ev_call1));
-  return collect_timing(m);
+  if ((rc = collect_timing(m))) return rc;
+  if (tainted) { m->st.bulk_ms = 0; m->st.bulk_launches = 0; m->st.bulk_bytes = 0; }  // samples include no-op launches
+  return GG_OK;
 }
 
 extern "C" {
@@ -684,7 +798,10 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   int rc = check_data(m, d);
   if (rc) return rc;
   if (m->pending && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
-  if (m->pending == 0) begin_call(m);
+  if (m->pending == 0) {
+    begin_call(m);
+    m->cur0 = m->cur; m->pcur0 = m->pcur;
+  }
   m->pend_data = d;
   m->beta = beta;
   for (int s = 0; s < n_sweeps; ++s) {
@@ -720,6 +837,7 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   m->beta = beta;
   if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
   if (rc) return rc;
+  if ((rc = drain_pipe(m))) return rc;
   begin_call(m);
   const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
   const bool do_params = (parts & GG_PART_PARAMS) && learn_params;
@@ -732,9 +850,11 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   }
   if (do_c) {
     if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false))) return rc;
-    if ((rc = launch_resolve(m, d, buf, m->sweep, false, true))) return rc;
+    const int pw = 1 - m->pcur;
+    if ((rc = launch_resolve(m, d, buf, m->sweep, false, true, pw, false))) return rc;
     m->st.resolve_rounds += 1;
-    if ((rc = finish_scan(m, d, buf, m->sweep, false, true))) return rc;
+    if ((rc = finish_scan(m, d, buf, m->sweep, false, true, pw))) return rc;
+    m->pcur = pw;   // the completed scan left the sort of the final labels there
     if ((rc = write_ctl_word(m, 5, 0))) return rc;
     m->st.label_changes = (uint64_t)m->h_rs[2];
   }
@@ -761,6 +881,7 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (rc) return rc;
   if ((rc = check_data(m, d))) return rc;
   if (n < 0 || n >= m->N) return gg_fail(GG_ERR_INVALID, "node %d out of range", n);
+  if ((rc = drain_pipe(m))) return rc;
   m->beta = 1.0;
   begin_call(m);
   const int buf = m->cur;
@@ -789,7 +910,13 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
   if ((rc = check_data(m, d))) return rc;
   begin_call(m);
   const int buf = m->cur;
-  if ((rc = enqueue_bulk(m, d, buf, 1, false))) return rc;
+  if (m->pipe && m->next_bulk && m->pend_data == d) {
+    // the statistics of the current labels are already (being) computed for the next sweep: reuse them
+    GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[buf], 0));
+  } else {
+    if ((rc = drain_pipe(m))) return rc;
+    if ((rc = enqueue_bulk(m, d, buf, 1, false))) return rc;
+  }
   if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
   const int K = m->K, B = m->B;
   const size_t KK = (size_t)K * K;
@@ -877,6 +1004,7 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
   int rc = model_sync(m);
   if (rc) return rc;
   if ((rc = check_data(m, d))) return rc;
+  if ((rc = drain_pipe(m))) return rc;
   const int t0 = m->timing;
   m->timing = 0;
   const int buf = m->cur;

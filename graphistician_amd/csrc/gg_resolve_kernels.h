@@ -32,6 +32,8 @@ struct gg_resolve_args {
   // tail, run when the scan completes: resample_m (adjacency.py:697-702 / weights.py:493-498)
   // and the label sort the next half-sweep's bulk kernel needs
   int tail_m, tail_sort;
+  int flush_on_change;   // pipelined mode: a scan that changed any label flushes the pipeline (the next sweep's
+                         // statistics were computed early under the unchanged labels)
   double* m;
   const double* pi;
   int32_t* perm;
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
     g.rs[0] = done ? 0 : pos;
     g.rs[1] = done ? 0 : nL;
     g.rs[2] += nchg;
-    if (done) g.rs[5] += 1; else g.rs[4] = 1;
+    if (done) g.rs[5] += 1;
+    if (!done || (g.flush_on_change && nchg > 0)) g.rs[4] = 1;
   }
 }
 
