@@ -474,11 +474,21 @@ struct gg_params_args {
   uint32_t m_site, m_sweep;
   const double* pi;
   double beta;   // tempering of the parameter posterior: counts weighted by beta (graph_models.py:180-181,366-367)
+  int sweep_from_ctl;   // graph replay: the sweep index lives in ctl[6]; the deferred m belongs to sweep - 1
 };
 
 template <bool ADJ, int B>
 __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
   if (g.ctl[4]) return;
+  if (g.sweep_from_ctl) {
+    g.sweep = (uint32_t)g.ctl[6];
+    g.m_sweep = g.sweep - 1u;
+  }
+  if (g.do_prep && blockIdx.x == 0 && threadIdx.x == 0) {   // a new scan follows: reset its per-scan words
+    g.ctl[7] = 0;
+    g.ctl[8] = 0;
+    g.ctl[9] = 0;
+  }
   const int K = g.K;
   constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
   constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;
@@ -772,8 +782,17 @@ template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
                                                    uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
                                                    double* __restrict__ lp_out, const int32_t* __restrict__ ctl,
-                                                   int stage_tables) {
-  if (ctl && ctl[4]) return;
+                                                   int stage_tables, int sweep_from_ctl, int round_mode) {
+  if (round_mode) {            // device-driven restart round: start where the scan stands, unless it is done
+    if (ctl[7]) return;
+    n_begin = ctl[0];
+    const int first = (int)blockIdx.x * (256 / x.Kp);
+    if (n_begin + first >= x.N) return;
+    if (ctl[8] > 0 && first >= ctl[8]) return;   // adaptive window chosen by the last resolve
+  } else if (ctl && ctl[4]) {
+    return;
+  }
+  if (sweep_from_ctl) sweep = (uint32_t)ctl[6];
   constexpr int NSI = ADJ ? 0 : NT - 1;
   extern __shared__ __align__(16) unsigned char s_spec[];
   const int K = x.K, Kp = x.Kp;

@@ -60,11 +60,17 @@ struct gg_model {
   hipStream_t sb;               // bulk statistics of the NEXT sweep run here, concurrently with the scan
   hipEvent_t ev_bulk[2], ev_scan;
   bool pipe;                    // cross-sweep pipelining enabled (scan models)
+  bool use_graph;               // replay pipelined sweeps from a captured hipGraph (one per buffer parity)
+  bool capturing;
+  hipGraphExec_t gexec[2][2];   // [cur][pcur]
+  const gg_data* gdata[2][2];
+  hipEvent_t ev_join;
   bool next_bulk;               // Gbuf[cur] already holds (is receiving) the next sweep's statistics
   int cur0, pcur0;              // buffer indices when the pending batch started
   uint32_t sweep;
   int Lmax, CH, max_idle;
   size_t resolve_lds;
+  bool resolve_stage;          // coefficient tables staged in the resolver's LDS
   // timing
   int timing;        // 0 = off; n > 0: HIP events around the bulk kernel of every n-th sweep
   std::vector<hipEvent_t> ev;
@@ -93,6 +99,8 @@ static size_t resolve_lds_bytes(const gg_model* m, int CH) {
   b += m->is_adj ? (size_t)CH * CH : (size_t)CH * CH * m->B * sizeof(int32_t);
   return (b + 15) & ~(size_t)15;
 }
+
+static size_t table_bytes(const gg_model* m) { return (size_t)2 * m->K * m->NT * m->Kp * sizeof(double); }
 
 extern "C" {
 
@@ -166,17 +174,26 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   while (CH > 1 && resolve_lds_bytes(m, CH) > 96 * 1024) CH >>= 1;
   m->CH = CH;
   m->resolve_lds = resolve_lds_bytes(m, CH);
-  m->max_idle = 2;
+  m->resolve_stage = (m->resolve_lds + table_bytes(m) <= 150 * 1024);
+  if (m->resolve_stage) m->resolve_lds += table_bytes(m);
+  m->max_idle = 1;
   GG_HIP(hipEventCreate(&m->ev_call0));
   GG_HIP(hipEventCreate(&m->ev_call1));
   GG_HIP(hipStreamCreate(&m->sb));
   GG_HIP(hipEventCreateWithFlags(&m->ev_bulk[0], hipEventDisableTiming));
   GG_HIP(hipEventCreateWithFlags(&m->ev_bulk[1], hipEventDisableTiming));
   GG_HIP(hipEventCreateWithFlags(&m->ev_scan, hipEventDisableTiming));
+  GG_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  {
+    // measured on MI355X / ROCm 7.2 (N=4096, K=16): replaying the two-stream sweep from a hipGraph costs
+    // ~55 us of host time per model-sweep (4.3k sweeps/s) against ~16 us for eager launches: opt-in only
+    const char* eg = getenv("GG_GRAPH");
+    m->use_graph = (eg && atoi(eg) == 1);
+  }
   {
     const char* e = getenv("GG_PIPELINE");
-    // eager cross-sweep pipelining costs more host API time (event records / waits) than it saves on the
-    // device at N = 4096; it is opt-in until the sweep is replayed from a hipGraph
+    // eager cross-sweep pipelining: exact, but its extra event records / waits make the host the bottleneck
+    // at N=4096 (11-13k sweeps/s against 17.5k serial); opt-in until launches get cheaper or N is large
     m->pipe = m->sbm && m->K > 1 && (e && atoi(e) == 1);
   }
   // defaults: uniform m, pi = 1, p = 0.5, standard NIW
@@ -217,7 +234,9 @@ int gg_model_destroy(gg_model* m) {
   if (m->ev_call1) hipEventDestroy(m->ev_call1);
   if (m->stream) hipStreamDestroy(m->stream);
   if (m->sb) hipStreamDestroy(m->sb);
-  for (hipEvent_t e : {m->ev_bulk[0], m->ev_bulk[1], m->ev_scan}) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : {m->ev_bulk[0], m->ev_bulk[1], m->ev_scan, m->ev_join}) if (e) hipEventDestroy(e);
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) if (m->gexec[a][b]) hipGraphExecDestroy(m->gexec[a][b]);
   delete m;
   return GG_OK;
 }
@@ -252,12 +271,17 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
     m->sweep = *(const uint32_t*)buf;
+    GG_HIP(hipMemcpy(m->rs + 6, &m->sweep, 4, hipMemcpyHostToDevice));   // device-side copy read by replayed sweeps
     return GG_OK;
   }
   if (id == GG_ST_NIW || id == GG_ST_NIW_SELF) {
     if (m->is_adj) return gg_fail(GG_ERR_INVALID, "NIW hypers on an adjacency model");
     size_t need = (B + B * B + 2) * 8;
     if (nbytes != need) return gg_fail(GG_ERR_INVALID, "NIW hypers: expected %zu bytes, got %zu", need, nbytes);
+    { int rc1 = drain_pipe(m); if (rc1) return rc1; }
+    for (int a = 0; a < 2; ++a)        // hyper-parameters are baked into captured kernel arguments
+      for (int b = 0; b < 2; ++b)
+        if (m->gexec[a][b]) { hipGraphExecDestroy(m->gexec[a][b]); m->gexec[a][b] = nullptr; }
     const double* d = (const double*)buf;
     gg_niw* h = id == GG_ST_NIW ? &m->niw : &m->niw_self;
     memset(h, 0, sizeof(gg_niw));
@@ -407,7 +431,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   const int ndirs = (dirs == 3) ? 2 : 1;
   const int32_t* ctl = pipelined ? m->rs : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+  const bool timed = !m->capturing && m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
   if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, st)); }
   if (m->is_adj) {
     int strips = (Np + 1023) / 1024;
@@ -445,7 +469,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
 
 // fused: pair tables (from buffer `buf`) -> parameter draw -> coefficient tables; optionally zero the other buffer
 static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, bool draw, bool prep, bool zero_other,
-                          uint32_t sweep, int pidx = -1) {
+                          uint32_t sweep, int pidx = -1, bool from_ctl = false) {
   if (pidx < 0) pidx = m->pcur;
   gg_params_args g;
   memset(&g, 0, sizeof(g));
@@ -474,6 +498,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   g.ctl = m->rs;
   g.pi = m->pi;
   g.beta = m->beta;
+  g.sweep_from_ctl = from_ctl ? 1 : 0;
   if (m->m_pending && prep) {
     g.draw_m = 1; g.m_site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M; g.m_sweep = m->m_sweep;
     m->m_pending = false;
@@ -492,20 +517,29 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   return GG_OK;
 }
 
-static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined) {
+static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined,
+                            bool from_ctl = false, int round_window = 0) {
   gg_node_ctx x = node_ctx(m, d, buf);
   const int K = m->K, per = 256 / m->Kp;
-  int nb = (m->N - n_begin + per - 1) / per;
+  const int count = round_window > 0 ? round_window : (m->N - n_begin);
+  int nb = (count + per - 1) / per;
   if (nb < 1) nb = 1;
   uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
   double* lpo = lp_node >= 0 ? m->lp_out : nullptr;
-  const int32_t* ctl = pipelined ? m->rs : nullptr;
+  const int32_t* ctl = (pipelined || round_window > 0) ? m->rs : nullptr;
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
-  const size_t tab_bytes = (size_t)2 * K * m->NT * m->Kp * sizeof(double);
-  const int stage = (lds + tab_bytes <= 48 * 1024) ? 1 : 0;
-  if (stage) lds += tab_bytes;
-#define SPEC(NTV, ADJV) \
-  k_speculate<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl, stage)
+  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += table_bytes(m);
+#define SPEC(NTV, ADJV)                                                                                                    \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set && lds > 48 * 1024) {                                                                                    \
+      GG_HIP(hipFuncSetAttribute((const void*)k_speculate<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    k_speculate<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl,    \
+                                                        stage, from_ctl ? 1 : 0, round_window > 0 ? 1 : 0);                \
+  } while (0)
   if (m->is_adj) SPEC(2, true);
   else if (m->B == 1) SPEC(3, false);
   else if (m->B == 2) SPEC(6, false);
@@ -517,14 +551,19 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
 
 // The tail of a completed scan sorts the final labels into perm buffer `pw` (default: the other one).
 static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort,
-                          int pw = -1, bool flush_on_change = false) {
+                          int pw = -1, bool flush_on_change = false, bool from_ctl = false, int round_window = 0) {
   if (pw < 0) pw = 1 - m->pcur;
   gg_resolve_args g;
   g.x = node_ctx(m, d, buf);
   g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
   g.tail_m = tail_m ? 1 : 0; g.tail_sort = tail_sort ? 1 : 0;
   g.m = m->m; g.pi = m->pi; g.perm = m->permb[pw]; g.lab_start = m->labb[pw];
+  g.perm_prev = m->permb[1 - pw]; g.lab_start_prev = m->labb[1 - pw];
   g.flush_on_change = flush_on_change ? 1 : 0;
+  g.sweep_from_ctl = from_ctl ? 1 : 0;
+  g.round_mode = round_window > 0 ? 1 : 0;
+  g.window = round_window;
+  g.stage_tables = m->resolve_stage ? 1 : 0;
   g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
   g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
@@ -575,24 +614,31 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
   return GG_OK;
 }
 
-// Finish a scan the pipeline left unfinished: rounds of (apply L, re-speculate the
-// remainder, resolve) with a host check after each, until the last node is done.
-// The final resolve sorts the labels into perm buffer `pw`.
+// Finish a scan the pipeline left unfinished.  Restart rounds are device-driven: each round is
+//   k_apply_L (pending changes -> G)  ->  k_speculate over the next window of nodes  ->  k_resolve
+// with every kernel reading the scan position from the control block and turning into a no-op once the
+// scan is done, so a batch of rounds is enqueued without host synchronisation; the host only checks
+// between batches.  The final resolve sorts the labels into perm buffer `pw`.
 static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort, int pw) {
   int rc;
-  for (int round = 0;; ++round) {
+  const int window = m->N < 4096 ? m->N : 4096;
+  int batch = 4;
+  long long rounds = 0;
+  for (;;) {
     if ((rc = read_ctl(m))) return rc;
     if (!m->h_rs[4] || m->h_rs[0] == 0) {   // scan complete (a set flag with pos == 0 is a pipeline flush, not a stall)
       if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
       return GG_OK;
     }
-    int pos = m->h_rs[0];
-    if ((rc = launch_apply_L(m, d, buf))) return rc;
-    if ((rc = write_ctl_word(m, 4, 0))) return rc;
-    if ((rc = launch_speculate(m, d, buf, pos, -1, sweep, false))) return rc;
-    if ((rc = launch_resolve(m, d, buf, sweep, tail_m, tail_sort, pw, false))) return rc;
-    m->st.resolve_rounds += 1;
-    if (round > 2 * m->N + 8) return gg_fail(GG_ERR_HIP, "resolve did not make progress (pos=%d)", pos);
+    for (int r = 0; r < batch; ++r) {
+      if ((rc = launch_apply_L(m, d, buf))) return rc;
+      if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, false, false, window))) return rc;
+      if ((rc = launch_resolve(m, d, buf, sweep, tail_m, tail_sort, pw, false, false, window))) return rc;
+    }
+    rounds += batch;
+    m->st.resolve_rounds += batch;
+    if (batch < 64) batch *= 2;
+    if (rounds > 4LL * m->N + 64) return gg_fail(GG_ERR_HIP, "resolve did not make progress (pos=%d)", m->h_rs[0]);
   }
 }
 
@@ -631,7 +677,11 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
 static int enqueue_sweep_pipe(gg_model* m, const gg_data* d, uint32_t sweep) {
   int rc;
   const int g = m->cur, P = m->pcur;
-  if (!m->next_bulk) {
+  const bool cap = m->capturing;
+  if (cap) {
+    // fork point of the captured graph: brings the bulk stream into the capture
+    GG_HIP(hipEventRecord(m->ev_scan, m->stream));
+  } else if (!m->next_bulk) {
     // prologue: statistics of THIS sweep (labels final on the scan stream)
     if ((rc = ensure_perm(m))) return rc;
     GG_HIP(hipEventRecord(m->ev_scan, m->stream));
@@ -650,11 +700,17 @@ static int enqueue_sweep_pipe(gg_model* m, const gg_data* d, uint32_t sweep) {
   }
   if ((rc = enqueue_bulk(m, d, 1 - g, 3, true, sweep + 1, m->sb, P))) return rc;
   GG_HIP(hipEventRecord(m->ev_bulk[1 - g], m->sb));
-  // this sweep's scan chain
-  GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[g], 0));
-  if ((rc = enqueue_params(m, d, g, true, true, true, false, sweep, P))) return rc;
-  if ((rc = launch_speculate(m, d, g, 0, -1, sweep, true))) return rc;
-  if ((rc = launch_resolve(m, d, g, sweep, false, true, 1 - P, true))) return rc;
+  // this sweep's scan chain (sweep index read from the control block: identical arguments every replay)
+  if (!cap) GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[g], 0));
+  if ((rc = enqueue_params(m, d, g, true, true, true, false, sweep, P, true))) return rc;
+  if ((rc = launch_speculate(m, d, g, 0, -1, sweep, true, true))) return rc;
+  if ((rc = launch_resolve(m, d, g, sweep, false, true, 1 - P, true, true))) return rc;
+  if (cap) {
+    // join the bulk stream back before the capture ends
+    GG_HIP(hipEventRecord(m->ev_join, m->sb));
+    GG_HIP(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    return GG_OK;
+  }
   GG_HIP(hipEventRecord(m->ev_scan, m->stream));
   m->st.resolve_rounds += 1;
   m->m_pending = true;
@@ -666,10 +722,49 @@ static int enqueue_sweep_pipe(gg_model* m, const gg_data* d, uint32_t sweep) {
   return GG_OK;
 }
 
+// One pipelined sweep replayed from a hipGraph captured for the current buffer parity.
+static int launch_sweep_graph(gg_model* m, const gg_data* d, uint32_t sweep) {
+  int rc;
+  const int g = m->cur, P = m->pcur;
+  if (m->gexec[g][P] && m->gdata[g][P] != d) {
+    GG_HIP(hipGraphExecDestroy(m->gexec[g][P]));
+    m->gexec[g][P] = nullptr;
+  }
+  if (!m->gexec[g][P]) {
+    hipGraph_t graph = nullptr;
+    GG_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
+    m->capturing = true;
+    rc = enqueue_sweep_pipe(m, d, 0);
+    m->capturing = false;
+    hipError_t e = hipStreamEndCapture(m->stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return gg_fail(GG_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    GG_HIP(hipGraphInstantiate(&m->gexec[g][P], graph, nullptr, nullptr, 0));
+    GG_HIP(hipGraphDestroy(graph));
+    m->gdata[g][P] = d;
+  }
+  GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[g], 0));   // this sweep's statistics (enqueued eagerly or by the last replay)
+  GG_HIP(hipGraphLaunch(m->gexec[g][P], m->stream));
+  GG_HIP(hipEventRecord(m->ev_scan, m->stream));             // eager marker: the replay (scan + early bulk) is done
+  GG_HIP(hipEventRecord(m->ev_bulk[1 - g], m->stream));
+  m->st.resolve_rounds += 1;
+  m->m_pending = true;
+  m->m_sweep = sweep;
+  m->cur = 1 - g;
+  m->pcur = 1 - P;
+  m->next_bulk = true;
+  return GG_OK;
+}
+
 static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
   const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
   if (!learn_params) return GG_OK;
-  return m->pipe ? enqueue_sweep_pipe(m, d, sweep) : enqueue_sweep_serial(m, d, sweep);
+  if (!m->pipe) return enqueue_sweep_serial(m, d, sweep);
+  // replay from the graph when the pipeline is primed (statistics of this sweep in flight, a predecessor
+  // sweep whose m is pending) and this sweep is not one of the HIP-event timing samples
+  const bool sampled = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0;
+  if (m->use_graph && m->next_bulk && m->m_pending && !sampled && m->beta == 1.0) return launch_sweep_graph(m, d, sweep);
+  return enqueue_sweep_pipe(m, d, sweep);
 }
 
 // Leave pipelined mode before anything else touches the statistics buffers or the scan stream's state.
@@ -748,6 +843,7 @@ static int model_sync(gg_model* m) {
     else { m->zeroed[1 - m->cur] = false; m->zeroed[m->cur] = true; }   // serial form: k_params of the last completed sweep zeroed it
     m->pending = 0;
     if ((rc = write_ctl_word(m, 5, 0))) return rc;
+    if ((rc = write_ctl_word(m, 6, (int32_t)m->sweep))) return rc;
     m->cur0 = m->cur; m->pcur0 = m->pcur;
     for (int i = 0; i < remaining; ++i)
       if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i))) return rc;

@@ -27,17 +27,24 @@ struct gg_resolve_args {
   int32_t* cnt;
   const int32_t* cand;
   int32_t* rs;   // control block: [0] pos, [1] nL, [2] label changes (accumulated), [3] status,
-                 //                [4] stalled (scan left unfinished: later pipeline kernels do nothing), [5] completed scans
+                 //   [4] stalled (scan left unfinished: later pipeline kernels do nothing), [5] completed scans,
+                 //   [6] sweep index (graph replay), [7] scan done, [8] next re-speculation window, [9] changes of this scan
   int32_t* L;    // [Lcap][3] = (node, old, new)
   // tail, run when the scan completes: resample_m (adjacency.py:697-702 / weights.py:493-498)
   // and the label sort the next half-sweep's bulk kernel needs
   int tail_m, tail_sort;
+  int round_mode;        // device-driven restart round: runs even if the stall flag is up, no-op once the scan is done
+  int window;            // phase A looks at [pos, pos + window) only (what was re-speculated); 0 = to the end
+  int stage_tables;      // coefficient tables fit in LDS next to the chunk statistics
+  int sweep_from_ctl;    // graph replay: sweep index = rs[6], advanced by the tail of a completed scan
   int flush_on_change;   // pipelined mode: a scan that changed any label flushes the pipeline (the next sweep's
                          // statistics were computed early under the unchanged labels)
   double* m;
   const double* pi;
   int32_t* perm;
   int32_t* lab_start;
+  const int32_t* perm_prev;       // the sort the scan started from: copied when no label changed
+  const int32_t* lab_start_prev;
   uint32_t site_m;
   int Lmax;
   int max_idle;
@@ -93,8 +100,17 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
   int* s_ctl = reinterpret_cast<int*>(s_raw + off); off += 8 * sizeof(int);
   int32_t* s_blkw = reinterpret_cast<int32_t*>(s_raw + off);           // [CH][CH][B] (weights)
   uint8_t* s_blka = reinterpret_cast<uint8_t*>(s_raw + off);           // [CH][CH]    (adjacency)
+  off += ADJ ? (size_t)CH * CH : (size_t)CH * CH * B * sizeof(int32_t);
+  off = (off + 15) & ~(size_t)15;
+  double* s_T = reinterpret_cast<double*>(s_raw + off);                // Tout | Tin when staged (phase B only)
+  const int ntab = K * NT * Kp;
+  bool tables_staged = false;
+  const double* To = g.stage_tables ? s_T : x.Tout;
+  const double* Ti = g.stage_tables ? s_T + ntab : x.Tin;
 
-  if (g.rs[4]) return;  // an earlier scan of this pipeline is unfinished
+  if (g.round_mode) { if (g.rs[7]) return; }
+  else if (g.rs[4]) return;  // an earlier scan of this pipeline is unfinished
+  if (g.sweep_from_ctl) g.sweep = (uint32_t)g.rs[6];
   int pos = g.rs[0];
   int nL = g.fresh ? 0 : g.rs[1];
   int nchg = 0;
@@ -105,15 +121,19 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
 
   // ---------------------------------------------------------------- phase A
   if (nL == 0) {
+    int wlen = g.window;
+    if (g.round_mode && g.rs[8] > 0 && g.rs[8] < wlen) wlen = g.rs[8];   // what k_speculate covered this round
+    const int wend = (wlen > 0 && pos + wlen < N) ? pos + wlen : N;
     int first = N;
-    for (int n = pos + tid; n < N; n += nth)
+    for (int n = pos + tid; n < wend; n += nth)
       if (g.cand[n] != g.c[n]) { first = n; break; }
     if (first < N) atomicMin(&s_ctl[0], first);
     __syncthreads();
     int ns = s_ctl[0];
     if (ns >= N) {
-      pos = N;
-      finished = true;
+      pos = wend;           // the whole window is final, unchanged
+      finished = true;      // nothing to fix in this launch (the scan itself is done only if pos == N)
+      if (g.round_mode && tid == 0) g.rs[8] = g.window;   // quiet stretch: widen the next window
     } else {
       int a = g.c[ns], b = g.cand[ns];
       __syncthreads();
@@ -122,7 +142,16 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
         s_cnt[a] -= 1; s_cnt[b] += 1;
         g.L[0] = ns; g.L[1] = a; g.L[2] = b;
       }
-      nL = 1; nchg = 1; pos = ns + 1;
+      nL = 1; nchg = 1;
+      // sparse regime (the change sits far from where the scan stood): leave the chunk loop out, the next
+      // round re-speculates a window after it; dense regime (burn-in): resolve chunk by chunk below
+      if (g.round_mode && ns - pos >= CH) finished = true;
+      if (g.round_mode) {
+        int dist = ns - pos + 1, w = 4 * dist;
+        w = w < 256 ? 256 : (w > g.window ? g.window : w);
+        if (tid == 0) g.rs[8] = w;
+      }
+      pos = ns + 1;
       __syncthreads();
     }
   }
@@ -131,6 +160,13 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
   int idle = 0;
   while (!finished && pos < N && nL < g.Lmax && idle < g.max_idle) {
+    if (g.stage_tables && !tables_staged) {
+      for (int idx = threadIdx.x; idx < ntab; idx += blockDim.x) {
+        s_T[idx] = x.Tout[idx];
+        s_T[ntab + idx] = x.Tin[idx];
+      }
+      tables_staged = true;   // visible after the barrier that follows the chunk loads
+    }
     const int pos0 = pos;
     const int nch = (N - pos0) < CH ? (N - pos0) : CH;
     // load chunk labels, statistics (coalesced over the node index) and the diagonal block
@@ -187,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
         const long long* b = ADJ ? nullptr : &s_gs[((size_t)(1 * CH + ii) * K + j) * NSI];
         gg_stats_to_double<NT, ADJ>(s_gc[(0 * CH + ii) * K + j], s_gc[(1 * CH + ii) * K + j], a, b, cx, sc1, sc2, so, si);
       };
-      double lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, x.Tout, x.Tin);
+      double lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, To, Ti);
       double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)n);
       int lab = gg_group_categorical(lp, k, K, Kp, u);
       if (active && k == 0 && lab != cn) {
@@ -246,15 +282,21 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
       }
     }
     if (g.tail_sort) {
-      if (tid == 0) {
-        int acc = 0;
-        for (int k = 0; k < K; ++k) { g.lab_start[k] = acc; s_cur[k] = acc; acc += s_cnt[k]; }
-        g.lab_start[K] = acc;
-      }
-      __syncthreads();
-      for (int n = tid; n < N; n += nth) {
-        int at = atomicAdd(&s_cur[g.c[n]], 1);
-        g.perm[at] = n;
+      if (g.rs[9] + nchg == 0) {
+        // no label changed in this scan: the sort it started from is still the sort of the labels
+        for (int n = tid; n < N; n += nth) g.perm[n] = g.perm_prev[n];
+        for (int k = tid; k <= K; k += nth) g.lab_start[k] = g.lab_start_prev[k];
+      } else {
+        if (tid == 0) {
+          int acc = 0;
+          for (int k = 0; k < K; ++k) { g.lab_start[k] = acc; s_cur[k] = acc; acc += s_cnt[k]; }
+          g.lab_start[K] = acc;
+        }
+        __syncthreads();
+        for (int n = tid; n < N; n += nth) {
+          int at = atomicAdd(&s_cur[g.c[n]], 1);
+          g.perm[at] = n;
+        }
       }
     }
   }
@@ -262,7 +304,12 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
     g.rs[0] = done ? 0 : pos;
     g.rs[1] = done ? 0 : nL;
     g.rs[2] += nchg;
-    if (done) g.rs[5] += 1;
+    g.rs[9] += nchg;
+    if (done) {
+      g.rs[5] += 1;
+      g.rs[7] = 1;
+      if (g.sweep_from_ctl) g.rs[6] += 1;
+    }
     if (!done || (g.flush_on_change && nchg > 0)) g.rs[4] = 1;
   }
 }
@@ -277,7 +324,7 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
   constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
   constexpr int NSI = NT - 1;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= x.N) return;
+  if (n >= x.N || rs[7]) return;
   const int nL = rs[1], Np = x.Np;
   for (int e = 0; e < nL; ++e) {
     const int n2 = L[e * 3], a = L[e * 3 + 1], b = L[e * 3 + 2];
