@@ -1,0 +1,156 @@
+"""GPU edge cases: ragged sizes, empty / complete graphs, empty blocks, single block, tiny N,
+self-connection conventions, B=4, model reuse across data sets, the Python-level data cache."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import planted_sbm, AdjState, WState
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from graphistician_amd import _abi
+    if _abi.device_count() < 1:
+        pytest.fail("no HIP device: the engine has no CPU fallback")
+    return _abi
+
+
+def run_adj(abi, A, st, seed, nsweeps, special=1, allow=1):
+    N, K = st.N, st.K
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=seed, tau1=st.tau1, tau0=st.tau0, allow_self_connections=allow,
+                  special_case_self_conns=special)
+    m.set(abi.ST_C, st.c, np.int32); m.set(abi.ST_M, st.m); m.set(abi.ST_PI, st.pi); m.set(abi.ST_P, st.p)
+    m.set(abi.ST_P_SELF, np.array([st.p_self]))
+    ps = st.p_self
+    for s in range(nsweeps):
+        m.resample(d, 1)
+        ps = O.sbm_adj_sweep(A, st.c, st.m, st.p, ps, st.pi, st.tau1, st.tau0, special, seed, s)
+        assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c), "sweep %d" % s
+    assert np.array_equal(m.get(abi.ST_P, (K, K)), st.p) and np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+    return m, d, ps
+
+
+@pytest.mark.parametrize("N,K", [(1, 2), (2, 2), (3, 3), (63, 2), (65, 5), (129, 33), (1000, 16)])
+def test_ragged_and_tiny_sizes(abi, N, K):
+    rng = np.random.RandomState(N)
+    A = (rng.rand(N, N) < 0.4).astype(np.uint8)
+    m, d, ps = run_adj(abi, A, AdjState(N, K, seed=N + 1), seed=3, nsweeps=3)
+    ll = m.log_likelihood(d)
+    st_ll = O.sbm_adj_loglik(A, m.get(abi.ST_C, (N,), np.int32), m.get(abi.ST_P, (K, K)), ps)
+    assert abs(ll - st_ll) <= 1e-10 * max(1.0, abs(st_ll))
+
+
+@pytest.mark.parametrize("fill", [0, 1])
+def test_empty_and_complete_graphs(abi, fill):
+    N, K = 70, 4
+    A = np.full((N, N), fill, dtype=np.uint8)
+    m, d, ps = run_adj(abi, A, AdjState(N, K, seed=5), seed=8, nsweeps=3)
+    assert np.isfinite(m.log_likelihood(d))
+    # weights on a graph without edges: every Gaussian is a prior draw, labels follow m only
+    W = np.random.RandomState(1).randn(N, N, 1)
+    st = WState(N, K, 1, seed=2)
+    q, shift = O.quantise(A, W)
+    dw = abi.DeviceData(A, W)
+    assert dw.info()["shift"] == shift
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=21, special_case_self_conns=1)
+    for sid, v, dt in ((abi.ST_C, st.c, np.int32), (abi.ST_M, st.m, np.float64), (abi.ST_PI, st.pi, np.float64),
+                       (abi.ST_MU, st.mu, np.float64), (abi.ST_SIGMA, st.sigma, np.float64),
+                       (abi.ST_NIW, st.niw, np.float64), (abi.ST_NIW_SELF, st.niw_self, np.float64)):
+        w.set(sid, v, dt)
+    for s in range(2):
+        w.resample(dw, 1)
+        O.sbm_w_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, st.niw, st.niw_self, 1, 21, s)
+    assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), st.c)
+    assert np.array_equal(w.get(abi.ST_MU, (K, K, 1)), st.mu)
+
+
+def test_single_block_and_empty_blocks(abi):
+    N = 90
+    A, W, _ = planted_sbm(N, 3, seed=3)
+    # C = 1: resample_c returns early (adjacency.py:657-658), p and m are still drawn
+    run_adj(abi, A, AdjState(N, 1, seed=1), seed=4, nsweeps=2)
+    # labels that leave most of the 40 blocks empty
+    st = AdjState(N, 40, seed=2)
+    st.c[:] = np.random.RandomState(0).choice(3, size=N)
+    run_adj(abi, A, st, seed=6, nsweeps=3)
+
+
+def test_self_connection_conventions(abi):
+    N, K = 80, 3
+    A, _, _ = planted_sbm(N, K, seed=12)
+    for special, allow in [(1, 1), (0, 1), (1, 0), (0, 0)]:
+        m, d, ps = run_adj(abi, A.copy(), AdjState(N, K, seed=7), seed=9, nsweeps=2, special=special, allow=allow)
+        ll = m.log_likelihood(d)
+        ref = O.sbm_adj_loglik(A, m.get(abi.ST_C, (N,), np.int32), m.get(abi.ST_P, (K, K)), ps, allow, special)
+        if np.isfinite(ref):
+            assert abs(ll - ref) <= 1e-10 * abs(ref)
+        else:
+            assert ll == ref          # -inf when a self edge exists but P_ii = 0 (adjacency.py:525-526)
+
+
+def test_weights_b4_chain(abi):
+    N, K, B = 60, 3, 4
+    A, W, _ = planted_sbm(N, K, B=B, seed=31)
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=32)
+    d = abi.DeviceData(A, W)
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=77, special_case_self_conns=1)
+    for sid, v, dt in ((abi.ST_C, st.c, np.int32), (abi.ST_M, st.m, np.float64), (abi.ST_PI, st.pi, np.float64),
+                       (abi.ST_MU, st.mu, np.float64), (abi.ST_SIGMA, st.sigma, np.float64),
+                       (abi.ST_MU_SELF, st.mu_self, np.float64), (abi.ST_SIGMA_SELF, st.sigma_self, np.float64),
+                       (abi.ST_NIW, st.niw, np.float64), (abi.ST_NIW_SELF, st.niw_self, np.float64)):
+        w.set(sid, v, dt)
+    for s in range(3):
+        w.resample(d, 1)
+        O.sbm_w_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, st.niw, st.niw_self, 1, 77, s)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), st.c)
+    assert np.array_equal(w.get(abi.ST_SIGMA, (K, K, B, B)), st.sigma)
+    with pytest.raises(abi.EngineError):
+        abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=3, seed=1)       # B = 3 is not supported by the HIP kernels
+
+
+def test_model_reuse_across_data_and_async_batches(abi):
+    """One model, two data sets, sweeps issued in async batches: same chain as the oracle."""
+    N, K = 140, 6
+    A1, _, _ = planted_sbm(N, K, seed=1)
+    A2, _, _ = planted_sbm(N, K, seed=2)
+    st = AdjState(N, K, seed=3)
+    d1, d2 = abi.DeviceData(A1, None), abi.DeviceData(A2, None)
+    m = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=55, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                  special_case_self_conns=1)
+    m.set(abi.ST_C, st.c, np.int32); m.set(abi.ST_M, st.m); m.set(abi.ST_PI, st.pi); m.set(abi.ST_P, st.p)
+    m.set(abi.ST_P_SELF, np.array([st.p_self]))
+    m.resample_async(d1, 3)
+    m.resample_async(d1, 2)
+    m.resample_async(d2, 4)          # switching data forces a sync in between
+    m.sync()
+    ps, s = st.p_self, 0
+    for A, n in ((A1, 5), (A2, 4)):
+        for _ in range(n):
+            ps = O.sbm_adj_sweep(A, st.c, st.m, st.p, ps, st.pi, 1.0, 1.0, 1, 55, s)
+            s += 1
+    assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c)
+    assert np.array_equal(m.get(abi.ST_M, (K,)), st.m) and m.sweep == 9
+    with pytest.raises(abi.EngineError):
+        m.resample(abi.DeviceData(A1[:50, :50], None), 1)           # N mismatch is an error, not a crash
+
+
+def test_python_data_cache_and_state_roundtrip(abi):
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd import engine
+    engine.clear_data_cache()
+    N = 64
+    A, _, _ = planted_sbm(N, 3, seed=9)
+    np.random.seed(1)
+    m = SBMAdjacencyDistribution(N, C=3, seed=5)
+    m.resample(A); m.resample(A)
+    assert len(engine._DATA_CACHE) == 1                  # same ndarray -> one upload
+    c1 = m.c.copy()
+    m.c = np.zeros(N, dtype=int)                         # host edit is pushed before the next sweep
+    m.resample(A)
+    assert m.c.shape == (N,) and m.engine_stats["sweeps"] == 3
+    m.c = c1
+    assert np.array_equal(m.c, c1)
