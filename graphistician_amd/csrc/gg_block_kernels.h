@@ -328,27 +328,6 @@ struct gg_adj_hyp {
   long long d1, d0;  // diagonal edge / non-edge counts
 };
 
-// adjacency.py:620-648 (SBM) and :153-181 (Beta-Bernoulli): one thread per block pair.
-__global__ void k_draw_p(const long long* __restrict__ tab, const int32_t* __restrict__ cnt, int K, gg_adj_hyp h,
-                         uint64_t seed, uint32_t sweep, double* __restrict__ p, double* __restrict__ p_self) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < K * K) {
-    int a = t / K, b = t % K;
-    long long n1 = tab[t];
-    long long pairs = (long long)cnt[a] * (long long)cnt[b];
-    if (a == b && h.special) pairs -= cnt[a];
-    if (h.bb && !h.special) { /* all entries incl. diagonal: tab already holds the diagonal */ }
-    long long n0 = pairs - n1;
-    gg_stream s;
-    gg_stream_init(&s, seed, h.bb ? GG_SITE_BB_P : GG_SITE_ADJ_P, sweep, (uint32_t)t);
-    p[t] = gg_beta(&s, h.tau1 + (double)n1, h.tau0 + (double)n0);
-  } else if (t == K * K && h.special) {
-    gg_stream s;
-    gg_stream_init(&s, seed, h.bb ? GG_SITE_BB_PSELF : GG_SITE_ADJ_PSELF, sweep, 0u);
-    *p_self = gg_beta(&s, h.tau1 + (double)h.d1, h.tau0 + (double)h.d0);
-  }
-}
-
 struct gg_w_hyp {
   gg_niw niw, niw_self;
   int special;
@@ -367,64 +346,6 @@ __device__ inline void gg_unpack_wstats(const long long* hl /* hi,lo pairs */, i
       s2[r * B + s] = v;
       s2[s * B + r] = v;
     }
-}
-
-// weights.py:399-413 resample_mu_and_Sig (and :154-162 for the NIW kind, K = 1).
-__global__ void k_draw_niw(const long long* __restrict__ tab, int K, int B, gg_w_hyp h, uint64_t seed,
-                           uint32_t sweep, double* __restrict__ mu, double* __restrict__ sigma,
-                           double* __restrict__ mu_self, double* __restrict__ sigma_self) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int NSI = B + B * (B + 1) / 2;
-  double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB], mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
-  if (t < K * K) {
-    const long long* e = tab + (size_t)t * (1 + 2 * NSI);
-    gg_unpack_wstats(e + 1, B, h.shift, s1, s2);
-    gg_stream s;
-    gg_stream_init(&s, seed, GG_SITE_W_NIW, sweep, (uint32_t)t);
-    gg_niw_posterior_draw(&s, &h.niw, B, (double)e[0], s1, s2, mo, so);
-    for (int i = 0; i < B; ++i) mu[(size_t)t * B + i] = mo[i];
-    for (int i = 0; i < B * B; ++i) sigma[(size_t)t * B * B + i] = so[i];
-  } else if (t == K * K && h.special) {
-    long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
-    for (int i = 0; i < NSI; ++i) { hl[2 * i] = h.dS[i] >> 32; hl[2 * i + 1] = h.dS[i] & 0xffffffffll; }
-    gg_unpack_wstats(hl, B, h.shift, s1, s2);
-    gg_stream s;
-    gg_stream_init(&s, seed, GG_SITE_W_NIW_SELF, sweep, 0u);
-    gg_niw_posterior_draw(&s, &h.niw_self, B, (double)h.d1, s1, s2, mo, so);
-    for (int i = 0; i < B; ++i) mu_self[i] = mo[i];
-    for (int i = 0; i < B * B; ++i) sigma_self[i] = so[i];
-  }
-}
-
-// Coefficient tables of the conditional (gg_lp.h): T[a][b][t]; Tout[j][t][k] = T[k][j][t];
-// Tin[j][t][k] = T[j][k][t] (k padded to Kp) so that lane k reads consecutive words.
-__global__ void k_prep_tables(int is_adj, int K, int Kp, int B, const double* __restrict__ m,
-                              const double* __restrict__ p, const double* __restrict__ mu,
-                              const double* __restrict__ sigma, double* __restrict__ logm, double* __restrict__ T,
-                              double* __restrict__ Tout, double* __restrict__ Tin, int* __restrict__ status) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int NT = is_adj ? 2 : (1 + B + B * (B + 1) / 2);
-  if (t < K * K) {
-    int a = t / K, b = t % K;
-    double e[GG_MAXNT];
-    if (is_adj) {
-      e[0] = gg_log(p[t]);
-      e[1] = gg_log(1.0 - p[t]);
-    } else {
-      if (gg_gauss_table(mu + (size_t)t * B, sigma + (size_t)t * B * B, B, e)) {
-        atomicOr(status, 1);
-        for (int i = 0; i < NT; ++i) e[i] = gg_nan();
-      }
-    }
-    for (int i = 0; i < NT; ++i) {
-      T[(size_t)t * NT + i] = e[i];
-      Tout[((size_t)b * NT + i) * Kp + a] = e[i];  // T[k=a][j=b]
-      Tin[((size_t)a * NT + i) * Kp + b] = e[i];   // T[j=a][k=b]
-    }
-  } else if (t < K * K + K) {
-    int k = t - K * K;
-    logm[k] = gg_log(m[k]);
-  }
 }
 
 // adjacency.py:697-702 / weights.py:493-498 resample_m.
