@@ -18,6 +18,7 @@
 //    double loop: parity is a float tolerance (north_star), not bit-exact.
 //  * All normals of a sweep are pre-drawn in parallel (counter-based RNG).
 #include <math.h>
+#include <stdlib.h>
 
 #include "gg_common.h"
 #include "spec/gg_pg.h"
@@ -183,13 +184,13 @@ __global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, i
 // The sequential part of _resample_F for one tile (eigenmodel.py:884-908), one workgroup.
 // Everything the per-node loop touches is staged in LDS first (T x T block of S and of the
 // symmetrised adjacency, the tile's statistics, normals and old features).
-template <int DM>
-__global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0, const double* __restrict__ S,
+template <int DM, bool FULL>
+__global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t0, const double* __restrict__ S,
                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                    double* __restrict__ F, const double* __restrict__ lmbda,
                                                    const double* __restrict__ mu0p, double sigma_F, int NCH,
                                                    const double* __restrict__ part, const double* __restrict__ Z,
-                                                   int* __restrict__ status) {
+                                                   int* __restrict__ status, int dbg) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   extern __shared__ __align__(16) unsigned char s_chain[];
   double* s_S = reinterpret_cast<double*>(s_chain);                 // [T][T+1]
@@ -202,20 +203,22 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
   signed char* s_a = reinterpret_cast<signed char*>(s_stat + NEGM + DM);  // [T][T]
   const int tid = threadIdx.x;
   const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
-  const int NEG = D * (D + 1) / 2, NE = NEG + D;
+  // FULL: D == DM, every bound below is a compile-time constant (no guards, no dynamic LDS indices)
+  const int D = FULL ? DM : Drt;
+  const int NEG = FULL ? NEGM : D * (D + 1) / 2, NE = NEG + D;
   const double mu0 = *mu0p;
-  for (int e = tid; e < T * T; e += 256) {
+  for (int e = tid; e < T * T; e += 512) {
     int i = e / T, j = e % T;
     s_S[i * (EIG_T + 1) + j] = S[(size_t)(t0 + i) * Np + t0 + j];
     s_a[i * EIG_T + j] = (signed char)((int)A[(size_t)(t0 + i) * Np + t0 + j] + (int)AT[(size_t)(t0 + i) * Np + t0 + j] - 1);
   }
-  for (int e = tid; e < T * NE; e += 256) {
+  for (int e = tid; e < T * NE; e += 512) {
     int i = e / NE, q = e % NE;
     double acc = 0.0;
     for (int c = 0; c < NCH; ++c) acc += part[((size_t)i * NCH + c) * NE + q];
     s_part[i * (NEGM + DM) + q] = acc;
   }
-  for (int e = tid; e < T * D; e += 256) {
+  for (int e = tid; e < T * D; e += 512) {
     int i = e / D, q = e % D;
     s_Z[i * DM + q] = Z[(size_t)(t0 + i) * D + q];
     s_Fo[i * DM + q] = F[(size_t)(t0 + i) * D + q];
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
   for (int nl = 0; nl < T; ++nl) {
     const int n = t0 + nl;
     const double* s_stat = s_part + nl * (NEGM + DM);   // this node's statistics, corrections already applied
-    if (tid == 0) {
+    if (tid == 0 && !(dbg & 1)) {
       // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
       double L[DM][DM], hh[DM], x[DM];
       {
@@ -237,13 +240,13 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
 #pragma unroll
           for (int b1 = a1; b1 < DM; ++b1) {
             double v = 0.0;
-            if (b1 < D) { v = s_stat[e++]; if (a1 == b1) v += 1.0 / sigma_F; }
+            if (FULL || b1 < D) { v = s_stat[e++]; if (a1 == b1) v += 1.0 / sigma_F; }
             else if (a1 == b1) v = 1.0;
             L[b1][a1] = v;   // lower triangle holds the precision
           }
       }
 #pragma unroll
-      for (int a1 = 0; a1 < DM; ++a1) hh[a1] = a1 < D ? s_stat[NEG + a1] : 0.0;
+      for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? s_stat[NEG + a1] : 0.0;
       bool ok = true;
       // Cholesky (left-looking, same order as gg_chol_d)
 #pragma unroll
@@ -253,7 +256,9 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
         for (int k = 0; k < j; ++k) dsum = gg_fma(-L[j][k], L[j][k], dsum);
         if (!(dsum > 0.0)) { ok = false; dsum = 1.0; }
         // one reciprocal square root per column instead of D divisions (float-tolerance path)
-        const double inv = rsqrt(dsum);
+        double inv = __builtin_amdgcn_rsq(dsum);               // hardware estimate, then two Newton steps
+        inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
+        inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
         L[j][j] = inv;           // the diagonal keeps 1 / L_jj: the solves only ever divide by it
 #pragma unroll
         for (int i = j + 1; i < DM; ++i) {
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
       // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision)
       double y[DM], zz[DM];
 #pragma unroll
-      for (int i = 0; i < DM; ++i) zz[i] = i < D ? s_Z[nl * DM + i] : 0.0;
+      for (int i = 0; i < DM; ++i) zz[i] = (FULL || i < D) ? s_Z[nl * DM + i] : 0.0;
 #pragma unroll
       for (int i = 0; i < DM; ++i) {
         double v = hh[i];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
       double fo[DM], fn[DM];
 #pragma unroll
       for (int a1 = 0; a1 < DM; ++a1) {
-        const double old = a1 < D ? s_Fo[nl * DM + a1] : 0.0;
+        const double old = (FULL || a1 < D) ? s_Fo[nl * DM + a1] : 0.0;
         if (!ok) x[a1] = old;
         fo[a1] = old * lam[a1];
         fn[a1] = x[a1] * lam[a1];
@@ -295,21 +300,21 @@ __global__ __launch_bounds__(256) void k_eig_chain(int N, int Np, int D, int t0,
         int e = 0;
 #pragma unroll
         for (int a1 = 0; a1 < DM; ++a1) {
-          if (a1 < D) s_dF[nl * DM + a1] = fn[a1] - fo[a1];
+          if (FULL || a1 < D) s_dF[nl * DM + a1] = fn[a1] - fo[a1];
 #pragma unroll
           for (int b1 = a1; b1 < DM; ++b1)
-            if (b1 < D) s_dP[nl * NEGM + (e++)] = fn[a1] * fn[b1] - fo[a1] * fo[b1];
+            if (FULL || b1 < D) s_dP[nl * NEGM + (e++)] = fn[a1] * fn[b1] - fo[a1] * fo[b1];
         }
       }
 #pragma unroll
       for (int a1 = 0; a1 < DM; ++a1)
-        if (a1 < D) F[(size_t)n * D + a1] = x[a1];
+        if (FULL || a1 < D) F[(size_t)n * D + a1] = x[a1];
     }
     __syncthreads();
     // right-looking update: push this node's rank-one change into the statistics of the later nodes
     // (same accumulation order as a per-node loop over the earlier nodes: partial, then n2 ascending)
-    const int rem = T - nl - 1;
-    for (int idx = tid; idx < rem * NE; idx += 256) {
+    const int rem = (dbg & 2) ? 0 : T - nl - 1;
+    for (int idx = tid; idx < rem * NE; idx += 512) {
       const int i = nl + 1 + idx / NE, e = idx % NE;
       const double sv = s_S[i * (EIG_T + 1) + nl];
       double* dst = s_part + i * (NEGM + DM) + e;
@@ -605,16 +610,20 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     return gg_fail(GG_ERR_INVALID, "eigenmodel: resample F / mu_0 / lambda needs the auxiliary variables (GG_PART_OMEGA) first");
   if (parts & GG_PART_F) {
     k_eig_normals<<<(N * D + 255) / 256, 256, 0, st>>>(e->Z, N * D, e->cfg.seed, GG_SITE_EIG_F, e->sweep);
+    static int dbg = -1;
+    if (dbg < 0) { const char* ev = getenv("GG_EIG_DBG"); dbg = ev ? atoi(ev) : 0; }
     const int DMv = e->DM, NEGMv = DMv * (DMv + 1) / 2;
     const size_t chain_lds = (((size_t)EIG_T * (EIG_T + 1) + (size_t)EIG_T * NEGMv + 3 * (size_t)EIG_T * DMv +
                                (size_t)EIG_T * (NEGMv + DMv) + (NEGMv + DMv)) * sizeof(double) + (size_t)EIG_T * EIG_T + 15) & ~(size_t)15;
     static bool attr4 = false, attr8 = false;
     if (DMv == 4 && !attr4) {
-      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
       attr4 = true;
     }
     if (DMv == 8 && !attr8) {
-      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
       attr8 = true;
     }
     for (int t0 = 0; t0 < N; t0 += EIG_T) {
@@ -622,8 +631,12 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
       dim3 grd(T, e->NCH);
 #define CALL(DMV)                                                                                                      \
   k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part); \
-  k_eig_chain<DMV><<<1, 256, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->cfg.sigma_F,  \
-                                              e->NCH, e->part, e->Z, e->status)
+  if (D == DMV)                                                                                                        \
+    k_eig_chain<DMV, true><<<1, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,          \
+                                                      e->cfg.sigma_F, e->NCH, e->part, e->Z, e->status, dbg);           \
+  else                                                                                                                 \
+    k_eig_chain<DMV, false><<<1, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,         \
+                                                       e->cfg.sigma_F, e->NCH, e->part, e->Z, e->status, dbg)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
