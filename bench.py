@@ -91,8 +91,56 @@ def cpu_baseline(abi, data, N, K, budget_s):
                 sample="%d full sweeps (adjacency + weights) of the same N=%d K=%d network, oracle/ C++ -O2, 1 thread" % (n, N, K))
 
 
+def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
+    """BASELINE.json configs[2]: logistic eigenmodel Gibbs, N=4096, D=8 (eigenmodel.py:836-857)."""
+    N, D = args.nodes, args.latent
+    rng = np.random.RandomState(1234)
+    F = rng.randn(N, D); lam = rng.randn(D); mu_mu0 = -1.2815515655446004     # Phi^{-1}(0.1), eigenmodel.py:56
+    mu0 = mu_mu0 + rng.randn()
+    Mu = mu0 + (F * lam).dot(F.T)
+    np.fill_diagonal(Mu, mu0)
+    A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-Mu))).astype(np.uint8)
+    data = abi.DeviceData(A, None, device=device)
+    m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=1 + rank, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0,
+                  mu_mu_0=mu_mu0, device=device)
+    crng = np.random.RandomState(1 + rank)
+    F0, l0, m0 = crng.randn(N, D), crng.randn(D), mu_mu0 + crng.randn()
+    m.set(abi.ST_F, F0); m.set(abi.ST_LMBDA, l0); m.set(abi.ST_MU0, np.array([m0])); m.set(abi.ST_MU_LMBDA, np.zeros(D))
+    m.resample(data, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    m.resample(data, args.steps)
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return
+    sweep_bytes = float(N) * N * (3 * 8 + 2 * 2)      # write S once, read it twice; A and A^T read in both passes
+    out = {"metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": world * args.steps / el,
+           "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "Logistic eigenmodel Gibbs (Polya-gamma), N=%d, D=%d (BASELINE.json configs[2])" % (N, D),
+                      "sweep_algorithmic_bytes": sweep_bytes},
+           "roofline": {"bound": "hbm", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": sweep_bytes * args.steps / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "whole-sweep effective rate; the sweep is bound by the sequential latent-feature scan "
+                                "(N dependent D x D solves) and the PG(1,z) draws, not by HBM (DESIGN.md section 7)"}}
+    if not args.no_cpu and world == 1:
+        from oracle import oracle as O
+        Fo, lo = F0.copy(), l0.copy()
+        t0 = time.perf_counter()
+        O.eig_sweep(A, Fo, lo, m0, np.zeros(D), mu_mu0, 1.0, 1.0, 1.0, 0, 1, 0)
+        el1 = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / el1, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                               "sample": "1 full sweep of the same N=%d D=%d network, oracle/ C++ -O2, 1 thread" % (N, D)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="sbm", choices=["sbm", "eigen"],
+                    help="sbm = BASELINE.json configs[1] (default, the headline); eigen = configs[2]")
+    ap.add_argument("--latent", type=int, default=8)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -151,6 +199,12 @@ def main():
     from graphistician_amd import _abi as abi
     N, K = args.nodes, args.blocks
     device = local_rank
+    if args.config == "eigen":
+        bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     truth = planted_truth(N, K, seed=1234)
     data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
                                         truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
