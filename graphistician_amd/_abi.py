@@ -33,7 +33,8 @@ class Config(C.Structure):
                 ("allow_self_connections", C.c_int32), ("special_case_self_conns", C.c_int32), ("device", C.c_int32),
                 ("seed", C.c_uint64), ("tau1", C.c_double), ("tau0", C.c_double), ("sigma_mu0", C.c_double),
                 ("sigma_F", C.c_double), ("sigma_lmbda", C.c_double), ("mu_mu_0", C.c_double),
-                ("lmbda_given", C.c_int32), ("reserved", C.c_int32)]
+                ("lmbda_given", C.c_int32), ("reserved", C.c_int32), ("shard_begin", C.c_int32),
+                ("shard_end", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -44,7 +45,8 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_shard_sizes", "gg_shard_tables",
+           "gg_shard_params", "gg_shard_next", "gg_shard_apply", "gg_shard_finish", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_selftest_math", "gg_selftest_draws"]
 
 
@@ -90,6 +92,14 @@ def lib():
         L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gg_set_timing.argtypes = [vp, C.c_int32]
         L.gg_bench_bulk.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.gg_data_create_shard.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
+        L.gg_shard_sizes.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gg_shard_tables.argtypes = [vp, vp, vp, vp]
+        L.gg_shard_params.argtypes = [vp, vp, vp, vp]
+        L.gg_shard_next.argtypes = [vp, vp, vp]
+        L.gg_shard_apply.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
+        L.gg_shard_finish.argtypes = [vp]
+        L.gg_shard_log_likelihood.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double)]
         L.gg_selftest_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, C.c_int64]
         L.gg_selftest_draws.argtypes = [C.c_int32, C.c_int32, C.c_uint64, vp, C.c_int32, vp, C.c_int64, C.c_int32]
         _lib = L
@@ -134,6 +144,25 @@ class DeviceData(object):
                 check(lib().gg_data_create(C.byref(self._h), N, 1, _ptr(A), None, device))
         self.N, self.B, self.device = N, B, device
         self.has_w = W is not None or handle is not None
+
+    @classmethod
+    def shard(cls, A, W, n0, n1, device=0):
+        """Column shard [n0, n1) of the network for a chain sharded over several GPUs."""
+        A = np.ascontiguousarray(np.asarray(A) != 0, dtype=np.uint8)
+        N = A.shape[0]
+        h = C.c_void_p()
+        if W is not None:
+            W = np.ascontiguousarray(W, dtype=np.float64)
+            if W.ndim == 2:
+                W = W[:, :, None].copy()
+            B = W.shape[2]
+            check(lib().gg_data_create_shard(C.byref(h), N, B, _ptr(A), _ptr(W), n0, n1, device))
+        else:
+            B = 1
+            check(lib().gg_data_create_shard(C.byref(h), N, 1, _ptr(A), None, n0, n1, device))
+        obj = cls(handle=h, N=N, B=B, device=device)
+        obj.has_w = W is not None
+        return obj
 
     @classmethod
     def synthetic_sbm(cls, N, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device=0):
@@ -216,6 +245,41 @@ class Model(object):
         lp = np.zeros(K)
         check(lib().gg_node_lp(self._h, data.handle, n, _ptr(lp)))
         return lp
+
+    # ---- sharded single chain (step API) ----
+    def shard_sizes(self):
+        a, b = C.c_int32(0), C.c_int32(0)
+        check(lib().gg_shard_sizes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def shard_tables(self, data):
+        nt, nd = self.shard_sizes()
+        t, d = np.zeros(nt, dtype=np.int64), np.zeros(nd, dtype=np.int64)
+        check(lib().gg_shard_tables(self._h, data.handle, _ptr(t), _ptr(d)))
+        return t, d
+
+    def shard_params(self, data, tables, diag):
+        t = np.ascontiguousarray(tables, dtype=np.int64)
+        d = np.ascontiguousarray(diag, dtype=np.int64)
+        check(lib().gg_shard_params(self._h, data.handle, _ptr(t), _ptr(d)))
+
+    def shard_next(self, data):
+        out = np.zeros(4, dtype=np.int32)
+        check(lib().gg_shard_next(self._h, data.handle, _ptr(out)))
+        return out
+
+    def shard_apply(self, data, node, a, b):
+        check(lib().gg_shard_apply(self._h, data.handle, int(node), int(a), int(b)))
+
+    def shard_finish(self):
+        check(lib().gg_shard_finish(self._h))
+
+    def shard_log_likelihood(self, data, tables, diag):
+        t = np.ascontiguousarray(tables, dtype=np.int64)
+        d = np.ascontiguousarray(diag, dtype=np.int64)
+        out = C.c_double(0)
+        check(lib().gg_shard_log_likelihood(self._h, data.handle, _ptr(t), _ptr(d), C.byref(out)))
+        return out.value
 
     def stats(self):
         s = Stats()

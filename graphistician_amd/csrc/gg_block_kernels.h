@@ -396,6 +396,8 @@ struct gg_params_args {
   const double* pi;
   double beta;   // tempering of the parameter posterior: counts weighted by beta (graph_models.py:180-181,366-367)
   int sweep_from_ctl;   // graph replay: the sweep index lives in ctl[6]; the deferred m belongs to sweep - 1
+  int n0, Nl;           // sharded chain: only nodes [n0, n0 + Nl) are stored locally (tables are then partial)
+  int tables_from_tab;  // sharded chain: the all-reduced tables are already in `tab`
 };
 
 template <bool ADJ, int B>
@@ -430,7 +432,8 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
 #pragma unroll
       for (int q = 0; q < NTAB; ++q) acc[q] = 0;
       for (int r = s0 + threadIdx.x; r < s1; r += blockDim.x) {
-        int n = g.perm[r];
+        int n = g.perm[r] - g.n0;
+        if (n < 0 || n >= g.Nl) continue;   // not an owned node
         acc[0] += g.Gcnt0[(size_t)b * g.Np + n];
         if (!ADJ)
 #pragma unroll
@@ -471,6 +474,9 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         s_tab[threadIdx.x] = v;
         g.tab[(size_t)t * NTAB + threadIdx.x] = v;
       }
+      __syncthreads();
+    } else if (g.tables_from_tab) {
+      if (threadIdx.x < NTAB) s_tab[threadIdx.x] = g.tab[(size_t)t * NTAB + threadIdx.x];
       __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -562,6 +568,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
 // ------------------------------------------------------------------ per-node conditional
 struct gg_node_ctx {
   double beta;     // AIS inverse temperature (1 = plain Gibbs)
+  int n0;          // global index of local node 0 (0 unless the chain is sharded); N = number of LOCAL nodes
   int N, Np, K, Kp, B, shift;
   int special;     // special_case_self_conns
   const int32_t* c;
@@ -678,7 +685,7 @@ __device__ __forceinline__ void gg_stats_to_double(int cnt_o, int cnt_i, const l
 
 template <int NT, bool ADJ>
 __device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n, int k) {
-  const int cn = x.c[n];
+  const int cn = x.c[x.n0 + n];
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
   constexpr int NSI = NT - 1;
   auto ld = [&](int j, double* so, double* si) {
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
     const int gc = x.Gcnt[d][gi];
     double* dst = s_st + (size_t)idx * NT;
     if (ADJ) {
-      const int cx = x.cnt[j] - (x.c[n] == j ? 1 : 0);
+      const int cx = x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0);
       dst[0] = (double)gc;
       dst[1] = (double)(cx - gc);
     } else {
@@ -763,7 +770,35 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
   const double* Ti = stage_tables ? s_T + ntab : x.Tin;
   double lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, To, Ti);
   if (lp_out && nn == lp_node && live && k < K) lp_out[k] = lp;
-  double u = gg_uniform_at(seed, site, sweep, (uint32_t)nn);
+  double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
   int lab = gg_group_categorical(lp, k, K, Kp, u);
   if (live && k == 0) cand[n] = lab;
+}
+
+// Sharded scan helpers -------------------------------------------------------------------------
+// First local node in [lo, hi) whose speculated label differs from its current one.
+__global__ __launch_bounds__(1024) void k_first_changer(const int32_t* __restrict__ c, const int32_t* __restrict__ cand,
+                                                        int n0, int lo, int hi, int32_t* __restrict__ out) {
+  __shared__ int s_first;
+  if (threadIdx.x == 0) s_first = 0x7fffffff;
+  __syncthreads();
+  for (int nl = lo + threadIdx.x; nl < hi; nl += blockDim.x)
+    if (cand[nl] != c[n0 + nl]) { atomicMin(&s_first, nl); break; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int f = s_first;
+    if (f == 0x7fffffff) { out[0] = 0x7fffffff; out[1] = 0; out[2] = 0; }
+    else { out[0] = n0 + f; out[1] = c[n0 + f]; out[2] = cand[f]; }
+  }
+}
+
+// Every rank applies the winning change to its copy of the labels and records it as the pending list L.
+__global__ void k_apply_change(int32_t* c, int32_t* cnt, int32_t* L, int32_t* rs, int n, int a, int b) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    c[n] = b;
+    cnt[a] -= 1; cnt[b] += 1;
+    L[0] = n; L[1] = a; L[2] = b;
+    rs[1] = 1;
+    rs[2] += 1;
+  }
 }

@@ -39,7 +39,8 @@ static inline int gg_nsi(int B) { return B + B * (B + 1) / 2; }
 //   dA, dWq : the diagonal, kept apart because the reference special-cases self connections
 struct gg_data {
   int device;
-  int N, B, Np;
+  int N, B, Np;      // N rows (all nodes); Np = padded number of stored columns
+  int n0, n1;        // stored columns = nodes [n0, n1) (0, N unless this is a shard)
   int has_w;
   int shift;
   long long n_edges;

@@ -172,6 +172,7 @@ int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const 
   memset(d, 0, sizeof(*d));
   d->device = device;
   d->N = N;
+  d->n0 = 0; d->n1 = N;
   d->B = W ? B : 1;
   d->Np = gg_round_up(N, 64);
   d->has_w = W ? 1 : 0;
@@ -239,7 +240,7 @@ int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, co
   if (rc) return rc;
   gg_data* d = new gg_data();
   memset(d, 0, sizeof(*d));
-  d->device = device; d->N = N; d->B = 1; d->Np = gg_round_up(N, 64); d->has_w = 1;
+  d->device = device; d->N = N; d->n0 = 0; d->n1 = N; d->B = 1; d->Np = gg_round_up(N, 64); d->has_w = 1;
   GG_HIP(hipStreamCreate(&d->stream));
   rc = alloc_data(d);
   if (rc) return rc;
@@ -278,6 +279,84 @@ int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, co
   diag_stats_host(d, hdA.data(), hdW.data());
   d->n_edges = -1;
   hipFree(dc); hipFree(dp); hipFree(dmu); hipFree(dsd);
+  *out = d;
+  return GG_OK;
+}
+
+int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t n0, int32_t n1,
+                         int32_t device) {
+  if (!out || !A || N <= 0 || n0 < 0 || n1 > N || n0 >= n1) return gg_fail(GG_ERR_INVALID, "gg_data_create_shard: bad arguments");
+  if (W && (B < 1 || B > GG_MAXB)) return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d not in 1..%d", B, GG_MAXB);
+  int rc = gg_ensure_device(device);
+  if (rc) return rc;
+  gg_data* d = new gg_data();
+  memset(d, 0, sizeof(*d));
+  d->device = device;
+  d->N = N; d->n0 = n0; d->n1 = n1;
+  d->B = W ? B : 1;
+  const int Nl = n1 - n0;
+  d->Np = gg_round_up(Nl, 64);
+  d->has_w = W ? 1 : 0;
+  GG_HIP(hipStreamCreate(&d->stream));
+  if ((rc = alloc_data(d))) return rc;
+  const size_t nA = (size_t)N * d->Np;
+  // column shard of A (in-edges of the owned nodes) and of A^T (their out-edges), diagonal apart
+  std::vector<uint8_t> hA(nA, 0), hAT(nA, 0), hdA(Nl, 0);
+  long long nedges = 0;
+  for (int i = 0; i < N; ++i)
+    for (int nl = 0; nl < Nl; ++nl) {
+      const int n = n0 + nl;
+      const uint8_t a_in = A[(size_t)i * N + n] ? 1 : 0;    // i -> n
+      const uint8_t a_out = A[(size_t)n * N + i] ? 1 : 0;   // n -> i
+      if (i == n) { hdA[nl] = a_in; nedges += a_in; continue; }
+      hA[(size_t)i * d->Np + nl] = a_in;
+      hAT[(size_t)i * d->Np + nl] = a_out;
+      nedges += a_in;
+    }
+  d->n_edges = nedges;
+  GG_HIP(hipMemcpyAsync(d->A, hA.data(), nA, hipMemcpyHostToDevice, d->stream));
+  GG_HIP(hipMemcpyAsync(d->AT, hAT.data(), nA, hipMemcpyHostToDevice, d->stream));
+  GG_HIP(hipMemcpyAsync(d->dA, hdA.data(), Nl, hipMemcpyHostToDevice, d->stream));
+  std::vector<int32_t> hW, hWT, hdW;
+  if (W) {
+    double wmax = 0.0;   // global scale: identical on every rank
+    for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
+      if (!A[ij]) continue;
+      for (int b = 0; b < B; ++b) {
+        double a = fabs(W[ij * B + b]);
+        if (!(a <= 1.7e308)) { gg_data_destroy(d); return gg_fail(GG_ERR_NUMERIC, "non-finite weight on an edge"); }
+        if (a > wmax) wmax = a;
+      }
+    }
+    if (wmax == 0.0) wmax = 1.0;
+    int e;
+    frexp(wmax, &e);
+    d->shift = gg_qbits(N) - e;
+    hW.assign(nA * B, 0); hWT.assign(nA * B, 0); hdW.assign((size_t)Nl * B, 0);
+    for (size_t x = 0; x < nA; ++x) { hW[x * B] = GG_NO_EDGE; hWT[x * B] = GG_NO_EDGE; }
+    for (int nl = 0; nl < Nl; ++nl) hdW[(size_t)nl * B] = GG_NO_EDGE;
+    for (int i = 0; i < N; ++i)
+      for (int nl = 0; nl < Nl; ++nl) {
+        const int n = n0 + nl;
+        const size_t in = (size_t)i * N + n, on = (size_t)n * N + i;
+        if (i == n) {
+          if (A[in]) for (int b = 0; b < B; ++b) hdW[(size_t)nl * B + b] = (int32_t)llrint(ldexp(W[in * B + b], d->shift));
+          continue;
+        }
+        if (A[in]) for (int b = 0; b < B; ++b) hW[((size_t)i * d->Np + nl) * B + b] = (int32_t)llrint(ldexp(W[in * B + b], d->shift));
+        if (A[on]) for (int b = 0; b < B; ++b) hWT[((size_t)i * d->Np + nl) * B + b] = (int32_t)llrint(ldexp(W[on * B + b], d->shift));
+      }
+    GG_HIP(hipMemcpyAsync(d->Wq, hW.data(), hW.size() * 4, hipMemcpyHostToDevice, d->stream));
+    GG_HIP(hipMemcpyAsync(d->WqT, hWT.data(), hWT.size() * 4, hipMemcpyHostToDevice, d->stream));
+    GG_HIP(hipMemcpyAsync(d->dWq, hdW.data(), hdW.size() * 4, hipMemcpyHostToDevice, d->stream));
+  }
+  {  // diagonal statistics of the owned nodes (the driver all-reduces them)
+    const int Nsave = d->N;
+    d->N = Nl;
+    diag_stats_host(d, hdA.data(), W ? hdW.data() : nullptr);
+    d->N = Nsave;
+  }
+  GG_HIP(hipStreamSynchronize(d->stream));
   *out = d;
   return GG_OK;
 }

@@ -25,7 +25,10 @@ struct gg_model {
   gg_config cfg;
   int kind;
   bool is_adj, is_block, sbm;
-  int N, K, Kp, B, NT, NSI, Np, NTAB;
+  int N, K, Kp, B, NT, NSI, Np, NTAB;   // N = all nodes (labels, rows); Np = padded number of OWNED nodes
+  int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded)
+  bool sharded;
+  int spos;                             // sharded scan position
   gg_eigen* eig;
   // device state
   int32_t *c, *cand, *cnt;
@@ -71,6 +74,7 @@ struct gg_model {
   int Lmax, CH, max_idle;
   size_t resolve_lds;
   bool resolve_stage;          // coefficient tables staged in the resolver's LDS
+  bool shard_from_tab;         // enqueue_params: take the (all-reduced) tables from `tab`
   // timing
   int timing;        // 0 = off; n > 0: HIP events around the bulk kernel of every n-th sweep
   std::vector<hipEvent_t> ev;
@@ -138,7 +142,13 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->NT = m->is_adj ? 2 : gg_nt_gauss(m->B);
   m->NSI = m->is_adj ? 0 : gg_nsi(m->B);
   m->NTAB = m->is_adj ? 1 : 1 + 2 * m->NSI;
-  m->Np = gg_round_up(m->N, 64);
+  m->n0 = 0; m->Nl = m->N; m->sharded = false;
+  if (cfg->shard_end > cfg->shard_begin) {
+    if (cfg->shard_begin < 0 || cfg->shard_end > m->N) { delete m; return gg_fail(GG_ERR_INVALID, "shard [%d,%d) outside [0,%d)", cfg->shard_begin, cfg->shard_end, m->N); }
+    m->n0 = cfg->shard_begin; m->Nl = cfg->shard_end - cfg->shard_begin;
+    m->sharded = !(m->n0 == 0 && m->Nl == m->N);
+  }
+  m->Np = gg_round_up(m->Nl, 64);
   // NIW / non-SBM weight kinds always keep a separate self Gaussian (weights.py:91-94)
   if (m->kind == GG_NIW_W || m->kind == GG_FIXED_W) m->cfg.special_case_self_conns = 1;
   GG_HIP(hipStreamCreate(&m->stream));
@@ -149,7 +159,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
       (rc = dmalloc(&m->labb[1], K + 1)) || (rc = dmalloc(&m->m, K)) ||
       (rc = dmalloc(&m->logm, K)) || (rc = dmalloc(&m->pi, K)) || (rc = dmalloc(&m->T, KK * NT)) ||
       (rc = dmalloc(&m->Tout, (size_t)K * NT * m->Kp)) || (rc = dmalloc(&m->Tin, (size_t)K * NT * m->Kp)) ||
-      (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 8)) || (rc = dmalloc(&m->lp_out, K)))
+      (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 32)) || (rc = dmalloc(&m->lp_out, K)))
     return rc;
   m->Gbytes = (size_t)2 * K * m->Np * (sizeof(int32_t) + (size_t)m->NSI * sizeof(long long));
   for (int b = 0; b < 2; ++b) {
@@ -167,7 +177,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->Lmax = N < 4096 ? N : 4096;
   if (m->Lmax < 1) m->Lmax = 1;
   if ((rc = dmalloc(&m->L, (size_t)m->Lmax * 3))) return rc;
-  GG_HIP(hipHostMalloc((void**)&m->h_rs, 8 * sizeof(int32_t)));
+  GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
   // resolve chunk: one Kp-lane group per node, LDS budget 96 KiB
   int CH = 1024 / m->Kp;
   if (CH > 64) CH = 64;
@@ -345,6 +355,8 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes) {
 static int check_data(const gg_model* m, const gg_data* d) {
   if (!d) return gg_fail(GG_ERR_INVALID, "null data handle");
   if (d->N != m->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, m->N);
+  if (d->n0 != m->n0 || d->n1 != m->n0 + m->Nl)
+    return gg_fail(GG_ERR_INVALID, "data holds nodes [%d,%d), model owns [%d,%d)", d->n0, d->n1, m->n0, m->n0 + m->Nl);
   if (d->device != m->cfg.device) return gg_fail(GG_ERR_INVALID, "data on device %d, model on device %d", d->device, m->cfg.device);
   if (!m->is_adj) {
     if (!d->has_w) return gg_fail(GG_ERR_INVALID, "weight model needs data created with W");
@@ -374,7 +386,8 @@ static long long* gs(const gg_model* m, int buf, int dir) {
 static gg_node_ctx node_ctx(const gg_model* m, const gg_data* d, int buf) {
   gg_node_ctx x;
   x.beta = m->beta;
-  x.N = m->N; x.Np = m->Np; x.K = m->K; x.Kp = m->Kp; x.B = m->B; x.shift = m->is_adj ? 0 : d->shift;
+  x.n0 = m->n0;
+  x.N = m->Nl; x.Np = m->Np; x.K = m->K; x.Kp = m->Kp; x.B = m->B; x.shift = m->is_adj ? 0 : d->shift;
   x.special = m->cfg.special_case_self_conns;
   x.c = m->c; x.cnt = m->cnt; x.logm = m->logm; x.T = m->T; x.Tout = m->Tout; x.Tin = m->Tin;
   x.Gcnt[0] = gcnt(m, buf, 0); x.Gcnt[1] = gcnt(m, buf, 1); x.GS[0] = gs(m, buf, 0); x.GS[1] = gs(m, buf, 1);
@@ -474,6 +487,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   gg_params_args g;
   memset(&g, 0, sizeof(g));
   g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.Kp = m->Kp; g.B = m->B; g.NSI = m->NSI; g.Np = m->Np; g.N = m->N;
+  g.n0 = m->n0; g.Nl = m->Nl;
   g.do_tables = tables; g.do_draw = draw; g.do_prep = prep;
   g.add_diag = m->cfg.special_case_self_conns ? 0 : 1;
   g.Gcnt0 = gcnt(m, buf, 0); g.GS0 = gs(m, buf, 0);
@@ -499,6 +513,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   g.pi = m->pi;
   g.beta = m->beta;
   g.sweep_from_ctl = from_ctl ? 1 : 0;
+  g.tables_from_tab = m->shard_from_tab ? 1 : 0;
   if (m->m_pending && prep) {
     g.draw_m = 1; g.m_site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M; g.m_sweep = m->m_sweep;
     m->m_pending = false;
@@ -518,10 +533,10 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
 }
 
 static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined,
-                            bool from_ctl = false, int round_window = 0) {
+                            bool from_ctl = false, int round_window = 0, int explicit_count = 0) {
   gg_node_ctx x = node_ctx(m, d, buf);
   const int K = m->K, per = 256 / m->Kp;
-  const int count = round_window > 0 ? round_window : (m->N - n_begin);
+  const int count = round_window > 0 ? round_window : (explicit_count > 0 ? explicit_count : (m->Nl - n_begin));
   int nb = (count + per - 1) / per;
   if (nb < 1) nb = 1;
   uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
@@ -589,7 +604,7 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
 
 static int launch_apply_L(gg_model* m, const gg_data* d, int buf) {
   gg_node_ctx x = node_ctx(m, d, buf);
-  int nb = (m->N + 255) / 256;
+  int nb = (m->Nl + 255) / 256;
 #define APL(NTV, ADJV)                                                                                             \
   k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0),   \
                                                   gs(m, buf, 1), d->A, d->AT, d->Wq, d->WqT)
@@ -603,7 +618,7 @@ static int launch_apply_L(gg_model* m, const gg_data* d, int buf) {
 }
 
 static int read_ctl(gg_model* m) {
-  GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));
   return GG_OK;
 }
@@ -891,6 +906,7 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
     }
     return GG_OK;
   }
+  if (m->sharded) return gg_fail(GG_ERR_INVALID, "this model owns a shard of the nodes: drive it with the gg_shard_* step API");
   int rc = check_data(m, d);
   if (rc) return rc;
   if (m->pending && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
@@ -994,35 +1010,12 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   return collect_timing(m);
 }
 
-// Closed forms from the K x K tables:
-//   adjacency (abstractions.py:111-115): sum_ab n1 log p + n0 log(1 - clip(p)) + diagonal terms;
-//   weights (weights.py:316-331): sum_ab [ n g + h.s1 + Q.s2 ] + self Gaussian on the diagonal edges.
-int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
-  if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood: null argument");
-  GG_HIP(hipSetDevice(m->cfg.device));
-  if (m->eig) return gg_eigen_log_likelihood(m->eig, d, out);
-  int rc = model_sync(m);
-  if (rc) return rc;
-  if ((rc = check_data(m, d))) return rc;
-  begin_call(m);
-  const int buf = m->cur;
-  if (m->pipe && m->next_bulk && m->pend_data == d) {
-    // the statistics of the current labels are already (being) computed for the next sweep: reuse them
-    GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[buf], 0));
-  } else {
-    if ((rc = drain_pipe(m))) return rc;
-    if ((rc = enqueue_bulk(m, d, buf, 1, false))) return rc;
-  }
-  if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
+// Closed forms from the K x K tables (shared by the single-GPU and the sharded path).
+static int loglik_from_tables(gg_model* m, const gg_data* d, const long long* tabp, const int32_t* cntp, double* out) {
   const int K = m->K, B = m->B;
   const size_t KK = (size_t)K * K;
-  std::vector<long long> tab(KK * m->NTAB);
-  std::vector<int32_t> cnt(K);
-  GG_HIP(hipMemcpyAsync(tab.data(), m->tab, tab.size() * 8, hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipMemcpyAsync(cnt.data(), m->cnt, K * 4, hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
-  GG_HIP(hipStreamSynchronize(m->stream));
-  if ((rc = collect_timing(m))) return rc;
+  const long long* tab = tabp;
+  const int32_t* cnt = cntp;
   const int special = m->cfg.special_case_self_conns;
   double ll = 0.0;
   if (m->is_adj) {
@@ -1091,6 +1084,38 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
   return GG_OK;
 }
 
+// Closed forms from the K x K tables:
+//   adjacency (abstractions.py:111-115): sum_ab n1 log p + n0 log(1 - clip(p)) + diagonal terms;
+//   weights (weights.py:316-331): sum_ab [ n g + h.s1 + Q.s2 ] + self Gaussian on the diagonal edges.
+int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
+  if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood: null argument");
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (m->eig) return gg_eigen_log_likelihood(m->eig, d, out);
+  int rc = model_sync(m);
+  if (rc) return rc;
+  if ((rc = check_data(m, d))) return rc;
+  begin_call(m);
+  const int buf = m->cur;
+  if (m->pipe && m->next_bulk && m->pend_data == d) {
+    // the statistics of the current labels are already (being) computed for the next sweep: reuse them
+    GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[buf], 0));
+  } else {
+    if ((rc = drain_pipe(m))) return rc;
+    if ((rc = enqueue_bulk(m, d, buf, 1, false))) return rc;
+  }
+  if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
+  const int K = m->K, B = m->B;
+  const size_t KK = (size_t)K * K;
+  std::vector<long long> tab(KK * m->NTAB);
+  std::vector<int32_t> cnt(K);
+  GG_HIP(hipMemcpyAsync(tab.data(), m->tab, tab.size() * 8, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipMemcpyAsync(cnt.data(), m->cnt, K * 4, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  GG_HIP(hipStreamSynchronize(m->stream));
+  if ((rc = collect_timing(m))) return rc;
+  return loglik_from_tables(m, d, tab.data(), cnt.data(), out);
+}
+
 // Microbenchmark of the bulk statistics kernel alone (both directions, current labels): average
 // device time per launch over `reps` launches, measured with HIP events on the model's stream.
 int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_launch, double* bytes_per_launch) {
@@ -1120,6 +1145,115 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
   m->timing = t0;
   m->st.bulk_bytes = 0; m->st.bulk_launches = 0;
   return GG_OK;
+}
+
+// ---- sharded single chain: step API (include/graphgibbs.h) ------------------------------------
+static int shard_check(gg_model* m, const gg_data* d) {
+  if (!m) return gg_fail(GG_ERR_INVALID, "null model");
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "sharding: block models only");
+  if (m->kind != GG_SBM_ADJ && m->kind != GG_SBM_GAUSS_W) return gg_fail(GG_ERR_UNSUPPORTED, "sharding: SBM kinds only");
+  return d ? check_data(m, d) : GG_OK;
+}
+
+int gg_shard_sizes(gg_model* m, int32_t* ntab_total, int32_t* ndiag) {
+  if (!m || m->eig) return gg_fail(GG_ERR_INVALID, "gg_shard_sizes: block model expected");
+  if (ntab_total) *ntab_total = m->K * m->K * m->NTAB;
+  if (ndiag) *ndiag = 1 + gg_nsi(GG_MAXB);
+  return GG_OK;
+}
+
+int gg_shard_tables(gg_model* m, const gg_data* d, int64_t* tables, int64_t* diag) {
+  int rc = shard_check(m, d);
+  if (rc) return rc;
+  if (!tables || !diag) return gg_fail(GG_ERR_INVALID, "gg_shard_tables: null output");
+  m->beta = 1.0;
+  const int buf = m->cur;
+  if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;
+  if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
+  GG_HIP(hipMemcpyAsync(tables, m->tab, (size_t)m->K * m->K * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipStreamSynchronize(m->stream));
+  diag[0] = d->d1;
+  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) diag[1 + i] = d->dS[i];
+  return GG_OK;
+}
+
+int gg_shard_params(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag) {
+  int rc = shard_check(m, d);
+  if (rc) return rc;
+  GG_HIP(hipMemcpyAsync(m->tab, tables, (size_t)m->K * m->K * m->NTAB * 8, hipMemcpyHostToDevice, m->stream));
+  // global diagonal statistics go into the kernel arguments through a temporary copy of the data header
+  gg_data dg = *d;
+  dg.d1 = diag[0];
+  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = diag[1 + i];
+  m->shard_from_tab = true;
+  rc = enqueue_params(m, &dg, m->cur, false, true, true, false, m->sweep);
+  m->shard_from_tab = false;
+  if (rc) return rc;
+  m->spos = 0;
+  return GG_OK;
+}
+
+int gg_shard_next(gg_model* m, const gg_data* d, int32_t out[4]) {
+  int rc = shard_check(m, d);
+  if (rc) return rc;
+  const int W = 4096;
+  const int wend = (m->spos + W < m->N) ? m->spos + W : m->N;
+  int lo = m->spos - m->n0, hi = wend - m->n0;
+  if (lo < 0) lo = 0;
+  if (hi > m->Nl) hi = m->Nl;
+  out[0] = 0x7fffffff; out[1] = 0; out[2] = 0; out[3] = wend;
+  if (hi > lo && m->K > 1) {
+    if ((rc = launch_speculate(m, d, m->cur, lo, -1, m->sweep, false, false, 0, hi - lo))) return rc;
+    k_first_changer<<<1, 1024, 0, m->stream>>>(m->c, m->cand, m->n0, lo, hi, m->rs + 12);
+    GG_HIP(hipGetLastError());
+    GG_HIP(hipMemcpyAsync(m->h_rs, m->rs + 12, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    GG_HIP(hipStreamSynchronize(m->stream));
+    out[0] = m->h_rs[0]; out[1] = m->h_rs[1]; out[2] = m->h_rs[2];
+  }
+  return GG_OK;
+}
+
+int gg_shard_apply(gg_model* m, const gg_data* d, int32_t node, int32_t a, int32_t b) {
+  int rc = shard_check(m, d);
+  if (rc) return rc;
+  if (node < 0) { m->spos = a; return GG_OK; }
+  if (node >= m->N || a < 0 || a >= m->K || b < 0 || b >= m->K) return gg_fail(GG_ERR_INVALID, "gg_shard_apply: bad change");
+  k_apply_change<<<1, 64, 0, m->stream>>>(m->c, m->cnt, m->L, m->rs, node, a, b);
+  GG_HIP(hipGetLastError());
+  if ((rc = launch_apply_L(m, d, m->cur))) return rc;     // statistics of the owned nodes (edges to / from `node`)
+  m->spos = node + 1;
+  m->perm_valid = false;
+  m->st.label_changes += 1;
+  return GG_OK;
+}
+
+int gg_shard_finish(gg_model* m) {
+  int rc = shard_check(m, nullptr);
+  if (rc) return rc;
+  k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+                                                      m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
+  GG_HIP(hipGetLastError());
+  GG_HIP(hipStreamSynchronize(m->stream));
+  m->sweep += 1;
+  m->st.sweeps += 1;
+  m->zeroed[m->cur] = false;
+  GG_HIP(hipMemcpy(m->rs + 6, &m->sweep, 4, hipMemcpyHostToDevice));
+  return GG_OK;
+}
+
+int gg_shard_log_likelihood(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag, double* out) {
+  int rc = shard_check(m, d);
+  if (rc) return rc;
+  if (!tables || !diag || !out) return gg_fail(GG_ERR_INVALID, "gg_shard_log_likelihood: null argument");
+  std::vector<int32_t> cnt(m->K);
+  if ((rc = ensure_perm(m))) return rc;
+  GG_HIP(hipMemcpyAsync(cnt.data(), m->cnt, m->K * 4, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipStreamSynchronize(m->stream));
+  gg_data dg = *d;
+  dg.d1 = diag[0];
+  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = diag[1 + i];
+  return loglik_from_tables(m, &dg, (const long long*)tables, cnt.data(), out);
 }
 
 int gg_last_stats(gg_model* m, gg_stats* out) {

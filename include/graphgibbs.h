@@ -66,6 +66,7 @@ typedef struct gg_config {
   double sigma_mu0, sigma_F, sigma_lmbda, mu_mu_0; /* eigenmodel.py:41-56 */
   int32_t lmbda_given;            /* eigenmodel.py:65-67 */
   int32_t reserved;
+  int32_t shard_begin, shard_end; /* sharded single chain: this rank owns nodes [shard_begin, shard_end); 0,0 = all */
 } gg_config;
 
 /* State ids for gg_get_state / gg_set_state.  Shapes in comments, C order. */
@@ -130,6 +131,11 @@ int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64
 int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
                        const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
                        int32_t device);
+/* Column shard for a chain sharded over several GPUs: this rank owns nodes
+ * [n0, n1) and stores A[:, n0:n1] and A[n0:n1, :]^T (same for W), i.e. everything the per-node statistics
+ * of its own nodes need.  A and W are the FULL (N,N[,B]) host arrays (the fixed-point scale is global). */
+int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t n0, int32_t n1,
+                         int32_t device);
 /* Copy the stored network back (de-quantised weights); W may be NULL. */
 int gg_data_download(const gg_data* d, uint8_t* A, double* W);
 
@@ -166,6 +172,25 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
 /* on = n > 0: record HIP events (on the engine stream) around the bulk kernel of every n-th sweep, so that
  * gg_last_stats reports bulk_ms / bulk_launches / bulk_bytes for the sampled launches; 0 = off. */
 int gg_set_timing(gg_model* m, int32_t on);
+
+/* ---- sharded single chain, step API (block models, beta = 1).  One half-sweep is
+ *   gg_shard_tables   -> [all-reduce SUM of tables and diag over ranks]
+ *   gg_shard_params   (draw parameters from the global tables; the scan position is reset)
+ *   loop: gg_shard_next -> [all-gather of (node, old, new); the smallest node wins] -> gg_shard_apply
+ *   gg_shard_finish   (resample_m)
+ * Every rank holds all labels; statistics of its own nodes are complete locally; all traffic is integer
+ * (exact, order independent), so the chain equals the single-GPU chain bit for bit for any number of ranks.
+ * tables: int64 [K*K*ntab]; diag: int64 [ndiag] (gg_shard_sizes). */
+int gg_shard_sizes(gg_model* m, int32_t* ntab_total, int32_t* ndiag);
+int gg_shard_tables(gg_model* m, const gg_data* d, int64_t* tables, int64_t* diag);
+int gg_shard_params(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag);
+/* out = {first local node in the current window whose draw differs from its label (INT32_MAX if none), old, new, window end} */
+int gg_shard_next(gg_model* m, const gg_data* d, int32_t out[4]);
+/* node >= 0: every rank applies the winning change; node < 0: nothing changed, move on to position `a` (the window end) */
+int gg_shard_apply(gg_model* m, const gg_data* d, int32_t node, int32_t a, int32_t b);
+int gg_shard_finish(gg_model* m);
+/* log-likelihood from all-reduced tables / diag (abstractions.py:111-115, weights.py:316-331) */
+int gg_shard_log_likelihood(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag, double* out);
 
 /* Device self-test of the shared arithmetic spec: evaluates exp/log/sqrt/div
  * on the device for n inputs (parity tests compare with the host build). */
