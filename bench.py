@@ -136,8 +136,63 @@ def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
     print(json.dumps(out))
 
 
+def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
+    """One Gaussian-SBM chain sharded over the ranks (strong scaling; BASELINE.json configs[3] at --nodes 65536
+    --blocks 64): exact — the same chain for any number of ranks (graphistician_amd/sharded.py)."""
+    from graphistician_amd import sharded as S
+    N, K = args.nodes, args.blocks
+    comm = S.TorchComm() if world > 1 else S.LocalComm()
+    n0, n1 = S.shard_range(N, rank, world)
+    truth = planted_truth(N, K, seed=1234)
+    data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                        truth["mu_self"], truth["sigma_self"], seed=1234, device=device, shard=(n0, n1))
+    rng = np.random.RandomState(1)                      # the same chain on every rank
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=3, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                    special_case_self_conns=1, device=device, shard_begin=n0, shard_end=n1)
+    m_a = rng.dirichlet(np.ones(K))
+    adj.set(abi.ST_PI, np.ones(K)); adj.set(abi.ST_M, m_a)
+    adj.set(abi.ST_C, rng.choice(K, p=m_a, size=N).astype(np.int32), np.int32)
+    adj.set(abi.ST_P, rng.beta(1.0, 1.0, size=(K, K))); adj.set(abi.ST_P_SELF, np.array([rng.beta(1.0, 1.0)]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=4, special_case_self_conns=1, device=device,
+                  shard_begin=n0, shard_end=n1)
+    m_w = rng.dirichlet(np.ones(K) * 10.0)
+    w.set(abi.ST_PI, np.ones(K) * 10.0); w.set(abi.ST_M, m_w)
+    w.set(abi.ST_C, rng.choice(K, p=m_w, size=N).astype(np.int32), np.int32)
+    w.set(abi.ST_MU, rng.randn(K, K, 1)); w.set(abi.ST_SIGMA, np.ones((K, K, 1, 1)))
+    niw = np.array([0.0, 1.0, 3.0, 1.0])
+    w.set(abi.ST_NIW, niw); w.set(abi.ST_NIW_SELF, niw)
+    for _ in range(args.warmup):
+        S.half_sweep(adj, data, comm); S.half_sweep(w, data, comm)
+    chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        S.half_sweep(adj, data, comm); S.half_sweep(w, data, comm)
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    chg = adj.stats()["label_changes"] + w.stats()["label_changes"] - chg0
+    digest = int(np.bitwise_xor.reduce(adj.get(abi.ST_C, (N,), np.int32) * np.arange(1, N + 1, dtype=np.int32)))
+    if rank == 0:
+        sweep_bytes = 2.0 * N * N * (1.0 + 4.0)
+        print(json.dumps({
+            "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": args.steps / el,
+            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int64 statistics / f64 conditionals (u8 adjacency, 24-bit fixed-point weights in int32)",
+            "data": "synthetic",
+            "config": {"workload": "ONE Gaussian SBM chain, N=%d, K=%d, B=1, node-sharded over %d rank(s)" % (N, K, world),
+                       "parallelism": "exact node sharding: all-reduce of K x K integer tables + all-gather of label changes",
+                       "label_changes_in_timed_region": int(chg), "labels_digest": digest,
+                       "sweep_algorithmic_bytes": sweep_bytes, "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9},
+            "roofline": {"bound": "hbm", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": sweep_bytes * args.steps / el / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                         "note": "whole-sweep effective rate over the aggregate HBM peak of the ranks"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--shard", action="store_true",
+                    help="one chain sharded over the ranks (strong scaling) instead of an independent chain per rank")
     ap.add_argument("--config", default="sbm", choices=["sbm", "eigen"],
                     help="sbm = BASELINE.json configs[1] (default, the headline); eigen = configs[2]")
     ap.add_argument("--latent", type=int, default=8)
@@ -199,6 +254,14 @@ def main():
     from graphistician_amd import _abi as abi
     N, K = args.nodes, args.blocks
     device = local_rank
+    if os.environ.get("GG_BENCH_SAME_DEVICE"):      # several ranks on one GPU (tests on a 1-GPU box)
+        device = 0
+    if args.shard:
+        bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.config == "eigen":
         bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks)
         if dist is not None:

@@ -45,7 +45,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_shard_sizes", "gg_shard_tables",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_shard_sizes", "gg_shard_tables",
            "gg_shard_params", "gg_shard_next", "gg_shard_apply", "gg_shard_finish", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_selftest_math", "gg_selftest_draws"]
 
@@ -93,6 +93,8 @@ def lib():
         L.gg_set_timing.argtypes = [vp, C.c_int32]
         L.gg_bench_bulk.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.gg_data_create_shard.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
+        L.gg_data_create_sbm_shard.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp, C.c_double,
+                                               C.c_double, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
         L.gg_shard_sizes.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.gg_shard_tables.argtypes = [vp, vp, vp, vp]
         L.gg_shard_params.argtypes = [vp, vp, vp, vp]
@@ -165,16 +167,21 @@ class DeviceData(object):
         return obj
 
     @classmethod
-    def synthetic_sbm(cls, N, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device=0):
-        """Planted Gaussian SBM (B = 1) generated on the device."""
+    def synthetic_sbm(cls, N, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device=0, shard=None):
+        """Planted Gaussian SBM (B = 1) generated on the device; shard=(n0, n1) generates that column shard only."""
         c = np.ascontiguousarray(c, dtype=np.int32)
         p = np.ascontiguousarray(p, dtype=np.float64)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         sigma = np.ascontiguousarray(sigma, dtype=np.float64)
         K = p.shape[0]
         h = C.c_void_p()
-        check(lib().gg_data_create_sbm(C.byref(h), N, K, _ptr(c), _ptr(p), float(p_self), _ptr(mu), _ptr(sigma),
-                                       float(mu_self), float(sigma_self), C.c_uint64(seed), device))
+        if shard is None:
+            check(lib().gg_data_create_sbm(C.byref(h), N, K, _ptr(c), _ptr(p), float(p_self), _ptr(mu), _ptr(sigma),
+                                           float(mu_self), float(sigma_self), C.c_uint64(seed), device))
+        else:
+            check(lib().gg_data_create_sbm_shard(C.byref(h), N, K, _ptr(c), _ptr(p), float(p_self), _ptr(mu), _ptr(sigma),
+                                                 float(mu_self), float(sigma_self), C.c_uint64(seed), int(shard[0]),
+                                                 int(shard[1]), device))
         return cls(handle=h, N=N, B=1, device=device)
 
     @property

@@ -98,6 +98,50 @@ __global__ void k_generate_sbm(uint8_t* A, int32_t* Wq, uint8_t* dA, int32_t* dW
   }
 }
 
+// Column shard [n0, n1) of the same synthetic network: entry (i, nl) of the shard of A is the edge
+// i -> n0+nl, of the shard of A^T the edge n0+nl -> i; both use the Philox counters of k_generate_sbm,
+// so the union of the shards IS the network k_generate_sbm produces.
+__device__ __forceinline__ int32_t gg_gen_edge(int i, int j, int K, const int32_t* c, const double* p, double p_self,
+                                               const double* mu, const double* sd, double mu_self, double sd_self,
+                                               uint64_t seed, double scale, int qmax, int* a_out) {
+  gg_u32x4 r = gg_philox4x32_10((uint32_t)j, (uint32_t)i, 0u, GG_SITE_DATA, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const int ab = c[i] * K + c[j];
+  const double pe = (i == j) ? p_self : p[ab];
+  const int a = gg_u53(r.v[0], r.v[1]) < pe;
+  gg_stream s;
+  gg_stream_init(&s, seed, GG_SITE_DATA, 1u + (uint32_t)i, (uint32_t)j);
+  const double z = gg_normal(&s);
+  const double w = (i == j) ? (mu_self + sd_self * z) : (mu[ab] + sd[ab] * z);
+  double qd = __builtin_rint(w * scale);
+  if (qd > (double)qmax) qd = (double)qmax;
+  if (qd < -(double)qmax) qd = -(double)qmax;
+  *a_out = a;
+  return a ? (int32_t)qd : GG_NO_EDGE;
+}
+
+__global__ void k_generate_sbm_shard(uint8_t* A, uint8_t* AT, int32_t* Wq, int32_t* WqT, uint8_t* dA, int32_t* dWq, int N,
+                                     int Np, int n0, int Nl, int K, const int32_t* __restrict__ c,
+                                     const double* __restrict__ p, double p_self, const double* __restrict__ mu,
+                                     const double* __restrict__ sd, double mu_self, double sd_self, uint64_t seed,
+                                     double scale, int qmax) {
+  const int nl = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (nl >= Nl) return;
+  const int n = n0 + nl;
+  int a_in, a_out;
+  const int32_t q_in = gg_gen_edge(i, n, K, c, p, p_self, mu, sd, mu_self, sd_self, seed, scale, qmax, &a_in);
+  if (i == n) {
+    dA[nl] = (uint8_t)a_in;
+    dWq[nl] = q_in;
+    return;   // the diagonal stays 0 / NO_EDGE in the shards
+  }
+  const int32_t q_out = gg_gen_edge(n, i, K, c, p, p_self, mu, sd, mu_self, sd_self, seed, scale, qmax, &a_out);
+  A[(size_t)i * Np + nl] = (uint8_t)a_in;
+  Wq[(size_t)i * Np + nl] = q_in;
+  AT[(size_t)i * Np + nl] = (uint8_t)a_out;
+  WqT[(size_t)i * Np + nl] = q_out;
+}
+
 // ---------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------
@@ -232,15 +276,34 @@ int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const 
   return GG_OK;
 }
 
+static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                           const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                           int32_t device, int32_t n0, int32_t n1);
+
 int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
                        const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
                        int32_t device) {
+  return create_sbm_impl(out, N, K, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device, 0, N);
+}
+
+int gg_data_create_sbm_shard(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                             const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                             int32_t n0, int32_t n1, int32_t device) {
+  if (n0 < 0 || n1 > N || n0 >= n1) return gg_fail(GG_ERR_INVALID, "gg_data_create_sbm_shard: bad node range");
+  return create_sbm_impl(out, N, K, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device, n0, n1);
+}
+
+static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                           const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                           int32_t device, int32_t n0, int32_t n1) {
   if (!out || N <= 0 || K <= 0 || !c || !p || !mu || !sigma) return gg_fail(GG_ERR_INVALID, "gg_data_create_sbm: bad arguments");
   int rc = gg_ensure_device(device);
   if (rc) return rc;
+  const bool shard = !(n0 == 0 && n1 == N);
+  const int Nl = n1 - n0;
   gg_data* d = new gg_data();
   memset(d, 0, sizeof(*d));
-  d->device = device; d->N = N; d->n0 = 0; d->n1 = N; d->B = 1; d->Np = gg_round_up(N, 64); d->has_w = 1;
+  d->device = device; d->N = N; d->n0 = n0; d->n1 = n1; d->B = 1; d->Np = gg_round_up(Nl, 64); d->has_w = 1;
   GG_HIP(hipStreamCreate(&d->stream));
   rc = alloc_data(d);
   if (rc) return rc;
@@ -265,18 +328,31 @@ int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, co
   GG_HIP(hipMemcpyAsync(dp, p, (size_t)K * K * 8, hipMemcpyHostToDevice, d->stream));
   GG_HIP(hipMemcpyAsync(dmu, mu, (size_t)K * K * 8, hipMemcpyHostToDevice, d->stream));
   GG_HIP(hipMemcpyAsync(dsd, sd.data(), (size_t)K * K * 8, hipMemcpyHostToDevice, d->stream));
-  dim3 grd((N + 255) / 256, N);
-  k_generate_sbm<<<grd, 256, 0, d->stream>>>(d->A, d->Wq, d->dA, d->dWq, N, d->Np, K, dc, dp, p_self, dmu, dsd, mu_self,
-                                             sqrt(sigma_self), seed, ldexp(1.0, d->shift), 1 << qb);
-  GG_HIP(hipGetLastError());
-  rc = make_transposes(d);
-  if (rc) return rc;
-  std::vector<uint8_t> hdA(N);
-  std::vector<int32_t> hdW(N);
-  GG_HIP(hipMemcpyAsync(hdA.data(), d->dA, N, hipMemcpyDeviceToHost, d->stream));
-  GG_HIP(hipMemcpyAsync(hdW.data(), d->dWq, (size_t)N * 4, hipMemcpyDeviceToHost, d->stream));
+  if (!shard) {
+    dim3 grd((N + 255) / 256, N);
+    k_generate_sbm<<<grd, 256, 0, d->stream>>>(d->A, d->Wq, d->dA, d->dWq, N, d->Np, K, dc, dp, p_self, dmu, dsd, mu_self,
+                                               sqrt(sigma_self), seed, ldexp(1.0, d->shift), 1 << qb);
+    GG_HIP(hipGetLastError());
+    rc = make_transposes(d);
+    if (rc) return rc;
+  } else {
+    dim3 grd((Nl + 255) / 256, N);
+    k_generate_sbm_shard<<<grd, 256, 0, d->stream>>>(d->A, d->AT, d->Wq, d->WqT, d->dA, d->dWq, N, d->Np, n0, Nl, K, dc, dp,
+                                                     p_self, dmu, dsd, mu_self, sqrt(sigma_self), seed,
+                                                     ldexp(1.0, d->shift), 1 << qb);
+    GG_HIP(hipGetLastError());
+  }
+  std::vector<uint8_t> hdA(Nl);
+  std::vector<int32_t> hdW(Nl);
+  GG_HIP(hipMemcpyAsync(hdA.data(), d->dA, Nl, hipMemcpyDeviceToHost, d->stream));
+  GG_HIP(hipMemcpyAsync(hdW.data(), d->dWq, (size_t)Nl * 4, hipMemcpyDeviceToHost, d->stream));
   GG_HIP(hipStreamSynchronize(d->stream));
-  diag_stats_host(d, hdA.data(), hdW.data());
+  {
+    const int Nsave = d->N;
+    d->N = Nl;
+    diag_stats_host(d, hdA.data(), hdW.data());
+    d->N = Nsave;
+  }
   d->n_edges = -1;
   hipFree(dc); hipFree(dp); hipFree(dmu); hipFree(dsd);
   *out = d;

@@ -136,6 +136,10 @@ int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, co
  * of its own nodes need.  A and W are the FULL (N,N[,B]) host arrays (the fixed-point scale is global). */
 int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t n0, int32_t n1,
                          int32_t device);
+/* The column shard [n0, n1) of the network gg_data_create_sbm generates (same Philox counters). */
+int gg_data_create_sbm_shard(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                             const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                             int32_t n0, int32_t n1, int32_t device);
 /* Copy the stored network back (de-quantised weights); W may be NULL. */
 int gg_data_download(const gg_data* d, uint8_t* A, double* W);
 

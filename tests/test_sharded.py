@@ -17,3 +17,25 @@ def test_sharded_chain_equals_single_chain(world, N, K):
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "SHARD-OK world=%d" % world in out.stdout, out.stdout[-1500:]
+
+
+@pytest.mark.gpu
+def test_sharded_bench_is_rank_count_invariant():
+    """bench.py --shard on device-generated data: 1 rank and 2 ranks (sharing the GPU, gloo) run the same chain."""
+    import json
+    digests = []
+    for world in (1, 2):
+        env = dict(os.environ, GG_BENCH_BACKEND="gloo", GG_BENCH_SAME_DEVICE="1")
+        base = [os.path.join(ROOT, "bench.py"), "--shard", "--nodes", "700", "--blocks", "6", "--steps", "3", "--warmup", "2",
+                "--gpus", str(world)]
+        if world == 1:
+            cmd = [sys.executable] + base
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                   "--master-addr", "127.0.0.1", "--master-port", "29561"] + base
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert r["n_gpus"] == world and r["scaling"] == "strong"
+        digests.append((r["config"]["labels_digest"], r["config"]["label_changes_in_timed_region"]))
+    assert digests[0] == digests[1], digests
