@@ -43,6 +43,29 @@ struct gg_eigen {
 };
 
 // ------------------------------------------------------------------ kernels
+typedef double gg_double4 __attribute__((ext_vector_type(4)));
+
+// psi tile = mu_0 + (F lambda) F^T for a 32 x 32 tile (eigenmodel.py:81) on the matrix cores:
+// v_mfma_f64_16x16x4_f64, one 16 x 16 block per wave (4 waves = the tile), DM / 4 k-steps.
+// Fragment layout, measured on gfx950 with tools/probe/mfma_f64_layout.hip: lane l supplies A[l % 16][l / 16]
+// and B[l / 16][l % 16]; it receives D[4 r + l / 16][l % 16] in component r.  s_fi holds the rows of F
+// scaled by lambda.
+template <int DM>
+__device__ __forceinline__ void eig_psi_tile_mfma(const double (*s_fi)[DM], const double (*s_fj)[DM], double mu0,
+                                                  double (*s_psi)[33]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bi = wave >> 1, bj = wave & 1;
+  gg_double4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < DM / 4; ++kk) {
+    const double a = s_fi[bi * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+    const double b = s_fj[bj * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s_psi[bi * 16 + 4 * r + (lane >> 4)][bj * 16 + (lane & 15)] = mu0 + acc[r];
+}
+
 __global__ void k_eig_normals(double* Z, int n, uint64_t seed, uint32_t site, uint32_t sweep) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) Z[i] = gg_normal_at(seed, site, sweep, (uint32_t)i);
@@ -63,6 +86,7 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
                                                    double* __restrict__ dO) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
   __shared__ double s_t[32][33];
+  __shared__ double s_psi[32][33];
   const int nt = (N + 31) / 32;
   int I, J;
   eig_tile_pair(blockIdx.x, nt, &I, &J);
@@ -75,6 +99,8 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
     s_fj[r][d] = (d < D && gj < N) ? F[(size_t)gj * D + d] : 0.0;
   }
   __syncthreads();
+  eig_psi_tile_mfma<DM>(s_fi, s_fj, mu0, s_psi);
+  __syncthreads();
   for (int e = tid; e < 1024; e += 256) {
     const int li = e >> 5, lj = e & 31;
     const int gi = I * 32 + li, gj = J * 32 + lj;
@@ -83,9 +109,7 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
       if (I == J && li == lj) {
         dO[gi] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gi, mu0);
       } else if (I < J || li < lj) {
-        double psi = mu0;
-#pragma unroll
-        for (int d = 0; d < DM; ++d) psi += s_fi[li][d] * s_fj[lj][d];
+        const double psi = s_psi[li][lj];
         double o1 = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gj, psi);
         double o2 = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gj, (uint32_t)gi, psi);
         val = o1 + o2;
@@ -450,6 +474,7 @@ __global__ __launch_bounds__(256) void k_eig_loglik(int N, int Np, int D, const 
                                                     const double* __restrict__ lmbda, const double* __restrict__ mu0p,
                                                     double* __restrict__ llpart) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
+  __shared__ double s_psi[32][33];
   __shared__ double s_w[4];
   const int I = blockIdx.y, J = blockIdx.x, tid = threadIdx.x;
   const double mu0 = *mu0p;
@@ -459,6 +484,8 @@ __global__ __launch_bounds__(256) void k_eig_loglik(int N, int Np, int D, const 
     s_fi[r][d] = (d < D && gi < N) ? F[(size_t)gi * D + d] * lmbda[d] : 0.0;
     s_fj[r][d] = (d < D && gj < N) ? F[(size_t)gj * D + d] : 0.0;
   }
+  __syncthreads();
+  eig_psi_tile_mfma<DM>(s_fi, s_fj, mu0, s_psi);
   __syncthreads();
   double ll = 0.0;
   for (int e = tid; e < 1024; e += 256) {
@@ -470,8 +497,7 @@ __global__ __launch_bounds__(256) void k_eig_loglik(int N, int Np, int D, const 
       if (gi == gj) {
         a = dA[gi];
       } else {
-#pragma unroll
-        for (int d = 0; d < DM; ++d) psi += s_fi[li][d] * s_fj[lj][d];
+        psi = s_psi[li][lj];
         a = A[(size_t)gi * Np + gj];
       }
       double P = 1.0 / (1.0 + gg_exp(-psi));
