@@ -358,10 +358,10 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
                                                     const double* __restrict__ F, double* __restrict__ gpart) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   constexpr int NGM = 2 + 2 * DM + NEGM;
-  const int i = blockIdx.x;
   double acc[NGM];
 #pragma unroll
   for (int e = 0; e < NGM; ++e) acc[e] = 0.0;
+  for (int i = blockIdx.x; i < N; i += gridDim.x) {   // a few rows per workgroup: <= 512 partials to sum afterwards
   double fi[DM];
 #pragma unroll
   for (int d = 0; d < DM; ++d) fi[d] = d < D ? F[(size_t)i * D + d] : 0.0;
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
       for (int b1 = a1; b1 < DM; ++b1) acc[e++] += sg * g[b1];
     }
   }
+  }
   __shared__ double s_red[4][NGM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -394,12 +395,12 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
   __syncthreads();
   if (threadIdx.x < NGM) {
     const int e = threadIdx.x;
-    gpart[(size_t)i * NGM + e] = (s_red[0][e] + s_red[1][e]) + (s_red[2][e] + s_red[3][e]);
+    gpart[(size_t)blockIdx.x * NGM + e] = (s_red[0][e] + s_red[1][e]) + (s_red[2][e] + s_red[3][e]);
   }
 }
 
 template <int DM>
-__global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int D, const double* __restrict__ gpart,
+__global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, const double* __restrict__ gpart,
                                                           const double* __restrict__ dO, const uint8_t* __restrict__ dA,
                                                           double* __restrict__ lmbda, double* __restrict__ mu0p,
                                                           const double* __restrict__ mu_lmbda, double mu_mu_0,
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int D, const do
     __shared__ double s_q[4][NGM];
     const int e = tid & 63, q = tid >> 6;
     if (e < NGM) {
-      const int lo = (int)((long long)N * q / 4), hi = (int)((long long)N * (q + 1) / 4);
+      const int lo = (int)((long long)NP * q / 4), hi = (int)((long long)NP * (q + 1) / 4);
       double v = 0.0;
       for (int i = lo; i < hi; ++i) v += gpart[(size_t)i * NGM + e];
       s_q[q][e] = v;
@@ -671,8 +672,8 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   const int do_lm = ((parts & GG_PART_LMBDA) && !e->cfg.lmbda_given) ? 1 : 0;
   if (do_mu0 || do_lm) {
 #define CALL(DMV)                                                                                                   \
-  k_eig_global<DMV><<<N, 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart);                                 \
-  k_eig_draw_globals<DMV><<<1, 256, 0, st>>>(N, D, e->gpart, e->dO, d->dA, e->lmbda, e->mu0, e->mu_lmbda,            \
+  k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart);               \
+  k_eig_draw_globals<DMV><<<1, 256, 0, st>>>(N, (N < 512 ? N : 512), D, e->gpart, e->dO, d->dA, e->lmbda, e->mu0, e->mu_lmbda,            \
                                              e->cfg.mu_mu_0, e->cfg.sigma_mu0, e->cfg.sigma_lmbda, do_mu0, do_lm,   \
                                              e->cfg.seed, e->sweep, e->status)
     EIG_DISPATCH(CALL);
