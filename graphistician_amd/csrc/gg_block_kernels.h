@@ -611,25 +611,12 @@ __device__ __forceinline__ int gg_group_categorical(double lp, int k, int K, int
   return idx > K - 1 ? K - 1 : idx;
 }
 
-// lp[k] of one node (gg_lp.h::gg_block_lp order).  `ld(j, so, si)` supplies the
-// node's out / in statistics towards block j as doubles in spec order.
-template <int NT, bool ADJ, class Loader>
-__device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld,
-                                                  const double* __restrict__ Tout, const double* __restrict__ Tin) {
+// Combination of the finished chains of node n, label k (the tail of gg_lp.h::gg_block_lp).
+template <int NT, bool ADJ>
+__device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n, int k, const double* acc_o,
+                                                    const double* acc_i) {
   if (k >= x.K) return -gg_inf();
-  const int K = x.K, Kp = x.Kp;
-  double acc_o[NT], acc_i[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { acc_o[t] = 0.0; acc_i[t] = 0.0; }
-  for (int j = 0; j < K; ++j) {
-    double so[NT], si[NT];
-    ld(j, so, si);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc_o[t] = gg_fma(Tout[((size_t)j * NT + t) * Kp + k], so[t], acc_o[t]);
-      acc_i[t] = gg_fma(Tin[((size_t)j * NT + t) * Kp + k], si[t], acc_i[t]);
-    }
-  }
+  const int K = x.K;
   double lp = x.logm[k];
 #pragma unroll
   for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_o[t], lp);
@@ -660,6 +647,101 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
     lp = gg_fma(x.beta, acc, lp);
   }
   return lp;
+}
+
+// lp[k] of one node (gg_lp.h::gg_block_lp order).  `ld(j, so, si)` supplies the
+// node's out / in statistics towards block j as doubles in spec order.
+template <int NT, bool ADJ, class Loader>
+__device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld,
+                                                  const double* __restrict__ Tout, const double* __restrict__ Tin) {
+  if (k >= x.K) return -gg_inf();
+  const int K = x.K, Kp = x.Kp;
+  double acc_o[NT], acc_i[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc_o[t] = 0.0; acc_i[t] = 0.0; }
+  // The table entries of UJ consecutive j are fetched as one batch before any of them is used (the
+  // compiler's own schedule waits for every load right where it issues it); the fma order is unchanged.
+  constexpr int UJ = NT <= 3 ? 8 : (NT <= 6 ? 4 : 2);
+  int j = 0;
+  for (; j + UJ <= K; j += UJ) {
+    double to[UJ][NT], ti[UJ][NT];
+#pragma unroll
+    for (int u = 0; u < UJ; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        to[u][t] = Tout[((size_t)(j + u) * NT + t) * Kp + k];
+        ti[u][t] = Tin[((size_t)(j + u) * NT + t) * Kp + k];
+      }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) {
+      double so[NT], si[NT];
+      ld(j + u, so, si);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc_o[t] = gg_fma(to[u][t], so[t], acc_o[t]);
+        acc_i[t] = gg_fma(ti[u][t], si[t], acc_i[t]);
+      }
+    }
+  }
+  for (; j < K; ++j) {
+    double so[NT], si[NT];
+    ld(j, so, si);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc_o[t] = gg_fma(Tout[((size_t)j * NT + t) * Kp + k], so[t], acc_o[t]);
+      acc_i[t] = gg_fma(Tin[((size_t)j * NT + t) * Kp + k], si[t], acc_i[t]);
+    }
+  }
+  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i);
+}
+
+// The same conditional for a workgroup of 4 waves that holds 4 nodes with Kp = 64 (33 <= K <= 64), when the
+// coefficient tables do not fit in LDS: the 2 NT independent fma chains (direction, statistic) are dealt
+// out to the waves, each wave running its chains for all 4 nodes, so every table entry is fetched once per
+// workgroup instead of once per node; the chains meet in LDS and wave i combines those of node i in the
+// order of gg_block_lp.  Same chains, same order, same bits.  s_st: [dir][j][4][NT], s_acc: [4][2 NT][64].
+template <int NT, bool ADJ>
+__device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const double* s_st, double* s_acc, int n) {
+  constexpr int NCH = 2 * NT, UJ = 32;
+  const int w = threadIdx.x >> 6, k = threadIdx.x & 63, K = x.K;
+  for (int ch = w; ch < NCH; ch += 4) {
+    const int d = ch / NT, t = ch % NT;
+    const double* Tb = (d == 0 ? x.Tout : x.Tin) + (size_t)t * 64 + k;
+    const double* sb = s_st + (size_t)d * K * 4 * NT + t;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (k < K) {
+      int j = 0;
+      for (; j + UJ <= K; j += UJ) {
+        double tv[UJ];
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) tv[u] = Tb[(size_t)(j + u) * NT * 64];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) {
+          const double* sp = sb + (size_t)(j + u) * 4 * NT;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = gg_fma(tv[u], sp[i * NT], acc[i]);
+        }
+      }
+      for (; j < K; ++j) {
+        const double tv = Tb[(size_t)j * NT * 64];
+        const double* sp = sb + (size_t)j * 4 * NT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = gg_fma(tv, sp[i * NT], acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_acc[(i * NCH + ch) * 64 + k] = acc[i];
+  }
+  __syncthreads();
+  double acc_o[NT], acc_i[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc_o[t] = s_acc[(w * NCH + t) * 64 + k];
+    acc_i[t] = s_acc[(w * NCH + NT + t) * 64 + k];
+  }
+  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i);
 }
 
 // Integer statistics -> spec-order doubles.
@@ -710,7 +792,7 @@ template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
                                                    uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
                                                    double* __restrict__ lp_out, const int32_t* __restrict__ ctl,
-                                                   int stage_tables, int sweep_from_ctl, int round_mode) {
+                                                   int stage_tables, int sweep_from_ctl, int round_mode, int32_t* __restrict__ ap) {
   if (round_mode) {            // device-driven restart round: start where the scan stands, unless it is done
     if (ctl[7]) return;
     n_begin = ctl[0];
@@ -735,7 +817,8 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
     const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
     const int n = (n0 + i < x.N) ? n0 + i : x.N - 1;
     const size_t gi = (size_t)j * x.Np + n;
-    const int gc = x.Gcnt[d][gi];
+    const size_t gd = (size_t)d * K * x.Np + gi;   // direction 1 follows direction 0 in the buffer
+    const int gc = x.Gcnt[0][gd];
     double* dst = s_st + (size_t)idx * NT;
     if (ADJ) {
       const int cx = x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0);
@@ -745,7 +828,7 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
       constexpr int B = (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
       dst[0] = (double)gc;
 #pragma unroll
-      for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)x.GS[d][gi * NSI + s] * (s < B ? sc1 : sc2);
+      for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
     }
   }
   const int ntab = K * NT * Kp;
@@ -766,13 +849,18 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
 #pragma unroll
     for (int t = 0; t < NT; ++t) { so[t] = a[t]; si[t] = b[t]; }
   };
-  const double* To = stage_tables ? s_T : x.Tout;
-  const double* Ti = stage_tables ? s_T + ntab : x.Tin;
-  double lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, To, Ti);
+  // (two call sites: the table pointers keep their address space, LDS or global, instead of becoming flat)
+  double lp;
+  if (stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab);
+  else if (Kp == 64) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T /* chains meet here */, nn);
+  else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
   if (lp_out && nn == lp_node && live && k < K) lp_out[k] = lp;
   double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
   int lab = gg_group_categorical(lp, k, K, Kp, u);
-  if (live && k == 0) cand[n] = lab;
+  if (live && k == 0) {
+    cand[n] = lab;
+    if (ap) ap[n] = 0;   // no entry of this scan's change list is applied to the node yet
+  }
 }
 
 // Sharded scan helpers -------------------------------------------------------------------------

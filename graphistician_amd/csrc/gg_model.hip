@@ -71,7 +71,9 @@ struct gg_model {
   bool next_bulk;               // Gbuf[cur] already holds (is receiving) the next sweep's statistics
   int cur0, pcur0;              // buffer indices when the pending batch started
   uint32_t sweep;
-  int Lmax, CH, max_idle;
+  int Lmax, Lcap, CH, max_idle;
+  long long* dbg;               // GG_ROUND_DBG: phase timestamps of k_round
+  int32_t* ap;                  // restart rounds: entries of L already applied to node n's statistics
   size_t resolve_lds;
   bool resolve_stage;          // coefficient tables staged in the resolver's LDS
   bool shard_from_tab;         // enqueue_params: take the (all-reduced) tables from `tab`
@@ -176,7 +178,11 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->beta = 1.0;
   m->Lmax = N < 4096 ? N : 4096;
   if (m->Lmax < 1) m->Lmax = 1;
-  if ((rc = dmalloc(&m->L, (size_t)m->Lmax * 3))) return rc;
+  m->Lcap = m->Lmax + 4096;   // the first resolve fills at most Lmax entries, restart rounds append behind them
+  if ((rc = dmalloc(&m->L, (size_t)m->Lcap * 3))) return rc;
+  if ((rc = dmalloc(&m->ap, (size_t)m->Nl + 1))) return rc;
+  m->dbg = nullptr;
+  if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
   // resolve chunk: one Kp-lane group per node, LDS budget 96 KiB
   int CH = 1024 / m->Kp;
@@ -236,7 +242,7 @@ int gg_model_destroy(gg_model* m) {
   if (m->eig) { gg_eigen_destroy(m->eig); delete m; return GG_OK; }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
-                  m->rs, m->L, m->lp_out};
+                  m->rs, m->L, m->lp_out, m->ap, m->dbg};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   for (hipEvent_t e : m->ev) hipEventDestroy(e);
@@ -545,15 +551,16 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
+  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
 #define SPEC(NTV, ADJV)                                                                                                    \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
     if (!attr_set && lds > 48 * 1024) {                                                                                    \
-      GG_HIP(hipFuncSetAttribute((const void*)k_speculate<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+      GG_HIP(hipFuncSetAttribute((const void*)k_speculate<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
     k_speculate<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl,    \
-                                                        stage, from_ctl ? 1 : 0, round_window > 0 ? 1 : 0);                \
+                                                        stage, from_ctl ? 1 : 0, round_window > 0 ? 1 : 0, m->ap);        \
   } while (0)
   if (m->is_adj) SPEC(2, true);
   else if (m->B == 1) SPEC(3, false);
@@ -583,6 +590,7 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
+  g.dbg = nullptr;
   size_t lds = m->resolve_lds;
 #define RES(NTV, ADJV)                                                                                           \
   do {                                                                                                           \
@@ -606,19 +614,66 @@ static int launch_apply_L(gg_model* m, const gg_data* d, int buf) {
   gg_node_ctx x = node_ctx(m, d, buf);
   int nb = (m->Nl + 255) / 256;
 #define APL(NTV, ADJV)                                                                                             \
-  k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0),   \
-                                                  gs(m, buf, 1), d->A, d->AT, d->Wq, d->WqT)
+  k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, m->ap, gcnt(m, buf, 0), gcnt(m, buf, 1),          \
+                                                  gs(m, buf, 0), gs(m, buf, 1), d->A, d->AT, d->Wq, d->WqT)
   if (m->is_adj) APL(2, true);
   else if (m->B == 1) APL(3, false);
   else if (m->B == 2) APL(6, false);
   else APL(15, false);
 #undef APL
   GG_HIP(hipGetLastError());
+  k_reset_L<<<1, 64, 0, m->stream>>>(m->rs);
+  GG_HIP(hipGetLastError());
+  return GG_OK;
+}
+
+// One restart round (k_round): lazy apply + re-speculation of the next window + resolution, one launch.
+static int launch_round(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort, int pw,
+                        int window, int round_id) {
+  gg_resolve_args g;
+  g.x = node_ctx(m, d, buf);
+  g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
+  g.tail_m = tail_m ? 1 : 0; g.tail_sort = tail_sort ? 1 : 0;
+  g.m = m->m; g.pi = m->pi; g.perm = m->permb[pw]; g.lab_start = m->labb[pw];
+  g.perm_prev = m->permb[1 - pw]; g.lab_start_prev = m->labb[1 - pw];
+  g.flush_on_change = 0; g.sweep_from_ctl = 0; g.round_mode = 1;
+  g.window = window;
+  g.stage_tables = 0;
+  g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
+  g.Lmax = m->Lcap; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 0;
+  g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
+  g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
+  g.dbg = m->dbg;
+  const int K = m->K, per = 256 / m->Kp;
+  int nb = (window + per - 1) / per;
+  if (nb > 512) nb = 512;   // groups beyond the grid are strided over
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
+               (size_t)(per + 8 + K) * sizeof(int) + 64;
+  if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
+  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += table_bytes(m);
+  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+#define RND(NTV, ADJV)                                                                                            \
+  do {                                                                                                            \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set && lds > 48 * 1024) {                                                                           \
+      GG_HIP(hipFuncSetAttribute((const void*)k_round<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      attr_set = true;                                                                                            \
+    }                                                                                                             \
+    k_round<NTV, ADJV><<<nb, 256, lds, m->stream>>>(g, m->ap, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0),      \
+                                                    gs(m, buf, 1), stage, round_id);                              \
+  } while (0)
+  if (m->is_adj) RND(2, true);
+  else if (m->B == 1) RND(3, false);
+  else if (m->B == 2) RND(6, false);
+  else RND(15, false);
+#undef RND
+  GG_HIP(hipGetLastError());
   return GG_OK;
 }
 
 static int read_ctl(gg_model* m) {
-  GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 24 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));
   return GG_OK;
 }
@@ -629,27 +684,54 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
   return GG_OK;
 }
 
-// Finish a scan the pipeline left unfinished.  Restart rounds are device-driven: each round is
-//   k_apply_L (pending changes -> G)  ->  k_speculate over the next window of nodes  ->  k_resolve
-// with every kernel reading the scan position from the control block and turning into a no-op once the
-// scan is done, so a batch of rounds is enqueued without host synchronisation; the host only checks
-// between batches.  The final resolve sorts the labels into perm buffer `pw`.
+// Finish a scan the pipeline left unfinished.  Restart rounds are device-driven: each round is ONE launch
+// (k_round: bring the next window's statistics up to date with the change list, re-speculate it, resolve it)
+// that reads the scan position from the control block and turns into a no-op once the scan is done, so a
+// batch of rounds is enqueued without host synchronisation; the host only checks between batches, and
+// flushes the change list into G chip-wide (k_apply_L) before a batch that could overflow it.
+// The round that completes the scan sorts the labels into perm buffer `pw`.
 static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort, int pw) {
   int rc;
-  const int window = m->N < 4096 ? m->N : 4096;
+  // at most 512 node groups per round (two workgroups per CU): beyond that a round's latency grows with the window
+  int window = m->N < 4096 ? m->N : 4096;
+  if (window > 512 * (256 / m->Kp)) window = 512 * (256 / m->Kp);
   int batch = 4;
   long long rounds = 0;
   for (;;) {
     if ((rc = read_ctl(m))) return rc;
+    if (m->dbg && rounds > 0) {
+      // phase times of the last round that ran: resolver workgroup and the mean over the active ones (us)
+      std::vector<long long> h(512 * 8 + 8);
+      GG_HIP(hipMemcpy(h.data(), m->dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      const int last = (int)h[512 * 8], nwg = (int)h[512 * 8 + 1];
+      const long long* t = &h[(size_t)last * 8];
+      fprintf(stderr, "[round dbg] %s nwg=%d resolver wg %d: ctl %.2f load %.2f apply %.2f conv %.2f lp %.2f ticket %.2f resolve %.2f | total %.2f us\n",
+              m->is_adj ? "adj" : "w", nwg, last, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
+              (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01, (t[7] - t[0]) * 0.01);
+      long long first_start = t[0], mx[8] = {0};
+      for (int w = 0; w < nwg; ++w) {
+        if (h[(size_t)w * 8] < first_start) first_start = h[(size_t)w * 8];
+        for (int q = 1; q < 7; ++q) { long long dlt = h[(size_t)w * 8 + q] - h[(size_t)w * 8 + q - 1]; if (dlt > mx[q]) mx[q] = dlt; }
+      }
+      fprintf(stderr, "[round dbg]   max over wgs: ctl %.2f load %.2f apply %.2f conv %.2f lp %.2f ticket %.2f ; first wg start -> resolver end %.2f us\n",
+              mx[1] * 0.01, mx[2] * 0.01, mx[3] * 0.01, mx[4] * 0.01, mx[5] * 0.01, mx[6] * 0.01, (t[7] - first_start) * 0.01);
+    }
     if (!m->h_rs[4] || m->h_rs[0] == 0) {   // scan complete (a set flag with pos == 0 is a pipeline flush, not a stall)
       if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
       return GG_OK;
     }
-    for (int r = 0; r < batch; ++r) {
+    if (m->h_rs[1] + batch > m->Lcap) {
       if ((rc = launch_apply_L(m, d, buf))) return rc;
-      if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, false, false, window))) return rc;
-      if ((rc = launch_resolve(m, d, buf, sweep, tail_m, tail_sort, pw, false, false, window))) return rc;
     }
+    int base;
+    {
+      unsigned long long st;
+      memcpy(&st, &m->h_rs[GG_RS_STATE], sizeof(st));
+      int q0, q1, q2, q3;
+      gg_unpack_state(st, &q0, &q1, &q2, &q3, &base);
+    }
+    for (int r = 0; r < batch; ++r)
+      if ((rc = launch_round(m, d, buf, sweep, tail_m, tail_sort, pw, window, base + r))) return rc;
     rounds += batch;
     m->st.resolve_rounds += batch;
     if (batch < 64) batch *= 2;

@@ -25,7 +25,7 @@ struct gg_resolve_args {
   gg_node_ctx x;
   int32_t* c;
   int32_t* cnt;
-  const int32_t* cand;
+  int32_t* cand;
   int32_t* rs;   // control block: [0] pos, [1] nL, [2] label changes (accumulated), [3] status,
                  //   [4] stalled (scan left unfinished: later pipeline kernels do nothing), [5] completed scans,
                  //   [6] sweep index (graph replay), [7] scan done, [8] next re-speculation window, [9] changes of this scan
@@ -56,7 +56,27 @@ struct gg_resolve_args {
   const int32_t* XWT;
   uint64_t seed;
   uint32_t site, sweep;
+  long long* dbg;   // optional phase timestamps of k_round (GG_ROUND_DBG), [workgroup][8]
 };
+
+
+// Round state of a scan in one 64-bit word (rs[16..17]) so that a restart round reads it with a single load:
+//   bits 0-23 pos | 24-37 nL | 38-50 next window (0 = full) | 51 scan done | 52-63 round counter (mod 4096)
+#define GG_RS_STATE 16
+#define GG_RS_MIN 18      // 64-bit: smallest (node << 12 | old << 6 | new) reported by this round's workgroups
+#define GG_NO_CHANGE 0xffffffffffffffffull
+__host__ __device__ inline unsigned long long gg_pack_state(int pos, int nL, int wlen, int fin, int seq) {
+  return (unsigned long long)(unsigned)pos | ((unsigned long long)(unsigned)nL << 24) |
+         ((unsigned long long)(unsigned)wlen << 38) | ((unsigned long long)(fin ? 1 : 0) << 51) |
+         ((unsigned long long)((unsigned)seq & 0xfffu) << 52);
+}
+__host__ __device__ inline void gg_unpack_state(unsigned long long w, int* pos, int* nL, int* wlen, int* fin, int* seq) {
+  *pos = (int)(w & 0xffffffu);
+  *nL = (int)((w >> 24) & 0x3fffu);
+  *wlen = (int)((w >> 38) & 0x1fffu);
+  *fin = (int)((w >> 51) & 1u);
+  *seq = (int)((w >> 52) & 0xfffu);
+}
 
 template <int NT, bool ADJ>
 __device__ __forceinline__ void gg_apply_edge(int* gc, long long* gs, int a, int b, int K, const int32_t* q,
@@ -76,6 +96,43 @@ __device__ __forceinline__ void gg_apply_edge(int* gc, long long* gs, int a, int
     for (int s = 0; s < NSI; ++s) {
       atomicAdd(reinterpret_cast<unsigned long long*>(&gs[a * NSI + s]), (unsigned long long)(-v[s]));
       atomicAdd(reinterpret_cast<unsigned long long*>(&gs[b * NSI + s]), (unsigned long long)v[s]);
+    }
+  }
+}
+
+// Tail of a completed scan: resample_m (adjacency.py:697-702 / weights.py:493-498) and the label sort the next
+// half-sweep's bulk kernel needs.  s_cnt = final block sizes (LDS), s_raw = at least 64 doubles + K ints of dead LDS.
+__device__ __forceinline__ void gg_scan_tail(const gg_resolve_args& g, const int* s_cnt, unsigned char* s_raw,
+                                             bool unchanged) {
+  const int N = g.x.N, K = g.x.K;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  double* s_gam = reinterpret_cast<double*>(s_raw);                  // [K]
+  int* s_cur = reinterpret_cast<int*>(s_raw + 64 * sizeof(double));  // [K]
+  if (g.tail_m) {
+    if (tid < K) s_gam[tid] = gg_dirichlet_gamma_at(g.seed, g.site_m, g.sweep, tid, g.pi[tid] + (double)s_cnt[tid]);
+    __syncthreads();
+    if (tid < K) {
+      double tot = 0.0;
+      for (int j = 0; j < K; ++j) tot += s_gam[j];
+      g.m[tid] = s_gam[tid] / tot;
+    }
+  }
+  if (g.tail_sort) {
+    if (unchanged) {
+      // no label changed in this scan: the sort it started from is still the sort of the labels
+      for (int n = tid; n < N; n += nth) g.perm[n] = g.perm_prev[n];
+      for (int k = tid; k <= K; k += nth) g.lab_start[k] = g.lab_start_prev[k];
+    } else {
+      if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < K; ++k) { g.lab_start[k] = acc; s_cur[k] = acc; acc += s_cnt[k]; }
+        g.lab_start[K] = acc;
+      }
+      __syncthreads();
+      for (int n = tid; n < N; n += nth) {
+        int at = atomicAdd(&s_cur[g.c[n]], 1);
+        g.perm[at] = n;
+      }
     }
   }
 }
@@ -105,8 +162,6 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
   double* s_T = reinterpret_cast<double*>(s_raw + off);                // Tout | Tin when staged (phase B only)
   const int ntab = K * NT * Kp;
   bool tables_staged = false;
-  const double* To = g.stage_tables ? s_T : x.Tout;
-  const double* Ti = g.stage_tables ? s_T + ntab : x.Tin;
 
   if (g.round_mode) { if (g.rs[7]) return; }
   else if (g.rs[4]) return;  // an earlier scan of this pipeline is unfinished
@@ -173,10 +228,10 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
     for (int i = tid; i < nch; i += nth) s_c[i] = g.c[pos0 + i];
     for (int idx = tid; idx < 2 * K * nch; idx += nth) {
       int i = idx % nch, j = (idx / nch) % K, d = idx / (nch * K);
-      size_t gi = (size_t)j * Np + pos0 + i;
-      s_gc[(d * CH + i) * K + j] = x.Gcnt[d][gi];
+      size_t gi = (size_t)d * K * Np + (size_t)j * Np + pos0 + i;   // direction 1 follows direction 0 in the buffer
+      s_gc[(d * CH + i) * K + j] = x.Gcnt[0][gi];
       if (!ADJ)
-        for (int s = 0; s < NSI; ++s) s_gs[((size_t)(d * CH + i) * K + j) * NSI + s] = x.GS[d][gi * NSI + s];
+        for (int s = 0; s < NSI; ++s) s_gs[((size_t)(d * CH + i) * K + j) * NSI + s] = x.GS[0][gi * NSI + s];
     }
     for (int idx = tid; idx < nch * nch; idx += nth) {
       int i2 = idx % nch, i1 = idx / nch;
@@ -223,7 +278,9 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
         const long long* b = ADJ ? nullptr : &s_gs[((size_t)(1 * CH + ii) * K + j) * NSI];
         gg_stats_to_double<NT, ADJ>(s_gc[(0 * CH + ii) * K + j], s_gc[(1 * CH + ii) * K + j], a, b, cx, sc1, sc2, so, si);
       };
-      double lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, To, Ti);
+      double lp;
+      if (g.stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, s_T, s_T + ntab);
+      else lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, x.Tout, x.Tin);
       double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)n);
       int lab = gg_group_categorical(lp, k, K, Kp, u);
       if (active && k == 0 && lab != cn) {
@@ -269,37 +326,7 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
   for (int k = tid; k < K; k += nth) g.cnt[k] = s_cnt[k];
   const bool done = pos >= N;
   __syncthreads();
-  if (done) {
-    double* s_gam = reinterpret_cast<double*>(s_raw);        // [K]   (chunk statistics are dead now)
-    int* s_cur = reinterpret_cast<int*>(s_raw + 64 * sizeof(double));  // [K]
-    if (g.tail_m) {
-      if (tid < K) s_gam[tid] = gg_dirichlet_gamma_at(g.seed, g.site_m, g.sweep, tid, g.pi[tid] + (double)s_cnt[tid]);
-      __syncthreads();
-      if (tid < K) {
-        double tot = 0.0;
-        for (int j = 0; j < K; ++j) tot += s_gam[j];
-        g.m[tid] = s_gam[tid] / tot;
-      }
-    }
-    if (g.tail_sort) {
-      if (g.rs[9] + nchg == 0) {
-        // no label changed in this scan: the sort it started from is still the sort of the labels
-        for (int n = tid; n < N; n += nth) g.perm[n] = g.perm_prev[n];
-        for (int k = tid; k <= K; k += nth) g.lab_start[k] = g.lab_start_prev[k];
-      } else {
-        if (tid == 0) {
-          int acc = 0;
-          for (int k = 0; k < K; ++k) { g.lab_start[k] = acc; s_cur[k] = acc; acc += s_cnt[k]; }
-          g.lab_start[K] = acc;
-        }
-        __syncthreads();
-        for (int n = tid; n < N; n += nth) {
-          int at = atomicAdd(&s_cur[g.c[n]], 1);
-          g.perm[at] = n;
-        }
-      }
-    }
-  }
+  if (done) gg_scan_tail(g, s_cnt, s_raw, g.rs[9] + nchg == 0);
   if (tid == 0) {
     g.rs[0] = done ? 0 : pos;
     g.rs[1] = done ? 0 : nL;
@@ -311,22 +338,27 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
       if (g.sweep_from_ctl) g.rs[6] += 1;
     }
     if (!done || (g.flush_on_change && nchg > 0)) g.rs[4] = 1;
+    // round state for the restart rounds that finish an incomplete scan (counter restarts at 0)
+    *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(done ? 0 : pos, done ? 0 : nL, 0, done ? 1 : 0, 0);
+    *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]) = GG_NO_CHANGE;
   }
 }
 
 // Apply the change list to the resident statistics of every node (chip-wide):
 // after it G is again the exact block histogram under the current labels.
+// Node n has entries [0, ap[n]) applied already (restart rounds apply L lazily to the nodes they
+// re-speculate); afterwards L is dead and k_reset_L empties it.
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* __restrict__ L,
-                                                 const int32_t* __restrict__ rs, int32_t* Gc0, int32_t* Gc1,
-                                                 long long* Gs0, long long* Gs1, const uint8_t* XA,
+                                                 const int32_t* __restrict__ rs, int32_t* __restrict__ ap, int32_t* Gc0,
+                                                 int32_t* Gc1, long long* Gs0, long long* Gs1, const uint8_t* XA,
                                                  const uint8_t* XAT, const int32_t* XW, const int32_t* XWT) {
   constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
   constexpr int NSI = NT - 1;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= x.N || rs[7]) return;
   const int nL = rs[1], Np = x.Np;
-  for (int e = 0; e < nL; ++e) {
+  for (int e = ap[n]; e < nL; ++e) {
     const int n2 = L[e * 3], a = L[e * 3 + 1], b = L[e * 3 + 2];
     const size_t at = (size_t)n2 * Np + n;
     if (ADJ) {
@@ -353,4 +385,282 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
       }
     }
   }
+  ap[n] = 0;
+}
+
+__global__ void k_reset_L(int32_t* rs) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !rs[7]) {
+    rs[1] = 0;
+    int pos, nL, wlen, fin, seq;
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(&rs[GG_RS_STATE]);
+    gg_unpack_state(*st, &pos, &nL, &wlen, &fin, &seq);
+    *st = gg_pack_state(pos, 0, wlen, fin, seq);
+  }
+}
+
+// One device-driven restart round in a single launch.  The scan stands at pos = rs[0] with the change
+// list L[0, nL) (nL = rs[1]); the round covers the window [pos, pos + wlen):
+//   every workgroup (groups of 256 / Kp nodes, grid-strided): brings its nodes' statistics up to date by
+//     applying the entries L[ap[n], nL) they have not seen yet (+-1 / +-q corrections from single rows of
+//     X and X^T, in LDS, written back to G), re-evaluates their conditionals and draws -> cand;
+//   the workgroup that finishes last (ticket in rs[10]) plays the resolver: the first node of the
+//     window whose draw differs from its label is the next exact change of the scan (every node
+//     before it saw all earlier changes); it is appended to L and the scan moves behind it.  A window
+//     without a change is final; the scan's tail runs when the last node is passed.
+// Statistics of nodes outside the window stay stale until a round reaches them (or k_apply_L
+// flushes L); nothing else reads G before the next bulk pass rebuilds it.
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __restrict__ ap, int32_t* Gc0, int32_t* Gc1,
+                                               long long* Gs0, long long* Gs1, int stage_tables, int round_id) {
+  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+  constexpr int NSI = NT - 1;
+  constexpr int U = 4;   // corrections in flight per thread
+#define GG_TS(slot) do { if (g.dbg && threadIdx.x == 0) g.dbg[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+  const long long ts0 = g.dbg ? wall_clock64() : 0;
+  const gg_node_ctx& x = g.x;
+  const int N = x.N, K = x.K, Kp = x.Kp, Np = x.Np;
+  const int per = 256 / Kp;
+  const int tid = threadIdx.x;
+
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  // [dir][j][i] integer statistics, then their spec-order doubles [dir][j][i][NT], then tables when staged
+  long long* s_gs = reinterpret_cast<long long*>(s_raw);
+  size_t off = ADJ ? 0 : (size_t)2 * K * per * NSI * sizeof(long long);
+  double* s_st = reinterpret_cast<double*>(s_raw + off); off += (size_t)2 * K * per * NT * sizeof(double);
+  double* s_T = reinterpret_cast<double*>(s_raw + off);
+  const int ntab = K * NT * Kp;
+  if (stage_tables) off += (size_t)2 * ntab * sizeof(double);
+  else if (Kp == 64) off += (size_t)4 * 2 * NT * 64 * sizeof(double);   // the split chains meet here (gg_lp_split4)
+  int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
+  int* s_ap = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
+  int* s_ctl = reinterpret_cast<int*>(s_raw + off); off += 8 * sizeof(int);
+  int* s_cnt = reinterpret_cast<int*>(s_raw + off);   // [K] (resolver only)
+  unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_ctl);   // s_ctl[0..1]
+
+  // The whole round state is one 64-bit word: a workgroup that starts after this round's resolver has
+  // published the next state sees a different round counter and leaves; one that starts before sees this
+  // round's state, under which every active workgroup has already drawn its ticket, so it is inactive.
+  int pos, nL, w8, fin, seq;
+  gg_unpack_state(*reinterpret_cast<const volatile unsigned long long*>(&g.rs[GG_RS_STATE]), &pos, &nL, &w8, &fin, &seq);
+  const long long ts1 = g.dbg ? wall_clock64() : 0;
+  if (seq != (round_id & 0xfff) || fin) return;   // stale launch, or the scan is done: no-op
+  int wlen = g.window;
+  if (w8 > 0 && w8 < wlen) wlen = w8;
+  const int wend = (pos + wlen < N) ? pos + wlen : N;
+  const int nact = (wend - pos + per - 1) / per;
+  const int nwg = nact < (int)gridDim.x ? nact : (int)gridDim.x;
+  if ((int)blockIdx.x >= nwg) return;
+  if (g.dbg && tid == 0) { g.dbg[(size_t)blockIdx.x * 8] = ts0; g.dbg[(size_t)blockIdx.x * 8 + 1] = ts1; }
+
+  const size_t dstride = (size_t)K * Np;   // direction 1 follows direction 0 in the buffer (Gc1 == Gc0 + dstride)
+  // Every launch starts with a cold L2: touch the coefficient tables now (one load per 128-byte line) so
+  // that they arrive while the statistics are being brought up to date, not when the conditional needs them.
+  long long pf = 0;
+  if (!stage_tables) {
+    const long long* to = reinterpret_cast<const long long*>(x.Tout);
+    const long long* ti = reinterpret_cast<const long long*>(x.Tin);
+    for (int idx = tid * 16; idx < ntab; idx += 256 * 16) pf ^= to[idx] ^ ti[idx];
+  }
+  if (stage_tables) {
+    for (int idx = tid; idx < ntab; idx += 256) {
+      s_T[idx] = x.Tout[idx];
+      s_T[ntab + idx] = x.Tin[idx];
+    }
+  }
+  const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  if (tid == 0) *s_min = GG_NO_CHANGE;
+  for (int grp = blockIdx.x; grp < nact; grp += gridDim.x) {
+    const int n0 = pos + grp * per;
+    __syncthreads();   // the previous group's LDS is dead
+    for (int idx = tid; idx < 2 * K * per; idx += 256) {
+      const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
+      const int n = (n0 + i < N) ? n0 + i : N - 1;
+      const size_t gi = d * dstride + (size_t)j * Np + n;
+      s_gc[idx] = Gc0[gi];
+      if (!ADJ)
+        for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = Gs0[gi * NSI + s];
+    }
+    if (tid < per) s_ap[tid] = (n0 + tid < wend) ? ap[n0 + tid] : nL;
+    if (tid == 0) s_ctl[5] = nL;
+    __syncthreads();
+    if (tid < per) atomicMin(&s_ctl[5], s_ap[tid]);
+    __syncthreads();
+    const int e0 = s_ctl[5];
+    GG_TS(2);
+    // pending corrections: item = (entry e, node i, direction d); U independent items per thread in flight.
+    // d = 0: edge (n0+i) -> n2 read from X^T row n2; d = 1: edge n2 -> (n0+i) read from X row n2
+    const int nitems = (nL - e0) * per * 2;
+    for (int base = tid; base < nitems; base += 256 * U) {
+      int ia[U], ib[U], ii[U], dd[U];
+      size_t at[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * 256;
+        const int d = idx & 1, i = (idx >> 1) % per, e = e0 + (idx >> 1) / per;
+        ok[u] = idx < nitems && e >= s_ap[i];
+        const int ee = ok[u] ? e : 0;
+        const int n2 = g.L[ee * 3];
+        ia[u] = g.L[ee * 3 + 1]; ib[u] = g.L[ee * 3 + 2];
+        ii[u] = i; dd[u] = d;
+        at[u] = ok[u] ? (size_t)n2 * Np + n0 + i : 0;
+      }
+      if (ADJ) {
+        uint8_t xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = dd[u] == 0 ? g.XAT[at[u]] : g.XA[at[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u] && xv[u] != 0) {
+            atomicSub(&s_gc[(dd[u] * K + ia[u]) * per + ii[u]], 1);
+            atomicAdd(&s_gc[(dd[u] * K + ib[u]) * per + ii[u]], 1);
+          }
+      } else {
+        int32_t q[U][B];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t* src = (dd[u] == 0 ? g.XWT : g.XW) + at[u] * B;
+#pragma unroll
+          for (int r = 0; r < B; ++r) q[u][r] = src[r];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u] && q[u][0] != GG_NO_EDGE) {
+            atomicSub(&s_gc[(dd[u] * K + ia[u]) * per + ii[u]], 1);
+            atomicAdd(&s_gc[(dd[u] * K + ib[u]) * per + ii[u]], 1);
+            long long v[NSI > 0 ? NSI : 1];
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < B; ++r) v[t++] = q[u][r];
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+              for (int s2 = r; s2 < B; ++s2) v[t++] = (long long)q[u][r] * (long long)q[u][s2];
+#pragma unroll
+            for (int s2 = 0; s2 < NSI; ++s2) {
+              atomicAdd(reinterpret_cast<unsigned long long*>(&s_gs[((size_t)(dd[u] * K + ia[u]) * per + ii[u]) * NSI + s2]),
+                        (unsigned long long)(-v[s2]));
+              atomicAdd(reinterpret_cast<unsigned long long*>(&s_gs[((size_t)(dd[u] * K + ib[u]) * per + ii[u]) * NSI + s2]),
+                        (unsigned long long)v[s2]);
+            }
+          }
+      }
+    }
+    __syncthreads();
+    GG_TS(3);
+    // write back what changed, convert to spec-order doubles
+    for (int idx = tid; idx < 2 * K * per; idx += 256) {
+      const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
+      const bool live = n0 + i < wend;
+      const int n = (n0 + i < N) ? n0 + i : N - 1;
+      const size_t gi = d * dstride + (size_t)j * Np + n;
+      const int gc = s_gc[idx];
+      const bool dirty = live && s_ap[i] < nL;
+      if (dirty) Gc0[gi] = gc;
+      double* dst = s_st + (size_t)idx * NT;
+      if (ADJ) {
+        const int cx = x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0);
+        dst[0] = (double)gc;
+        dst[1] = (double)(cx - gc);
+      } else {
+        dst[0] = (double)gc;
+#pragma unroll
+        for (int s = 0; s < NSI; ++s) {
+          const long long v = s_gs[(size_t)idx * NSI + s];
+          if (dirty) Gs0[gi * NSI + s] = v;
+          dst[1 + s] = (double)v * (s < B ? sc1 : sc2);
+        }
+      }
+    }
+    if (tid < per && n0 + tid < wend) ap[n0 + tid] = nL;
+    __syncthreads();
+    GG_TS(4);
+    asm volatile("" ::"v"(pf));   // (keeps the prefetch loads alive)
+    {
+      const int i = tid / Kp, k = tid % Kp;
+      const int n = n0 + i;
+      const bool live = n < wend;
+      const int nn = (n < N) ? n : N - 1;
+      auto ld = [&](int j, double* so, double* si) {
+        const double* a = s_st + (size_t)((0 * K + j) * per + i) * NT;
+        const double* b = s_st + (size_t)((1 * K + j) * per + i) * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { so[t] = a[t]; si[t] = b[t]; }
+      };
+      double lp;
+      if (stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab);
+      else if (Kp == 64) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T, nn);
+      else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
+      double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + nn));
+      int lab = gg_group_categorical(lp, k, K, Kp, u);
+      if (live && k == 0) {
+        const int cn = x.c[x.n0 + n];
+        if (lab != cn)
+          atomicMin(s_min, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
+      }
+    }
+  }
+  // ---- last workgroup out resolves the window.  Each workgroup reports its first changer with a
+  // device-scope atomic min and only then (the min has returned) draws its ticket: whoever sees the last
+  // ticket sees every report.
+  GG_TS(5);
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long mine = *s_min;
+    if (mine != GG_NO_CHANGE) {
+      unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]), mine);
+      asm volatile("" ::"v"(old) : "memory");   // the ticket is not drawn before the min has been performed
+    }
+    s_ctl[6] = (atomicAdd(&g.rs[10], 1) == nwg - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  GG_TS(6);
+  if (!s_ctl[6]) return;
+  // resolver (uniform values, one lane writes)
+  unsigned long long best = GG_NO_CHANGE;
+  if (tid == 0) {
+    best = atomicExch(reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]), GG_NO_CHANGE);
+    *s_min = best;
+  }
+  __syncthreads();
+  best = *s_min;
+  int newpos, nchg = 0, wnext;
+  if (best == GG_NO_CHANGE) {
+    newpos = wend;                              // the whole window is final, unchanged
+    wnext = 0;                                  // quiet stretch: full window next
+  } else {
+    const int ns = (int)(best >> 12), a = (int)((best >> 6) & 63u), b = (int)(best & 63u);
+    if (tid == 0) {
+      g.c[ns] = b;
+      atomicSub(&g.cnt[a], 1);
+      atomicAdd(&g.cnt[b], 1);
+      g.L[nL * 3] = ns; g.L[nL * 3 + 1] = a; g.L[nL * 3 + 2] = b;
+    }
+    int w = 4 * (ns - pos + 1);
+    wnext = w < 256 ? 256 : (w > g.window ? g.window : w);
+    nchg = 1;
+    newpos = ns + 1;
+  }
+  const bool done = newpos >= N;
+  if (done) {
+    __threadfence();
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) s_cnt[k] = __hip_atomic_load(&g.cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    gg_scan_tail(g, s_cnt, s_raw, g.rs[9] + nchg == 0);
+  }
+  if (tid == 0) {
+    g.rs[0] = done ? 0 : newpos;
+    g.rs[1] = done ? 0 : nL + nchg;
+    g.rs[2] += nchg;
+    g.rs[9] += nchg;
+    g.rs[8] = wnext;
+    __hip_atomic_store(&g.rs[10], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done) { g.rs[5] += 1; g.rs[7] = 1; }
+    else g.rs[4] = 1;
+    *reinterpret_cast<volatile unsigned long long*>(&g.rs[GG_RS_STATE]) =
+        gg_pack_state(done ? 0 : newpos, done ? 0 : nL + nchg, wnext, done ? 1 : 0, round_id + 1);
+    if (g.dbg) { g.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64(); g.dbg[512 * 8] = blockIdx.x; g.dbg[512 * 8 + 1] = nwg; }
+  }
+#undef GG_TS
 }

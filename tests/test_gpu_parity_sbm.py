@@ -112,7 +112,7 @@ def test_adj_sweep_parts_bitexact(abi, N, K, special):
     assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
 
 
-@pytest.mark.parametrize("N,K", [(120, 4), (400, 16)])
+@pytest.mark.parametrize("N,K", [(120, 4), (400, 16), (300, 40), (520, 64)])
 def test_adj_chain_bitexact(abi, N, K):
     """Several full sweeps from a random start: burn-in (many label changes per scan) then steady state."""
     A, W, _ = planted_sbm(N, K, seed=11)
@@ -149,7 +149,8 @@ def test_w_node_lp_bitexact(abi, N, K, B, special):
         assert np.array_equal(lp_g, lp_o), (n, lp_g - lp_o)
 
 
-@pytest.mark.parametrize("N,K,B,special", [(60, 3, 1, 1), (150, 6, 2, 0), (260, 16, 1, 1)])
+@pytest.mark.parametrize("N,K,B,special", [(60, 3, 1, 1), (150, 6, 2, 0), (260, 16, 1, 1), (300, 48, 1, 1), (260, 40, 2, 0),
+                                           (330, 24, 2, 1)])
 def test_w_chain_bitexact(abi, N, K, B, special):
     A, W, _ = planted_sbm(N, K, B=B, seed=5 * N)
     q, shift = O.quantise(A, W)
