@@ -614,10 +614,10 @@ __device__ __forceinline__ int gg_group_categorical(double lp, int k, int K, int
 // Combination of the finished chains of node n, label k (the tail of gg_lp.h::gg_block_lp).
 template <int NT, bool ADJ>
 __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n, int k, const double* acc_o,
-                                                    const double* acc_i) {
+                                                    const double* acc_i, const double* logm_k = nullptr) {
   if (k >= x.K) return -gg_inf();
   const int K = x.K;
-  double lp = x.logm[k];
+  double lp = logm_k ? *logm_k : x.logm[k];
 #pragma unroll
   for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_o[t], lp);
 #pragma unroll
@@ -651,7 +651,7 @@ __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n,
 
 // lp[k] of one node (gg_lp.h::gg_block_lp order).  `ld(j, so, si)` supplies the
 // node's out / in statistics towards block j as doubles in spec order.
-template <int NT, bool ADJ, class Loader>
+template <int NT, bool ADJ, int UJ_ = 0, class Loader>
 __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld,
                                                   const double* __restrict__ Tout, const double* __restrict__ Tin) {
   if (k >= x.K) return -gg_inf();
@@ -661,7 +661,7 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
   for (int t = 0; t < NT; ++t) { acc_o[t] = 0.0; acc_i[t] = 0.0; }
   // The table entries of UJ consecutive j are fetched as one batch before any of them is used (the
   // compiler's own schedule waits for every load right where it issues it); the fma order is unchanged.
-  constexpr int UJ = NT <= 3 ? 8 : (NT <= 6 ? 4 : 2);
+  constexpr int UJ = UJ_ > 0 ? UJ_ : (NT <= 3 ? 8 : (NT <= 6 ? 4 : 2));   // (UJ_: callers short of registers ask for less)
   int j = 0;
   for (; j + UJ <= K; j += UJ) {
     double to[UJ][NT], ti[UJ][NT];
@@ -703,36 +703,59 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
 // order of gg_block_lp.  Same chains, same order, same bits.  s_st: [dir][j][4][NT], s_acc: [4][2 NT][64].
 template <int NT, bool ADJ>
 __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const double* s_st, double* s_acc, int n) {
-  constexpr int NCH = 2 * NT, UJ = 32;
+  constexpr int NCH = 2 * NT;
+  constexpr int CPW = (NCH + 3) / 4;                                         // chains per wave
+  constexpr int UJ = CPW == 1 ? 64 : (CPW == 2 ? 32 : (CPW <= 4 ? 16 : 8));   // table entries in flight per chain
   const int w = threadIdx.x >> 6, k = threadIdx.x & 63, K = x.K;
-  for (int ch = w; ch < NCH; ch += 4) {
-    const int d = ch / NT, t = ch % NT;
-    const double* Tb = (d == 0 ? x.Tout : x.Tin) + (size_t)t * 64 + k;
-    const double* sb = s_st + (size_t)d * K * 4 * NT + t;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (k < K) {
-      int j = 0;
-      for (; j + UJ <= K; j += UJ) {
-        double tv[UJ];
+  // values the tail needs, fetched now so that their latency hides behind the chains
+  const double logm_k = x.logm[k < K ? k : 0];
+  double acc[CPW][4];
 #pragma unroll
-        for (int u = 0; u < UJ; ++u) tv[u] = Tb[(size_t)(j + u) * NT * 64];
-        asm volatile("" ::: "memory");
+  for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int u = 0; u < UJ; ++u) {
-          const double* sp = sb + (size_t)(j + u) * 4 * NT;
+    for (int i = 0; i < 4; ++i) acc[c][i] = 0.0;
+  if (k < K) {
+    for (int j = 0; j < K; j += UJ) {
+      double tv[CPW][UJ];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = gg_fma(tv[u], sp[i * NT], acc[i]);
+      for (int c = 0; c < CPW; ++c) {
+        const int ch = w + 4 * c;
+        if (ch < NCH) {
+          const int d = ch / NT, t = ch % NT;
+          const double* Tb = (d == 0 ? x.Tout : x.Tin) + (size_t)t * 64 + k;
+#pragma unroll
+          for (int u = 0; u < UJ; ++u) {
+            const int jj = (j + u < K) ? j + u : K - 1;
+            tv[c][u] = Tb[(size_t)jj * NT * 64];
+          }
         }
       }
-      for (; j < K; ++j) {
-        const double tv = Tb[(size_t)j * NT * 64];
-        const double* sp = sb + (size_t)j * 4 * NT;
+      asm volatile("" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = gg_fma(tv, sp[i * NT], acc[i]);
+      for (int c = 0; c < CPW; ++c) {
+        const int ch = w + 4 * c;
+        if (ch < NCH) {
+          const int d = ch / NT, t = ch % NT;
+          const double* sb = s_st + (size_t)d * K * 4 * NT + t;
+#pragma unroll
+          for (int u = 0; u < UJ; ++u) {
+            if (j + u < K) {
+              const double* sp = sb + (size_t)(j + u) * 4 * NT;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[c][i] = gg_fma(tv[c][u], sp[i * NT], acc[c][i]);
+            }
+          }
+        }
       }
     }
+  }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_acc[(i * NCH + ch) * 64 + k] = acc[i];
+  for (int c = 0; c < CPW; ++c) {
+    const int ch = w + 4 * c;
+    if (ch < NCH) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s_acc[(i * NCH + ch) * 64 + k] = acc[c][i];
+    }
   }
   __syncthreads();
   double acc_o[NT], acc_i[NT];
@@ -741,7 +764,7 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
     acc_o[t] = s_acc[(w * NCH + t) * 64 + k];
     acc_i[t] = s_acc[(w * NCH + NT + t) * 64 + k];
   }
-  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i);
+  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, &logm_k);
 }
 
 // Integer statistics -> spec-order doubles.

@@ -279,8 +279,9 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
         gg_stats_to_double<NT, ADJ>(s_gc[(0 * CH + ii) * K + j], s_gc[(1 * CH + ii) * K + j], a, b, cx, sc1, sc2, so, si);
       };
       double lp;
-      if (g.stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, s_T, s_T + ntab);
-      else lp = gg_node_lp_core<NT, ADJ>(x, n, k, ld, x.Tout, x.Tin);
+      constexpr int UJR = NT == 2 ? 4 : (NT == 3 ? 2 : 1);   // 1024 threads: 128 VGPRs per lane
+      if (g.stage_tables) lp = gg_node_lp_core<NT, ADJ, UJR>(x, n, k, ld, s_T, s_T + ntab);
+      else lp = gg_node_lp_core<NT, ADJ, UJR>(x, n, k, ld, x.Tout, x.Tin);
       double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)n);
       int lab = gg_group_categorical(lp, k, K, Kp, u);
       if (active && k == 0 && lab != cn) {
