@@ -287,8 +287,7 @@ def main():
     for _ in range(args.steps):
         adj.resample_async(data, 1)
         w.resample_async(data, 1)
-    adj.sync()
-    w.sync()
+    abi.sync_many([adj, w])
     barrier()
     el = time.perf_counter() - t0
     sa, sw = adj.stats(), w.stats()

@@ -45,7 +45,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_shard_sizes", "gg_shard_tables",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_shard_sizes", "gg_shard_tables",
            "gg_shard_params", "gg_shard_next", "gg_shard_apply", "gg_shard_finish", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_selftest_math", "gg_selftest_draws"]
 
@@ -87,6 +87,7 @@ def lib():
         L.gg_resample_part.argtypes = [vp, vp, C.c_int32, C.c_double]
         L.gg_resample_async.argtypes = [vp, vp, C.c_int32, C.c_double]
         L.gg_sync.argtypes = [vp]
+        L.gg_sync_many.argtypes = [C.POINTER(vp), C.c_int32]
         L.gg_log_likelihood.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gg_node_lp.argtypes = [vp, vp, C.c_int32, vp]
         L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -320,6 +321,13 @@ class Model(object):
             self.close()
         except Exception:
             pass
+
+
+def sync_many(models):
+    """gg_sync for several independent models at once (their restart rounds overlap on the device)."""
+    models = [m for m in models if m is not None]
+    arr = (C.c_void_p * len(models))(*[m._h for m in models])
+    check(lib().gg_sync_many(arr, len(models)))
 
 
 def selftest_math(op, x, y=None, device=0):

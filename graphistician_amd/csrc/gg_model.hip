@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "gg_common.h"
+#include <thread>
 #include "gg_block_kernels.h"
 #include "gg_resolve_kernels.h"
 
@@ -1010,6 +1011,29 @@ int gg_sync(gg_model* m) {
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return GG_OK;
   return model_sync(m);
+}
+
+// Completes the pending sweeps of several independent models.  A scan that the optimistic pipeline left
+// unfinished is finished by host-enqueued restart rounds, which keep only part of the chip busy; driving
+// every model from its own host thread lets the rounds (and bulk passes) of different models overlap.
+int gg_sync_many(gg_model** ms, int32_t n) {
+  if (n < 0 || (n > 0 && !ms)) return gg_fail(GG_ERR_INVALID, "gg_sync_many: bad arguments");
+  if (n == 0) return GG_OK;
+  if (n == 1) return gg_sync(ms[0]);
+  std::vector<int> rcs((size_t)n, GG_OK);
+  std::vector<std::string> errs((size_t)n);
+  std::vector<std::thread> th;
+  for (int i = 1; i < n; ++i)
+    th.emplace_back([&, i]() {
+      rcs[(size_t)i] = gg_sync(ms[i]);
+      if (rcs[(size_t)i]) errs[(size_t)i] = gg_err_text;   // the error text is thread-local
+    });
+  rcs[0] = gg_sync(ms[0]);
+  if (rcs[0]) errs[0] = gg_err_text;
+  for (auto& t : th) t.join();
+  for (int i = 0; i < n; ++i)
+    if (rcs[(size_t)i]) { gg_err_text = errs[(size_t)i]; return rcs[(size_t)i]; }
+  return GG_OK;
 }
 
 int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {

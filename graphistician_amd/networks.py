@@ -4,6 +4,8 @@ pair (adjacency distribution, weight distribution) driven by
 engine; the (A, W) pair is uploaded once and cached by identity (engine.py)."""
 import numpy as np
 
+from . import _abi
+
 from . import adjacency
 from . import weights
 from .abstractions import NetworkDistribution, AdjacencyDistribution, WeightDistribution, GibbsSampling
@@ -78,6 +80,12 @@ class FactorizedNetworkDistribution(NetworkDistribution, GibbsSampling):
         d = self._device_data(data)
         self.adjacency.resample(d if hasattr(self.adjacency, "_engine") else data[0])
         self.weights.resample(d)
+        # both halves are enqueued stream-ordered on their own models; finishing them together lets the
+        # engine overlap whatever it still has to do for either (gg_sync_many)
+        engines = [getattr(part, "_model", None) for part in (self.adjacency, self.weights)]
+        engines = [e for e in engines if e is not None]
+        if len(engines) > 1:
+            _abi.sync_many(engines)
 
     def meanfieldupdate(self, expected_suff_stats):
         # networks.py:73-75 (a stub in the reference as well)

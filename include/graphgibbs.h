@@ -160,6 +160,9 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta);
  * FactorizedNetworkDistribution.resample (networks.py:69-71), which share only the data, overlap. */
 int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta);
 int gg_sync(gg_model* m);
+/* gg_sync for n independent models at once, each driven from its own host thread so that the work the
+ * host enqueues while finishing their scans overlaps on the device (the two halves of networks.py:69-71). */
+int gg_sync_many(gg_model** models, int32_t n);
 
 /* abstractions.py:111-115 (adjacency kinds), weights.py:316-331 /
  * abstractions.py:257-274 (weight kinds), eigenmodel.py:110-129. */
