@@ -277,8 +277,9 @@ def main():
         adj.resample(data, 1)
         w.resample(data, 1)
     chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
-    adj.set_timing(8)   # HIP events around the bulk kernel of every 8th sweep (on the engine streams)
-    w.set_timing(8)
+    every = 8 if N <= 8192 else 1
+    adj.set_timing(every)   # HIP events around the bulk kernel of every n-th sweep (on the engine streams)
+    w.set_timing(every)
     barrier()
     t0 = time.perf_counter()
     # One step = one FactorizedNetworkDistribution.resample((A,W)): the two halves are independent
@@ -318,7 +319,9 @@ def main():
             "dtype": "int64 statistics / f64 conditionals (u8 adjacency, 24-bit fixed-point weights in int32)",
             "data": "synthetic",
             "config": {
-                "workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1, dense adjacency (BASELINE.json configs[1])" % (N, K),
+                "workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1, dense adjacency (%s)" % (
+                    N, K, "BASELINE.json configs[1]" if (N, K) == (4096, 16) else
+                    ("BASELINE.json configs[3] on one GPU" if (N, K) == (65536, 64) else "same recipe, other size")),
                 "parallelism": "independent chain per GPU" if world > 1 else "single GPU",
                 "label_changes_in_timed_region": int(chg),
                 "sweep_algorithmic_bytes": sweep_bytes,
@@ -332,7 +335,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "traffic_note": "null here: at N=4096 the 160 MB working set sits in the 256 MiB Infinity Cache, where the "
+                "traffic_note": "null here: PMC counters need their own rocprofv3 pass; at N=4096 the 160 MB working set also sits in the 256 MiB Infinity Cache, where the "
                                 "memory-side counters under-report.  Measured at N=32768 with rocprofv3 --pmc FETCH_SIZE / "
                                 "WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 correction): 8.74 GB per launch vs "
                                 "8.59 GB algorithmic (ratio 1.018), profiles/r01_pmc_bulk_traffic.json",
@@ -340,7 +343,7 @@ def main():
                 "launch_bytes": alg_bytes,
                 "sampled_launches": int(bulk["w_n"]),
                 "standalone_GBs": sw_b / sw_ms / 1e6,
-                "note": "achieved = in-situ (HIP events on the engine stream around every 8th launch inside the timed "
+                "note": "achieved = in-situ (HIP events on the engine stream around every n-th launch inside the timed "
                         "region, with the adjacency model's kernels running concurrently on another stream); "
                         "standalone_GBs = the same kernel launched back to back alone",
                 "adj_kernel": {"kernel": "k_bulk_adj", "launch_ms": bulk["adj_ms"] / max(bulk["adj_n"], 1),

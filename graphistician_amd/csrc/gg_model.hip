@@ -82,6 +82,8 @@ struct gg_model {
   int timing;        // 0 = off; n > 0: HIP events around the bulk kernel of every n-th sweep
   std::vector<hipEvent_t> ev;
   size_t ev_used;
+  std::vector<uint32_t> ev_sweep;   // sweep index of each timed launch (event pair); ~0u = the launch was a no-op
+  std::vector<double> ev_bytes;
   hipEvent_t ev_call0, ev_call1;
   gg_stats st;
 };
@@ -459,7 +461,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
     k_bulk_adj<<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1),
                                            dir0, ctl);
-    if (timed) m->st.bulk_bytes += (double)ndirs * N * (double)N;
+    if (timed) m->ev_bytes.push_back((double)ndirs * N * (double)N);
   } else {
     int SC = 64 * (4 / m->B);
     int strips = (Np + SC - 1) / SC;
@@ -476,10 +478,10 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
       case 4: BULKW(4, 4); break;
     }
 #undef BULKW
-    if (timed) m->st.bulk_bytes += (double)ndirs * N * (double)N * 4.0 * m->B;
+    if (timed) m->ev_bytes.push_back((double)ndirs * N * (double)N * 4.0 * m->B);
   }
   if (timed) {
-    m->st.bulk_launches += 1;
+    m->ev_sweep.push_back(sweep);
     GG_HIP(hipEventRecord(e1, st));
   }
   GG_HIP(hipGetLastError());
@@ -877,6 +879,7 @@ static int drain_pipe(gg_model* m) {
 
 static void begin_call(gg_model* m) {
   m->ev_used = 0;
+  m->ev_sweep.clear(); m->ev_bytes.clear();
   m->st.bulk_bytes = 0; m->st.bulk_ms = 0; m->st.bulk_launches = 0; m->st.total_ms = 0;
   hipEventRecord(m->ev_call0, m->stream);
 }
@@ -885,10 +888,14 @@ static int collect_timing(gg_model* m) {
   float ms = 0;
   GG_HIP(hipEventElapsedTime(&ms, m->ev_call0, m->ev_call1));
   m->st.total_ms = ms;
+  m->st.bulk_ms = 0; m->st.bulk_launches = 0; m->st.bulk_bytes = 0;
   for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
+    if (i / 2 < m->ev_sweep.size() && m->ev_sweep[i / 2] == ~0u) continue;   // the launch was a no-op behind a stalled scan
     float t = 0;
     GG_HIP(hipEventElapsedTime(&t, m->ev[i], m->ev[i + 1]));
     m->st.bulk_ms += t;
+    m->st.bulk_launches += 1;
+    if (i / 2 < m->ev_bytes.size()) m->st.bulk_bytes += m->ev_bytes[i / 2];
   }
   return GG_OK;
 }
@@ -900,7 +907,6 @@ static int model_sync(gg_model* m) {
   int rc;
   const gg_data* d = m->pend_data;
   const bool scan = m->sbm && m->K > 1;
-  bool tainted = false;
   GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   for (;;) {
     if (m->pipe) GG_HIP(hipStreamSynchronize(m->sb));
@@ -917,7 +923,6 @@ static int model_sync(gg_model* m) {
       m->st.sweeps += (uint64_t)m->pending;
       break;
     }
-    tainted = true;
     // ctl[5] scans completed before the flag went up.  pos != 0: the next one is stuck mid-scan.
     const int done = scan ? m->h_rs[5] : m->pending;
     const bool mid = m->h_rs[0] != 0;
@@ -932,6 +937,8 @@ static int model_sync(gg_model* m) {
     m->m_pending = true;
     m->m_sweep = m->sweep + (uint32_t)(completed - 1);
     const int remaining = m->pending - completed;
+    for (uint32_t& sw : m->ev_sweep)    // timed launches of the sweeps behind the stall did nothing
+      if (sw != ~0u && sw >= m->sweep + (uint32_t)completed) sw = ~0u;
     m->sweep += (uint32_t)completed;
     m->st.sweeps += (uint64_t)completed;
     m->cur = (m->cur0 + completed) & 1;
@@ -963,7 +970,6 @@ static int model_sync(gg_model* m) {
   m->st.label_changes = (uint64_t)m->h_rs[2];
   GG_HIP(hipEventSynchronize(m->ev_call1));
   if ((rc = collect_timing(m))) return rc;
-  if (tainted) { m->st.bulk_ms = 0; m->st.bulk_launches = 0; m->st.bulk_bytes = 0; }  // samples include no-op launches
   return GG_OK;
 }
 
