@@ -1042,6 +1042,29 @@ int gg_sync_many(gg_model** ms, int32_t n) {
   return GG_OK;
 }
 
+// n_sweeps x resample(data) for several independent models, each enqueued and completed from its own host
+// thread: the launch cost of one model's sweeps no longer delays the other's (networks.py:69-71 run n times,
+// the halves being independent given the data).
+int gg_resample_many(gg_model** ms, const gg_data* const* ds, int32_t n, int32_t n_sweeps, double beta) {
+  if (n < 0 || (n > 0 && (!ms || !ds))) return gg_fail(GG_ERR_INVALID, "gg_resample_many: bad arguments");
+  if (n == 0) return GG_OK;
+  std::vector<int> rcs((size_t)n, GG_OK);
+  std::vector<std::string> errs((size_t)n);
+  auto run = [&](int i) {
+    int rc = gg_resample_async(ms[i], ds[i], n_sweeps, beta);
+    if (!rc) rc = gg_sync(ms[i]);
+    rcs[(size_t)i] = rc;
+    if (rc) errs[(size_t)i] = gg_err_text;   // the error text is thread-local
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < n; ++i) th.emplace_back(run, i);
+  run(0);
+  for (auto& t : th) t.join();
+  for (int i = 0; i < n; ++i)
+    if (rcs[(size_t)i]) { gg_err_text = errs[(size_t)i]; return rcs[(size_t)i]; }
+  return GG_OK;
+}
+
 int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
   int rc = gg_resample_async(m, d, n_sweeps, beta);
   if (rc) return rc;

@@ -65,6 +65,23 @@ __global__ void k_draws(int what, uint64_t seed, const double* prm, int nprm, do
   }
 }
 
+__global__ __launch_bounds__(256) void k_stream_probe(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                                      unsigned long long* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int acc = 0;
+  for (; i + 3 * stride < n16; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
+    uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    if (dst) { dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d; }
+    else acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n16; i += stride) {
+    uint4 a = src[i];
+    if (dst) dst[i] = a; else acc += a.x ^ a.y ^ a.z ^ a.w;
+  }
+  if (!dst && acc == 0x12345u) atomicAdd(sink, 1ull);   // (never true for the fill pattern; keeps the loads)
+}
+
 extern "C" {
 
 int gg_selftest_math(int32_t device, int32_t op, const double* x, const double* y, double* out, int64_t n) {
@@ -100,6 +117,40 @@ int gg_selftest_draws(int32_t device, int32_t what, uint64_t seed, const double*
   GG_HIP(hipGetLastError());
   GG_HIP(hipMemcpy(out, dout, no * 8, hipMemcpyDeviceToHost));
   hipFree(dp); hipFree(dout);
+  return GG_OK;
+}
+
+// Memory-system probe for the roofline: the rate at which this device streams `bytes` of HBM-resident data
+// with the access pattern of the bulk kernels (16-byte loads, every lane its own column of a row-major
+// matrix) and nothing else.  mode 0: read only (a checksum keeps the loads alive); mode 1: copy (read + write).
+int gg_bench_stream(int32_t device, int64_t bytes, int32_t reps, int32_t mode, double* ms_per_pass) {
+  if (bytes < (1 << 20) || reps < 1 || !ms_per_pass || (mode != 0 && mode != 1))
+    return gg_fail(GG_ERR_INVALID, "gg_bench_stream: bad arguments");
+  int rc = gg_ensure_device(device);
+  if (rc) return rc;
+  const size_t n16 = (size_t)bytes / 16;
+  uint4 *src = nullptr, *dst = nullptr;
+  unsigned long long* sink = nullptr;
+  GG_HIP(hipMalloc((void**)&src, n16 * 16));
+  GG_HIP(hipMemset(src, 1, n16 * 16));
+  if (mode == 1) GG_HIP(hipMalloc((void**)&dst, n16 * 16));
+  GG_HIP(hipMalloc((void**)&sink, 8));
+  GG_HIP(hipMemset(sink, 0, 8));
+  hipEvent_t e0, e1;
+  GG_HIP(hipEventCreate(&e0));
+  GG_HIP(hipEventCreate(&e1));
+  const int nb = 256 * 16;   // 16 workgroups per CU, grid-strided
+  k_stream_probe<<<nb, 256>>>(src, dst, n16, sink);   // warm-up
+  GG_HIP(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) k_stream_probe<<<nb, 256>>>(src, dst, n16, sink);
+  GG_HIP(hipEventRecord(e1, 0));
+  GG_HIP(hipEventSynchronize(e1));
+  GG_HIP(hipGetLastError());
+  float ms = 0;
+  GG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_pass = ms / reps;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(src); if (dst) hipFree(dst); hipFree(sink);
   return GG_OK;
 }
 

@@ -163,6 +163,8 @@ int gg_sync(gg_model* m);
 /* gg_sync for n independent models at once, each driven from its own host thread so that the work the
  * host enqueues while finishing their scans overlaps on the device (the two halves of networks.py:69-71). */
 int gg_sync_many(gg_model** models, int32_t n);
+/* n_sweeps x resample for n independent models (models[i] on data[i]), one host thread per model. */
+int gg_resample_many(gg_model** models, const gg_data* const* data, int32_t n, int32_t n_sweeps, double beta);
 
 /* abstractions.py:111-115 (adjacency kinds), weights.py:316-331 /
  * abstractions.py:257-274 (weight kinds), eigenmodel.py:110-129. */
@@ -176,6 +178,9 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp);
 int gg_last_stats(gg_model* m, gg_stats* out);
 /* Device time of the bulk statistics kernel alone (HIP events on the engine stream), for the roofline line. */
 int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_launch, double* bytes_per_launch);
+/* Measured ceiling beside the nominal HBM peak: streams `bytes` of device memory `reps`
+ * times with 16-byte loads; mode 0 = read only, 1 = copy.  Average device ms per pass. */
+int gg_bench_stream(int32_t device, int64_t bytes, int32_t reps, int32_t mode, double* ms_per_pass);
 /* on = n > 0: record HIP events (on the engine stream) around the bulk kernel of every n-th sweep, so that
  * gg_last_stats reports bulk_ms / bulk_launches / bulk_bytes for the sampled launches; 0 = off. */
 int gg_set_timing(gg_model* m, int32_t on);

@@ -281,3 +281,47 @@ def pg1_vec(seed, z, n):
     out = np.empty(n)
     lib().orc_pg1_vec(C.c_uint64(seed), C.c_double(z), _f64(out), C.c_longlong(n))
     return out
+
+
+# ---------------------------------------------------------------- optimised CPU flavour (oracle_fast.cpp, OpenMP)
+class FastSweeper(object):
+    """Same chain as sbm_adj_sweep / sbm_w_sweep (bit for bit), organised for speed: per-node block statistics
+    built once per half-sweep in an OpenMP pass, O(K^2) per scanned node, O(N) per label change."""
+
+    def __init__(self, A, q=None, shift=0, threads=None):
+        if threads is None:   # the CPU share of this process, at most 16 (a one-GPU box's share)
+            threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+        self.A8 = np.ascontiguousarray(A != 0, dtype=np.uint8)
+        self.q = q
+        N = A.shape[0]
+        B = q.shape[2] if q is not None else 1
+        lib().orc_fast_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_fast_create(N, B, _p(self.A8, C.c_uint8), _i32(q) if q is not None else None, int(shift), int(threads)))
+        self.threads = int(threads)
+
+    def adj_sweep(self, c, m, p, p_self, pi, tau1, tau0, special, seed, sweep):
+        ps = np.array([p_self], dtype=np.float64)
+        rc = lib().orc_fast_adj_sweep(self.h, m.shape[0], _i32(c), _f64(m), _f64(p), _f64(ps),
+                                      _f64(np.ascontiguousarray(pi, dtype=np.float64)), C.c_double(tau1), C.c_double(tau0),
+                                      int(special), C.c_uint64(seed), C.c_uint32(sweep))
+        if rc:
+            raise RuntimeError("oracle fast adj sweep failed rc=%d" % rc)
+        return float(ps[0])
+
+    def w_sweep(self, c, m, mu, sigma, mu_self, sigma_self, pi, niw, niw_self, special, seed, sweep):
+        rc = lib().orc_fast_w_sweep(self.h, m.shape[0], _i32(c), _f64(m), _f64(mu), _f64(sigma), _f64(mu_self), _f64(sigma_self),
+                                    _f64(np.ascontiguousarray(pi, dtype=np.float64)), _f64(niw), _f64(niw_self), int(special),
+                                    C.c_uint64(seed), C.c_uint32(sweep))
+        if rc:
+            raise RuntimeError("oracle fast w sweep failed rc=%d" % rc)
+
+    def close(self):
+        if self.h:
+            lib().orc_fast_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -277,3 +277,25 @@ def test_geweke_sbm_adjacency_prior_recovery():
     assert stats.kstest(np.array(p00)[thin], "uniform").pvalue > 1e-3
     assert stats.kstest(np.array(pss)[thin], "uniform").pvalue > 1e-3
     assert stats.kstest(np.array(ms)[thin], "beta", args=(2.0, 2.0)).pvalue > 1e-3
+
+
+# ---------------------------------------------------------------- optimised CPU flavour == plain oracle
+@pytest.mark.parametrize("N,K,B,special", [(150, 5, 1, 1), (130, 4, 2, 0), (97, 3, 1, 0)])
+def test_fast_cpu_flavour_is_the_same_chain(N, K, B, special):
+    """oracle_fast.cpp (bench.py's multi-threaded cpu_baseline) must produce the plain oracle's chain bit for bit."""
+    A, W, _ = planted_sbm(N, K, B=B, seed=N)
+    q, shift = O.quantise(A, W)
+    fs = O.FastSweeper(A, q, shift)
+    s1, s2 = AdjState(N, K, seed=3), AdjState(N, K, seed=3)
+    ps1 = ps2 = 0.5
+    for sw in range(4):
+        ps1 = O.sbm_adj_sweep(A, s1.c, s1.m, s1.p, ps1, s1.pi, 1.0, 1.0, special, 9, sw)
+        ps2 = fs.adj_sweep(s2.c, s2.m, s2.p, ps2, s2.pi, 1.0, 1.0, special, 9, sw)
+        assert np.array_equal(s1.c, s2.c) and np.array_equal(s1.p, s2.p) and np.array_equal(s1.m, s2.m) and ps1 == ps2
+    w1, w2 = WState(N, K, B, seed=4), WState(N, K, B, seed=4)
+    for sw in range(4):
+        O.sbm_w_sweep(A, q, shift, w1.c, w1.m, w1.mu, w1.sigma, w1.mu_self, w1.sigma_self, w1.pi, w1.niw, w1.niw_self, special, 12, sw)
+        fs.w_sweep(w2.c, w2.m, w2.mu, w2.sigma, w2.mu_self, w2.sigma_self, w2.pi, w2.niw, w2.niw_self, special, 12, sw)
+        assert np.array_equal(w1.c, w2.c) and np.array_equal(w1.mu, w2.mu) and np.array_equal(w1.sigma, w2.sigma)
+        assert np.array_equal(w1.m, w2.m) and np.array_equal(w1.mu_self, w2.mu_self) and np.array_equal(w1.sigma_self, w2.sigma_self)
+    fs.close()
