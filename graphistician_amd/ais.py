@@ -32,6 +32,11 @@ def prior_draw(model):
         model.initialize_from_prior()
     elif isinstance(model, BetaBernoulliAdjacencyDistribution):
         model.initialize_from_prior()
+    elif hasattr(model, "adjacency") and hasattr(model, "weights"):
+        # a whole network (networks.py:9-75): both halves from their priors; the tempered path raises the JOINT
+        # likelihood p(A | .) p(W | A, .) to beta (weights: build-defined, see weights.py)
+        prior_draw(model.adjacency)
+        model.weights.initialize_from_prior()
     else:
         raise NotImplementedError("AIS is defined for the Beta-Bernoulli (Erdos-Renyi) and SBM adjacency models")
 
@@ -40,7 +45,7 @@ def estimate_marginal_likelihood(model, A, N_samples=1000, B=100, steps_per_B=11
                                  reference_order=False):
     """log p(A) under `model` by AIS; all sweeps and likelihood evaluations run on the engine."""
     betas = np.linspace(0, 1, B)
-    data = model._data(A)
+    data = model._device_data(A) if hasattr(model, "_device_data") else model._data(A)
     log_weights = np.zeros(N_samples)
     for m in range(N_samples):
         prior_draw(model)

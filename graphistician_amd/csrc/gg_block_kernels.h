@@ -504,7 +504,11 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
           gg_unpack_wstats(s_tab + 1, B, g.wh.shift, s1, s2);
           gg_stream s;
           gg_stream_init(&s, g.seed, GG_SITE_W_NIW, g.sweep, (uint32_t)t);
-          gg_niw_posterior_draw(&s, &g.wh.niw, B, (double)s_tab[0], s1, s2, mo, so);
+          // tempered posterior (build-defined for the weights: Gaussian likelihood to the power beta scales the
+          // sufficient statistics, as graph_models.py:366-367 does for the adjacency counts); beta = 1: x * 1.0 == x
+          for (int i = 0; i < B; ++i) s1[i] *= g.beta;
+          for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
+          gg_niw_posterior_draw(&s, &g.wh.niw, B, g.beta * (double)s_tab[0], s1, s2, mo, so);
           for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
           for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
         } else {
@@ -539,7 +543,9 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         gg_unpack_wstats(hl, B, g.wh.shift, s1, s2);
         gg_stream s;
         gg_stream_init(&s, g.seed, GG_SITE_W_NIW_SELF, g.sweep, 0u);
-        gg_niw_posterior_draw(&s, &g.wh.niw_self, B, (double)g.wh.d1, s1, s2, mo, so);
+        for (int i = 0; i < B; ++i) s1[i] *= g.beta;
+        for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
+        gg_niw_posterior_draw(&s, &g.wh.niw_self, B, g.beta * (double)g.wh.d1, s1, s2, mo, so);
         for (int i = 0; i < B; ++i) g.mu_self[i] = mo[i];
         for (int i = 0; i < B * B; ++i) g.sigma_self[i] = so[i];
       }

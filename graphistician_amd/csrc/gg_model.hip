@@ -986,8 +986,8 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
-  if (beta != 1.0 && (m->eig || !m->is_adj))
-    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals are defined for the adjacency models only (graph_models.py:168-371)");
+  if (beta != 1.0 && m->eig)
+    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: block models only (the reference leaves the eigenmodel's undefined, graph_models.py:478)");
   if (m->eig) {
     for (int s = 0; s < n_sweeps; ++s) {
       int rc = gg_eigen_resample(m->eig, d, GG_PART_ALL);
@@ -1076,8 +1076,8 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
-  if (beta != 1.0 && (m->eig || !m->is_adj))
-    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals are defined for the adjacency models only (graph_models.py:168-371)");
+  if (beta != 1.0 && m->eig)
+    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: block models only (the reference leaves the eigenmodel's undefined, graph_models.py:478)");
   if (m->eig) return gg_eigen_resample(m->eig, d, parts);
   int rc = model_sync(m);
   if (rc) return rc;

@@ -32,6 +32,8 @@ class FactorizedNetworkDistribution(NetworkDistribution, GibbsSampling):
         return self._weights
 
     def _device_data(self, data):
+        if isinstance(data, _abi.DeviceData):   # already resident
+            return data
         A, W = data
         dev = getattr(self._weights, "_device", getattr(self._adjacency, "_device", 0))
         return as_device_data(A, W, device=dev)
@@ -75,11 +77,15 @@ class FactorizedNetworkDistribution(NetworkDistribution, GibbsSampling):
         pll += self.weights.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=M)
         return pll
 
-    def resample(self, data):
-        # networks.py:69-71
+    def resample(self, data, beta=1.0):
+        # networks.py:69-71; beta < 1 tempers both halves' likelihoods (AIS over whole networks)
         d = self._device_data(data)
-        self.adjacency.resample(d if hasattr(self.adjacency, "_engine") else data[0])
-        self.weights.resample(d)
+        if beta == 1.0:
+            self.adjacency.resample(d if hasattr(self.adjacency, "_engine") else data[0])
+            self.weights.resample(d)
+        else:
+            self.adjacency.resample(d if hasattr(self.adjacency, "_engine") else data[0], beta=beta)
+            self.weights.resample(d, beta=beta)
         # both halves are enqueued stream-ordered on their own models; finishing them together lets the
         # engine overlap whatever it still has to do for either (gg_sync_many)
         engines = [getattr(part, "_model", None) for part in (self.adjacency, self.weights)]

@@ -245,11 +245,12 @@ class NIWGaussianWeightDistribution(_WeightsBase):
         Lrow[-1, :, :] = Lcol[-1, :, :] = self._self_gaussian.sigma_chol
         return Murow, Mucol, Lrow, Lcol
 
-    def resample(self, data):
-        """weights.py:154-162."""
+    def resample(self, data, beta=1.0):
+        """weights.py:154-162.  beta < 1: tempered posterior (build-defined for weights: the Gaussian likelihood
+        to the power beta scales the sufficient statistics, the way graph_models.py:366-367 scales counts)."""
         d = self._data(data)
         assert d.N == self.N and d.B == self.B
-        self._engine().resample_async(d, 1)
+        self._engine().resample_async(d, 1, beta)
         self._mark_stale("_mu", "_sigma", "_mu_self", "_sigma_self")
 
 
@@ -404,28 +405,28 @@ class SBMGaussianWeightDistribution(_WeightsBase):
         return Murow, Mucol, Lrow, Lcol
 
     # -- Gibbs (weights.py:394-498): on the device ---------------------------------
-    def _run(self, data, parts):
+    def _run(self, data, parts, beta=1.0):
         d = self._data(data) if data is not None else None
         assert d is None or (d.N == self.N and d.B == self.B)
         eng = self._engine()
         if parts == _abi.PART_ALL:
-            eng.resample_async(d, 1)    # stream-ordered: the next state read (or log_likelihood) waits for it
+            eng.resample_async(d, 1, beta)    # stream-ordered: the next state read (or log_likelihood) waits for it
         else:
-            eng.resample_part(d, parts)
+            eng.resample_part(d, parts, beta)
             if parts == _abi.PART_M:
                 eng.sweep = eng.sweep + 1
         self._mark_stale("c", "m", "_mu", "_sigma", "_mu_self", "_sigma_self")
 
-    def resample(self, data):
-        self._run(data, _abi.PART_ALL)
+    def resample(self, data, beta=1.0):
+        self._run(data, _abi.PART_ALL, beta)
 
-    def resample_mu_and_Sig(self, A, W):
-        self._run((A, W), _abi.PART_PARAMS)
+    def resample_mu_and_Sig(self, A, W, beta=1.0):
+        self._run((A, W), _abi.PART_PARAMS, beta)
 
-    def resample_c(self, A, W):
+    def resample_c(self, A, W, beta=1.0):
         if self.C == 1:
             return
-        self._run((A, W), _abi.PART_C)
+        self._run((A, W), _abi.PART_C, beta)
 
     def resample_m(self):
         self._run(None, _abi.PART_M)

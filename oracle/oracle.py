@@ -135,12 +135,13 @@ def const_adj_loglik(A, p, p_self):
 
 # ---------------------------------------------------------------- Gaussian weights
 def sbm_w_sweep(A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, niw, niw_self, special, seed, sweep,
-                parts=PART_ALL):
+                parts=PART_ALL, beta=1.0):
     N, K, B = A.shape[0], m.shape[0], q.shape[2]
     A8, pA = _u8(A != 0)
-    rc = lib().orc_sbm_w_sweep(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma),
-                               _f64(mu_self), _f64(sigma_self), _f64(np.ascontiguousarray(pi, dtype=np.float64)),
-                               _f64(niw), _f64(niw_self), int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts))
+    rc = lib().orc_sbm_w_sweep_beta(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma),
+                                    _f64(mu_self), _f64(sigma_self), _f64(np.ascontiguousarray(pi, dtype=np.float64)),
+                                    _f64(niw), _f64(niw_self), int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts),
+                                    C.c_double(beta))
     if rc:
         raise RuntimeError("oracle sbm_w_sweep failed rc=%d" % rc)
 
@@ -164,11 +165,11 @@ def sbm_w_loglik(A, q, shift, c, mu, sigma, mu_self, sigma_self, special=True):
                                   _f64(sigma_self), int(special))
 
 
-def niw_w_sweep(A, q, shift, mu, sigma, mu_self, sigma_self, niw, niw_self, seed, sweep):
+def niw_w_sweep(A, q, shift, mu, sigma, mu_self, sigma_self, niw, niw_self, seed, sweep, beta=1.0):
     N, B = A.shape[0], q.shape[2]
     A8, pA = _u8(A != 0)
-    rc = lib().orc_niw_w_sweep(N, B, pA, _i32(q), int(shift), _f64(mu), _f64(sigma), _f64(mu_self), _f64(sigma_self),
-                               _f64(niw), _f64(niw_self), C.c_uint64(seed), C.c_uint32(sweep))
+    rc = lib().orc_niw_w_sweep_beta(N, B, pA, _i32(q), int(shift), _f64(mu), _f64(sigma), _f64(mu_self), _f64(sigma_self),
+                                    _f64(niw), _f64(niw_self), C.c_uint64(seed), C.c_uint32(sweep), C.c_double(beta))
     if rc:
         raise RuntimeError("oracle niw_w_sweep failed rc=%d" % rc)
 

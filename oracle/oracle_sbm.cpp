@@ -333,7 +333,7 @@ static void unpack_niw(const double* packed, int B, gg_niw* h) {
 static void sbm_w_resample_mu_sig(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift,
                                   const int32_t* c, double* mu, double* sigma, double* mu_self,
                                   double* sigma_self, const gg_niw* h, const gg_niw* hs, int special,
-                                  uint64_t seed, uint32_t sweep) {
+                                  uint64_t seed, uint32_t sweep, double beta = 1.0) {
   std::vector<WStat> st((size_t)K * K);
   for (auto& s : st) wstat_zero(&s);
   WStat sd;
@@ -352,6 +352,10 @@ static void sbm_w_resample_mu_sig(int N, int K, int B, const uint8_t* A, const i
   for (int c1 = 0; c1 < K; ++c1)
     for (int c2 = 0; c2 < K; ++c2) {
       wstat_to_double(&st[(size_t)c1 * K + c2], B, shift, &n, s1, s2);
+      // tempered posterior (build-defined, mirrors graph_models.py:366-367): statistics weighted by beta
+      n *= beta;
+      for (int r = 0; r < B; ++r) s1[r] *= beta;
+      for (int r = 0; r < B * B; ++r) s2[r] *= beta;
       gg_stream s;
       gg_stream_init(&s, seed, GG_SITE_W_NIW, sweep, (uint32_t)(c1 * K + c2));
       gg_niw_posterior_draw(&s, h, B, n, s1, s2, mu + (size_t)(c1 * K + c2) * B,
@@ -359,6 +363,9 @@ static void sbm_w_resample_mu_sig(int N, int K, int B, const uint8_t* A, const i
     }
   if (special) {
     wstat_to_double(&sd, B, shift, &n, s1, s2);
+    n *= beta;
+    for (int r = 0; r < B; ++r) s1[r] *= beta;
+    for (int r = 0; r < B * B; ++r) s2[r] *= beta;
     gg_stream s;
     gg_stream_init(&s, seed, GG_SITE_W_NIW_SELF, sweep, 0u);
     gg_niw_posterior_draw(&s, hs, B, n, s1, s2, mu_self, sigma_self);
@@ -387,7 +394,7 @@ static int sbm_w_tables(int K, int B, const double* m, const double* mu, const d
 // Sufficient-statistic form of weights.py:451-470 (_evaluate_lkhd) for node n1.
 static void sbm_w_node_lp(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift,
                           const int32_t* c, const double* logm, const double* T, int special, int n1,
-                          double* lp) {
+                          double* lp, double beta = 1.0) {
   int NT = gg_nt_gauss(B);
   std::vector<WStat> so(K), si(K);
   for (int k = 0; k < K; ++k) { wstat_zero(&so[k]); wstat_zero(&si[k]); }
@@ -410,19 +417,19 @@ static void sbm_w_node_lp(int N, int K, int B, const uint8_t* A, const int32_t* 
     pack_stat(&ss, B, shift, self);
     selfp = self;
   }
-  for (int k = 0; k < K; ++k) lp[k] = gg_block_lp(k, K, NT, logm, T, dso.data(), dsi.data(), selfp);
+  for (int k = 0; k < K; ++k) lp[k] = gg_block_lp(k, K, NT, logm, T, dso.data(), dsi.data(), selfp, beta);
 }
 
 // weights.py:415-488 resample_c.
 static int sbm_w_resample_c(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift,
                             int32_t* c, const double* m, const double* mu, const double* sigma,
-                            int special, uint64_t seed, uint32_t sweep) {
+                            int special, uint64_t seed, uint32_t sweep, double beta = 1.0) {
   if (K == 1) return 0;  // weights.py:421-422
   int NT = gg_nt_gauss(B);
   std::vector<double> logm(K), T((size_t)K * K * NT), lp(K), scratch(2 * gg_next_pow2(K));
   if (sbm_w_tables(K, B, m, mu, sigma, logm.data(), T.data())) return -2;
   for (int n1 = 0; n1 < N; ++n1) {
-    sbm_w_node_lp(N, K, B, A, q, shift, c, logm.data(), T.data(), special, n1, lp.data());
+    sbm_w_node_lp(N, K, B, A, q, shift, c, logm.data(), T.data(), special, n1, lp.data(), beta);
     double u = gg_uniform_at(seed, GG_SITE_W_C, sweep, (uint32_t)n1);
     c[n1] = gg_categorical(lp.data(), K, u, scratch.data());
   }
@@ -431,22 +438,30 @@ static int sbm_w_resample_c(int N, int K, int B, const uint8_t* A, const int32_t
 
 // weights.py:394-397 resample = resample_mu_and_Sig -> resample_c -> resample_m.
 // niw / niw_self: packed [mu_0, sigma_0, nu_0, kappa_0].
-int orc_sbm_w_sweep(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, int32_t* c,
-                    double* m, double* mu, double* sigma, double* mu_self, double* sigma_self,
-                    const double* pi, const double* niw, const double* niw_self, int special,
-                    uint64_t seed, uint32_t sweep, int parts) {
+int orc_sbm_w_sweep_beta(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, int32_t* c,
+                         double* m, double* mu, double* sigma, double* mu_self, double* sigma_self,
+                         const double* pi, const double* niw, const double* niw_self, int special,
+                         uint64_t seed, uint32_t sweep, int parts, double beta) {
   if (B > GG_MAXB) return -1;
   gg_niw h, hs;
   unpack_niw(niw, B, &h);
   unpack_niw(niw_self, B, &hs);
   if (parts & ORC_PART_PARAMS)
-    sbm_w_resample_mu_sig(N, K, B, A, q, shift, c, mu, sigma, mu_self, sigma_self, &h, &hs, special, seed, sweep);
+    sbm_w_resample_mu_sig(N, K, B, A, q, shift, c, mu, sigma, mu_self, sigma_self, &h, &hs, special, seed, sweep, beta);
   if (parts & ORC_PART_C) {
-    int rc = sbm_w_resample_c(N, K, B, A, q, shift, c, m, mu, sigma, special, seed, sweep);
+    int rc = sbm_w_resample_c(N, K, B, A, q, shift, c, m, mu, sigma, special, seed, sweep, beta);
     if (rc) return rc;
   }
   if (parts & ORC_PART_M) resample_m(N, K, c, pi, m, seed, GG_SITE_W_M, sweep);
   return 0;
+}
+
+int orc_sbm_w_sweep(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, int32_t* c,
+                    double* m, double* mu, double* sigma, double* mu_self, double* sigma_self,
+                    const double* pi, const double* niw, const double* niw_self, int special,
+                    uint64_t seed, uint32_t sweep, int parts) {
+  return orc_sbm_w_sweep_beta(N, K, B, A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, niw, niw_self, special,
+                              seed, sweep, parts, 1.0);
 }
 
 int orc_sbm_w_node_lp(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift,
@@ -528,16 +543,21 @@ double orc_sbm_w_loglik(int N, int K, int B, const uint8_t* A, const int32_t* q,
 
 // weights.py:154-162 NIWGaussianWeightDistribution.resample: one Gaussian for
 // the off-diagonal edges, one for the self edges.
-int orc_niw_w_sweep(int N, int B, const uint8_t* A, const int32_t* q, int shift, double* mu,
-                    double* sigma, double* mu_self, double* sigma_self, const double* niw,
-                    const double* niw_self, uint64_t seed, uint32_t sweep) {
+int orc_niw_w_sweep_beta(int N, int B, const uint8_t* A, const int32_t* q, int shift, double* mu,
+                         double* sigma, double* mu_self, double* sigma_self, const double* niw,
+                         const double* niw_self, uint64_t seed, uint32_t sweep, double beta) {
   if (B > GG_MAXB) return -1;
   gg_niw h, hs;
   unpack_niw(niw, B, &h);
   unpack_niw(niw_self, B, &hs);
   std::vector<int32_t> c(N, 0);
-  sbm_w_resample_mu_sig(N, 1, B, A, q, shift, c.data(), mu, sigma, mu_self, sigma_self, &h, &hs, 1, seed, sweep);
+  sbm_w_resample_mu_sig(N, 1, B, A, q, shift, c.data(), mu, sigma, mu_self, sigma_self, &h, &hs, 1, seed, sweep, beta);
   return 0;
+}
+int orc_niw_w_sweep(int N, int B, const uint8_t* A, const int32_t* q, int shift, double* mu,
+                    double* sigma, double* mu_self, double* sigma_self, const double* niw,
+                    const double* niw_self, uint64_t seed, uint32_t sweep) {
+  return orc_niw_w_sweep_beta(N, B, A, q, shift, mu, sigma, mu_self, sigma_self, niw, niw_self, seed, sweep, 1.0);
 }
 
 // ---------------------------------------------------------------------------

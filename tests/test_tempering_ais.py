@@ -72,11 +72,77 @@ def test_engine_tempered_sweeps_bitexact(beta):
         assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c), (beta, s)
         assert np.array_equal(m.get(abi.ST_P, (K, K)), st.p)
         assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
-    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=1, special_case_self_conns=1)
-    dw = abi.DeviceData(A, np.zeros((N, N, 1)))
-    if beta != 1.0:
-        with pytest.raises(abi.EngineError):
-            w.resample(dw, 1, beta)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta,B", [(0.0, 1), (0.37, 1), (0.6, 2), (1.0, 2)])
+def test_engine_tempered_weight_sweeps_bitexact(beta, B):
+    """Tempered weight halves (build-defined: the Gaussian likelihood to the power beta): SBM Gaussian and NIW."""
+    from graphistician_amd import _abi as abi
+    from tests.helpers import WState
+    N, K = 140, 4
+    A, W, _ = planted_sbm(N, K, B=B, seed=8)
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=5)
+    d = abi.DeviceData(A, W)
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=41, special_case_self_conns=1)
+    w.set(abi.ST_C, st.c, np.int32); w.set(abi.ST_M, st.m); w.set(abi.ST_PI, st.pi)
+    w.set(abi.ST_MU, st.mu); w.set(abi.ST_SIGMA, st.sigma); w.set(abi.ST_NIW, st.niw); w.set(abi.ST_NIW_SELF, st.niw_self)
+    for s in range(4):
+        w.resample(d, 1, beta)
+        O.sbm_w_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, st.niw, st.niw_self, 1, 41, s,
+                      beta=beta)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), st.c), (beta, s)
+        assert np.array_equal(w.get(abi.ST_MU, (K, K, B)), st.mu)
+        assert np.array_equal(w.get(abi.ST_SIGMA, (K, K, B, B)), st.sigma)
+        assert np.array_equal(w.get(abi.ST_MU_SELF, (B,)), st.mu_self)
+    # single Gaussian (weights.py:154-162)
+    g = abi.Model(kind=abi.NIW_W, N=N, K=1, B=B, seed=43)
+    niw = O.pack_niw(np.zeros(B), np.eye(B), B + 2, 1.0)
+    g.set(abi.ST_NIW, niw); g.set(abi.ST_NIW_SELF, niw)
+    mu, sig, mus, sigs = np.zeros(B), np.eye(B), np.zeros(B), np.eye(B)
+    for s in range(3):
+        g.resample(d, 1, beta)
+        O.niw_w_sweep(A, q, shift, mu, sig, mus, sigs, niw, niw, 43, s, beta=beta)
+        assert np.array_equal(g.get(abi.ST_MU, (B,)), mu) and np.array_equal(g.get(abi.ST_SIGMA, (B, B)), sig)
+
+
+def niw_log_marginal_1d(x, mu0, s0, nu0, k0):
+    """log p(x_1..x_n) under x ~ N(mu, s2), (mu, s2) ~ NIW(mu0, s0, nu0, k0) in one dimension (closed form)."""
+    from scipy.special import gammaln
+    n = len(x)
+    if n == 0:
+        return 0.0
+    xb = x.mean()
+    kn, nun = k0 + n, nu0 + n
+    sn = s0 + ((x - xb) ** 2).sum() + k0 * n / kn * (xb - mu0) ** 2
+    return (-0.5 * n * np.log(np.pi) + gammaln(nun / 2.0) - gammaln(nu0 / 2.0) + 0.5 * nu0 * np.log(s0) - 0.5 * nun * np.log(sn)
+            + 0.5 * (np.log(k0) - np.log(kn)))
+
+
+@pytest.mark.gpu
+def test_engine_ais_whole_network_matches_closed_form():
+    """AIS over a whole Gaussian Erdos-Renyi network (Beta-Bernoulli adjacency + NIW weights): both halves tempered on
+    the engine; evidence = Beta-Bernoulli evidence x NIW evidence of the off-diagonal and of the self edges."""
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import BetaBernoulliAdjacencyDistribution
+    from graphistician_amd.weights import NIWGaussianWeightDistribution
+    from graphistician_amd.ais import estimate_marginal_likelihood
+    rng = np.random.RandomState(5)
+    N = 9
+    A = (rng.rand(N, N) < 0.4).astype(np.uint8)
+    W = 0.7 + 1.3 * rng.randn(N, N, 1)
+    np.random.seed(1)
+    net = FactorizedNetworkDistribution(N, BetaBernoulliAdjacencyDistribution, dict(tau1=1.0, tau0=1.0, seed=3),
+                                        NIWGaussianWeightDistribution, dict(B=1, seed=4))
+    lz = estimate_marginal_likelihood(net, (A, W), N_samples=64, B=60, steps_per_B=1)
+    off = ~np.eye(N, dtype=bool)
+    g = net.weights._gaussian
+    exact = er_log_marginal(A, 1.0, 1.0)
+    exact += niw_log_marginal_1d(W[..., 0][off & (A == 1)], float(g.mu_0[0]), float(g.sigma_0[0, 0]), float(g.nu_0), float(g.kappa_0))
+    gs = net.weights._self_gaussian
+    exact += niw_log_marginal_1d(W[..., 0][(~off) & (A == 1)], float(gs.mu_0[0]), float(gs.sigma_0[0, 0]), float(gs.nu_0), float(gs.kappa_0))
+    assert abs(lz - exact) < 0.6, (lz, exact)
 
 
 @pytest.mark.gpu
