@@ -35,6 +35,7 @@ struct gg_eigen {
   double *S, *dO, *Z;
   double *part, *gpart, *llpart;
   int* status;
+  long long* dbgbuf;   // GG_EIG_DBG: cycle counters of the chain's solver wave
   hipStream_t stream;
   uint32_t sweep;
   bool have_omega;
@@ -143,15 +144,16 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
 //   G_n[a,b] = sum_{nn != n} S[n,nn] ft_a ft_b,  h_n[a] = sum_{nn != n} ((A[n,nn]+A[nn,n]-1) - mu_0 S[n,nn]) ft_a,
 // ft = F[nn] * lambda.  One workgroup per (node, chunk of EIG_CHN neighbours).
 template <int DM>
-__global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
+__device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0, const double* __restrict__ S,
                                                         const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                         const double* __restrict__ F, const double* __restrict__ lmbda,
                                                         const double* __restrict__ mu0p, int NCH,
-                                                        double* __restrict__ part) {
+                                                        double* __restrict__ part, int ex_lo, int ex_hi, int node, int c) {
+  // nodes [ex_lo, ex_hi) (the previous tile, whose scan is still running) are left out: the chain adds them
   constexpr int NEGM = DM * (DM + 1) / 2;
-  const int n = t0 + blockIdx.x;
+  const int n = t0 + node;
   if (n >= N) return;
-  const int c = blockIdx.y;
+  const int nth = blockDim.x;
   const double mu0 = *mu0p;
   double g[NEGM], h[DM], lam[DM];
 #pragma unroll
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, i
 #pragma unroll
   for (int d = 0; d < DM; ++d) { h[d] = 0.0; lam[d] = d < D ? lmbda[d] : 0.0; }
   const int lo = c * EIG_CHN, hi = (lo + EIG_CHN < N) ? lo + EIG_CHN : N;
-  for (int nn = lo + threadIdx.x; nn < hi; nn += 1024) {
-    if (nn == n) continue;
+  for (int nn = lo + threadIdx.x; nn < hi; nn += nth) {
+    if (nn == n || (nn >= ex_lo && nn < ex_hi)) continue;
     const double s = S[(size_t)n * Np + nn];
     const double a = (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
     const double v = a - mu0 * s;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, i
   if (threadIdx.x < NEGM + DM) {
     const int e = threadIdx.x;
     double v = 0.0;
-    for (int w = 0; w < 16; ++w) v += s_red[w][e];
+    for (int w = 0; w < (nth >> 6); ++w) v += s_red[w][e];
     // map padded index -> compact index
     int out = -1;
     if (e < NEGM) {
@@ -201,21 +203,38 @@ __global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, i
     } else if (e - NEGM < D) {
       out = NEG + (e - NEGM);
     }
-    if (out >= 0) part[((size_t)blockIdx.x * NCH + c) * (NEG + D) + out] = v;
+    if (out >= 0) part[((size_t)node * NCH + c) * (NEG + D) + out] = v;
   }
 }
 
 // The sequential part of _resample_F for one tile (eigenmodel.py:884-908), one workgroup.
 // Everything the per-node loop touches is staged in LDS first (T x T block of S and of the
 // symmetrised adjacency, the tile's statistics, normals and old features).
+template <int DM>
+__global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
+                                                        const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                        const double* __restrict__ F, const double* __restrict__ lmbda,
+                                                        const double* __restrict__ mu0p, int NCH,
+                                                        double* __restrict__ part, int ex_lo, int ex_hi) {
+  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, ex_hi, blockIdx.x, blockIdx.y);
+}
+
 template <int DM, bool FULL>
 __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t0, const double* __restrict__ S,
                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                    double* __restrict__ F, const double* __restrict__ lmbda,
                                                    const double* __restrict__ mu0p, double sigma_F, int NCH,
                                                    const double* __restrict__ part, const double* __restrict__ Z,
-                                                   int* __restrict__ status, int dbg) {
+                                                   int* __restrict__ status, long long* __restrict__ dbg,
+                                                   double* __restrict__ part_next) {
   constexpr int NEGM = DM * (DM + 1) / 2;
+  if (blockIdx.x > 0) {
+    // riders: the statistics of the NEXT tile (all nodes outside this tile and the next), computed while
+    // workgroup 0 scans this one; the next launch's chain adds this tile's nodes with their new features
+    const int idx = blockIdx.x - 1;
+    eig_tile_stats_body<DM>(N, Np, Drt, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, t0 + EIG_T, idx / NCH, idx % NCH);
+    return;
+  }
   extern __shared__ __align__(16) unsigned char s_chain[];
   double* s_S = reinterpret_cast<double*>(s_chain);                 // [T][T+1]
   double* s_dP = s_S + EIG_T * (EIG_T + 1);                         // [T][NEGM]
@@ -231,11 +250,36 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
   const int D = FULL ? DM : Drt;
   const int NEG = FULL ? NEGM : D * (D + 1) / 2, NE = NEG + D;
   const double mu0 = *mu0p;
-  for (int e = tid; e < T * T; e += 512) {
-    int i = e / T, j = e % T;
-    s_S[i * (EIG_T + 1) + j] = S[(size_t)(t0 + i) * Np + t0 + j];
-    s_a[i * EIG_T + j] = (signed char)((int)A[(size_t)(t0 + i) * Np + t0 + j] + (int)AT[(size_t)(t0 + i) * Np + t0 + j] - 1);
-  }
+  const long long c_start = dbg ? clock64() : 0;
+  const int p0 = t0 - EIG_T;     // first node of the previous tile (left out by the statistics kernel)
+  // block loader: rows of this tile x columns [c0, c0 + W) of S and of a = A + A^T - 1, into s_S / s_a
+  auto load_block = [&](int c0, int W) {
+    // (all of a thread's loads are issued before the first LDS store: 8 x 3 loads in flight instead of 3)
+    constexpr int PER = EIG_T * EIG_T / 512;
+    double sv[PER];
+    int av[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 512;
+      const int i = e / W, j = e % W;
+      const bool in = e < T * W;
+      const size_t at = in ? (size_t)(t0 + i) * Np + c0 + j : (size_t)t0 * Np + c0;
+      sv[u] = S[at];
+      av[u] = (int)A[at] + (int)AT[at] - 1;
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 512;
+      if (e < T * W) {
+        const int i = e / W, j = e % W;
+        s_S[i * (EIG_T + 1) + j] = sv[u];
+        s_a[i * EIG_T + j] = (signed char)av[u];
+      }
+    }
+  };
+  if (p0 >= 0) load_block(p0, EIG_T); else load_block(t0, T);
+  if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[5], (unsigned long long)(clock64() - c_start));
   for (int e = tid; e < T * NE; e += 512) {
     int i = e / NE, q = e % NE;
     double acc = 0.0;
@@ -250,102 +294,201 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
   double lam[DM];
 #pragma unroll
   for (int a1 = 0; a1 < DM; ++a1) lam[a1] = a1 < D ? lmbda[a1] : 0.0;
-  __syncthreads();
-  for (int nl = 0; nl < T; ++nl) {
-    const int n = t0 + nl;
-    const double* s_stat = s_part + nl * (NEGM + DM);   // this node's statistics, corrections already applied
-    if (tid == 0 && !(dbg & 1)) {
-      // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
-      double L[DM][DM], hh[DM], x[DM];
-      {
-        int e = 0;
+  if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[6], (unsigned long long)(clock64() - c_start));
+  // The statistics kernel ran while the previous tile was still being scanned and left its nodes out: add
+  // them now, with their new features (s_dF is free until the scan starts: it holds f * lambda of those nodes).
+  if (p0 >= 0) {
+    for (int e = tid; e < EIG_T * D; e += 512) {
+      int m = e / D, q = e % D;
+      s_dF[m * DM + q] = F[(size_t)(p0 + m) * D + q] * lmbda[q];
+    }
+    __syncthreads();
+    // C[i][e] = sum_m X[i][m] Y[m][e] over the 64 nodes m of the previous tile: a 64 x 64 x NE product, on the
+    // matrix cores (v_mfma_f64_16x16x4_f64; fragment layout as in eig_psi_tile_mfma).  Precision entries
+    // (e < NEG): X = S, Y[m][e] = g_m[a] g_m[b]; mean entries: X = a - mu_0 S, Y[m][q] = g_m[q].
+    {
+      const int wv = tid >> 6, l = tid & 63;
+      const int ncb = (NEG + 15) / 16;            // column blocks of the precision part
+      const int nblk = 4 * (ncb + 1);             // + one column block for the mean part
+      for (int blk = wv; blk < nblk; blk += 8) {
+        const int bi = blk & 3, cb = blk >> 2;
+        const bool mean = cb == ncb;
+        const int col = (mean ? 0 : cb * 16) + (l & 15);
+        int a1 = 0, b1 = 0;
+        bool cvalid;
+        if (mean) { a1 = col; cvalid = col < D; }
+        else { cvalid = col < NEG; if (cvalid) { int rem = col; while (rem >= D - a1) { rem -= D - a1; ++a1; } b1 = a1 + rem; } }
+        const int row = bi * 16 + (l & 15);
+        gg_double4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int kk = 0; kk < EIG_T / 4; ++kk) {
+          const int m = kk * 4 + (l >> 4);
+          const double sv = s_S[row * (EIG_T + 1) + m];
+          const double xa = mean ? gg_fma(-mu0, sv, (double)s_a[row * EIG_T + m]) : sv;
+          double yb = 0.0;
+          if (cvalid) yb = mean ? s_dF[m * DM + a1] : s_dF[m * DM + a1] * s_dF[m * DM + b1];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
+        }
+        // lane l holds C[16 bi + 4 r + l / 16][col block + l % 16] in component r
+        if (cvalid) {
+          const int e = mean ? NEG + a1 : col;
 #pragma unroll
-        for (int a1 = 0; a1 < DM; ++a1)
-#pragma unroll
-          for (int b1 = a1; b1 < DM; ++b1) {
-            double v = 0.0;
-            if (FULL || b1 < D) { v = s_stat[e++]; if (a1 == b1) v += 1.0 / sigma_F; }
-            else if (a1 == b1) v = 1.0;
-            L[b1][a1] = v;   // lower triangle holds the precision
+          for (int r = 0; r < 4; ++r) {
+            const int i = bi * 16 + 4 * r + (l >> 4);
+            if (i < T) s_part[i * (NEGM + DM) + e] += acc[r];
           }
-      }
-#pragma unroll
-      for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? s_stat[NEG + a1] : 0.0;
-      bool ok = true;
-      // Cholesky (left-looking, same order as gg_chol_d)
-#pragma unroll
-      for (int j = 0; j < DM; ++j) {
-        double dsum = L[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) dsum = gg_fma(-L[j][k], L[j][k], dsum);
-        if (!(dsum > 0.0)) { ok = false; dsum = 1.0; }
-        // one reciprocal square root per column instead of D divisions (float-tolerance path)
-        double inv = __builtin_amdgcn_rsq(dsum);               // hardware estimate, then two Newton steps
-        inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
-        inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
-        L[j][j] = inv;           // the diagonal keeps 1 / L_jj: the solves only ever divide by it
-#pragma unroll
-        for (int i = j + 1; i < DM; ++i) {
-          double v = L[i][j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) v = gg_fma(-L[i][k], L[j][k], v);
-          L[i][j] = v * inv;
         }
       }
-      // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision)
-      double y[DM], zz[DM];
-#pragma unroll
-      for (int i = 0; i < DM; ++i) zz[i] = (FULL || i < D) ? s_Z[nl * DM + i] : 0.0;
-#pragma unroll
-      for (int i = 0; i < DM; ++i) {
-        double v = hh[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) v = gg_fma(-L[i][k], y[k] - zz[k], v);
-        y[i] = gg_fma(v, L[i][i], zz[i]);
+    }
+    __syncthreads();
+    if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[7], (unsigned long long)(clock64() - c_start));
+    load_block(t0, T);   // now the tile's own block, which the scan works on
+  }
+  // progress words (LDS): s_prog[0] = nodes whose rank-one change is published; s_prog[1 + w] = changes
+  // updater wave w has applied
+  volatile int* s_prog = reinterpret_cast<volatile int*>(s_a + EIG_T * EIG_T);
+  if (tid < 16) s_prog[tid] = 0;
+  __syncthreads();
+  // The scan is a software pipeline inside the workgroup.  Wave 0 (the solver) runs the per-node critical
+  // path only: fold the previous node's rank-one change into this node's statistics, solve the D x D
+  // Gaussian conditional, publish the new rank-one change.  Waves 1-7 (updaters) push every published
+  // change into the statistics of the nodes two or more positions later, in the background; each (node,
+  // entry) is always owned by the same updater lane, so changes reach it in ascending order, and the solver
+  // waits, before node nl, until every updater has applied change nl-2.  Accumulation order per entry is the
+  // same as before: partial sums, then the earlier nodes of the tile in ascending order.
+  const int wave = tid >> 6, lane = tid & 63;
+  const double inv_sigma_F = 1.0 / sigma_F;
+  if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(clock64() - c_start));
+  if (wave == 0) {
+    long long c_wait = 0, c_fold = 0, c_solve = 0;
+    for (int nl = 0; nl < T; ++nl) {
+      const int n = t0 + nl;
+      double* my = s_part + nl * (NEGM + DM);
+      const long long c0 = dbg ? clock64() : 0;
+      if (nl >= 2) {
+        for (int spin = 0;; ++spin) {
+          const int ok = (lane >= 1 && lane <= 7) ? (s_prog[lane] >= nl - 1) : 1;
+          if (__all(ok)) break;
+          if (spin > (1 << 22)) { if (lane == 0) atomicOr(status, 2); break; }   // never spin forever
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __threadfence_block();
       }
-#pragma unroll
-      for (int i = DM - 1; i >= 0; --i) {
-        double v = y[i];
-#pragma unroll
-        for (int k = i + 1; k < DM; ++k) v = gg_fma(-L[k][i], x[k], v);
-        x[i] = v * L[i][i];
+      const long long c1 = dbg ? clock64() : 0;
+      if (nl >= 1 && lane < NE) {
+        const int src = nl - 1, e = lane;
+        const double sv = s_S[nl * (EIG_T + 1) + src];
+        if (e < NEG) my[e] = gg_fma(sv, s_dP[src * NEGM + e], my[e]);
+        else my[e] = gg_fma(gg_fma(-mu0, sv, (double)s_a[nl * EIG_T + src]), s_dF[src * DM + (e - NEG)], my[e]);
       }
-      double fo[DM], fn[DM];
+      __threadfence_block();
+      const long long c2 = dbg ? clock64() : 0;
+      if (lane == 0) {
+        const double* s_stat = my;   // this node's statistics, corrections already applied
+        // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
+        double L[DM][DM], hh[DM], x[DM];
+        {
+          int e = 0;
 #pragma unroll
-      for (int a1 = 0; a1 < DM; ++a1) {
-        const double old = (FULL || a1 < D) ? s_Fo[nl * DM + a1] : 0.0;
-        if (!ok) x[a1] = old;
-        fo[a1] = old * lam[a1];
-        fn[a1] = x[a1] * lam[a1];
-      }
-      if (!ok) atomicOr(status, 1);
-      // rank-one change of this node's outer product, seen by the later nodes of the tile
-      {
-        int e = 0;
+          for (int a1 = 0; a1 < DM; ++a1)
+#pragma unroll
+            for (int b1 = a1; b1 < DM; ++b1) {
+              double v = 0.0;
+              if (FULL || b1 < D) { v = s_stat[e++]; if (a1 == b1) v += inv_sigma_F; }
+              else if (a1 == b1) v = 1.0;
+              L[b1][a1] = v;   // lower triangle holds the precision
+            }
+        }
+#pragma unroll
+        for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? s_stat[NEG + a1] : 0.0;
+        bool ok = true;
+        // Cholesky (left-looking, same order as gg_chol_d)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) {
+          double dsum = L[j][j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) dsum = gg_fma(-L[j][k], L[j][k], dsum);
+          if (!(dsum > 0.0)) { ok = false; dsum = 1.0; }
+          // one reciprocal square root per column instead of D divisions (float-tolerance path)
+          double inv = __builtin_amdgcn_rsq(dsum);               // hardware estimate, then two Newton steps
+          inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
+          inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
+          L[j][j] = inv;           // the diagonal keeps 1 / L_jj: the solves only ever divide by it
+#pragma unroll
+          for (int i = j + 1; i < DM; ++i) {
+            double v = L[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v = gg_fma(-L[i][k], L[j][k], v);
+            L[i][j] = v * inv;
+          }
+        }
+        // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision)
+        double y[DM], zz[DM];
+#pragma unroll
+        for (int i = 0; i < DM; ++i) zz[i] = (FULL || i < D) ? s_Z[nl * DM + i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < DM; ++i) {
+          double v = hh[i];
+#pragma unroll
+          for (int k = 0; k < i; ++k) v = gg_fma(-L[i][k], y[k] - zz[k], v);
+          y[i] = gg_fma(v, L[i][i], zz[i]);
+        }
+#pragma unroll
+        for (int i = DM - 1; i >= 0; --i) {
+          double v = y[i];
+#pragma unroll
+          for (int k = i + 1; k < DM; ++k) v = gg_fma(-L[k][i], x[k], v);
+          x[i] = v * L[i][i];
+        }
+        double fo[DM], fn[DM];
 #pragma unroll
         for (int a1 = 0; a1 < DM; ++a1) {
-          if (FULL || a1 < D) s_dF[nl * DM + a1] = fn[a1] - fo[a1];
-#pragma unroll
-          for (int b1 = a1; b1 < DM; ++b1)
-            if (FULL || b1 < D) s_dP[nl * NEGM + (e++)] = fn[a1] * fn[b1] - fo[a1] * fo[b1];
+          const double old = (FULL || a1 < D) ? s_Fo[nl * DM + a1] : 0.0;
+          if (!ok) x[a1] = old;
+          fo[a1] = old * lam[a1];
+          fn[a1] = x[a1] * lam[a1];
         }
-      }
+        if (!ok) atomicOr(status, 1);
+        // rank-one change of this node's outer product, seen by the later nodes of the tile
+        {
+          int e = 0;
 #pragma unroll
-      for (int a1 = 0; a1 < DM; ++a1)
-        if (FULL || a1 < D) F[(size_t)n * D + a1] = x[a1];
+          for (int a1 = 0; a1 < DM; ++a1) {
+            if (FULL || a1 < D) s_dF[nl * DM + a1] = fn[a1] - fo[a1];
+#pragma unroll
+            for (int b1 = a1; b1 < DM; ++b1)
+              if (FULL || b1 < D) s_dP[nl * NEGM + (e++)] = fn[a1] * fn[b1] - fo[a1] * fo[b1];
+          }
+        }
+#pragma unroll
+        for (int a1 = 0; a1 < DM; ++a1)
+          if (FULL || a1 < D) F[(size_t)n * D + a1] = x[a1];
+        __threadfence_block();
+        s_prog[0] = nl + 1;   // change nl is published
+      }
+      __threadfence_block();
+      if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_fold += c2 - c1; c_solve += c3 - c2; }
     }
-    __syncthreads();
-    // right-looking update: push this node's rank-one change into the statistics of the later nodes
-    // (same accumulation order as a per-node loop over the earlier nodes: partial, then n2 ascending)
-    const int rem = (dbg & 2) ? 0 : T - nl - 1;
-    for (int idx = tid; idx < rem * NE; idx += 512) {
-      const int i = nl + 1 + idx / NE, e = idx % NE;
-      const double sv = s_S[i * (EIG_T + 1) + nl];
-      double* dst = s_part + i * (NEGM + DM) + e;
-      if (e < NEG) *dst = gg_fma(sv, s_dP[nl * NEGM + e], *dst);
-      else *dst = gg_fma(gg_fma(-mu0, sv, (double)s_a[i * EIG_T + nl]), s_dF[nl * DM + (e - NEG)], *dst);
+    if (dbg && lane == 0) { atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)c_wait); atomicAdd((unsigned long long*)&dbg[1], (unsigned long long)c_fold); atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)c_solve); atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T); }
+  } else {
+    const int u = tid - 64, NU = 512 - 64;
+    for (int k = 0; k + 2 < T; ++k) {          // change k goes to nodes k+2 .. T-1 (node k+1 is the solver's)
+      for (int spin = 0; s_prog[0] < k + 1; ++spin) {
+        if (spin > (1 << 22)) { if (lane == 0) atomicOr(status, 2); break; }   // never spin forever
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __threadfence_block();
+      for (int idx = u; idx < T * NE; idx += NU) {   // fixed ownership of (node, entry) by lane
+        const int i = idx / NE, e = idx % NE;
+        if (i < k + 2) continue;
+        const double sv = s_S[i * (EIG_T + 1) + k];
+        double* dst = s_part + i * (NEGM + DM) + e;
+        if (e < NEG) *dst = gg_fma(sv, s_dP[k * NEGM + e], *dst);
+        else *dst = gg_fma(gg_fma(-mu0, sv, (double)s_a[i * EIG_T + k]), s_dF[k * DM + (e - NEG)], *dst);
+      }
+      __threadfence_block();
+      if (lane == 0) s_prog[wave] = k + 1;
     }
-    __syncthreads();
   }
 }
 
@@ -539,8 +682,8 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   const size_t N = e->N, D = e->D;
   if ((rc = emalloc(&e->F, N * D)) || (rc = emalloc(&e->lmbda, D)) || (rc = emalloc(&e->mu0, 1)) ||
       (rc = emalloc(&e->mu_lmbda, D)) || (rc = emalloc(&e->S, N * e->Np)) || (rc = emalloc(&e->dO, N)) ||
-      (rc = emalloc(&e->Z, N * D)) || (rc = emalloc(&e->part, (size_t)EIG_T * e->NCH * e->NE)) ||
-      (rc = emalloc(&e->gpart, N * e->NG)) || (rc = emalloc(&e->status, 1)))
+      (rc = emalloc(&e->Z, N * D)) || (rc = emalloc(&e->part, (size_t)2 * EIG_T * e->NCH * e->NE)) ||
+      (rc = emalloc(&e->gpart, N * e->NG)) || (rc = emalloc(&e->status, 1)) || (rc = emalloc(&e->dbgbuf, 8)))
     return rc;
   const size_t nt = (N + 31) / 32;
   if ((rc = emalloc(&e->llpart, nt * nt))) return rc;
@@ -637,11 +780,13 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     return gg_fail(GG_ERR_INVALID, "eigenmodel: resample F / mu_0 / lambda needs the auxiliary variables (GG_PART_OMEGA) first");
   if (parts & GG_PART_F) {
     k_eig_normals<<<(N * D + 255) / 256, 256, 0, st>>>(e->Z, N * D, e->cfg.seed, GG_SITE_EIG_F, e->sweep);
-    static int dbg = -1;
-    if (dbg < 0) { const char* ev = getenv("GG_EIG_DBG"); dbg = ev ? atoi(ev) : 0; }
+    static int dbgon = -1;
+    if (dbgon < 0) { const char* ev = getenv("GG_EIG_DBG"); dbgon = ev ? atoi(ev) : 0; }
+    long long* dbg = dbgon ? e->dbgbuf : nullptr;
+    if (dbg) GG_HIP(hipMemsetAsync(dbg, 0, 8 * sizeof(long long), st));
     const int DMv = e->DM, NEGMv = DMv * (DMv + 1) / 2;
     const size_t chain_lds = (((size_t)EIG_T * (EIG_T + 1) + (size_t)EIG_T * NEGMv + 3 * (size_t)EIG_T * DMv +
-                               (size_t)EIG_T * (NEGMv + DMv) + (NEGMv + DMv)) * sizeof(double) + (size_t)EIG_T * EIG_T + 15) & ~(size_t)15;
+                               (size_t)EIG_T * (NEGMv + DMv) + (NEGMv + DMv)) * sizeof(double) + (size_t)EIG_T * EIG_T + 64 + 15) & ~(size_t)15;
     static bool attr4 = false, attr8 = false;
     if (DMv == 4 && !attr4) {
       GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
@@ -653,17 +798,28 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
       GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
       attr8 = true;
     }
-    for (int t0 = 0; t0 < N; t0 += EIG_T) {
-      const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
-      dim3 grd(T, e->NCH);
+    // Tile 0's statistics in a launch of their own; every chain launch then carries, as extra workgroups, the
+    // statistics of the tile after it (all nodes outside both tiles), and adds the previous tile's nodes itself.
+    const size_t part_stride = (size_t)EIG_T * e->NCH * e->NE;
+    {
+      dim3 grd(N < EIG_T ? N : EIG_T, e->NCH);
+#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, 0)
+      EIG_DISPATCH(CALL);
+#undef CALL
+    }
+    int ti = 0;
+    for (int t0 = 0; t0 < N; t0 += EIG_T, ++ti) {
+      double* partb = e->part + (size_t)(ti & 1) * part_stride;
+      double* partn = e->part + (size_t)((ti + 1) & 1) * part_stride;
+      const int Tn = (t0 + EIG_T < N) ? ((N - t0 - EIG_T < EIG_T) ? (N - t0 - EIG_T) : EIG_T) : 0;
+      const int grid = 1 + Tn * e->NCH;
 #define CALL(DMV)                                                                                                      \
-  k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part); \
   if (D == DMV)                                                                                                        \
-    k_eig_chain<DMV, true><<<1, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,          \
-                                                      e->cfg.sigma_F, e->NCH, e->part, e->Z, e->status, dbg);           \
+    k_eig_chain<DMV, true><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,       \
+                                                         e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn);   \
   else                                                                                                                 \
-    k_eig_chain<DMV, false><<<1, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,         \
-                                                       e->cfg.sigma_F, e->NCH, e->part, e->Z, e->status, dbg)
+    k_eig_chain<DMV, false><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,      \
+                                                          e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -687,6 +843,11 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   float ms = 0;
   GG_HIP(hipEventElapsedTime(&ms, e->e0, e->e1));
   e->st.total_ms = ms;
+  if (getenv("GG_EIG_DBG") && (parts & GG_PART_F)) {
+    long long h[8];
+    (void)hipMemcpy(h, e->dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
+    if (h[3]) fprintf(stderr, "[eig chain] per node: wait %.0f fold %.0f solve %.0f shader clocks (%lld nodes); prologue %.0f clocks per tile (block %.0f, +loads %.0f, +cross %.0f)\n", (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / ((h[3] + EIG_T - 1) / EIG_T), (double)h[5] / 64, (double)h[6] / 64, (double)h[7] / 64);
+  }
   if (stv) {
     int z = 0;
     (void)hipMemcpy(e->status, &z, sizeof(int), hipMemcpyHostToDevice);
