@@ -347,8 +347,10 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
   // progress words (LDS): s_prog[0] = nodes whose rank-one change is published; s_prog[1 + w] = changes
   // updater wave w has applied
   volatile int* s_prog = reinterpret_cast<volatile int*>(s_a + EIG_T * EIG_T);
-  if (tid < 16) s_prog[tid] = 0;
+  if (tid < 16) s_prog[tid] = (tid == 2) ? 0xff : 0;   // bytes 8..15: one progress byte per updater wave (byte 8 unused: 255)
   __syncthreads();
+  volatile unsigned char* s_progb = reinterpret_cast<volatile unsigned char*>(s_prog + 2);
+  volatile unsigned long long* s_progq = reinterpret_cast<volatile unsigned long long*>(s_prog + 2);
   // The scan is a software pipeline inside the workgroup.  Wave 0 (the solver) runs the per-node critical
   // path only: fold the previous node's rank-one change into this node's statistics, solve the D x D
   // Gaussian conditional, publish the new rank-one change.  Waves 1-7 (updaters) push every published
@@ -360,31 +362,38 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
   const double inv_sigma_F = 1.0 / sigma_F;
   if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(clock64() - c_start));
   if (wave == 0) {
-    long long c_wait = 0, c_fold = 0, c_solve = 0;
-    for (int nl = 0; nl < T; ++nl) {
-      const int n = t0 + nl;
-      double* my = s_part + nl * (NEGM + DM);
-      const long long c0 = dbg ? clock64() : 0;
-      if (nl >= 2) {
-        for (int spin = 0;; ++spin) {
-          const int ok = (lane >= 1 && lane <= 7) ? (s_prog[lane] >= nl - 1) : 1;
-          if (__all(ok)) break;
-          if (spin > (1 << 22)) { if (lane == 0) atomicOr(status, 2); break; }   // never spin forever
-          __builtin_amdgcn_s_sleep(1);
+    if (lane == 0) {   // the critical path is one lane's dependent arithmetic; the rest of the wave stays out of it
+      long long c_wait = 0, c_solve = 0;
+      double dPp[NEGM], dFp[DM];   // the previous node's rank-one change (registers)
+#pragma unroll
+      for (int e = 0; e < NEGM; ++e) dPp[e] = 0.0;
+#pragma unroll
+      for (int a1 = 0; a1 < DM; ++a1) dFp[a1] = 0.0;
+      bool ready = true;           // "every updater has applied change nl-2", checked one node ahead
+      for (int nl = 0; nl < T; ++nl) {
+        const int n = t0 + nl;
+        const double* s_stat = s_part + nl * (NEGM + DM);
+        const long long c0 = dbg ? clock64() : 0;
+        if (!ready) {
+          for (int spin = 0;; ++spin) {
+            const unsigned long long q = *s_progq;   // one load: the seven progress bytes
+            int mn = 255;
+#pragma unroll
+            for (int w = 1; w <= 7; ++w) { const int v = (int)((q >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
+            if (mn >= nl - 1) break;
+            if (spin > (1 << 22)) { atomicOr(status, 2); break; }   // never spin forever
+            __builtin_amdgcn_s_sleep(1);
+          }
         }
         __threadfence_block();
-      }
-      const long long c1 = dbg ? clock64() : 0;
-      if (nl >= 1 && lane < NE) {
-        const int src = nl - 1, e = lane;
-        const double sv = s_S[nl * (EIG_T + 1) + src];
-        if (e < NEG) my[e] = gg_fma(sv, s_dP[src * NEGM + e], my[e]);
-        else my[e] = gg_fma(gg_fma(-mu0, sv, (double)s_a[nl * EIG_T + src]), s_dF[src * DM + (e - NEG)], my[e]);
-      }
-      __threadfence_block();
-      const long long c2 = dbg ? clock64() : 0;
-      if (lane == 0) {
-        const double* s_stat = my;   // this node's statistics, corrections already applied
+        const long long c1 = dbg ? clock64() : 0;
+        // statistics of this node with the previous node's change folded in (same order as the updaters':
+        // earlier changes first, the previous node's last)
+        double svp = 0.0, cfp = 0.0;
+        if (nl >= 1) {
+          svp = s_S[nl * (EIG_T + 1) + nl - 1];
+          cfp = gg_fma(-mu0, svp, (double)s_a[nl * EIG_T + nl - 1]);
+        }
         // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
         double L[DM][DM], hh[DM], x[DM];
         {
@@ -394,13 +403,13 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
 #pragma unroll
             for (int b1 = a1; b1 < DM; ++b1) {
               double v = 0.0;
-              if (FULL || b1 < D) { v = s_stat[e++]; if (a1 == b1) v += inv_sigma_F; }
+              if (FULL || b1 < D) { v = gg_fma(svp, dPp[e], s_stat[e]); ++e; if (a1 == b1) v += inv_sigma_F; }
               else if (a1 == b1) v = 1.0;
               L[b1][a1] = v;   // lower triangle holds the precision
             }
         }
 #pragma unroll
-        for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? s_stat[NEG + a1] : 0.0;
+        for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? gg_fma(cfp, dFp[a1], s_stat[NEG + a1]) : 0.0;
         bool ok = true;
         // Cholesky (left-looking, same order as gg_chol_d)
 #pragma unroll
@@ -433,12 +442,21 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           for (int k = 0; k < i; ++k) v = gg_fma(-L[i][k], y[k] - zz[k], v);
           y[i] = gg_fma(v, L[i][i], zz[i]);
         }
+        // progress of the updaters, read now for the NEXT node (needs change nl-1 applied everywhere): the
+        // words arrive while the back substitution runs
+        const unsigned long long pq = *s_progq;   // one load: the seven progress bytes
 #pragma unroll
         for (int i = DM - 1; i >= 0; --i) {
           double v = y[i];
 #pragma unroll
           for (int k = i + 1; k < DM; ++k) v = gg_fma(-L[k][i], x[k], v);
           x[i] = v * L[i][i];
+        }
+        {
+          int mn = 255;
+#pragma unroll
+          for (int w = 1; w <= 7; ++w) { const int v = (int)((pq >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
+          ready = (nl + 1 < 2) || (mn >= nl);
         }
         double fo[DM], fn[DM];
 #pragma unroll
@@ -454,10 +472,11 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           int e = 0;
 #pragma unroll
           for (int a1 = 0; a1 < DM; ++a1) {
-            if (FULL || a1 < D) s_dF[nl * DM + a1] = fn[a1] - fo[a1];
+            dFp[a1] = fn[a1] - fo[a1];
+            if (FULL || a1 < D) s_dF[nl * DM + a1] = dFp[a1];
 #pragma unroll
             for (int b1 = a1; b1 < DM; ++b1)
-              if (FULL || b1 < D) s_dP[nl * NEGM + (e++)] = fn[a1] * fn[b1] - fo[a1] * fo[b1];
+              if (FULL || b1 < D) { dPp[e] = fn[a1] * fn[b1] - fo[a1] * fo[b1]; s_dP[nl * NEGM + e] = dPp[e]; ++e; }
           }
         }
 #pragma unroll
@@ -465,29 +484,52 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           if (FULL || a1 < D) F[(size_t)n * D + a1] = x[a1];
         __threadfence_block();
         s_prog[0] = nl + 1;   // change nl is published
+        if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_solve += c3 - c1; }
       }
-      __threadfence_block();
-      if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_fold += c2 - c1; c_solve += c3 - c2; }
+      if (dbg) { atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)c_wait); atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)c_solve); atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T); }
     }
-    if (dbg && lane == 0) { atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)c_wait); atomicAdd((unsigned long long*)&dbg[1], (unsigned long long)c_fold); atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)c_solve); atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T); }
   } else {
-    const int u = tid - 64, NU = 512 - 64;
+    // updaters: every lane owns up to RU fixed (node, entry) pairs and keeps their running values in registers;
+    // per change it needs two or three independent LDS reads per pair (issued as one batch), one fma, one store
+    constexpr int NU = 512 - 64;
+    constexpr int RU = (EIG_T * (NEGM + DM) + NU - 1) / NU;
+    const int u = tid - 64;
+    int ui[RU], ue[RU];
+    double val[RU];
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      const int idx = u + NU * r;
+      const bool v = idx < T * NE;
+      ui[r] = v ? idx / NE : -1;
+      ue[r] = v ? idx % NE : 0;
+      val[r] = v ? s_part[ui[r] * (NEGM + DM) + ue[r]] : 0.0;
+    }
     for (int k = 0; k + 2 < T; ++k) {          // change k goes to nodes k+2 .. T-1 (node k+1 is the solver's)
       for (int spin = 0; s_prog[0] < k + 1; ++spin) {
         if (spin > (1 << 22)) { if (lane == 0) atomicOr(status, 2); break; }   // never spin forever
         __builtin_amdgcn_s_sleep(1);
       }
       __threadfence_block();
-      for (int idx = u; idx < T * NE; idx += NU) {   // fixed ownership of (node, entry) by lane
-        const int i = idx / NE, e = idx % NE;
-        if (i < k + 2) continue;
-        const double sv = s_S[i * (EIG_T + 1) + k];
-        double* dst = s_part + i * (NEGM + DM) + e;
-        if (e < NEG) *dst = gg_fma(sv, s_dP[k * NEGM + e], *dst);
-        else *dst = gg_fma(gg_fma(-mu0, sv, (double)s_a[i * EIG_T + k]), s_dF[k * DM + (e - NEG)], *dst);
+      double sv[RU], dd[RU], aa[RU];
+#pragma unroll
+      for (int r = 0; r < RU; ++r) {
+        const bool act = ui[r] >= k + 2;
+        const int i = act ? ui[r] : 0, e = ue[r];
+        sv[r] = s_S[i * (EIG_T + 1) + k];
+        dd[r] = (e < NEG) ? s_dP[k * NEGM + e] : s_dF[k * DM + (e - NEG)];
+        aa[r] = (double)s_a[i * EIG_T + k];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < RU; ++r) {
+        if (ui[r] >= k + 2) {
+          const double coef = (ue[r] < NEG) ? sv[r] : gg_fma(-mu0, sv[r], aa[r]);
+          val[r] = gg_fma(coef, dd[r], val[r]);
+          s_part[ui[r] * (NEGM + DM) + ue[r]] = val[r];
+        }
       }
       __threadfence_block();
-      if (lane == 0) s_prog[wave] = k + 1;
+      if (lane == 0) s_progb[wave] = (unsigned char)(k + 1);
     }
   }
 }
