@@ -168,9 +168,14 @@ def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
     mu0 = mu_mu0 + rng.randn()
     Mu = mu0 + (F * lam).dot(F.T)
     np.fill_diagonal(Mu, mu0)
-    A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-Mu))).astype(np.uint8)
+    probit = args.config == "probit"
+    if probit:
+        from scipy.special import ndtr
+        A = (rng.rand(N, N) < ndtr(Mu)).astype(np.uint8)
+    else:
+        A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-Mu))).astype(np.uint8)
     data = abi.DeviceData(A, None, device=device)
-    m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=1 + rank, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0,
+    m = abi.Model(kind=abi.PROBIT_EIG if probit else abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=1 + rank, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0,
                   mu_mu_0=mu_mu0, device=device)
     crng = np.random.RandomState(1 + rank)
     F0, l0, m0 = crng.randn(N, D), crng.randn(D), mu_mu0 + crng.randn()
@@ -188,7 +193,8 @@ def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "Logistic eigenmodel Gibbs (Polya-gamma), N=%d, D=%d (BASELINE.json configs[2])" % (N, D),
+           "config": {"workload": ("Probit eigenmodel Gibbs (truncated-normal auxiliaries), N=%d, D=%d (SURVEY.md 8f rank 2)" % (N, D)) if probit else
+                                  ("Logistic eigenmodel Gibbs (Polya-gamma), N=%d, D=%d (BASELINE.json configs[2])" % (N, D)),
                       "sweep_algorithmic_bytes": sweep_bytes},
            "roofline": {"bound": "hbm", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": sweep_bytes * args.steps / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -198,7 +204,7 @@ def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
         from oracle import oracle as O
         Fo, lo = F0.copy(), l0.copy()
         t0 = time.perf_counter()
-        O.eig_sweep(A, Fo, lo, m0, np.zeros(D), mu_mu0, 1.0, 1.0, 1.0, 0, 1, 0)
+        (O.probit_sweep if probit else O.eig_sweep)(A, Fo, lo, m0, np.zeros(D), mu_mu0, 1.0, 1.0, 1.0, 0, 1, 0)
         el1 = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / el1, "unit": "sweeps/s", "cores": 1, "kind": "port",
                                "sample": "1 full sweep of the same N=%d D=%d network, oracle/ C++ -O2, 1 thread" % (N, D)}
@@ -262,7 +268,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shard", action="store_true",
                     help="one chain sharded over the ranks (strong scaling) instead of an independent chain per rank")
-    ap.add_argument("--config", default="sbm", choices=["sbm", "eigen"],
+    ap.add_argument("--config", default="sbm", choices=["sbm", "eigen", "probit"],
                     help="sbm = BASELINE.json configs[1] (default, the headline); eigen = configs[2]")
     ap.add_argument("--latent", type=int, default=8)
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,7 +337,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if args.config == "eigen":
+    if args.config in ("eigen", "probit"):
         bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks)
         if dist is not None:
             dist.barrier()

@@ -22,6 +22,7 @@
 
 #include "gg_common.h"
 #include "spec/gg_pg.h"
+#include "spec/gg_probit.h"
 
 #define EIG_T 64          // nodes per tile of the F scan
 #define EIG_CHN 4096      // neighbours per workgroup in k_eig_tile_stats (1024 threads x 4)
@@ -29,6 +30,7 @@
 struct gg_eigen {
   gg_config cfg;
   int N, D, Np, DM;
+  int probit;            // GG_PROBIT_EIG: buffer S holds Z_ij + Z_ji, the pair weight is the constant 2
   int NEG, NE, NG;        // D(D+1)/2, NEG + D, 2 + 2D + NEG
   int NCH;
   double *F, *lmbda, *mu0, *mu_lmbda;
@@ -140,6 +142,66 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
   }
 }
 
+// Probit auxiliaries (eigenmodel.py:274-293): Z_ij ~ N(psi_ij, 1) truncated to Z > 0 where A_ij = 1 and Z < 0 where
+// A_ij = 0.  Z enters the conditionals only through Z_ij + Z_ji off the diagonal (:312-321, :339-346, :363-372),
+// which is what this kernel stores in S (symmetric, diagonal 0): same tiling as k_eig_omega.
+template <int DM>
+__global__ __launch_bounds__(256) void k_eig_z(int N, int Np, int D, const double* __restrict__ F,
+                                               const double* __restrict__ lmbda, const double* __restrict__ mu0p,
+                                               const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                               uint64_t seed, uint32_t sweep, double* __restrict__ S) {
+  __shared__ double s_fi[32][DM], s_fj[32][DM];
+  __shared__ double s_t[32][33];
+  __shared__ double s_psi[32][33];
+  const int nt = (N + 31) / 32;
+  int I, J;
+  eig_tile_pair(blockIdx.x, nt, &I, &J);
+  const int tid = threadIdx.x;
+  const double mu0 = *mu0p;
+  for (int e = tid; e < 32 * DM; e += 256) {
+    int r = e / DM, d = e % DM;
+    int gi = I * 32 + r, gj = J * 32 + r;
+    s_fi[r][d] = (d < D && gi < N) ? F[(size_t)gi * D + d] * lmbda[d] : 0.0;
+    s_fj[r][d] = (d < D && gj < N) ? F[(size_t)gj * D + d] : 0.0;
+  }
+  __syncthreads();
+  eig_psi_tile_mfma<DM>(s_fi, s_fj, mu0, s_psi);
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256) {
+    const int li = e >> 5, lj = e & 31;
+    const int gi = I * 32 + li, gj = J * 32 + lj;
+    double val = 0.0;
+    if (gi < N && gj < N && (I < J || li < lj)) {
+      const double psi = s_psi[li][lj];
+      const size_t at = (size_t)gi * Np + gj;
+      const double z1 = gg_truncnorm_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gj, psi, A[at] ? 1 : 0);
+      const double z2 = gg_truncnorm_at(seed, sweep, (uint32_t)N, (uint32_t)gj, (uint32_t)gi, psi, AT[at] ? 1 : 0);
+      val = z1 + z2;
+    }
+    if (I < J || li <= lj) s_t[li][lj] = val;
+  }
+  __syncthreads();
+  if (I == J) {
+    for (int e = tid; e < 1024; e += 256) {
+      const int li = e >> 5, lj = e & 31;
+      if (li > lj) s_t[li][lj] = s_t[lj][li];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 1024; e += 256) {
+    const int li = e >> 5, lj = e & 31;
+    const int gi = I * 32 + li, gj = J * 32 + lj;
+    if (gi < N && gj < N) S[(size_t)gi * Np + gj] = s_t[li][lj];
+  }
+  if (I < J) {
+    for (int e = tid; e < 1024; e += 256) {
+      const int lj = e >> 5, li = e & 31;   // transposed tile, coalesced over li
+      const int gi = I * 32 + li, gj = J * 32 + lj;
+      if (gi < N && gj < N) S[(size_t)gj * Np + gi] = s_t[li][lj];
+    }
+  }
+}
+
 // Gram statistics of the tile's nodes against the current F (eigenmodel.py:894-901):
 //   G_n[a,b] = sum_{nn != n} S[n,nn] ft_a ft_b,  h_n[a] = sum_{nn != n} ((A[n,nn]+A[nn,n]-1) - mu_0 S[n,nn]) ft_a,
 // ft = F[nn] * lambda.  One workgroup per (node, chunk of EIG_CHN neighbours).
@@ -148,7 +210,8 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
                                                         const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                         const double* __restrict__ F, const double* __restrict__ lmbda,
                                                         const double* __restrict__ mu0p, int NCH,
-                                                        double* __restrict__ part, int ex_lo, int ex_hi, int node, int c) {
+                                                        double* __restrict__ part, int ex_lo, int ex_hi, int node, int c,
+                                                        int probit) {
   // nodes [ex_lo, ex_hi) (the previous tile, whose scan is still running) are left out: the chain adds them
   constexpr int NEGM = DM * (DM + 1) / 2;
   const int n = t0 + node;
@@ -163,8 +226,10 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
   const int lo = c * EIG_CHN, hi = (lo + EIG_CHN < N) ? lo + EIG_CHN : N;
   for (int nn = lo + threadIdx.x; nn < hi; nn += nth) {
     if (nn == n || (nn >= ex_lo && nn < ex_hi)) continue;
-    const double s = S[(size_t)n * Np + nn];
-    const double a = (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
+    // logistic: s = omega_ij + omega_ji, a = kappa_ij + kappa_ji; probit (eigenmodel.py:312-321): s = 2, a = Z_ij + Z_ji
+    const double raw = S[(size_t)n * Np + nn];
+    const double s = probit ? 2.0 : raw;
+    const double a = probit ? raw : (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
     const double v = a - mu0 * s;
     double ft[DM];
 #pragma unroll
@@ -215,8 +280,8 @@ __global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, i
                                                         const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                         const double* __restrict__ F, const double* __restrict__ lmbda,
                                                         const double* __restrict__ mu0p, int NCH,
-                                                        double* __restrict__ part, int ex_lo, int ex_hi) {
-  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, ex_hi, blockIdx.x, blockIdx.y);
+                                                        double* __restrict__ part, int ex_lo, int ex_hi, int probit) {
+  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, ex_hi, blockIdx.x, blockIdx.y, probit);
 }
 
 template <int DM, bool FULL>
@@ -226,13 +291,13 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
                                                    const double* __restrict__ mu0p, double sigma_F, int NCH,
                                                    const double* __restrict__ part, const double* __restrict__ Z,
                                                    int* __restrict__ status, long long* __restrict__ dbg,
-                                                   double* __restrict__ part_next) {
+                                                   double* __restrict__ part_next, int probit) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   if (blockIdx.x > 0) {
     // riders: the statistics of the NEXT tile (all nodes outside this tile and the next), computed while
     // workgroup 0 scans this one; the next launch's chain adds this tile's nodes with their new features
     const int idx = blockIdx.x - 1;
-    eig_tile_stats_body<DM>(N, Np, Drt, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, t0 + EIG_T, idx / NCH, idx % NCH);
+    eig_tile_stats_body<DM>(N, Np, Drt, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, t0 + EIG_T, idx / NCH, idx % NCH, probit);
     return;
   }
   extern __shared__ __align__(16) unsigned char s_chain[];
@@ -323,8 +388,9 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
 #pragma unroll 4
         for (int kk = 0; kk < EIG_T / 4; ++kk) {
           const int m = kk * 4 + (l >> 4);
-          const double sv = s_S[row * (EIG_T + 1) + m];
-          const double xa = mean ? gg_fma(-mu0, sv, (double)s_a[row * EIG_T + m]) : sv;
+          const double raw = s_S[row * (EIG_T + 1) + m];
+          const double sv = probit ? 2.0 : raw;
+          const double xa = mean ? gg_fma(-mu0, sv, probit ? raw : (double)s_a[row * EIG_T + m]) : sv;
           double yb = 0.0;
           if (cvalid) yb = mean ? s_dF[m * DM + a1] : s_dF[m * DM + a1] * s_dF[m * DM + b1];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
@@ -391,8 +457,9 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
         // earlier changes first, the previous node's last)
         double svp = 0.0, cfp = 0.0;
         if (nl >= 1) {
-          svp = s_S[nl * (EIG_T + 1) + nl - 1];
-          cfp = gg_fma(-mu0, svp, (double)s_a[nl * EIG_T + nl - 1]);
+          const double raw = s_S[nl * (EIG_T + 1) + nl - 1];
+          svp = probit ? 2.0 : raw;
+          cfp = gg_fma(-mu0, svp, probit ? raw : (double)s_a[nl * EIG_T + nl - 1]);
         }
         // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
         double L[DM][DM], hh[DM], x[DM];
@@ -523,7 +590,8 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
 #pragma unroll
       for (int r = 0; r < RU; ++r) {
         if (ui[r] >= k + 2) {
-          const double coef = (ue[r] < NEG) ? sv[r] : gg_fma(-mu0, sv[r], aa[r]);
+          const double svr = probit ? 2.0 : sv[r];
+          const double coef = (ue[r] < NEG) ? svr : gg_fma(-mu0, svr, probit ? sv[r] : aa[r]);
           val[r] = gg_fma(coef, dd[r], val[r]);
           s_part[ui[r] * (NEGM + DM) + ue[r]] = val[r];
         }
@@ -540,7 +608,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
 template <int DM>
 __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const double* __restrict__ S,
                                                     const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
-                                                    const double* __restrict__ F, double* __restrict__ gpart) {
+                                                    const double* __restrict__ F, double* __restrict__ gpart, int probit) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   constexpr int NGM = 2 + 2 * DM + NEGM;
   double acc[NGM];
@@ -551,8 +619,9 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
 #pragma unroll
   for (int d = 0; d < DM; ++d) fi[d] = d < D ? F[(size_t)i * D + d] : 0.0;
   for (int j = i + 1 + threadIdx.x; j < N; j += 256) {
-    const double s = S[(size_t)i * Np + j];
-    const double a = (double)((int)A[(size_t)i * Np + j] + (int)AT[(size_t)i * Np + j] - 1);
+    const double raw = S[(size_t)i * Np + j];
+    const double s = probit ? 2.0 : raw;
+    const double a = probit ? raw : (double)((int)A[(size_t)i * Np + j] + (int)AT[(size_t)i * Np + j] - 1);
     double g[DM];
 #pragma unroll
     for (int d = 0; d < DM; ++d) g[d] = d < D ? fi[d] * F[(size_t)j * D + d] : 0.0;
@@ -590,7 +659,7 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, 
                                                           double* __restrict__ lmbda, double* __restrict__ mu0p,
                                                           const double* __restrict__ mu_lmbda, double mu_mu_0,
                                                           double sigma_mu0, double sigma_lmbda, int do_mu0, int do_lmbda,
-                                                          uint64_t seed, uint32_t sweep, int* __restrict__ status) {
+                                                          uint64_t seed, uint32_t sweep, int* __restrict__ status, int probit) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   constexpr int NGM = 2 + 2 * DM + NEGM;
   __shared__ double s_tot[NGM + 2];
@@ -611,7 +680,8 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, 
   }
   // diagonal: sum omega_ii and sum (A_ii - 1/2)
   double so = 0.0, sk = 0.0;
-  for (int i = tid; i < N; i += 256) { so += dO[i]; sk += (dA[i] ? 1.0 : 0.0) - 0.5; }
+  if (!probit)   // (the probit bias update leaves the diagonal out altogether: eigenmodel.py:339-346)
+    for (int i = tid; i < N; i += 256) { so += dO[i]; sk += (dA[i] ? 1.0 : 0.0) - 0.5; }
   for (int dl = 32; dl >= 1; dl >>= 1) { so += __shfl_down(so, dl); sk += __shfl_down(sk, dl); }
   if ((tid & 63) == 0) { s_w[tid >> 6][0] = so; s_w[tid >> 6][1] = sk; }
   __syncthreads();
@@ -658,7 +728,7 @@ template <int DM>
 __global__ __launch_bounds__(256) void k_eig_loglik(int N, int Np, int D, const uint8_t* __restrict__ A,
                                                     const uint8_t* __restrict__ dA, const double* __restrict__ F,
                                                     const double* __restrict__ lmbda, const double* __restrict__ mu0p,
-                                                    double* __restrict__ llpart) {
+                                                    double* __restrict__ llpart, int probit) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
   __shared__ double s_psi[32][33];
   __shared__ double s_w[4];
@@ -686,7 +756,7 @@ __global__ __launch_bounds__(256) void k_eig_loglik(int N, int Np, int D, const 
         psi = s_psi[li][lj];
         a = A[(size_t)gi * Np + gj];
       }
-      double P = 1.0 / (1.0 + gg_exp(-psi));
+      double P = probit ? gg_norm_cdf(psi) : 1.0 / (1.0 + gg_exp(-psi));   // eigenmodel.py:228-237 / :803-811
       P = P < 1e-16 ? 1e-16 : (P > 1.0 - 1e-16 ? 1.0 - 1e-16 : P);
       ll += a ? gg_log(P) : gg_log(1.0 - P);
     }
@@ -713,6 +783,7 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   gg_eigen* e = new gg_eigen();
   e->cfg = *cfg;
   e->N = cfg->N; e->D = cfg->D; e->Np = gg_round_up(cfg->N, 64);
+  e->probit = cfg->kind == GG_PROBIT_EIG ? 1 : 0;
   e->DM = cfg->D <= 4 ? 4 : 8;
   e->NEG = e->D * (e->D + 1) / 2; e->NE = e->NEG + e->D;
   e->NG = 2 + 2 * e->DM + e->DM * (e->DM + 1) / 2;
@@ -813,9 +884,15 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   if (parts & GG_PART_OMEGA) {
     const int nt = (N + 31) / 32;
     const int npairs = nt * (nt + 1) / 2;
-#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO)
-    EIG_DISPATCH(CALL);
+    if (e->probit) {
+#define CALL(DMV) k_eig_z<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, d->A, d->AT, e->cfg.seed, e->sweep, e->S)
+      EIG_DISPATCH(CALL);
 #undef CALL
+    } else {
+#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO)
+      EIG_DISPATCH(CALL);
+#undef CALL
+    }
     e->have_omega = true;
   }
   if ((parts & (GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) && !e->have_omega)
@@ -845,7 +922,7 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     const size_t part_stride = (size_t)EIG_T * e->NCH * e->NE;
     {
       dim3 grd(N < EIG_T ? N : EIG_T, e->NCH);
-#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, 0)
+#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, 0, e->probit)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -858,10 +935,10 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
 #define CALL(DMV)                                                                                                      \
   if (D == DMV)                                                                                                        \
     k_eig_chain<DMV, true><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,       \
-                                                         e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn);   \
+                                                         e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit); \
   else                                                                                                                 \
     k_eig_chain<DMV, false><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,      \
-                                                          e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn)
+                                                          e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -870,10 +947,10 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   const int do_lm = ((parts & GG_PART_LMBDA) && !e->cfg.lmbda_given) ? 1 : 0;
   if (do_mu0 || do_lm) {
 #define CALL(DMV)                                                                                                   \
-  k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart);               \
+  k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart, e->probit);    \
   k_eig_draw_globals<DMV><<<1, 256, 0, st>>>(N, (N < 512 ? N : 512), D, e->gpart, e->dO, d->dA, e->lmbda, e->mu0, e->mu_lmbda,            \
                                              e->cfg.mu_mu_0, e->cfg.sigma_mu0, e->cfg.sigma_lmbda, do_mu0, do_lm,   \
-                                             e->cfg.seed, e->sweep, e->status)
+                                             e->cfg.seed, e->sweep, e->status, e->probit)
     EIG_DISPATCH(CALL);
 #undef CALL
   }
@@ -904,7 +981,7 @@ int gg_eigen_log_likelihood(gg_eigen* e, const gg_data* d, double* out) {
   if (d->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, e->N);
   const int N = e->N, nt = (N + 31) / 32;
   dim3 grd(nt, nt);
-#define CALL(DMV) k_eig_loglik<DMV><<<grd, 256, 0, e->stream>>>(N, e->Np, e->D, d->A, d->dA, e->F, e->lmbda, e->mu0, e->llpart)
+#define CALL(DMV) k_eig_loglik<DMV><<<grd, 256, 0, e->stream>>>(N, e->Np, e->D, d->A, d->dA, e->F, e->lmbda, e->mu0, e->llpart, e->probit)
   EIG_DISPATCH(CALL);
 #undef CALL
   GG_HIP(hipGetLastError());

@@ -115,7 +115,7 @@ extern "C" {
 
 int gg_model_create(gg_model** out, const gg_config* cfg) {
   if (!out || !cfg) return gg_fail(GG_ERR_INVALID, "gg_model_create: null argument");
-  if (cfg->kind == GG_LOGISTIC_EIG) {
+  if (cfg->kind == GG_LOGISTIC_EIG || cfg->kind == GG_PROBIT_EIG) {
     int rc = gg_ensure_device(cfg->device);
     if (rc) return rc;
     gg_model* m = new gg_model();

@@ -34,7 +34,8 @@ enum gg_site {
   GG_SITE_EIG_MU0 = 13,    //                                   eigenmodel.py:932
   GG_SITE_EIG_LMBDA = 14,  //                                   eigenmodel.py:965
   GG_SITE_INIT = 15,       // prior draws at construction
-  GG_SITE_DATA = 16        // synthetic data generation (rvs)
+  GG_SITE_DATA = 16,       // synthetic data generation (rvs)
+  GG_SITE_EIG_Z = 17       // truncated-normal auxiliaries of the probit eigenmodel   eigenmodel.py:291
 };
 
 struct gg_u32x4 { uint32_t v[4]; };

@@ -20,6 +20,8 @@ class LogisticEigenmodel(AdjacencyDistribution, GibbsSampling, EngineBacked):
     """A_ij ~ Bern(logistic(mu_0 + f_i^T Lambda f_j)); f_i ~ N(0, sigma_F I), lambda ~ N(mu_lmbda, sigma_lmbda I),
     mu_0 ~ N(mu_mu_0, sigma_mu0)."""
 
+    _kind = _abi.LOGISTIC_EIG
+
     _fields = {"F": (_abi.ST_F, np.float64, lambda s: (s.N, s.D)),
                "lmbda": (_abi.ST_LMBDA, np.float64, lambda s: (s.D,)),
                "_mu0": (_abi.ST_MU0, np.float64, lambda s: (1,)),
@@ -38,7 +40,7 @@ class LogisticEigenmodel(AdjacencyDistribution, GibbsSampling, EngineBacked):
         self.sigma_F = sigma_F
         self.sigma_lmbda = sigma_lmbda
         self.lmbda_given = lmbda is not None
-        self._init_engine(device=device, seed=seed, kind=_abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1,
+        self._init_engine(device=device, seed=seed, kind=self._kind, N=N, D=D, K=1, B=1,
                           sigma_mu0=sigma_mu0, sigma_F=sigma_F, sigma_lmbda=sigma_lmbda, mu_mu_0=self.mu_mu_0,
                           lmbda_given=1 if self.lmbda_given else 0)
         if self.lmbda_given:
@@ -142,3 +144,34 @@ class LogisticEigenmodel(AdjacencyDistribution, GibbsSampling, EngineBacked):
 
     def _resample_lmbda(self, A):
         self._run(A, _abi.PART_LMBDA)
+
+
+class ProbitEigenmodel(LogisticEigenmodel):
+    """A_ij ~ Bern(Phi(mu_0 + f_i^T Lambda f_j)) with truncated-normal auxiliaries Z (Albert & Chib):
+    graphistician/eigenmodel.py `_ProbitEigenmodelBase` (:223-237), `_GibbsProbitEigenmodel` (:239-379).
+    Same state and constructor as the logistic model; the engine kind differs."""
+
+    _kind = _abi.PROBIT_EIG
+
+    @property
+    def P(self):
+        # eigenmodel.py:228-237
+        from scipy.special import erf
+        P = 0.5 * (1 + erf(self.Mu / np.sqrt(2.0)))
+        return np.clip(P, 1e-16, 1 - 1e-16)
+
+    def sample_predictive_parameters(self):
+        from scipy.special import erf
+        f = np.sqrt(self.sigma_F) * np.random.randn(self.D)
+        Fe = np.vstack((self.F, f[None, :]))
+        Mu = self.mu_0 + (Fe * self.lmbda[None, :]).dot(Fe.T)
+        np.fill_diagonal(Mu, self.mu_0)
+        P = np.clip(0.5 * (1 + erf(Mu / np.sqrt(2.0))), 1e-16, 1 - 1e-16)
+        return P[-1, :], P[:, -1]
+
+    def resample(self, A):
+        """eigenmodel.py:246-272: Z -> F -> mu_0 -> lambda."""
+        self._run(A, _abi.PART_ALL)
+
+    def _resample_Z(self, A):
+        self._run(A, _abi.PART_OMEGA)

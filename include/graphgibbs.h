@@ -41,6 +41,7 @@ enum gg_status {
  *  GG_NIW_W         weights.py:68-162     NIWGaussianWeightDistribution
  *  GG_FIXED_W       weights.py:9-65       FixedGaussianWeightDistribution
  *  GG_LOGISTIC_EIG  eigenmodel.py:822-965 _GibbsLogisticEigenmodel
+ *  GG_PROBIT_EIG    eigenmodel.py:239-379 _GibbsProbitEigenmodel (same state ids; the auxiliaries are Z, not omega)
  */
 enum gg_kind {
   GG_SBM_ADJ = 1,
@@ -49,7 +50,8 @@ enum gg_kind {
   GG_SBM_GAUSS_W = 4,
   GG_NIW_W = 5,
   GG_FIXED_W = 6,
-  GG_LOGISTIC_EIG = 7
+  GG_LOGISTIC_EIG = 7,
+  GG_PROBIT_EIG = 8
 };
 
 typedef struct gg_config {

@@ -278,6 +278,46 @@ def eig_loglik(A, F, lmbda, mu_0):
     return lib().orc_eig_loglik(N, D, pA, _f64(F), _f64(lmbda), C.c_double(mu_0))
 
 
+def probit_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given, seed, sweep,
+                 parts=PART_EIG_ALL, Z=None):
+    """Probit eigenmodel (eigenmodel.py:246-379): in-place sweep of (F, lmbda); returns (mu_0, Z)."""
+    N, D = F.shape
+    A8, pA = _u8(A != 0)
+    if Z is None:
+        Z = np.zeros((N, N))
+    mu = C.c_double(float(mu_0))
+    rc = lib().orc_probit_sweep(N, D, pA, _f64(F), _f64(lmbda), C.byref(mu), _f64(Z),
+                                _f64(np.ascontiguousarray(mu_lmbda, dtype=np.float64)), C.c_double(mu_mu_0),
+                                C.c_double(sigma_mu0), C.c_double(sigma_F), C.c_double(sigma_lmbda), int(lmbda_given),
+                                C.c_uint64(seed), C.c_uint32(sweep), int(parts))
+    if rc:
+        raise RuntimeError("oracle probit_sweep failed rc=%d" % rc)
+    return mu.value, Z
+
+
+def probit_loglik(A, F, lmbda, mu_0):
+    N, D = F.shape
+    A8, pA = _u8(A != 0)
+    lib().orc_probit_loglik.restype = C.c_double
+    return lib().orc_probit_loglik(N, D, pA, _f64(F), _f64(lmbda), C.c_double(mu_0))
+
+
+def ndtri_vec(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.empty_like(p)
+    lib().orc_ndtri_vec(_f64(p), _f64(out), C.c_longlong(p.size))
+    return out
+
+
+def truncnorm_vec(u, mu, a):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    mu = np.ascontiguousarray(mu, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    out = np.empty_like(u)
+    lib().orc_truncnorm_vec(_f64(u), _f64(mu), _i32(a), _f64(out), C.c_longlong(u.size))
+    return out
+
+
 def pg1_vec(seed, z, n):
     out = np.empty(n)
     lib().orc_pg1_vec(C.c_uint64(seed), C.c_double(z), _f64(out), C.c_longlong(n))

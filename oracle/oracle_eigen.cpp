@@ -146,3 +146,116 @@ void orc_pg1_vec(uint64_t seed, double z, double* out, long long n) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Probit eigenmodel (eigenmodel.py:223-379).  Written the way the reference writes
+// it: dense N x N Z, double loops; the precision uses the constant 2 per unordered pair (:319) and the mean
+// the centred auxiliaries zcent = Z - mu_0 (:312-321).
+// ---------------------------------------------------------------------------
+#include "../graphistician_amd/csrc/spec/gg_probit.h"
+
+extern "C" {
+
+// eigenmodel.py:274-293 _resample_Z: truncated normals around Mu (diagonal Mu = mu_0), lower bound 0 where
+// A == 1, upper bound 0 where A == 0.
+void orc_probit_resample_Z(int N, int D, const uint8_t* A, const double* F, const double* lmbda, double mu_0,
+                           uint64_t seed, uint32_t sweep, double* Z) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j)
+      Z[(size_t)i * N + j] = gg_truncnorm_at(seed, sweep, (uint32_t)N, (uint32_t)i, (uint32_t)j,
+                                             eig_psi(N, D, F, lmbda, mu_0, i, j), A[(size_t)i * N + j] ? 1 : 0);
+}
+
+// eigenmodel.py:295-329 _resample_F.
+int orc_probit_resample_F(int N, int D, const double* Z, double* F, const double* lmbda, double mu_0, double sigma_F,
+                          uint64_t seed, uint32_t sweep) {
+  std::vector<double> prec((size_t)D * D), h(D), z(D), x(D);
+  for (int n = 0; n < N; ++n) {
+    for (int a = 0; a < D * D; ++a) prec[a] = 0.0;
+    for (int a = 0; a < D; ++a) { prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0; }
+    for (int nn = 0; nn < N; ++nn) {
+      if (nn == n) continue;
+      const double* f = F + (size_t)nn * D;
+      const double z1 = Z[(size_t)nn * N + n] - mu_0, z2 = Z[(size_t)n * N + nn] - mu_0;
+      for (int a = 0; a < D; ++a) {
+        for (int b = 0; b < D; ++b) prec[a * D + b] += 2.0 * f[a] * f[b] * lmbda[a] * lmbda[b];
+        h[a] += z1 * f[a] * lmbda[a];
+        h[a] += z2 * f[a] * lmbda[a];
+      }
+    }
+    for (int a = 0; a < D; ++a) z[a] = gg_normal_at(seed, GG_SITE_EIG_F, sweep, (uint32_t)(n * D + a));
+    if (gg_gauss_from_precision(prec.data(), h.data(), z.data(), D, x.data())) return -5;
+    for (int a = 0; a < D; ++a) F[(size_t)n * D + a] = x[a];
+  }
+  return 0;
+}
+
+// eigenmodel.py:331-352 _resample_mu_0: N^2 - N observations, residual Z - F Lambda F^T off the diagonal.
+double orc_probit_resample_mu0(int N, int D, const double* Z, const double* F, const double* lmbda, double mu_mu_0,
+                               double sigma_mu0, uint64_t seed, uint32_t sweep) {
+  double prec = 1.0 / sigma_mu0 + ((double)N * N - N), h = mu_mu_0 / sigma_mu0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j)
+      if (i != j) h += Z[(size_t)i * N + j] - eig_psi(N, D, F, lmbda, 0.0, i, j);
+  const double var = 1.0 / prec;
+  return var * h + gg_sqrt(var) * gg_normal_at(seed, GG_SITE_EIG_MU0, sweep, 0u);
+}
+
+// eigenmodel.py:354-379 _resample_lmbda.
+int orc_probit_resample_lmbda(int N, int D, const double* Z, const double* F, double* lmbda, double mu_0,
+                              const double* mu_lmbda, double sigma_lmbda, uint64_t seed, uint32_t sweep) {
+  std::vector<double> prec((size_t)D * D, 0.0), h(D), z(D), x(D);
+  for (int a = 0; a < D; ++a) { prec[a * D + a] = 1.0 / sigma_lmbda; h[a] = mu_lmbda[a] / sigma_lmbda; }
+  for (int n1 = 0; n1 < N; ++n1)
+    for (int n2 = n1 + 1; n2 < N; ++n2) {
+      const double* f1 = F + (size_t)n1 * D;
+      const double* f2 = F + (size_t)n2 * D;
+      const double z12 = Z[(size_t)n1 * N + n2] - mu_0, z21 = Z[(size_t)n2 * N + n1] - mu_0;
+      for (int a = 0; a < D; ++a) {
+        for (int b = 0; b < D; ++b) prec[a * D + b] += 2.0 * f1[a] * f1[b] * f2[a] * f2[b];
+        h[a] += z12 * f1[a] * f2[a];
+        h[a] += z21 * f1[a] * f2[a];
+      }
+    }
+  for (int a = 0; a < D; ++a) z[a] = gg_normal_at(seed, GG_SITE_EIG_LMBDA, sweep, (uint32_t)a);
+  if (gg_gauss_from_precision(prec.data(), h.data(), z.data(), D, x.data())) return -5;
+  for (int a = 0; a < D; ++a) lmbda[a] = x[a];
+  return 0;
+}
+
+// eigenmodel.py:246-272 resample: Z -> F -> mu_0 -> lambda.  Z is an output (N x N).
+int orc_probit_sweep(int N, int D, const uint8_t* A, double* F, double* lmbda, double* mu_0, double* Z,
+                     const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
+                     int lmbda_given, uint64_t seed, uint32_t sweep, int parts) {
+  if (D > GG_MAXD) return -1;
+  if (parts & ORC_PART_OMEGA) orc_probit_resample_Z(N, D, A, F, lmbda, *mu_0, seed, sweep, Z);
+  if (parts & ORC_PART_F) {
+    int rc = orc_probit_resample_F(N, D, Z, F, lmbda, *mu_0, sigma_F, seed, sweep);
+    if (rc) return rc;
+  }
+  if (parts & ORC_PART_MU0) *mu_0 = orc_probit_resample_mu0(N, D, Z, F, lmbda, mu_mu_0, sigma_mu0, seed, sweep);
+  if ((parts & ORC_PART_LMBDA) && !lmbda_given) {
+    int rc = orc_probit_resample_lmbda(N, D, Z, F, lmbda, *mu_0, mu_lmbda, sigma_lmbda, seed, sweep);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// eigenmodel.py:110-129 log_likelihood with P = clip(Phi(Mu), 1e-16, 1 - 1e-16) (:228-237).
+double orc_probit_loglik(int N, int D, const uint8_t* A, const double* F, const double* lmbda, double mu_0) {
+  double ll = 0.0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      double P = gg_norm_cdf(eig_psi(N, D, F, lmbda, mu_0, i, j));
+      P = P < 1e-16 ? 1e-16 : (P > 1 - 1e-16 ? 1 - 1e-16 : P);
+      ll += A[(size_t)i * N + j] ? log(P) : log(1.0 - P);
+    }
+  return ll;
+}
+
+void orc_ndtri_vec(const double* p, double* out, long long n) { for (long long i = 0; i < n; ++i) out[i] = gg_ndtri(p[i]); }
+void orc_truncnorm_vec(const double* u, const double* mu, const int32_t* a, double* out, long long n) {
+  for (long long i = 0; i < n; ++i) out[i] = gg_truncnorm(u[i], mu[i], a[i]);
+}
+
+}  // extern "C"

@@ -168,3 +168,152 @@ def test_engine_chain_matches_oracle():
     assert np.allclose(m.lmbda, lo, rtol=1e-6, atol=1e-8) and abs(m.mu_0 - mo) < 1e-7
     assert abs(m.log_likelihood(A) - O.eig_loglik(A, Fo, lo, mo)) <= 1e-7 * abs(O.eig_loglik(A, Fo, lo, mo))
     assert np.isfinite(m.log_probability(A))
+
+
+# ================================================================ probit eigenmodel (eigenmodel.py:223-379)
+def probit_F_conditional(Z, F, lmbda, mu_0, sigma_F, n):
+    """eigenmodel.py:301-321 written out with numpy."""
+    N, D = F.shape
+    llT = np.outer(lmbda, lmbda)
+    prec = np.eye(D) / sigma_F
+    h = np.zeros(D)
+    zc = Z - mu_0
+    for nn in range(N):
+        if nn == n:
+            continue
+        prec += 2 * np.outer(F[nn], F[nn]) * llT
+        h += zc[nn, n] * F[nn] * lmbda
+        h += zc[n, nn] * F[nn] * lmbda
+    return prec, h
+
+
+def make_probit_case(N, D, seed):
+    rng = np.random.RandomState(seed)
+    F = rng.randn(N, D)
+    lmbda = rng.randn(D)
+    mu_0 = -0.4
+    P = stats.norm.cdf(R.eigen_Mu(F, lmbda, mu_0))
+    A = (rng.rand(N, N) < P).astype(np.uint8)
+    return A, np.ascontiguousarray(rng.randn(N, D) * 0.8), np.ascontiguousarray(rng.randn(D)), 0.2
+
+
+def test_ndtri_and_truncnorm_spec():
+    """Phi^{-1} (AS 241) against scipy; the truncated-normal inversion of internals/utils.py:53-76 against scipy's law."""
+    from scipy.special import ndtri
+    p = np.concatenate([np.logspace(-15, -1, 200), np.linspace(0.001, 0.999, 2001), 1 - np.logspace(-15, -1, 200)])
+    d, r = O.ndtri_vec(p), ndtri(p)
+    assert np.max(np.abs(d - r) / np.maximum(np.abs(r), 1e-300)) < 5e-15
+    rng = np.random.RandomState(0)
+    for mu, a in [(0.3, 1), (-1.2, 1), (2.0, 0), (-0.5, 0)]:
+        u = rng.rand(20000)
+        z = O.truncnorm_vec(u, np.full(u.size, mu), np.full(u.size, a))
+        lo, hi = (0, np.inf) if a else (-np.inf, 0)
+        assert np.all(z > 0) if a else np.all(z < 0)
+        assert stats.kstest(z, stats.truncnorm(lo - mu, hi - mu, loc=mu).cdf).pvalue > 1e-3
+
+
+def test_probit_oracle_follows_the_reference_formulas():
+    N, D, seed = 9, 2, 6
+    A, F, lmbda, mu_0 = make_probit_case(N, D, 2)
+    sF, sm, sl, mm, ml = 1.3, 0.9, 1.1, -0.4, np.zeros(D) + 0.2
+    _, Z = O.probit_sweep(A, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_OMEGA)
+    assert np.all(Z[A == 1] > 0) and np.all(Z[A == 0] < 0)          # eigenmodel.py:283-288
+    Fo = F.copy()
+    O.probit_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_F, Z=Z)
+    Fp = F.copy()
+    for n in range(N):
+        prec, h = probit_F_conditional(Z, Fp, lmbda, mu_0, sF, n)
+        z = np.array([O.normal_at(seed, SITE_F, 3, n * D + d) for d in range(D)])
+        Fp[n] = gauss_from_precision(prec, h, z)
+    assert np.allclose(Fo, Fp, rtol=1e-10, atol=1e-12)
+    # mu_0 (eigenmodel.py:331-352)
+    mu_new, _ = O.probit_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_MU0, Z=Z)
+    Zc = Z - (Fo * lmbda[None, :]).dot(Fo.T)
+    np.fill_diagonal(Zc, 0.0)
+    prec = 1.0 / sm + N * N - N
+    h = mm / sm + Zc.sum()
+    assert abs(mu_new - (h / prec + np.sqrt(1 / prec) * O.normal_at(seed, SITE_MU0, 3, 0))) < 1e-12
+    # lambda (eigenmodel.py:354-379)
+    lo = lmbda.copy()
+    O.probit_sweep(A, Fo, lo, mu_new, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_LMBDA, Z=Z)
+    prec, h = np.eye(D) / sl, ml / sl
+    zc = Z - mu_new
+    for n1 in range(N):
+        for n2 in range(n1 + 1, N):
+            prec = prec + 2 * np.outer(Fo[n1], Fo[n1]) * np.outer(Fo[n2], Fo[n2])
+            h = h + (zc[n1, n2] + zc[n2, n1]) * Fo[n1] * Fo[n2]
+    z = np.array([O.normal_at(seed, SITE_LMBDA, 3, d) for d in range(D)])
+    assert np.allclose(lo, gauss_from_precision(prec, h, z), rtol=1e-10, atol=1e-12)
+    # log-likelihood (eigenmodel.py:110-129 with the probit link :228-237)
+    P = np.clip(stats.norm.cdf(R.eigen_Mu(Fo, lo, mu_new)), 1e-16, 1 - 1e-16)
+    assert abs(O.probit_loglik(A, Fo, lo, mu_new) - (A * np.log(P) + (1 - A) * np.log(1 - P)).sum()) < 1e-9
+
+
+def test_geweke_probit_prior_recovery():
+    """The methodology of test/test_probit_eigenmodel_geweke.py, with assertions."""
+    N, D, iters = 6, 2, 3000
+    rng = np.random.RandomState(2)
+    sF, sm, sl, mm, ml = 1.0, 1.0, 1.0, stats.norm.ppf(0.3), np.zeros(D)
+    F = np.ascontiguousarray(rng.randn(N, D))
+    lmbda = np.ascontiguousarray(rng.randn(D))
+    mu_0 = mm + rng.randn()
+    mus, lams, fs = [], [], []
+    for it in range(iters):
+        A = (rng.rand(N, N) < stats.norm.cdf(R.eigen_Mu(F, lmbda, mu_0))).astype(np.uint8)
+        mu_0, _ = O.probit_sweep(A, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, 98, it)
+        mus.append(mu_0); lams.append(lmbda[0]); fs.append(F[0, 0])
+    thin = slice(200, None, 5)
+    assert stats.kstest(np.array(mus)[thin], "norm", args=(mm, 1.0)).pvalue > 1e-3
+    assert stats.kstest(np.array(lams)[thin], "norm").pvalue > 1e-3
+    assert stats.kstest(np.array(fs)[thin], "norm").pvalue > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D", [(50, 2), (130, 8), (200, 5)])
+def test_probit_engine_parts_match_oracle(N, D):
+    from graphistician_amd import _abi as abi
+    A, F, lmbda, mu_0 = make_probit_case(N, D, N)
+    sF, sm, sl, mm, ml = 1.2, 0.8, 1.5, -0.3, np.zeros(D) + 0.1
+    seed = 78
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.PROBIT_EIG, N=N, D=D, K=1, B=1, seed=seed, sigma_mu0=sm, sigma_F=sF, sigma_lmbda=sl,
+                  mu_mu_0=mm, lmbda_given=0)
+    m.set(abi.ST_F, F); m.set(abi.ST_LMBDA, lmbda); m.set(abi.ST_MU0, np.array([mu_0])); m.set(abi.ST_MU_LMBDA, ml)
+    m.resample_part(d, abi.PART_OMEGA)
+    _, Z = O.probit_sweep(A, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_OMEGA)
+    S = m.get(abi.ST_OMEGA_S, (N, N))
+    ref = Z + Z.T
+    np.fill_diagonal(ref, 0.0)
+    assert np.allclose(S, ref, rtol=1e-9, atol=1e-12)
+    m.resample_part(d, abi.PART_F)
+    Fo = F.copy()
+    O.probit_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_F, Z=Z)
+    assert np.allclose(m.get(abi.ST_F, (N, D)), Fo, rtol=1e-8, atol=1e-10)
+    m.resample_part(d, abi.PART_MU0)
+    mu_new, _ = O.probit_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_MU0, Z=Z)
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - mu_new) < 1e-9
+    m.resample_part(d, abi.PART_LMBDA)
+    lo = lmbda.copy()
+    O.probit_sweep(A, Fo, lo, mu_new, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_LMBDA, Z=Z)
+    assert np.allclose(m.get(abi.ST_LMBDA, (D,)), lo, rtol=1e-8, atol=1e-10)
+    ll = m.log_likelihood(d)
+    assert abs(ll - O.probit_loglik(A, Fo, lo, mu_new)) <= 1e-9 * abs(ll)
+
+
+@pytest.mark.gpu
+def test_probit_engine_chain_matches_oracle():
+    from graphistician_amd.eigenmodel import ProbitEigenmodel
+    N, D = 96, 3
+    A, F, lmbda, mu_0 = make_probit_case(N, D, 3)
+    np.random.seed(0)
+    m = ProbitEigenmodel(N, D, p=0.3, seed=4243)
+    m.F, m.lmbda, m.mu_0 = F, lmbda, mu_0
+    Fo, lo, mo = F.copy(), lmbda.copy(), mu_0
+    for s in range(3):
+        m.resample(A)
+        mo, _ = O.probit_sweep(A, Fo, lo, mo, np.zeros(D), m.mu_mu_0, 1.0, 1.0, 1.0, 0, 4243, s)
+    assert np.allclose(m.F, Fo, rtol=1e-6, atol=1e-8)
+    assert np.allclose(m.lmbda, lo, rtol=1e-6, atol=1e-8) and abs(m.mu_0 - mo) < 1e-7
+    ref = O.probit_loglik(A, Fo, lo, mo)
+    assert abs(m.log_likelihood(A) - ref) <= 1e-7 * abs(ref)
+    assert m.P.min() >= 1e-16 and np.isfinite(m.log_probability(A))
