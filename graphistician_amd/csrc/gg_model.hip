@@ -74,6 +74,9 @@ struct gg_model {
   uint32_t sweep;
   int Lmax, Lcap, CH, max_idle;
   long long* dbg;               // GG_ROUND_DBG: phase timestamps of k_round
+  bool incr;                    // GG_INCREMENTAL=1: G is carried from sweep to sweep (changes flushed in), no bulk pass
+  bool G_valid;                 // incr: Gbuf[cur] is the exact histogram of G_data under the current labels
+  const gg_data* G_data;
   int32_t* ap;                  // restart rounds: entries of L already applied to node n's statistics
   size_t resolve_lds;
   bool resolve_stage;          // coefficient tables staged in the resolver's LDS
@@ -185,6 +188,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if ((rc = dmalloc(&m->L, (size_t)m->Lcap * 3))) return rc;
   if ((rc = dmalloc(&m->ap, (size_t)m->Nl + 1))) return rc;
   m->dbg = nullptr;
+  m->incr = false; m->G_valid = false; m->G_data = nullptr;
   if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
   // resolve chunk: one Kp-lane group per node, LDS budget 96 KiB
@@ -214,6 +218,9 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     // eager cross-sweep pipelining: exact, but its extra event records / waits make the host the bottleneck
     // at N=4096 (11-13k sweeps/s against 17.5k serial); opt-in until launches get cheaper or N is large
     m->pipe = m->sbm && m->K > 1 && (e && atoi(e) == 1);
+    // incremental statistics (opt-in, see enqueue_sweep_incr): not combined with the pipelined or sharded forms
+    const char* ei = getenv("GG_INCREMENTAL");
+    m->incr = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (ei && atoi(ei) == 1);
   }
   // defaults: uniform m, pi = 1, p = 0.5, standard NIW
   std::vector<double> ones(K, 1.0), um(K, 1.0 / K), half(KK, 0.5);
@@ -318,6 +325,7 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
     for (int n = 0; n < m->N; ++n)
       if (c[n] < 0 || c[n] >= m->K) return gg_fail(GG_ERR_INVALID, "label c[%d]=%d out of range [0,%d)", n, c[n], m->K);
     m->perm_valid = false;
+    m->G_valid = false;
     { int rc1 = drain_pipe(m); if (rc1) return rc1; }
   }
   GG_HIP(hipMemcpyAsync(p, buf, nbytes, hipMemcpyHostToDevice, m->stream));
@@ -594,6 +602,7 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = nullptr;
+  g.keep_L = m->incr ? 1 : 0;
   size_t lds = m->resolve_lds;
 #define RES(NTV, ADJV)                                                                                           \
   do {                                                                                                           \
@@ -613,19 +622,19 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   return GG_OK;
 }
 
-static int launch_apply_L(gg_model* m, const gg_data* d, int buf) {
+static int launch_apply_L(gg_model* m, const gg_data* d, int buf, int mode = 0) {
   gg_node_ctx x = node_ctx(m, d, buf);
   int nb = (m->Nl + 255) / 256;
 #define APL(NTV, ADJV)                                                                                             \
   k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, m->ap, gcnt(m, buf, 0), gcnt(m, buf, 1),          \
-                                                  gs(m, buf, 0), gs(m, buf, 1), d->A, d->AT, d->Wq, d->WqT)
+                                                  gs(m, buf, 0), gs(m, buf, 1), d->A, d->AT, d->Wq, d->WqT, mode)
   if (m->is_adj) APL(2, true);
   else if (m->B == 1) APL(3, false);
   else if (m->B == 2) APL(6, false);
   else APL(15, false);
 #undef APL
   GG_HIP(hipGetLastError());
-  k_reset_L<<<1, 64, 0, m->stream>>>(m->rs);
+  k_reset_L<<<1, 64, 0, m->stream>>>(m->rs, mode);
   GG_HIP(hipGetLastError());
   return GG_OK;
 }
@@ -647,6 +656,7 @@ static int launch_round(gg_model* m, const gg_data* d, int buf, uint32_t sweep, 
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = m->dbg;
+  g.keep_L = m->incr ? 1 : 0;
   const int K = m->K, per = 256 / m->Kp;
   int nb = (window + per - 1) / per;
   if (nb > 512) nb = 512;   // groups beyond the grid are strided over
@@ -768,6 +778,31 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
   return GG_OK;
 }
 
+// Incremental form (GG_INCREMENTAL=1, scan models): the per-node statistics G are exact integers, so instead of
+// recounting them from X and X^T every sweep they are carried over: a scan's accepted changes are flushed
+// into G (k_apply_L: rows of X / X^T of the changed nodes only), and a bulk pass runs only when G is not
+// known to match the labels (first sweep, labels or data replaced from outside).  Same chain bit for bit;
+// the sweep no longer streams the N x N data, so it is reported separately from the default path.
+static int enqueue_sweep_incr(gg_model* m, const gg_data* d, uint32_t sweep) {
+  int rc;
+  const int buf = m->cur, P = m->pcur;
+  if (!m->G_valid || m->G_data != d) {
+    m->zeroed[buf] = false;
+    if ((rc = enqueue_bulk(m, d, buf, 3, true, sweep))) return rc;
+    m->G_valid = true;
+    m->G_data = d;
+  }
+  if ((rc = enqueue_params(m, d, buf, true, true, true, false, sweep, P))) return rc;
+  if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
+  if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
+  if ((rc = launch_apply_L(m, d, buf, 1))) return rc;   // the scan's changes -> G (no-op behind a stall)
+  m->st.resolve_rounds += 1;
+  m->m_pending = true;
+  m->m_sweep = sweep;
+  m->pcur = 1 - P;
+  return GG_OK;
+}
+
 // Pipelined form (scan models): the bulk statistics of sweep i+1 are computed on a second stream
 // WHILE sweep i's params -> speculate -> resolve chain runs, under the labels sweep i starts with.
 // They are exactly the statistics sweep i+1 needs iff sweep i's scan changes no label; a scan that
@@ -859,6 +894,7 @@ static int launch_sweep_graph(gg_model* m, const gg_data* d, uint32_t sweep) {
 static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
   const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
   if (!learn_params) return GG_OK;
+  if (m->incr) return enqueue_sweep_incr(m, d, sweep);
   if (!m->pipe) return enqueue_sweep_serial(m, d, sweep);
   // replay from the graph when the pipeline is primed (statistics of this sweep in flight, a predecessor
   // sweep whose m is pending) and this sweep is not one of the HIP-event timing samples
@@ -930,7 +966,8 @@ static int model_sync(gg_model* m) {
     if (mid) {
       const int s_idx = done;                          // index of the stalled sweep within the batch
       const int buf_s = (m->cur0 + s_idx) & 1, P_s = (m->pcur0 + s_idx) & 1;
-      if ((rc = finish_scan(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
+      if ((rc = finish_scan(m, d, m->incr ? m->cur0 : buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
+      if (m->incr && (rc = launch_apply_L(m, d, m->cur0, 2))) return rc;   // what the rounds applied lazily -> all of G
     } else {
       if ((rc = write_ctl_word(m, 4, 0))) return rc;
     }
@@ -941,10 +978,11 @@ static int model_sync(gg_model* m) {
       if (sw != ~0u && sw >= m->sweep + (uint32_t)completed) sw = ~0u;
     m->sweep += (uint32_t)completed;
     m->st.sweeps += (uint64_t)completed;
-    m->cur = (m->cur0 + completed) & 1;
+    m->cur = m->incr ? m->cur0 : ((m->cur0 + completed) & 1);
     m->pcur = (m->pcur0 + completed) & 1;
     m->next_bulk = false;
     if (m->pipe) m->zeroed[0] = m->zeroed[1] = false;
+    else if (m->incr) { m->zeroed[0] = m->zeroed[1] = false; }
     else { m->zeroed[1 - m->cur] = false; m->zeroed[m->cur] = true; }   // serial form: k_params of the last completed sweep zeroed it
     m->pending = 0;
     if ((rc = write_ctl_word(m, 5, 0))) return rc;
@@ -1081,6 +1119,7 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   if (m->eig) return gg_eigen_resample(m->eig, d, parts);
   int rc = model_sync(m);
   if (rc) return rc;
+  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   m->beta = beta;
   if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
   if (rc) return rc;
@@ -1126,6 +1165,7 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: block models only");
   int rc = model_sync(m);
   if (rc) return rc;
+  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   if ((rc = check_data(m, d))) return rc;
   if (n < 0 || n >= m->N) return gg_fail(GG_ERR_INVALID, "node %d out of range", n);
   if ((rc = drain_pipe(m))) return rc;
@@ -1228,6 +1268,7 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
   if (m->eig) return gg_eigen_log_likelihood(m->eig, d, out);
   int rc = model_sync(m);
   if (rc) return rc;
+  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   if ((rc = check_data(m, d))) return rc;
   begin_call(m);
   const int buf = m->cur;
@@ -1259,6 +1300,7 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
   if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "gg_bench_bulk: block models only");
   int rc = model_sync(m);
   if (rc) return rc;
+  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   if ((rc = check_data(m, d))) return rc;
   if ((rc = drain_pipe(m))) return rc;
   const int t0 = m->timing;

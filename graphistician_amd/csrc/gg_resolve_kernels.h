@@ -57,6 +57,7 @@ struct gg_resolve_args {
   uint64_t seed;
   uint32_t site, sweep;
   long long* dbg;   // optional phase timestamps of k_round (GG_ROUND_DBG), [workgroup][8]
+  int keep_L;       // incremental statistics: a completed scan leaves its change list in place for the flush into G
 };
 
 
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
   if (done) gg_scan_tail(g, s_cnt, s_raw, g.rs[9] + nchg == 0);
   if (tid == 0) {
     g.rs[0] = done ? 0 : pos;
-    g.rs[1] = done ? 0 : nL;
+    g.rs[1] = (done && !g.keep_L) ? 0 : nL;
     g.rs[2] += nchg;
     g.rs[9] += nchg;
     if (done) {
@@ -353,11 +354,14 @@ template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* __restrict__ L,
                                                  const int32_t* __restrict__ rs, int32_t* __restrict__ ap, int32_t* Gc0,
                                                  int32_t* Gc1, long long* Gs0, long long* Gs1, const uint8_t* XA,
-                                                 const uint8_t* XAT, const int32_t* XW, const int32_t* XWT) {
+                                                 const uint8_t* XAT, const int32_t* XW, const int32_t* XWT, int mode) {
+  // mode 0: flush between restart rounds (nothing to do once the scan is done); mode 1: end-of-scan flush of
+  // the incremental-statistics pipeline (nothing to do behind a stalled scan: the slow path flushes); 2: always
   constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
   constexpr int NSI = NT - 1;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= x.N || rs[7]) return;
+  if (n >= x.N) return;
+  if (mode == 0 ? rs[7] != 0 : (mode == 1 ? rs[4] != 0 : false)) return;
   const int nL = rs[1], Np = x.Np;
   for (int e = ap[n]; e < nL; ++e) {
     const int n2 = L[e * 3], a = L[e * 3 + 1], b = L[e * 3 + 2];
@@ -389,8 +393,8 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
   ap[n] = 0;
 }
 
-__global__ void k_reset_L(int32_t* rs) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && !rs[7]) {
+__global__ void k_reset_L(int32_t* rs, int mode) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(mode == 0 ? rs[7] != 0 : (mode == 1 ? rs[4] != 0 : false))) {
     rs[1] = 0;
     int pos, nL, wlen, fin, seq;
     unsigned long long* st = reinterpret_cast<unsigned long long*>(&rs[GG_RS_STATE]);
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
   }
   if (tid == 0) {
     g.rs[0] = done ? 0 : newpos;
-    g.rs[1] = done ? 0 : nL + nchg;
+    g.rs[1] = (done && !g.keep_L) ? 0 : nL + nchg;
     g.rs[2] += nchg;
     g.rs[9] += nchg;
     g.rs[8] = wnext;

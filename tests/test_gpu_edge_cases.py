@@ -154,3 +154,42 @@ def test_python_data_cache_and_state_roundtrip(abi):
     assert m.c.shape == (N,) and m.engine_stats["sweeps"] == 3
     m.c = c1
     assert np.array_equal(m.c, c1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(150, 5), (420, 40)])
+def test_incremental_statistics_mode_is_the_same_chain(abi, N, K, monkeypatch):
+    """GG_INCREMENTAL=1: per-node statistics carried from sweep to sweep (changes flushed in) instead of recounted.
+    Same labels and parameters bit for bit, through burn-in, across calls that invalidate the carried statistics
+    (log_likelihood, node_lp) and after the labels are replaced from outside."""
+    monkeypatch.setenv("GG_INCREMENTAL", "1")
+    A, W, _ = planted_sbm(N, K, seed=21)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=3), WState(N, K, 1, seed=4)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=51, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=52, special_case_self_conns=1)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    ps = sa.p_self
+    sweep = 0
+    for phase in range(3):
+        n = 3 if phase < 2 else 2
+        adj.resample_async(d, n); w.resample_async(d, n)
+        abi.sync_many([adj, w])
+        for _ in range(n):
+            ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 51, sweep)
+            O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 52, sweep)
+            sweep += 1
+        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), phase
+        assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), phase
+        assert np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu) and np.array_equal(w.get(abi.ST_SIGMA, (K, K, 1, 1)), sw.sigma)
+        if phase == 0:       # calls that rebuild the statistics buffers
+            adj.log_likelihood(d); w.log_likelihood(d); adj.node_lp(d, 1, K)
+        if phase == 1:       # labels replaced from outside
+            rng = np.random.RandomState(9)
+            sa.c[:] = rng.choice(K, size=N); sw.c[:] = rng.choice(K, size=N)
+            adj.set(abi.ST_C, sa.c, np.int32); w.set(abi.ST_C, sw.c, np.int32)
