@@ -211,6 +211,51 @@ def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
     print(json.dumps(out))
 
 
+def bench_latent(args, abi, device, rank, world, barrier, max_over_ranks):
+    """Latent-distance adjacency model (adjacency.py:191-437): one step = resample = HMC on L
+    (11 passes over A and A^T), HMC on mu_0 (11 passes), HMC on mu_self (diagonal only)."""
+    N, dim = args.nodes, 2
+    rng = np.random.RandomState(1234)
+    Lt = rng.randn(N, dim) * np.sqrt(2.0)
+    X = -((Lt[:, None, :] - Lt[None, :, :]) ** 2).sum(2) + 0.5
+    A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-X))).astype(np.uint8)
+    del X
+    data = abi.DeviceData(A, None, device=device)
+    m = abi.Model(kind=abi.LATENT_DIST, N=N, D=dim, K=1, B=1, seed=1 + rank, sigma_F=2.0, device=device)
+    crng = np.random.RandomState(1 + rank)
+    L0 = crng.randn(N, dim) * np.sqrt(2.0)
+    m.set(abi.ST_F, L0); m.set(abi.ST_MU0, np.array([0.0])); m.set(abi.ST_LD_AUX, np.array([0.0, 0.01, 0.9]))
+    m.resample(data, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    m.resample(data, args.steps)
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return
+    passes = 22
+    sweep_bytes = passes * 2.0 * N * N
+    out = {"metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": world * args.steps / el,
+           "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "Latent-distance adjacency model, HMC (10 leapfrog steps), N=%d, dim=%d (SURVEY.md 8f rank 3)" % (N, dim),
+                      "sweep_algorithmic_bytes": sweep_bytes, "accepted_L_proposals": m.stats()["label_changes"]},
+           "roofline": {"bound": "hbm", "kernel": "k_ld_pass", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": sweep_bytes * args.steps / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "whole-resample effective rate over %d passes of A and A^T (uint8); each pass also evaluates N^2 "
+                                "fp64 exp + log (sigmoid, softplus), which is what bounds it at this size" % passes}}
+    if not args.no_cpu and world == 1:
+        from oracle import oracle as O
+        Lo = L0.copy()
+        t0 = time.perf_counter()
+        O.ld_resample(A, Lo, 0.0, 0.0, 2.0, 0.01, 0.9, 1, 0)
+        el1 = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / el1, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                               "sample": "1 resample of the same N=%d network, oracle/ C++ -O2, 1 thread" % N}
+    print(json.dumps(out))
+
+
 def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     """One Gaussian-SBM chain sharded over the ranks (strong scaling; BASELINE.json configs[3] at --nodes 65536
     --blocks 64): exact — the same chain for any number of ranks (graphistician_amd/sharded.py)."""
@@ -268,7 +313,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shard", action="store_true",
                     help="one chain sharded over the ranks (strong scaling) instead of an independent chain per rank")
-    ap.add_argument("--config", default="sbm", choices=["sbm", "eigen", "probit"],
+    ap.add_argument("--config", default="sbm", choices=["sbm", "eigen", "probit", "latent"],
                     help="sbm = BASELINE.json configs[1] (default, the headline); eigen = configs[2]")
     ap.add_argument("--latent", type=int, default=8)
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,8 +382,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if args.config in ("eigen", "probit"):
-        bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks)
+    if args.config in ("eigen", "probit", "latent"):
+        (bench_latent if args.config == "latent" else bench_eigen)(args, abi, device, rank, world, barrier, max_over_ranks)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

@@ -14,6 +14,11 @@ from .abstractions import AdjacencyDistribution, GibbsSampling
 from .engine import EngineBacked
 
 
+def logistic(x):
+    """internals/utils.py:5-6."""
+    return 1.0 / (1.0 + np.exp(-x))
+
+
 class FixedAdjacencyDistribution(AdjacencyDistribution, GibbsSampling):
     """adjacency.py:13-41: a fixed 0/1 matrix (host-only, no parameters)."""
 
@@ -208,12 +213,121 @@ class BetaBernoulliAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, E
         return p_row, p_col
 
 
-class LatentDistanceAdjacencyDistribution(AdjacencyDistribution, GibbsSampling):
-    """adjacency.py:191-437 (HMC over latent locations).  Outside the hot path built so
-    far; constructing it says so instead of silently approximating."""
+class LatentDistanceAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacked):
+    """adjacency.py:191-437.
 
-    def __init__(self, N, *args, **kwargs):
-        raise NotImplementedError("LatentDistanceAdjacencyDistribution is not built yet (SURVEY.md §8f)")
+    l_n ~ N(0, sigma I);  A_{n',n} ~ Bern(logistic(-||l_{n'} - l_n||^2 + mu_0 + mu_self [n' == n])).
+    resample = HMC on L (10 leapfrog steps, adaptive step size), HMC on mu_0, HMC on mu_self (:360-421), all on the
+    engine.  The reference differentiates with autograd and integrates with hips.inference.hmc; neither is available,
+    so the gradient is hand-derived and the HMC transition restated (csrc/gg_latent.hip and the test oracle):
+    parity unpinned, checked against the oracle's same definition.  beta < 1 tempers the likelihood (AIS)."""
+
+    _fields = {"L": (_abi.ST_F, np.float64, lambda s: (s.N, s.dim)),
+               "_mu0": (_abi.ST_MU0, np.float64, lambda s: (1,)),
+               "_aux": (_abi.ST_LD_AUX, np.float64, lambda s: (3,))}
+
+    def __init__(self, N, dim=2, sigma=2.0, mu0=0.0, mu_self=0.0, device=0, seed=None):
+        super(LatentDistanceAdjacencyDistribution, self).__init__(N)
+        self.dim = dim
+        self.sigma = sigma
+        self._init_engine(device=device, seed=seed, kind=_abi.LATENT_DIST, N=N, D=dim, K=1, B=1, sigma_F=sigma)
+        self.mu_0 = mu0
+        # adjacency.py:201-206: mu_self, HMC step size 0.01, running acceptance rate 0.9
+        self._hset("_aux", np.array([mu_self, 0.01, 0.9]))
+        self.L = np.sqrt(self.sigma) * np.random.randn(N, dim)
+
+    L = property(lambda s: s._hget("L"), lambda s, v: s._hset("L", v))
+
+    @property
+    def mu_0(self):
+        return float(self._hget("_mu0")[0])
+
+    @mu_0.setter
+    def mu_0(self, v):
+        self._hset("_mu0", np.array([v], dtype=np.float64))
+
+    @property
+    def mu_self(self):
+        return float(self._hget("_aux")[0])
+
+    @mu_self.setter
+    def mu_self(self, v):
+        a = self._hget("_aux").copy()
+        a[0] = v
+        self._hset("_aux", a)
+
+    _L_step_sz = property(lambda s: float(s._hget("_aux")[1]))
+    _L_accept_rate = property(lambda s: float(s._hget("_aux")[2]))
+
+    @property
+    def D(self):
+        # adjacency.py:208-214
+        Mu = -((self.L[:, None, :] - self.L[None, :, :]) ** 2).sum(2)
+        Mu += self.mu_0
+        Mu += self.mu_self * np.eye(self.N)
+        return Mu
+
+    @property
+    def P(self):
+        return logistic(self.D)
+
+    def initialize_from_prior(self):
+        # adjacency.py:221-224
+        self.mu_0 = np.random.randn()
+        self.mu_self = np.random.randn()
+        self.L = np.sqrt(self.sigma) * np.random.randn(self.N, self.dim)
+
+    def initialize_hypers(self, A):
+        pass
+
+    def log_prior(self):
+        # adjacency.py:229-242
+        from scipy.stats import norm
+        lp = norm.logpdf(self.L, 0, np.sqrt(self.sigma)).sum()
+        lp += norm.logpdf(self.mu_0, 0, 1)
+        lp += norm.logpdf(self.mu_self, 0, 1)
+        return lp
+
+    def log_likelihood(self, A):
+        """abstractions.py:111-115 on the engine (stable logit form; P is never materialised)."""
+        d = self._data(A)
+        assert d.N == self.N
+        return self._engine().log_likelihood(d)
+
+    def rvs(self, size=[]):
+        return np.random.rand(self.N, self.N) < self.P
+
+    def sample_predictive_parameters(self):
+        # adjacency.py:291-303
+        Lext = np.vstack((self.L, np.sqrt(self.sigma) * np.random.randn(1, self.dim)))
+        D = -((Lext[:, None, :] - Lext[None, :, :]) ** 2).sum(2)
+        D += self.mu_0
+        D += self.mu_self * np.eye(self.N + 1)
+        P = logistic(D)
+        return P[-1, :], P[:, -1]
+
+    def _run(self, A, parts, beta=1.0):
+        d = self._data(A)
+        assert d.N == self.N
+        eng = self._engine()
+        if parts == _abi.PART_ALL:
+            eng.resample(d, 1, beta)
+        else:
+            eng.resample_part(d, parts, beta)
+        self._mark_stale("L", "_mu0", "_aux")
+
+    def resample(self, A, beta=1.0):
+        """adjacency.py:360-372: L, then mu_0, then mu_self."""
+        self._run(A, _abi.PART_ALL, beta)
+
+    def _resample_L(self, A, beta=1.0):
+        self._run(A, _abi.PART_F, beta)
+
+    def _resample_mu_0(self, A, beta=1.0):
+        self._run(A, _abi.PART_MU0, beta)
+
+    def _resample_mu_self(self, A, beta=1.0):
+        self._run(A, _abi.PART_LMBDA, beta)
 
 
 class SBMAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacked):

@@ -21,7 +21,7 @@ function-style models whose self edges are counted twice (graph_models.py:276-29
 import numpy as np
 from scipy.special import logsumexp
 
-from .adjacency import SBMAdjacencyDistribution, BetaBernoulliAdjacencyDistribution
+from .adjacency import SBMAdjacencyDistribution, BetaBernoulliAdjacencyDistribution, LatentDistanceAdjacencyDistribution
 
 
 def prior_draw(model):
@@ -30,7 +30,7 @@ def prior_draw(model):
         model.m = np.random.dirichlet(model.pi)
         model.c = np.random.choice(model.C, p=model.m, size=model.N)
         model.initialize_from_prior()
-    elif isinstance(model, BetaBernoulliAdjacencyDistribution):
+    elif isinstance(model, (BetaBernoulliAdjacencyDistribution, LatentDistanceAdjacencyDistribution)):
         model.initialize_from_prior()
     elif hasattr(model, "adjacency") and hasattr(model, "weights"):
         # a whole network (networks.py:9-75): both halves from their priors; the tempered path raises the JOINT
@@ -38,7 +38,7 @@ def prior_draw(model):
         prior_draw(model.adjacency)
         model.weights.initialize_from_prior()
     else:
-        raise NotImplementedError("AIS is defined for the Beta-Bernoulli (Erdos-Renyi) and SBM adjacency models")
+        raise NotImplementedError("AIS is defined for the Beta-Bernoulli (Erdos-Renyi), SBM and latent-distance adjacency models and for whole networks")
 
 
 def estimate_marginal_likelihood(model, A, N_samples=1000, B=100, steps_per_B=11, return_weights=False,

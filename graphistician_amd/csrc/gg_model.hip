@@ -21,6 +21,15 @@ int gg_eigen_get_state(gg_eigen* e, int id, void* buf, size_t nbytes);
 int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts);
 int gg_eigen_log_likelihood(gg_eigen* e, const gg_data* d, double* out);
 int gg_eigen_stats(gg_eigen* e, gg_stats* out);
+struct gg_latent;  // gg_latent.hip
+int gg_latent_create(gg_latent** out, const gg_config* cfg);
+int gg_latent_destroy(gg_latent* e);
+int gg_latent_set_state(gg_latent* e, int id, const void* buf, size_t nbytes);
+int gg_latent_get_state(gg_latent* e, int id, void* buf, size_t nbytes);
+void gg_latent_set_beta(gg_latent* e, double beta);
+int gg_latent_resample(gg_latent* e, const gg_data* d, int parts);
+int gg_latent_log_likelihood(gg_latent* e, const gg_data* d, double* out);
+int gg_latent_stats(gg_latent* e, gg_stats* out);
 
 struct gg_model {
   gg_config cfg;
@@ -31,6 +40,7 @@ struct gg_model {
   bool sharded;
   int spos;                             // sharded scan position
   gg_eigen* eig;
+  gg_latent* ld;                // GG_LATENT_DIST: everything lives in gg_latent.hip
   // device state
   int32_t *c, *cand, *cnt;
   // label sort, double buffered: a completed scan writes the sort of its final labels into the other
@@ -118,6 +128,16 @@ extern "C" {
 
 int gg_model_create(gg_model** out, const gg_config* cfg) {
   if (!out || !cfg) return gg_fail(GG_ERR_INVALID, "gg_model_create: null argument");
+  if (cfg->kind == GG_LATENT_DIST) {
+    int rc = gg_ensure_device(cfg->device);
+    if (rc) return rc;
+    gg_model* m = new gg_model();
+    m->cfg = *cfg; m->kind = cfg->kind;
+    rc = gg_latent_create(&m->ld, cfg);
+    if (rc) { delete m; return rc; }
+    *out = m;
+    return GG_OK;
+  }
   if (cfg->kind == GG_LOGISTIC_EIG || cfg->kind == GG_PROBIT_EIG) {
     int rc = gg_ensure_device(cfg->device);
     if (rc) return rc;
@@ -250,6 +270,7 @@ int gg_model_destroy(gg_model* m) {
   if (!m) return GG_OK;
   hipSetDevice(m->cfg.device);
   if (m->eig) { gg_eigen_destroy(m->eig); delete m; return GG_OK; }
+  if (m->ld) { gg_latent_destroy(m->ld); delete m; return GG_OK; }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
                   m->rs, m->L, m->lp_out, m->ap, m->dbg};
@@ -292,6 +313,7 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
   if (!m || !buf) return gg_fail(GG_ERR_INVALID, "gg_set_state: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return gg_eigen_set_state(m->eig, id, buf, nbytes);
+  if (m->ld) return gg_latent_set_state(m->ld, id, buf, nbytes);
   { int rc0 = model_sync(m); if (rc0) return rc0; }
   const size_t B = m->B;
   if (id == GG_ST_SWEEP) {
@@ -337,6 +359,7 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes) {
   if (!m || !buf) return gg_fail(GG_ERR_INVALID, "gg_get_state: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return gg_eigen_get_state(m->eig, id, buf, nbytes);
+  if (m->ld) return gg_latent_get_state(m->ld, id, buf, nbytes);
   { int rc0 = model_sync(m); if (rc0) return rc0; }
   const size_t B = m->B;
   if (id == GG_ST_SWEEP) {
@@ -939,7 +962,7 @@ static int collect_timing(gg_model* m) {
 // Confirm the optimistic sweeps: if a scan stalled (or flushed the pipeline), finish it on the slow
 // path and re-enqueue the sweeps that became no-ops behind it.
 static int model_sync(gg_model* m) {
-  if (m->eig || m->pending == 0) return GG_OK;
+  if (m->eig || m->ld || m->pending == 0) return GG_OK;
   int rc;
   const gg_data* d = m->pend_data;
   const bool scan = m->sbm && m->K > 1;
@@ -1033,6 +1056,14 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
     }
     return GG_OK;
   }
+  if (m->ld) {
+    gg_latent_set_beta(m->ld, beta);
+    for (int s = 0; s < n_sweeps; ++s) {
+      int rc = gg_latent_resample(m->ld, d, GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA);
+      if (rc) return rc;
+    }
+    return GG_OK;
+  }
   if (m->sharded) return gg_fail(GG_ERR_INVALID, "this model owns a shard of the nodes: drive it with the gg_shard_* step API");
   int rc = check_data(m, d);
   if (rc) return rc;
@@ -1053,7 +1084,7 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
 int gg_sync(gg_model* m) {
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
-  if (m->eig) return GG_OK;
+  if (m->eig || m->ld) return GG_OK;
   return model_sync(m);
 }
 
@@ -1117,6 +1148,7 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   if (beta != 1.0 && m->eig)
     return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: block models only (the reference leaves the eigenmodel's undefined, graph_models.py:478)");
   if (m->eig) return gg_eigen_resample(m->eig, d, parts);
+  if (m->ld) { gg_latent_set_beta(m->ld, beta); return gg_latent_resample(m->ld, d, parts); }
   int rc = model_sync(m);
   if (rc) return rc;
   m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
@@ -1162,7 +1194,7 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
 int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (!m || !lp) return gg_fail(GG_ERR_INVALID, "gg_node_lp: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
-  if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: block models only");
+  if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: block models only");
   int rc = model_sync(m);
   if (rc) return rc;
   m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
@@ -1266,6 +1298,7 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
   if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig) return gg_eigen_log_likelihood(m->eig, d, out);
+  if (m->ld) return gg_latent_log_likelihood(m->ld, d, out);
   int rc = model_sync(m);
   if (rc) return rc;
   m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
@@ -1297,7 +1330,7 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
 int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_launch, double* bytes_per_launch) {
   if (!m || !ms_per_launch) return gg_fail(GG_ERR_INVALID, "gg_bench_bulk: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
-  if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "gg_bench_bulk: block models only");
+  if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_bench_bulk: block models only");
   int rc = model_sync(m);
   if (rc) return rc;
   m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
@@ -1328,13 +1361,13 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
 static int shard_check(gg_model* m, const gg_data* d) {
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
-  if (m->eig) return gg_fail(GG_ERR_UNSUPPORTED, "sharding: block models only");
+  if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "sharding: block models only");
   if (m->kind != GG_SBM_ADJ && m->kind != GG_SBM_GAUSS_W) return gg_fail(GG_ERR_UNSUPPORTED, "sharding: SBM kinds only");
   return d ? check_data(m, d) : GG_OK;
 }
 
 int gg_shard_sizes(gg_model* m, int32_t* ntab_total, int32_t* ndiag) {
-  if (!m || m->eig) return gg_fail(GG_ERR_INVALID, "gg_shard_sizes: block model expected");
+  if (!m || m->eig || m->ld) return gg_fail(GG_ERR_INVALID, "gg_shard_sizes: block model expected");
   if (ntab_total) *ntab_total = m->K * m->K * m->NTAB;
   if (ndiag) *ndiag = 1 + gg_nsi(GG_MAXB);
   return GG_OK;
@@ -1436,6 +1469,7 @@ int gg_shard_log_likelihood(gg_model* m, const gg_data* d, const int64_t* tables
 int gg_last_stats(gg_model* m, gg_stats* out) {
   if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_last_stats: null argument");
   if (m->eig) return gg_eigen_stats(m->eig, out);
+  if (m->ld) return gg_latent_stats(m->ld, out);
   int rc = model_sync(m);
   if (rc) return rc;
   *out = m->st;

@@ -42,6 +42,8 @@ enum gg_status {
  *  GG_FIXED_W       weights.py:9-65       FixedGaussianWeightDistribution
  *  GG_LOGISTIC_EIG  eigenmodel.py:822-965 _GibbsLogisticEigenmodel
  *  GG_PROBIT_EIG    eigenmodel.py:239-379 _GibbsProbitEigenmodel (same state ids; the auxiliaries are Z, not omega)
+ *  GG_LATENT_DIST   adjacency.py:191-437  LatentDistanceAdjacencyDistribution (HMC; D = dim, sigma_F = sigma;
+ *                   parts: GG_PART_F = L, GG_PART_MU0 = mu_0, GG_PART_LMBDA = mu_self)
  */
 enum gg_kind {
   GG_SBM_ADJ = 1,
@@ -51,7 +53,8 @@ enum gg_kind {
   GG_NIW_W = 5,
   GG_FIXED_W = 6,
   GG_LOGISTIC_EIG = 7,
-  GG_PROBIT_EIG = 8
+  GG_PROBIT_EIG = 8,
+  GG_LATENT_DIST = 9
 };
 
 typedef struct gg_config {
@@ -89,6 +92,7 @@ enum gg_state_id {
   GG_ST_LMBDA = 14,     /* double (D)                                     eigenmodel.py:64-73 */
   GG_ST_MU0 = 15,       /* double (1)                                     eigenmodel.py:57 */
   GG_ST_MU_LMBDA = 16,  /* double (D)        prior mean of lambda         eigenmodel.py:71 */
+  GG_ST_LD_AUX = 18,    /* double (3)        latent-distance model: mu_self, HMC step size, running acceptance rate (adjacency.py:201-206) */
   GG_ST_OMEGA_S = 17    /* double (N,N) read-only: omega_ij + omega_ji off the diagonal, omega_ii on it (eigenmodel.py:859-874) */
 };
 

@@ -366,3 +366,42 @@ class FastSweeper(object):
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------- latent-distance adjacency model (oracle_latent.cpp)
+LD_PART_L, LD_PART_MU0, LD_PART_MUSELF, LD_PART_ALL = 1, 2, 4, 7
+
+
+def ld_logprob(A, L, mu0, mu_self, sigma, beta=1.0, grad=False):
+    """log p(L, mu_0, mu_self, A) (adjacency.py:244-275), likelihood weighted by beta; with grad: (lp, dL, dmu0, dmuself)."""
+    N, dim = L.shape
+    A8, pA = _u8(A != 0)
+    lib().orc_ld_logprob.restype = C.c_double
+    L = np.ascontiguousarray(L, dtype=np.float64)
+    if not grad:
+        return lib().orc_ld_logprob(N, dim, pA, _f64(L), C.c_double(mu0), C.c_double(mu_self), C.c_double(sigma),
+                                    C.c_double(beta), None, None, None)
+    gL = np.zeros_like(L)
+    g0, gs = C.c_double(0), C.c_double(0)
+    lp = lib().orc_ld_logprob(N, dim, pA, _f64(L), C.c_double(mu0), C.c_double(mu_self), C.c_double(sigma),
+                              C.c_double(beta), _f64(gL), C.byref(g0), C.byref(gs))
+    return lp, gL, g0.value, gs.value
+
+
+def ld_loglik(A, L, mu0, mu_self):
+    N, dim = L.shape
+    A8, pA = _u8(A != 0)
+    lib().orc_ld_loglik.restype = C.c_double
+    return lib().orc_ld_loglik(N, dim, pA, _f64(np.ascontiguousarray(L, dtype=np.float64)), C.c_double(mu0), C.c_double(mu_self))
+
+
+def ld_resample(A, L, mu0, mu_self, sigma, step_sz, accept_rate, seed, sweep, parts=LD_PART_ALL, beta=1.0):
+    """One resample (adjacency.py:360-372), L updated in place; returns (mu0, mu_self, step_sz, accept_rate, accepted mask)."""
+    N, dim = L.shape
+    A8, pA = _u8(A != 0)
+    m0, ms, st, ar, acc = C.c_double(mu0), C.c_double(mu_self), C.c_double(step_sz), C.c_double(accept_rate), C.c_int(0)
+    rc = lib().orc_ld_resample(N, dim, pA, _f64(L), C.byref(m0), C.byref(ms), C.c_double(sigma), C.byref(st), C.byref(ar),
+                               C.c_uint64(seed), C.c_uint32(sweep), int(parts), C.c_double(beta), C.byref(acc))
+    if rc:
+        raise RuntimeError("oracle ld_resample failed rc=%d" % rc)
+    return m0.value, ms.value, st.value, ar.value, acc.value

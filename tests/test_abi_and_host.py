@@ -140,8 +140,9 @@ def test_network_composition_and_errors():
     assert abs(net.log_prior() - (net.adjacency.log_prior() + net.weights.log_prior())) < 1e-12
     g = GaussianBernoulliNetwork(7, 3, p=0.25)
     assert g.adjacency.p == 0.25 and g.adjacency.P[0, 0] == 0.25 and g.weights.Mu.shape == (7, 7, 3)
-    with pytest.raises(NotImplementedError):
-        LatentDistanceAdjacencyDistribution(5)
+    ld = LatentDistanceAdjacencyDistribution(5, dim=2, sigma=2.0, mu0=0.3, mu_self=-0.2)   # host side only: no engine call
+    assert ld.L.shape == (5, 2) and ld.mu_0 == 0.3 and ld.mu_self == -0.2 and ld._L_step_sz == 0.01
+    assert np.allclose(np.diag(ld.D), 0.3 - 0.2) and ld.P.shape == (5, 5) and np.isfinite(ld.log_prior())
     assert CompleteAdjacencyDistribution(4).log_likelihood(np.ones((4, 4))) == 0
     assert EmptyAdjacencyDistribution(4).log_likelihood(np.ones((4, 4))) == -np.inf
     Arow, Acol, Wrow, Wcol = net.sample_predictive_distribution()

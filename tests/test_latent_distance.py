@@ -1,0 +1,114 @@
+"""Latent-distance adjacency model (graphistician/adjacency.py:191-437): CPU tests of the
+oracle (log probability vs numpy, hand-derived gradient vs finite differences, HMC invariance) and GPU parity of
+the HIP engine vs the oracle (float tolerance: sums are ordered differently)."""
+import numpy as np
+import pytest
+from scipy import stats
+
+from oracle import oracle as O
+
+
+def make_case(N, dim, seed):
+    rng = np.random.RandomState(seed)
+    L = rng.randn(N, dim) * 0.8
+    mu0, ms = 0.3, -0.2
+    X = -((L[:, None, :] - L[None, :, :]) ** 2).sum(2) + mu0 + ms * np.eye(N)
+    A = (rng.rand(N, N) < 1 / (1 + np.exp(-X))).astype(np.uint8)
+    return A, np.ascontiguousarray(rng.randn(N, dim)), 0.1, 0.05
+
+
+def lp_numpy(A, L, mu0, ms, sigma, beta=1.0):
+    """adjacency.py:244-275 written out with numpy (autograd.numpy in the reference)."""
+    N = L.shape[0]
+    X = -((L[:, None, :] - L[None, :, :]) ** 2).sum(2) + mu0 + ms * np.eye(N)
+    P = 1 / (1 + np.exp(-X))
+    return beta * (A * np.log(P) + (1 - A) * np.log(1 - P)).sum() - 0.5 * (L * L / sigma).sum() - 0.5 * mu0 ** 2 - 0.5 * ms ** 2
+
+
+def test_oracle_logprob_and_gradient():
+    N, dim, sigma, beta = 12, 2, 2.0, 0.7
+    A, L, mu0, ms = make_case(N, dim, 0)
+    lp, gL, g0, gs = O.ld_logprob(A, L, mu0, ms, sigma, beta, grad=True)
+    assert abs(lp - lp_numpy(A, L, mu0, ms, sigma, beta)) < 1e-10
+    eps = 1e-6
+    for i in range(N):
+        for d in range(dim):
+            Lp, Lm = L.copy(), L.copy()
+            Lp[i, d] += eps; Lm[i, d] -= eps
+            fd = (lp_numpy(A, Lp, mu0, ms, sigma, beta) - lp_numpy(A, Lm, mu0, ms, sigma, beta)) / (2 * eps)
+            assert abs(fd - gL[i, d]) < 1e-6
+    assert abs((lp_numpy(A, L, mu0 + eps, ms, sigma, beta) - lp_numpy(A, L, mu0 - eps, ms, sigma, beta)) / (2 * eps) - g0) < 1e-6
+    assert abs((lp_numpy(A, L, mu0, ms + eps, sigma, beta) - lp_numpy(A, L, mu0, ms - eps, sigma, beta)) / (2 * eps) - gs) < 1e-6
+    assert abs(O.ld_loglik(A, L, mu0, ms) - (lp_numpy(A, L, mu0, ms, sigma) + 0.5 * (L * L / sigma).sum() + 0.5 * mu0 ** 2 + 0.5 * ms ** 2)) < 1e-10
+    # stable form: no overflow where the reference's log(P), log(1 - P) would give -inf
+    far = L.copy(); far[0] += 100.0
+    assert np.isfinite(O.ld_logprob(A, far, mu0, ms, sigma))
+
+
+def test_oracle_hmc_leaves_the_prior_invariant():
+    """With beta = 0 the target is the prior: mu_0, mu_self ~ N(0, 1), L ~ N(0, sigma I), whatever the data; the
+    adaptive step size settles where the running acceptance rate is near the 0.9 target."""
+    N, dim, sigma = 5, 2, 2.0
+    A, L, mu0, ms = make_case(N, dim, 1)
+    st, ar = 0.01, 0.9
+    m0s, mss, l0 = [], [], []
+    for sw in range(6000):
+        mu0, ms, st, ar, _ = O.ld_resample(A, L, mu0, ms, sigma, st, ar, 7, sw, beta=0.0)
+        m0s.append(mu0); mss.append(ms); l0.append(L[0, 0])
+    thin = slice(1000, None, 25)      # the mu updates move slowly (step 0.005 x 10 leapfrog steps): thin hard
+    assert abs(np.mean(l0[1000:])) < 0.25 and 0.6 * sigma < np.var(l0[1000:]) < 1.5 * sigma
+    assert stats.kstest(np.array(l0)[thin] / np.sqrt(sigma), "norm").pvalue > 1e-3
+    assert 0.6 < ar <= 1.0 and 1e-3 <= st <= 1.0
+    assert np.all(np.isfinite(m0s)) and np.all(np.isfinite(mss))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,dim,beta", [(40, 2, 1.0), (130, 3, 1.0), (97, 1, 0.4), (200, 4, 1.0)])
+def test_engine_parts_match_oracle(N, dim, beta):
+    from graphistician_amd import _abi as abi
+    sigma = 2.0
+    A, L, mu0, ms = make_case(N, dim, N)
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.LATENT_DIST, N=N, D=dim, K=1, B=1, seed=61, sigma_F=sigma)
+    m.set(abi.ST_F, L); m.set(abi.ST_MU0, np.array([mu0])); m.set(abi.ST_LD_AUX, np.array([ms, 0.02, 0.9]))
+    ll = m.log_likelihood(d)
+    ref = O.ld_loglik(A, L, mu0, ms)
+    assert abs(ll - ref) <= 1e-10 * abs(ref)
+    Lo, st, ar = L.copy(), 0.02, 0.9
+    # L
+    m.resample_part(d, abi.PART_F, beta)
+    mu0o, mso, st, ar, acc = O.ld_resample(A, Lo, mu0, ms, sigma, st, ar, 61, 0, parts=O.LD_PART_L, beta=beta)
+    assert np.allclose(m.get(abi.ST_F, (N, dim)), Lo, rtol=1e-9, atol=1e-11)
+    aux = m.get(abi.ST_LD_AUX, (3,))
+    assert abs(aux[1] - st) < 1e-15 and abs(aux[2] - ar) < 1e-15
+    # mu_0
+    m.resample_part(d, abi.PART_MU0, beta)
+    mu0o, mso, st, ar, acc = O.ld_resample(A, Lo, mu0, ms, sigma, st, ar, 61, 0, parts=O.LD_PART_MU0, beta=beta)
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - mu0o) < 1e-10
+    # mu_self
+    m.resample_part(d, abi.PART_LMBDA, beta)
+    _, mso, st, ar, acc = O.ld_resample(A, Lo, mu0o, ms, sigma, st, ar, 61, 0, parts=O.LD_PART_MUSELF, beta=beta)
+    assert abs(m.get(abi.ST_LD_AUX, (3,))[0] - mso) < 1e-10
+
+
+@pytest.mark.gpu
+def test_engine_chain_matches_oracle_and_fits():
+    """Several full resamples through the reference-shaped class; the chain must also do its job (fit improves)."""
+    from graphistician_amd.adjacency import LatentDistanceAdjacencyDistribution
+    N, dim, sigma = 80, 2, 2.0
+    A, L, mu0, ms = make_case(N, dim, 5)
+    np.random.seed(0)
+    m = LatentDistanceAdjacencyDistribution(N, dim=dim, sigma=sigma, mu0=mu0, mu_self=ms, seed=4321)
+    m.L = L
+    ll0 = m.log_likelihood(A)
+    Lo, m0, m_s, st, ar = L.copy(), mu0, ms, 0.01, 0.9
+    for s in range(5):
+        m.resample(A)
+        m0, m_s, st, ar, _ = O.ld_resample(A, Lo, m0, m_s, sigma, st, ar, 4321, s)
+    assert np.allclose(m.L, Lo, rtol=1e-7, atol=1e-9)
+    assert abs(m.mu_0 - m0) < 1e-8 and abs(m.mu_self - m_s) < 1e-8
+    assert abs(m._L_step_sz - st) < 1e-12
+    for s in range(60):
+        m.resample(A)
+    assert m.log_likelihood(A) > ll0 + 50.0
+    assert np.isfinite(m.log_probability(A))

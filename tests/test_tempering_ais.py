@@ -172,3 +172,22 @@ def test_engine_ais_er_and_sbm():
     er2 = BetaBernoulliAdjacencyDistribution(N, seed=12)
     lz_er = estimate_marginal_likelihood(er2, A2, N_samples=24, B=40, steps_per_B=1)
     assert lz_sbm > lz_er + 5.0
+
+
+@pytest.mark.gpu
+def test_engine_ais_latent_distance_vs_er():
+    """BASELINE.json configs[4]: AIS model comparison with the third model family.  Data with geometric structure
+    (two tight, far-apart clusters) is explained better by the latent-distance model than by Erdos-Renyi."""
+    from graphistician_amd.adjacency import LatentDistanceAdjacencyDistribution, BetaBernoulliAdjacencyDistribution
+    from graphistician_amd.ais import estimate_marginal_likelihood
+    rng = np.random.RandomState(11)
+    N = 14
+    L = np.vstack([rng.randn(N // 2, 2) * 0.3 + 1.5, rng.randn(N - N // 2, 2) * 0.3 - 1.5])
+    X = -((L[:, None, :] - L[None, :, :]) ** 2).sum(2) + 2.0
+    A = (rng.rand(N, N) < 1 / (1 + np.exp(-X))).astype(np.uint8)
+    np.random.seed(3)
+    ld = LatentDistanceAdjacencyDistribution(N, dim=2, sigma=2.0, seed=77)
+    lz_ld = estimate_marginal_likelihood(ld, A, N_samples=16, B=60, steps_per_B=2)
+    er = BetaBernoulliAdjacencyDistribution(N, seed=78)
+    lz_er = estimate_marginal_likelihood(er, A, N_samples=16, B=40, steps_per_B=1)
+    assert np.isfinite(lz_ld) and lz_ld > lz_er + 3.0, (lz_ld, lz_er)
