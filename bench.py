@@ -391,7 +391,11 @@ def main():
     truth = planted_truth(N, K, seed=1234)
     data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
                                         truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
-    adj, w = build_models(abi, N, K, chain_seed=1 + rank, device=device)
+    # Weak scaling needs the same work on every GPU: how many labels a chain keeps changing per sweep (and so how
+    # much of the scan's slow path it exercises) depends on its prior draw, so every rank runs a replica of the
+    # SAME chain (GG_BENCH_CHAIN_SEED, default 1).  Independent chains differ only in this seed.
+    chain_seed = int(os.environ.get("GG_BENCH_CHAIN_SEED", "1"))
+    adj, w = build_models(abi, N, K, chain_seed=chain_seed, device=device)
 
     for _ in range(args.warmup):
         adj.resample(data, 1)
@@ -447,7 +451,8 @@ def main():
                 "workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1, dense adjacency (%s)" % (
                     N, K, "BASELINE.json configs[1]" if (N, K) == (4096, 16) else
                     ("BASELINE.json configs[3] on one GPU" if (N, K) == (65536, 64) else "same recipe, other size")),
-                "parallelism": "independent chain per GPU" if world > 1 else "single GPU",
+                "parallelism": "one replica of the chain per GPU, no collective" if world > 1 else "single GPU",
+                "chain_seed": chain_seed,
                 "label_changes_in_timed_region": int(chg),
                 "sweep_algorithmic_bytes": sweep_bytes,
                 "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9,
@@ -483,7 +488,7 @@ def main():
             _progress("incremental-statistics variant")
             try:
                 os.environ["GG_INCREMENTAL"] = "1"
-                adj_i, w_i = build_models(abi, N, K, chain_seed=1 + rank, device=device)
+                adj_i, w_i = build_models(abi, N, K, chain_seed=chain_seed, device=device)
                 for _ in range(args.warmup):
                     adj_i.resample(data, 1); w_i.resample(data, 1)
                 t0i = time.perf_counter()

@@ -398,6 +398,7 @@ struct gg_params_args {
   int sweep_from_ctl;   // graph replay: the sweep index lives in ctl[6]; the deferred m belongs to sweep - 1
   int n0, Nl;           // sharded chain: only nodes [n0, n0 + Nl) are stored locally (tables are then partial)
   int tables_from_tab;  // sharded chain: the all-reduced tables are already in `tab`
+  unsigned long long* bar;   // k_scan's barrier counter + first-changer words, re-armed for the scan that follows
 };
 
 template <bool ADJ, int B>
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
     g.ctl[8] = 0;
     g.ctl[9] = 0;
   }
+  if (g.do_prep && g.bar && blockIdx.x == 0) { g.bar[threadIdx.x] = 0ull; g.bar[256 + threadIdx.x] = 0ull; }   // k_scan's exchange slots: tag 0 = never written
   const int K = g.K;
   constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
   constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;

@@ -12,6 +12,7 @@
 #include <thread>
 #include "gg_block_kernels.h"
 #include "gg_resolve_kernels.h"
+#include "gg_scan_kernels.h"
 
 struct gg_eigen;  // gg_eigen.hip
 int gg_eigen_create(gg_eigen** out, const gg_config* cfg);
@@ -84,6 +85,8 @@ struct gg_model {
   uint32_t sweep;
   int Lmax, Lcap, CH, max_idle;
   long long* dbg;               // GG_ROUND_DBG: phase timestamps of k_round
+  unsigned long long* bar;      // k_scan: grid-barrier counter + first-changer words
+  bool use_scan;                // the scan runs as one resident-grid launch (k_scan) instead of speculate + resolve (+ rounds)
   bool incr;                    // GG_INCREMENTAL=1: G is carried from sweep to sweep (changes flushed in), no bulk pass
   bool G_valid;                 // incr: Gbuf[cur] is the exact histogram of G_data under the current labels
   const gg_data* G_data;
@@ -209,6 +212,8 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if ((rc = dmalloc(&m->ap, (size_t)m->Nl + 1))) return rc;
   m->dbg = nullptr;
   m->incr = false; m->G_valid = false; m->G_data = nullptr;
+  m->bar = nullptr; m->use_scan = false;
+  if ((rc = dmalloc(&m->bar, (size_t)512))) return rc;
   if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
   // resolve chunk: one Kp-lane group per node, LDS budget 96 KiB
@@ -239,6 +244,12 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     // at N=4096 (11-13k sweeps/s against 17.5k serial); opt-in until launches get cheaper or N is large
     m->pipe = m->sbm && m->K > 1 && (e && atoi(e) == 1);
     // incremental statistics (opt-in, see enqueue_sweep_incr): not combined with the pipelined or sharded forms
+    // GG_SCAN=1 (experiment): the whole scan as one resident-grid launch (k_scan).  Exact, never stalls the sweep
+    // pipeline, but every accepted change costs a grid-wide exchange whose floor is the cross-XCD visibility
+    // latency (measured 8-9 us per exchange on MI355X): 25 us for a quiet scan against 13 us for speculate +
+    // resolve, 15-20 us per change against 17-24 us for a restart round.  Not faster anywhere yet: opt-in.
+    const char* es = getenv("GG_SCAN");
+    m->use_scan = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (es && atoi(es) == 1);
     const char* ei = getenv("GG_INCREMENTAL");
     m->incr = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (ei && atoi(ei) == 1);
   }
@@ -273,7 +284,7 @@ int gg_model_destroy(gg_model* m) {
   if (m->ld) { gg_latent_destroy(m->ld); delete m; return GG_OK; }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
-                  m->rs, m->L, m->lp_out, m->ap, m->dbg};
+                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   for (hipEvent_t e : m->ev) hipEventDestroy(e);
@@ -550,6 +561,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   g.m = m->m; g.logm = m->logm; g.p = m->p; g.p_self = m->p_self; g.mu = m->mu; g.sigma = m->sigma;
   g.mu_self = m->mu_self; g.sigma_self = m->sigma_self; g.T = m->T; g.Tout = m->Tout; g.Tin = m->Tin;
   g.ctl = m->rs;
+  g.bar = m->bar;
   g.pi = m->pi;
   g.beta = m->beta;
   g.sweep_from_ctl = from_ctl ? 1 : 0;
@@ -720,6 +732,51 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
   return GG_OK;
 }
 
+// The whole scan in one launch (k_scan: resident grid, one barrier round per accepted change).
+static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw) {
+  gg_scan_args a;
+  gg_resolve_args& g = a.r;
+  g.x = node_ctx(m, d, buf);
+  g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
+  g.tail_m = 0; g.tail_sort = tail_sort ? 1 : 0;
+  g.m = m->m; g.pi = m->pi; g.perm = m->permb[pw]; g.lab_start = m->labb[pw];
+  g.perm_prev = m->permb[1 - pw]; g.lab_start_prev = m->labb[1 - pw];
+  g.flush_on_change = 0; g.sweep_from_ctl = 0; g.round_mode = 0; g.window = 0;
+  g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
+  g.Lmax = m->Lcap; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
+  g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
+  g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
+  g.dbg = m->dbg;
+  g.keep_L = m->incr ? 1 : 0;
+  a.ap = m->ap; a.Gc0 = gcnt(m, buf, 0); a.Gs0 = gs(m, buf, 0); a.bar = m->bar; a.Lcap = m->Lcap;
+  const int K = m->K, per = 256 / m->Kp;
+  const int ngroups = (m->Nl + per - 1) / per;
+  a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
+               (size_t)(per + K + 8) * sizeof(int) + 64;
+  if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
+  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += table_bytes(m);
+  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);
+  g.stage_tables = stage;
+#define SCN(NTV, ADJV)                                                                                            \
+  do {                                                                                                            \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set && lds > 48 * 1024) {                                                                           \
+      GG_HIP(hipFuncSetAttribute((const void*)k_scan<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+      attr_set = true;                                                                                            \
+    }                                                                                                             \
+    k_scan<NTV, ADJV><<<a.G, 256, lds, m->stream>>>(a);                                                            \
+  } while (0)
+  if (m->is_adj) SCN(2, true);
+  else if (m->B == 1) SCN(3, false);
+  else if (m->B == 2) SCN(6, false);
+  else SCN(15, false);
+#undef SCN
+  GG_HIP(hipGetLastError());
+  return GG_OK;
+}
+
 // Finish a scan the pipeline left unfinished.  Restart rounds are device-driven: each round is ONE launch
 // (k_round: bring the next window's statistics up to date with the change list, re-speculate it, resolve it)
 // that reads the scan position from the control block and turns into a no-op once the scan is done, so a
@@ -785,8 +842,12 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
   if ((rc = enqueue_bulk(m, d, buf, scan ? 3 : 1, true, sweep))) return rc;
   if ((rc = enqueue_params(m, d, buf, true, true, scan, true, sweep, P))) return rc;
   if (scan) {
-    if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
-    if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
+    if (m->use_scan) {
+      if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P))) return rc;
+    } else {
+      if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
+      if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
+    }
     m->st.resolve_rounds += 1;
     m->m_pending = true;   // drawn by the next sweep's k_params (or at the next sync)
     m->m_sweep = sweep;
@@ -816,8 +877,12 @@ static int enqueue_sweep_incr(gg_model* m, const gg_data* d, uint32_t sweep) {
     m->G_data = d;
   }
   if ((rc = enqueue_params(m, d, buf, true, true, true, false, sweep, P))) return rc;
-  if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
-  if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
+  if (m->use_scan) {
+    if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P))) return rc;
+  } else {
+    if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
+    if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
+  }
   if ((rc = launch_apply_L(m, d, buf, 1))) return rc;   // the scan's changes -> G (no-op behind a stall)
   m->st.resolve_rounds += 1;
   m->m_pending = true;
@@ -971,10 +1036,13 @@ static int model_sync(gg_model* m) {
     if (m->pipe) GG_HIP(hipStreamSynchronize(m->sb));
     if ((rc = read_ctl(m))) return rc;
     if (m->h_rs[3]) {
+      const int st3 = m->h_rs[3];
       write_ctl_word(m, 3, 0);
       m->pending = 0;
       m->next_bulk = false;
       m->zeroed[0] = m->zeroed[1] = false;
+      m->G_valid = false;
+      if (st3 & 2) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out (the resident grid did not assemble); set GG_SCAN=0");
       return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
     }
     if (!m->h_rs[4]) {  // nothing stalled or flushed: every enqueued sweep completed
@@ -1029,6 +1097,12 @@ static int model_sync(gg_model* m) {
     if ((rc = read_ctl(m))) return rc;
   }
   m->st.label_changes = (uint64_t)m->h_rs[2];
+  if (m->dbg && m->use_scan) {
+    long long h[6];
+    GG_HIP(hipMemcpy(h, m->dbg, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[3]) fprintf(stderr, "[scan dbg] %s last scan: %lld rounds; per round eval %.2f exchange %.2f apply %.2f us; group loads %.2f us; kernel %.2f us\n",
+                      m->is_adj ? "adj" : "w", h[3], h[0] * 0.01 / h[3], h[1] * 0.01 / h[3], h[2] * 0.01 / h[3], h[4] * 0.01, h[5] * 0.01);
+  }
   GG_HIP(hipEventSynchronize(m->ev_call1));
   if ((rc = collect_timing(m))) return rc;
   return GG_OK;

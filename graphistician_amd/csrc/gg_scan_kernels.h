@@ -1,0 +1,363 @@
+// gg_scan_kernels.h — the whole sequential node scan (adjacency.py:650-695, weights.py:415-488) in ONE launch.
+//
+// k_speculate + k_resolve finish a scan in-stream only when label changes are rare; otherwise the host has to
+// drive restart rounds (k_round), one launch per accepted change.  k_scan keeps the grid resident instead:
+//   * G workgroups (<= 256, one per CU); workgroup b owns node groups b, b + G, ... (256 / Kp nodes each) and
+//     works on band r = groups [r G, (r+1) G) together with all the others;
+//   * per iteration every workgroup re-evaluates the nodes of its group that lie at or behind the scan position
+//     (statistics and, when they fit, coefficient tables stay in LDS), reports its first changer with a
+//     device-scope atomicMin, and meets the others at a grid barrier (one counter, bounded spin);
+//   * the minimum is the next exact change of the scan: every workgroup applies it to its own group's
+//     statistics (one byte / one int32 per node and direction from row f of X and X^T), the scan position
+//     moves behind it, and the loop continues; a band without a change is final and the grid moves on.
+// Cost: one barrier round (a few us) per accepted change instead of a kernel launch (and, before, a host round
+// trip), and no stall of the optimistic sweep pipeline.  Same statistics, same conditional, same draw as the
+// sequential loop: bit-exact (tests/test_gpu_parity_sbm.py run through this kernel).
+//
+// Grid barrier: all G workgroups must be resident.  G <= 256 workgroups of 256 threads with <= 64 KB LDS is far
+// below what the chip holds (even with the other model's kernels in flight), and every spin is bounded: on a
+// timeout the kernel raises status bit 2 and leaves, the host reports it (no hang).
+#pragma once
+#include "gg_resolve_kernels.h"
+
+#define GG_SCAN_MAXWG 256
+#define GG_BAR_SPIN_LIMIT (1 << 22)
+
+struct gg_scan_args {
+  gg_resolve_args r;          // labels, tables, data rows, RNG addressing, tail outputs (perm / lab_start)
+  int32_t* ap;                // entries of L already contained in a node's written-back statistics
+  int32_t* Gc0;               // statistics buffers (direction 1 follows direction 0)
+  long long* Gs0;
+  unsigned long long* bar;    // G exchange slots (tag << 48 | payload), zeroed by k_params before every scan
+  int Lcap;
+  int G;                      // workgroups in the grid
+};
+
+// Grid-wide exchange that doubles as the barrier: workgroup b publishes (round tag << 48 | payload) in its own
+// slot with one write-through store; everybody polls all G slots (one coalesced load per poll, lane t reads
+// slot t) until every tag equals this round's, and takes the minimum payload.  No read-modify-write atomics, no
+// counter to reset; the slots (2 x GG_SCAN_MAXWG) are zeroed (tag 0 = never) by k_params before every scan.
+// Returns false on timeout.
+#define GG_SLOT_NONE 0xffffffffffffull
+__device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int G, unsigned tag, unsigned long long mine,
+                                                 bool release, unsigned long long* s_min, int32_t* rs, unsigned long long* best) {
+  const int tid = threadIdx.x;
+  // two slot arrays, alternating by round: a workgroup can be one round ahead of the slowest one (never two), and
+  // must not overwrite the value the slow ones are still polling for
+  slots += (tag & 1u) * GG_SCAN_MAXWG;
+  __syncthreads();
+  if (tid == 0) {
+    *s_min = GG_SLOT_NONE;
+    if (release) __threadfence();   // plain global writes of this workgroup (labels, change list) come first
+    __hip_atomic_store(&slots[blockIdx.x], ((unsigned long long)(tag & 0xffffu) << 48) | (mine & GG_SLOT_NONE), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  bool okall = false;
+  for (int spin = 0; spin < GG_BAR_SPIN_LIMIT; ++spin) {
+    int ok = 1;
+    unsigned long long v = GG_SLOT_NONE;
+    if (tid < G) {
+      const unsigned long long w = __hip_atomic_load(&slots[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = (unsigned)(w >> 48) == (tag & 0xffffu);
+      v = w & GG_SLOT_NONE;
+    }
+    if (__syncthreads_and(ok)) {
+      if (v != GG_SLOT_NONE) atomicMin(s_min, v);
+      okall = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (!okall && tid == 0) atomicOr(&rs[3], 2);
+  __threadfence();
+  __syncthreads();
+  *best = *s_min;
+  __syncthreads();
+  return okall;
+}
+
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
+  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+  constexpr int NSI = NT - 1;
+  constexpr int U = 4;
+  const gg_resolve_args& g = a.r;
+  const gg_node_ctx& x = g.x;
+  if (g.rs[4]) return;   // an earlier scan of this pipeline is unfinished (uniform: set by a previous launch)
+  const int N = x.N, K = x.K, Kp = x.Kp, Np = x.Np;
+  const int per = 256 / Kp;
+  const int tid = threadIdx.x, b = blockIdx.x, G = a.G;
+  const int ngroups = (N + per - 1) / per;
+  const int stage_tables = g.stage_tables;
+
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  long long* s_gs = reinterpret_cast<long long*>(s_raw);
+  size_t off = ADJ ? 0 : (size_t)2 * K * per * NSI * sizeof(long long);
+  double* s_st = reinterpret_cast<double*>(s_raw + off); off += (size_t)2 * K * per * NT * sizeof(double);
+  double* s_T = reinterpret_cast<double*>(s_raw + off);
+  const int ntab = K * NT * Kp;
+  if (stage_tables) off += (size_t)2 * ntab * sizeof(double);
+  else if (Kp == 64) off += (size_t)4 * 2 * NT * 64 * sizeof(double);
+  int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
+  int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
+  int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);
+  off = (off + 7) & ~(size_t)7;
+  unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_raw + off); off += 2 * sizeof(unsigned long long);
+
+  for (int k = tid; k < K; k += 256) s_cnt[k] = g.cnt[k];
+  if (stage_tables) {
+    for (int idx = tid; idx < ntab; idx += 256) { s_T[idx] = x.Tout[idx]; s_T[ntab + idx] = x.Tin[idx]; }
+  }
+  for (int n = b * 256 + tid; n < N; n += G * 256) a.ap[n] = 0;   // nothing of this scan's list is in G yet
+  const size_t dstride = (size_t)K * Np;
+  const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+
+  int pos = 0, nL = 0, nchg = 0;
+  unsigned long long it = 0;     // barrier rounds so far (identical in every workgroup)
+  int wi = 0;                    // evaluation rounds so far: selects the rotating first-changer word
+  bool alive = true;
+  long long t_eval = 0, t_xchg = 0, t_apply = 0, t_load = 0;
+  const long long t_begin = g.dbg ? wall_clock64() : 0;
+
+  // move one edge's statistics of node i (LDS) from block ba to block bb
+  auto move_edge = [&](int d, int i, int ba, int bb, const int32_t* q) {
+    atomicSub(&s_gc[(d * K + ba) * per + i], 1);
+    atomicAdd(&s_gc[(d * K + bb) * per + i], 1);
+    if (!ADJ) {
+      long long v[NSI > 0 ? NSI : 1];
+      int t = 0;
+#pragma unroll
+      for (int r = 0; r < B; ++r) v[t++] = q[r];
+#pragma unroll
+      for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int s2 = r; s2 < B; ++s2) v[t++] = (long long)q[r] * (long long)q[s2];
+#pragma unroll
+      for (int s2 = 0; s2 < NSI; ++s2) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&s_gs[((size_t)(d * K + ba) * per + i) * NSI + s2]), (unsigned long long)(-v[s2]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&s_gs[((size_t)(d * K + bb) * per + i) * NSI + s2]), (unsigned long long)v[s2]);
+      }
+    }
+  };
+
+  for (int band = 0; band * G < ngroups && alive; ++band) {
+    const int grp = band * G + b;
+    const bool has = grp < ngroups;
+    const int n0 = grp * per;
+    if (pos < band * G * per) pos = band * G * per;
+    __syncthreads();
+    if (has) {
+      // the group's statistics as the bulk pass left them, plus every change accepted so far
+      for (int idx = tid; idx < 2 * K * per; idx += 256) {
+        const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
+        const int n = (n0 + i < N) ? n0 + i : N - 1;
+        const size_t gi = d * dstride + (size_t)j * Np + n;
+        s_gc[idx] = a.Gc0[gi];
+        if (!ADJ)
+          for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = a.Gs0[gi * NSI + s];
+      }
+      if (tid < per) s_c[tid] = (n0 + tid < N) ? g.c[n0 + tid] : 0;
+      __syncthreads();
+      const int nitems = nL * per * 2;
+      for (int base = tid; base < nitems; base += 256 * U) {
+        int ia[U], ib[U], ii[U], dd[U];
+        size_t at[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * 256;
+          const int d = idx & 1, i = (idx >> 1) % per, e = (idx >> 1) / per;
+          ok[u] = idx < nitems && n0 + i < N;
+          const int ee = ok[u] ? e : 0;
+          const int n2 = g.L[ee * 3];
+          ia[u] = g.L[ee * 3 + 1]; ib[u] = g.L[ee * 3 + 2];
+          ii[u] = i; dd[u] = d;
+          at[u] = ok[u] ? (size_t)n2 * Np + n0 + i : 0;
+        }
+        if (ADJ) {
+          uint8_t xv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) xv[u] = dd[u] == 0 ? g.XAT[at[u]] : g.XA[at[u]];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (ok[u] && xv[u] != 0) move_edge(dd[u], ii[u], ia[u], ib[u], nullptr);
+        } else {
+          int32_t q[U][B];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int32_t* src = (dd[u] == 0 ? g.XWT : g.XW) + at[u] * B;
+#pragma unroll
+            for (int r = 0; r < B; ++r) q[u][r] = src[r];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (ok[u] && q[u][0] != GG_NO_EDGE) move_edge(dd[u], ii[u], ia[u], ib[u], q[u]);
+        }
+      }
+    }
+    if (g.dbg) t_load += wall_clock64() - t_begin - t_load - t_eval - t_xchg - t_apply;
+    // ---- iterate until the band holds no further change
+    for (;;) {
+      const long long c0 = g.dbg ? wall_clock64() : 0;
+      __syncthreads();
+      if (tid == 0) *s_min = GG_NO_CHANGE;
+      if (has) {
+        for (int idx = tid; idx < 2 * K * per; idx += 256) {
+          const int i = idx % per, j = (idx / per) % K;
+          const int gc = s_gc[idx];
+          double* dst = s_st + (size_t)idx * NT;
+          if (ADJ) {
+            const int cx = s_cnt[j] - (s_c[i] == j ? 1 : 0);
+            dst[0] = (double)gc;
+            dst[1] = (double)(cx - gc);
+          } else {
+            dst[0] = (double)gc;
+#pragma unroll
+            for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)s_gs[(size_t)idx * NSI + s] * (s < B ? sc1 : sc2);
+          }
+        }
+      }
+      __syncthreads();
+      {
+        const int i = tid / Kp, k = tid % Kp;
+        const int n = n0 + i;
+        const bool live = has && n < N && n >= pos;
+        const int nn = (has && n < N) ? n : N - 1;
+        auto ld = [&](int j, double* so, double* si) {
+          const double* pa = s_st + (size_t)((0 * K + j) * per + i) * NT;
+          const double* pb = s_st + (size_t)((1 * K + j) * per + i) * NT;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) { so[t] = pa[t]; si[t] = pb[t]; }
+        };
+        double lp;
+        if (stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab);
+        else if (Kp == 64) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T, nn);
+        else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
+        const double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + nn));
+        const int lab = gg_group_categorical(lp, k, K, Kp, u);
+        if (live && k == 0) {
+          const int cn = s_c[i];
+          if (lab != cn) atomicMin(s_min, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
+        }
+      }
+      __syncthreads();
+      const long long c1 = g.dbg ? wall_clock64() : 0;
+      unsigned long long best;
+      {
+        const unsigned long long mine = *s_min;   // this workgroup's first changer (48-bit payload) or none
+        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, b == 0, s_min, g.rs, &best)) {
+          alive = false;
+          break;
+        }
+      }
+      ++it; ++wi;
+      if (best == GG_SLOT_NONE) best = GG_NO_CHANGE;
+      const long long c2 = g.dbg ? wall_clock64() : 0;
+      t_eval += c1 - c0; t_xchg += c2 - c1;
+      if (best == GG_NO_CHANGE) break;   // the band is final
+      const int f = (int)(best >> 12), ca = (int)((best >> 6) & 63u), cb = (int)(best & 63u);
+      if (tid == 0) {
+        s_cnt[ca] -= 1; s_cnt[cb] += 1;
+        if (has && f >= n0 && f < n0 + per) s_c[f - n0] = cb;
+        if (b == 0) {
+          g.c[f] = cb;
+          if (nL < a.Lcap) { g.L[nL * 3] = f; g.L[nL * 3 + 1] = ca; g.L[nL * 3 + 2] = cb; }
+        }
+      }
+      // statistics of my group's nodes: the edges to / from f move from block ca to block cb
+      if (has && tid < per * 2) {
+        const int d = tid & 1, i = tid >> 1;
+        if (n0 + i < N && n0 + i != f) {
+          const size_t at = (size_t)f * Np + n0 + i;
+          if (ADJ) {
+            if ((d == 0 ? g.XAT[at] : g.XA[at]) != 0) move_edge(d, i, ca, cb, nullptr);
+          } else {
+            const int32_t* q = (d == 0 ? g.XWT : g.XW) + at * B;
+            int32_t qq[B];
+#pragma unroll
+            for (int r = 0; r < B; ++r) qq[r] = q[r];
+            if (qq[0] != GG_NO_EDGE) move_edge(d, i, ca, cb, qq);
+          }
+        }
+      }
+      nL += 1; nchg += 1;
+      pos = f + 1;
+      if (g.dbg) { __syncthreads(); t_apply += wall_clock64() - c2; }
+      if (nL >= a.Lcap) {
+        // the list is full: bring the statistics of every node that is not in LDS right now up to date in G
+        // (earlier bands: written back with ap entries applied; later bands: as the bulk pass left them), then
+        // start a fresh list.  Grid-wide, followed by a barrier.
+        __syncthreads();
+        for (int n = b * 256 + tid; n < N; n += G * 256) {
+          const int ng = n / per;
+          if (ng >= band * G && ng < (band + 1) * G) { a.ap[n] = 0; continue; }   // in some workgroup's LDS
+          for (int e = a.ap[n]; e < nL; ++e) {
+            const int n2 = g.L[e * 3], ba = g.L[e * 3 + 1], bb = g.L[e * 3 + 2];
+            const size_t at = (size_t)n2 * Np + n;
+            for (int d = 0; d < 2; ++d) {
+              if (ADJ) {
+                if ((d == 0 ? g.XAT[at] : g.XA[at]) != 0) { a.Gc0[d * dstride + (size_t)ba * Np + n] -= 1; a.Gc0[d * dstride + (size_t)bb * Np + n] += 1; }
+              } else {
+                const int32_t* q = (d == 0 ? g.XWT : g.XW) + at * B;
+                if (q[0] == GG_NO_EDGE) continue;
+                a.Gc0[d * dstride + (size_t)ba * Np + n] -= 1;
+                a.Gc0[d * dstride + (size_t)bb * Np + n] += 1;
+                long long v[NSI > 0 ? NSI : 1];
+                int t = 0;
+                for (int r = 0; r < B; ++r) v[t++] = q[r];
+                for (int r = 0; r < B; ++r)
+                  for (int s2 = r; s2 < B; ++s2) v[t++] = (long long)q[r] * (long long)q[s2];
+                for (int s2 = 0; s2 < NSI; ++s2) {
+                  a.Gs0[(d * dstride + (size_t)ba * Np + n) * NSI + s2] -= v[s2];
+                  a.Gs0[(d * dstride + (size_t)bb * Np + n) * NSI + s2] += v[s2];
+                }
+              }
+            }
+          }
+          a.ap[n] = 0;
+        }
+        {
+          unsigned long long dummy;
+          if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), GG_SLOT_NONE, true, s_min, g.rs, &dummy)) { alive = false; break; }
+        }
+        ++it;
+        nL = 0;
+      }
+    }
+    if (!alive) break;
+    // the band is final: write the group's statistics back (exact under the labels so far) for the incremental path
+    __syncthreads();
+    if (has && g.keep_L) {
+      for (int idx = tid; idx < 2 * K * per; idx += 256) {
+        const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
+        if (n0 + i >= N) continue;
+        const size_t gi = d * dstride + (size_t)j * Np + n0 + i;
+        a.Gc0[gi] = s_gc[idx];
+        if (!ADJ)
+          for (int s = 0; s < NSI; ++s) a.Gs0[gi * NSI + s] = s_gs[(size_t)idx * NSI + s];
+      }
+      if (tid < per && n0 + tid < N) a.ap[n0 + tid] = nL;
+    }
+  }
+  // ---- tail: workgroup 0 publishes the result of the scan
+  if (b != 0 || !alive) return;
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) g.cnt[k] = s_cnt[k];
+  __threadfence();
+  __syncthreads();
+  gg_scan_tail(g, s_cnt, s_raw, g.rs[9] + nchg == 0);
+  if (g.dbg && tid == 0) {
+    g.dbg[0] = t_eval; g.dbg[1] = t_xchg; g.dbg[2] = t_apply; g.dbg[3] = (long long)it; g.dbg[4] = t_load;
+    g.dbg[5] = wall_clock64() - t_begin;
+  }
+  if (tid == 0) {
+    g.rs[0] = 0;
+    g.rs[1] = g.keep_L ? nL : 0;
+    g.rs[2] += nchg;
+    g.rs[9] += nchg;
+    g.rs[5] += 1;
+    g.rs[7] = 1;
+    *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(0, g.keep_L ? nL : 0, 0, 1, 0);
+  }
+}

@@ -193,3 +193,31 @@ def test_incremental_statistics_mode_is_the_same_chain(abi, N, K, monkeypatch):
             rng = np.random.RandomState(9)
             sa.c[:] = rng.choice(K, size=N); sw.c[:] = rng.choice(K, size=N)
             adj.set(abi.ST_C, sa.c, np.int32); w.set(abi.ST_C, sw.c, np.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(300, 7), (1100, 64)])
+def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
+    """GG_SCAN=1: the scan as one resident-grid launch (k_scan: grid-wide exchange per accepted change).  Same chain bit
+    for bit, burn-in included; N=1100, K=64 needs two bands of node groups (lazy change list at band load)."""
+    monkeypatch.setenv("GG_SCAN", "1")
+    A, W, _ = planted_sbm(N, K, seed=31)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=5), WState(N, K, 1, seed=6)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=71, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=72, special_case_self_conns=1)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    ps = sa.p_self
+    nsw = 4
+    abi.resample_many([adj, w], d, nsw)        # both grids resident at the same time
+    for s in range(nsw):
+        ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 71, s)
+        O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 72, s)
+    assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p)
+    assert np.array_equal(adj.get(abi.ST_M, (K,)), sa.m)
+    assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu)
+    assert adj.stats()["label_changes"] > 0
