@@ -85,7 +85,9 @@ struct gg_model {
   uint32_t sweep;
   int Lmax, Lcap, CH, max_idle;
   long long* dbg;               // GG_ROUND_DBG: phase timestamps of k_round
-  unsigned long long* bar;      // k_scan: grid-barrier counter + first-changer words
+  unsigned long long* bar;      // k_scan: exchange slots
+  int depth;                    // sweeps enqueued ahead of confirmation: halves to 1 when a scan stalls, doubles on clean batches
+  int todo;                     // sweeps requested but not enqueued yet (depth-limited)
   bool use_scan;                // the scan runs as one resident-grid launch (k_scan) instead of speculate + resolve (+ rounds)
   bool incr;                    // GG_INCREMENTAL=1: G is carried from sweep to sweep (changes flushed in), no bulk pass
   bool G_valid;                 // incr: Gbuf[cur] is the exact histogram of G_data under the current labels
@@ -213,6 +215,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->dbg = nullptr;
   m->incr = false; m->G_valid = false; m->G_data = nullptr;
   m->bar = nullptr; m->use_scan = false;
+  m->depth = 1 << 20; m->todo = 0;
   if ((rc = dmalloc(&m->bar, (size_t)512))) return rc;
   if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
@@ -1027,7 +1030,7 @@ static int collect_timing(gg_model* m) {
 // Confirm the optimistic sweeps: if a scan stalled (or flushed the pipeline), finish it on the slow
 // path and re-enqueue the sweeps that became no-ops behind it.
 static int model_sync(gg_model* m) {
-  if (m->eig || m->ld || m->pending == 0) return GG_OK;
+  if (m->eig || m->ld || (m->pending == 0 && m->todo == 0)) return GG_OK;
   int rc;
   const gg_data* d = m->pend_data;
   const bool scan = m->sbm && m->K > 1;
@@ -1039,6 +1042,7 @@ static int model_sync(gg_model* m) {
       const int st3 = m->h_rs[3];
       write_ctl_word(m, 3, 0);
       m->pending = 0;
+      m->todo = 0;
       m->next_bulk = false;
       m->zeroed[0] = m->zeroed[1] = false;
       m->G_valid = false;
@@ -1048,8 +1052,23 @@ static int model_sync(gg_model* m) {
     if (!m->h_rs[4]) {  // nothing stalled or flushed: every enqueued sweep completed
       m->sweep += (uint32_t)m->pending;
       m->st.sweeps += (uint64_t)m->pending;
-      break;
+      m->pending = 0;
+      if (m->todo == 0) break;
+      // a clean batch: look further ahead again
+      if (m->depth < (1 << 20)) m->depth *= 2;
+      const int take = m->todo < m->depth ? m->todo : m->depth;
+      m->cur0 = m->cur; m->pcur0 = m->pcur;
+      if (scan && (rc = write_ctl_word(m, 5, 0))) return rc;
+      for (int i = 0; i < take; ++i)
+        if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i))) return rc;
+      m->pending = take;
+      m->todo -= take;
+      GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+      continue;
     }
+    // A scan stalled: the sweeps enqueued behind it ran as no-ops and must be enqueued again.  A chain that keeps
+    // changing labels stalls every sweep, so stop running ahead (depth 1) until batches come back clean.
+    m->depth = 1;
     // ctl[5] scans completed before the flag went up.  pos != 0: the next one is stuck mid-scan.
     const int done = scan ? m->h_rs[5] : m->pending;
     const bool mid = m->h_rs[0] != 0;
@@ -1076,13 +1095,17 @@ static int model_sync(gg_model* m) {
     else if (m->incr) { m->zeroed[0] = m->zeroed[1] = false; }
     else { m->zeroed[1 - m->cur] = false; m->zeroed[m->cur] = true; }   // serial form: k_params of the last completed sweep zeroed it
     m->pending = 0;
-    if ((rc = write_ctl_word(m, 5, 0))) return rc;
-    if ((rc = write_ctl_word(m, 6, (int32_t)m->sweep))) return rc;
+    // words 5 (completed scans of the batch) and 6 (sweep index) in one stream-ordered copy from pinned staging
+    m->h_rs[24] = 0; m->h_rs[25] = (int32_t)m->sweep;
+    GG_HIP(hipMemcpyAsync(m->rs + 5, m->h_rs + 24, 2 * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
     m->cur0 = m->cur; m->pcur0 = m->pcur;
-    for (int i = 0; i < remaining; ++i)
+    m->todo += remaining;
+    const int take = m->todo < m->depth ? m->todo : m->depth;
+    for (int i = 0; i < take; ++i)
       if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i))) return rc;
-    m->pending = remaining;
-    if (remaining == 0) break;
+    m->pending = take;
+    m->todo -= take;
+    if (take == 0) break;
     GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   }
   m->pending = 0;
@@ -1141,14 +1164,15 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   if (m->sharded) return gg_fail(GG_ERR_INVALID, "this model owns a shard of the nodes: drive it with the gg_shard_* step API");
   int rc = check_data(m, d);
   if (rc) return rc;
-  if (m->pending && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
-  if (m->pending == 0) {
+  if ((m->pending || m->todo) && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
+  if (m->pending == 0 && m->todo == 0) {
     begin_call(m);
     m->cur0 = m->cur; m->pcur0 = m->pcur;
   }
   m->pend_data = d;
   m->beta = beta;
   for (int s = 0; s < n_sweeps; ++s) {
+    if (m->todo > 0 || m->pending >= m->depth) { m->todo += 1; continue; }   // not further ahead than `depth`
     if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)m->pending))) return rc;
     m->pending += 1;
   }
