@@ -504,8 +504,11 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
     int strips = (Np + 1023) / 1024;
     int RW = bulk_rw(m, strips, ndirs);
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
-    k_bulk_adj<<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1),
-                                           dir0, ctl);
+    // non-temporal loads once a pass streams more than the Infinity Cache holds (see gg_stream_load)
+    if ((double)ndirs * N * (double)Np > 200e6)
+      k_bulk_adj<true><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
+    else
+      k_bulk_adj<false><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
     if (timed) m->ev_bytes.push_back((double)ndirs * N * (double)N);
   } else {
     int SC = 64 * (4 / m->B);
@@ -514,9 +517,14 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
     static int unroll = -1;
     if (unroll < 0) { const char* e = getenv("GG_BULK_UNROLL"); unroll = e ? atoi(e) : 4; }
+    const bool ntl = (double)ndirs * N * (double)Np * 4.0 * m->B > 200e6;   // beyond the Infinity Cache: see gg_stream_load
 #define BULKW(BV, UV)                                                                                                 \
-  k_bulk_w<BV, UV><<<grd, 256, 0, st>>>(d->WqT, d->Wq, Np, perm, lab_start, K, RW, gcnt(m, buf, 0),         \
-                                               gcnt(m, buf, 1), gs(m, buf, 0), gs(m, buf, 1), dir0, ctl)
+  do {                                                                                                                \
+    if (ntl) k_bulk_w<BV, UV, true><<<grd, 256, 0, st>>>(d->WqT, d->Wq, Np, perm, lab_start, K, RW, gcnt(m, buf, 0),    \
+                                                         gcnt(m, buf, 1), gs(m, buf, 0), gs(m, buf, 1), dir0, ctl);    \
+    else k_bulk_w<BV, UV, false><<<grd, 256, 0, st>>>(d->WqT, d->Wq, Np, perm, lab_start, K, RW, gcnt(m, buf, 0),      \
+                                                      gcnt(m, buf, 1), gs(m, buf, 0), gs(m, buf, 1), dir0, ctl);      \
+  } while (0)
     switch (m->B) {
       case 1: if (unroll >= 8) BULKW(1, 8); else if (unroll >= 4) BULKW(1, 4); else BULKW(1, 2); break;
       case 2: BULKW(2, 4); break;

@@ -65,18 +65,21 @@ __global__ void k_draws(int what, uint64_t seed, const double* prm, int nprm, do
   }
 }
 
-__global__ __launch_bounds__(256) void k_stream_probe(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+typedef unsigned int gg_probe_u4 __attribute__((ext_vector_type(4)));
+template <bool NTL>
+__global__ __launch_bounds__(256) void k_stream_probe(const gg_probe_u4* __restrict__ src, gg_probe_u4* __restrict__ dst, size_t n16,
                                                       unsigned long long* __restrict__ sink) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int acc = 0;
+  auto ld = [&](size_t k) { return NTL ? __builtin_nontemporal_load(&src[k]) : src[k]; };
   for (; i + 3 * stride < n16; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
-    uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    gg_probe_u4 a = ld(i), b = ld(i + stride), c = ld(i + 2 * stride), d = ld(i + 3 * stride);
     if (dst) { dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d; }
     else acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
   }
   for (; i < n16; i += stride) {
-    uint4 a = src[i];
+    gg_probe_u4 a = ld(i);
     if (dst) dst[i] = a; else acc += a.x ^ a.y ^ a.z ^ a.w;
   }
   if (!dst && acc == 0x12345u) atomicAdd(sink, 1ull);   // (never true for the fill pattern; keeps the loads)
@@ -129,7 +132,7 @@ int gg_bench_stream(int32_t device, int64_t bytes, int32_t reps, int32_t mode, d
   int rc = gg_ensure_device(device);
   if (rc) return rc;
   const size_t n16 = (size_t)bytes / 16;
-  uint4 *src = nullptr, *dst = nullptr;
+  gg_probe_u4 *src = nullptr, *dst = nullptr;
   unsigned long long* sink = nullptr;
   GG_HIP(hipMalloc((void**)&src, n16 * 16));
   GG_HIP(hipMemset(src, 1, n16 * 16));
@@ -140,9 +143,13 @@ int gg_bench_stream(int32_t device, int64_t bytes, int32_t reps, int32_t mode, d
   GG_HIP(hipEventCreate(&e0));
   GG_HIP(hipEventCreate(&e1));
   const int nb = 256 * 16;   // 16 workgroups per CU, grid-strided
-  k_stream_probe<<<nb, 256>>>(src, dst, n16, sink);   // warm-up
+  // the same streaming hint as the bulk kernels: non-temporal loads beyond the Infinity Cache (gg_stream_load)
+  const bool ntl = (double)bytes > 200e6;
+  if (ntl) k_stream_probe<true><<<nb, 256>>>(src, dst, n16, sink); else k_stream_probe<false><<<nb, 256>>>(src, dst, n16, sink);   // warm-up
   GG_HIP(hipEventRecord(e0, 0));
-  for (int r = 0; r < reps; ++r) k_stream_probe<<<nb, 256>>>(src, dst, n16, sink);
+  for (int r = 0; r < reps; ++r) {
+    if (ntl) k_stream_probe<true><<<nb, 256>>>(src, dst, n16, sink); else k_stream_probe<false><<<nb, 256>>>(src, dst, n16, sink);
+  }
   GG_HIP(hipEventRecord(e1, 0));
   GG_HIP(hipEventSynchronize(e1));
   GG_HIP(hipGetLastError());
