@@ -468,7 +468,7 @@ def main():
                 "traffic_note": "null here: PMC counters need their own rocprofv3 pass; at N=4096 the 160 MB working set also sits in the 256 MiB Infinity Cache, where the "
                                 "memory-side counters under-report.  Measured at N=32768 with rocprofv3 --pmc FETCH_SIZE / "
                                 "WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 correction): 8.74 GB per launch vs "
-                                "8.59 GB algorithmic (ratio 1.018), profiles/r01_pmc_bulk_traffic.json",
+                                "8.59 GB algorithmic (ratio 1.018), profiles/r01_pmc_bulk_traffic_nt.json",
                 "launch_ms": per_launch_ms,
                 "launch_bytes": alg_bytes,
                 "sampled_launches": int(bulk["w_n"]),
