@@ -57,8 +57,52 @@ def er_case(N, B, seed, nsweeps):
                 out_sigma_self=sigs, ll_a=ll_a, ll_w=ll_w)
 
 
+def eigen_case(N, D, seed, nsweeps, probit):
+    """Config 3 (logistic) / SURVEY 8f rank 2 (probit): eigenmodel sweeps from a fixed start."""
+    rng = np.random.RandomState(seed)
+    Ft, lt, m0t = rng.randn(N, D), rng.randn(D), -0.5
+    Mu = m0t + (Ft * lt).dot(Ft.T)
+    np.fill_diagonal(Mu, m0t)
+    if probit:
+        from scipy.special import ndtr
+        A = (rng.rand(N, N) < ndtr(Mu)).astype(np.uint8)
+    else:
+        A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-Mu))).astype(np.uint8)
+    F = np.ascontiguousarray(rng.randn(N, D) * 0.7)
+    lmbda = np.ascontiguousarray(rng.randn(D))
+    mu0 = 0.1
+    init = dict(init_F=F.copy(), init_lmbda=lmbda.copy(), init_mu0=mu0)
+    sweep = O.probit_sweep if probit else O.eig_sweep
+    for s in range(nsweeps):
+        mu0, _ = sweep(A, F, lmbda, mu0, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 5000 + seed, s)
+    ll = (O.probit_loglik if probit else O.eig_loglik)(A, F, lmbda, mu0)
+    out = dict(N=N, D=D, nsweeps=nsweeps, probit=int(probit), seed=5000 + seed, A=A, out_F=F, out_lmbda=lmbda, out_mu0=mu0, ll=ll)
+    out.update(init)
+    return out
+
+
+def latent_case(N, dim, seed, nsweeps):
+    """latent-distance adjacency model, HMC resamples from a fixed start."""
+    rng = np.random.RandomState(seed)
+    Lt = rng.randn(N, dim)
+    X = -((Lt[:, None, :] - Lt[None, :, :]) ** 2).sum(2) + 0.4
+    A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-X))).astype(np.uint8)
+    L = np.ascontiguousarray(rng.randn(N, dim))
+    init = dict(init_L=L.copy(), init_mu0=0.1, init_mu_self=-0.1)
+    mu0, ms, st, ar = 0.1, -0.1, 0.01, 0.9
+    for s in range(nsweeps):
+        mu0, ms, st, ar, _ = O.ld_resample(A, L, mu0, ms, 2.0, st, ar, 6000 + seed, s)
+    out = dict(N=N, dim=dim, nsweeps=nsweeps, seed=6000 + seed, sigma=2.0, A=A, out_L=L, out_mu0=mu0, out_mu_self=ms,
+               out_step=st, out_rate=ar, ll=O.ld_loglik(A, L, mu0, ms))
+    out.update(init)
+    return out
+
+
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "sbm_n64_k4_b1.npz"), **sbm_case(64, 4, 1, 7, 6, 1))
     np.savez_compressed(os.path.join(HERE, "sbm_n48_k3_b2_nospecial.npz"), **sbm_case(48, 3, 2, 9, 4, 0))
     np.savez_compressed(os.path.join(HERE, "er_n50_b2.npz"), **er_case(50, 2, 1234, 5))
+    np.savez_compressed(os.path.join(HERE, "eigen_logistic_n40_d3.npz"), **eigen_case(40, 3, 11, 3, False))
+    np.savez_compressed(os.path.join(HERE, "eigen_probit_n40_d3.npz"), **eigen_case(40, 3, 12, 3, True))
+    np.savez_compressed(os.path.join(HERE, "latent_n40_dim2.npz"), **latent_case(40, 2, 13, 4))
     print("golden fixtures written to", HERE)

@@ -102,3 +102,72 @@ def test_engine_reproduces_er_golden():
     ll = net.log_likelihood(data)
     ref = float(g["ll_a"]) + float(g["ll_w"])
     assert abs(ll - ref) <= 1e-9 * abs(ref)
+
+
+# ---------------------------------------------------------------- eigenmodels and latent-distance model
+EIG_FIXTURES = ["eigen_logistic_n40_d3.npz", "eigen_probit_n40_d3.npz"]
+
+
+def _run_eigen_oracle(g):
+    F, lmbda, mu0 = g["init_F"].copy(), g["init_lmbda"].copy(), float(g["init_mu0"])
+    probit = int(g["probit"]) == 1
+    sweep = O.probit_sweep if probit else O.eig_sweep
+    for s in range(int(g["nsweeps"])):
+        mu0, _ = sweep(g["A"], F, lmbda, mu0, np.zeros(int(g["D"])), -0.3, 1.0, 1.0, 1.0, 0, int(g["seed"]), s)
+    return F, lmbda, mu0
+
+
+@pytest.mark.parametrize("name", EIG_FIXTURES)
+def test_oracle_reproduces_eigen_golden(name):
+    g = np.load(os.path.join(G, name))
+    F, lmbda, mu0 = _run_eigen_oracle(g)
+    assert np.allclose(F, g["out_F"], rtol=1e-12, atol=1e-13) and np.allclose(lmbda, g["out_lmbda"], rtol=1e-12, atol=1e-13)
+    assert abs(mu0 - float(g["out_mu0"])) < 1e-12
+    ll = (O.probit_loglik if int(g["probit"]) else O.eig_loglik)(g["A"], F, lmbda, mu0)
+    assert abs(ll - float(g["ll"])) <= 1e-10 * abs(ll)
+
+
+def test_oracle_reproduces_latent_golden():
+    g = np.load(os.path.join(G, "latent_n40_dim2.npz"))
+    L, mu0, ms, st, ar = g["init_L"].copy(), float(g["init_mu0"]), float(g["init_mu_self"]), 0.01, 0.9
+    for s in range(int(g["nsweeps"])):
+        mu0, ms, st, ar, _ = O.ld_resample(g["A"], L, mu0, ms, float(g["sigma"]), st, ar, int(g["seed"]), s)
+    assert np.allclose(L, g["out_L"], rtol=1e-12, atol=1e-13)
+    assert abs(mu0 - float(g["out_mu0"])) < 1e-12 and abs(ms - float(g["out_mu_self"])) < 1e-12
+    assert abs(st - float(g["out_step"])) < 1e-15 and abs(ar - float(g["out_rate"])) < 1e-15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", EIG_FIXTURES)
+def test_engine_reproduces_eigen_golden(name):
+    from graphistician_amd import _abi as abi
+    g = np.load(os.path.join(G, name))
+    N, D = int(g["N"]), int(g["D"])
+    kind = abi.PROBIT_EIG if int(g["probit"]) else abi.LOGISTIC_EIG
+    d = abi.DeviceData(g["A"], None)
+    m = abi.Model(kind=kind, N=N, D=D, K=1, B=1, seed=int(g["seed"]), sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=-0.3,
+                  lmbda_given=0)
+    m.set(abi.ST_F, g["init_F"]); m.set(abi.ST_LMBDA, g["init_lmbda"]); m.set(abi.ST_MU0, np.array([float(g["init_mu0"])]))
+    m.set(abi.ST_MU_LMBDA, np.zeros(D))
+    m.resample(d, int(g["nsweeps"]))
+    assert np.allclose(m.get(abi.ST_F, (N, D)), g["out_F"], rtol=1e-6, atol=1e-8)
+    assert np.allclose(m.get(abi.ST_LMBDA, (D,)), g["out_lmbda"], rtol=1e-6, atol=1e-8)
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - float(g["out_mu0"])) < 1e-7
+    assert abs(m.log_likelihood(d) - float(g["ll"])) <= 1e-7 * abs(float(g["ll"]))
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_latent_golden():
+    from graphistician_amd import _abi as abi
+    g = np.load(os.path.join(G, "latent_n40_dim2.npz"))
+    N, dim = int(g["N"]), int(g["dim"])
+    d = abi.DeviceData(g["A"], None)
+    m = abi.Model(kind=abi.LATENT_DIST, N=N, D=dim, K=1, B=1, seed=int(g["seed"]), sigma_F=float(g["sigma"]))
+    m.set(abi.ST_F, g["init_L"]); m.set(abi.ST_MU0, np.array([float(g["init_mu0"])]))
+    m.set(abi.ST_LD_AUX, np.array([float(g["init_mu_self"]), 0.01, 0.9]))
+    m.resample(d, int(g["nsweeps"]))
+    assert np.allclose(m.get(abi.ST_F, (N, dim)), g["out_L"], rtol=1e-7, atol=1e-9)
+    aux = m.get(abi.ST_LD_AUX, (3,))
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - float(g["out_mu0"])) < 1e-8 and abs(aux[0] - float(g["out_mu_self"])) < 1e-8
+    assert abs(aux[1] - float(g["out_step"])) < 1e-12
+    assert abs(m.log_likelihood(d) - float(g["ll"])) <= 1e-8 * abs(float(g["ll"]))
