@@ -86,6 +86,7 @@ struct gg_model {
   int Lmax, Lcap, CH, max_idle;
   long long* dbg;               // GG_ROUND_DBG: phase timestamps of k_round
   unsigned long long* bar;      // k_scan: exchange slots
+  int round_hint;               // restart rounds the last unfinished scan needed: size of the first batch next time
   int depth;                    // sweeps enqueued ahead of confirmation: halves to 1 when a scan stalls, doubles on clean batches
   int todo;                     // sweeps requested but not enqueued yet (depth-limited)
   bool use_scan;                // the scan runs as one resident-grid launch (k_scan) instead of speculate + resolve (+ rounds)
@@ -215,7 +216,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->dbg = nullptr;
   m->incr = false; m->G_valid = false; m->G_data = nullptr;
   m->bar = nullptr; m->use_scan = false;
-  m->depth = 1 << 20; m->todo = 0;
+  m->depth = 1 << 20; m->todo = 0; m->round_hint = 0;
   if ((rc = dmalloc(&m->bar, (size_t)512))) return rc;
   if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
@@ -799,8 +800,11 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   // at most 512 node groups per round (two workgroups per CU): beyond that a round's latency grows with the window
   int window = m->N < 4096 ? m->N : 4096;
   if (window > 512 * (256 / m->Kp)) window = 512 * (256 / m->Kp);
-  int batch = 4;
+  // first batch: what the previous unfinished scan needed plus a margin (rounds behind the end of the scan are
+  // cheap no-ops, a second batch costs a host round trip)
+  int batch = m->round_hint > 4 ? m->round_hint : 4;
   long long rounds = 0;
+  int seq_first = -1;
   for (;;) {
     if ((rc = read_ctl(m))) return rc;
     if (m->dbg && rounds > 0) {
@@ -822,6 +826,15 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     }
     if (!m->h_rs[4] || m->h_rs[0] == 0) {   // scan complete (a set flag with pos == 0 is a pipeline flush, not a stall)
       if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
+      if (seq_first >= 0) {
+        unsigned long long st;
+        memcpy(&st, &m->h_rs[GG_RS_STATE], sizeof(st));
+        int q0, q1, q2, q3, seq_now;
+        gg_unpack_state(st, &q0, &q1, &q2, &q3, &seq_now);
+        const int used = (seq_now - seq_first) & 0xfff;           // rounds that actually ran
+        int hint = used + used / 4 + 2;
+        m->round_hint = hint > 256 ? 256 : hint;
+      }
       return GG_OK;
     }
     if (m->h_rs[1] + batch > m->Lcap) {
@@ -834,6 +847,7 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
       int q0, q1, q2, q3;
       gg_unpack_state(st, &q0, &q1, &q2, &q3, &base);
     }
+    if (seq_first < 0) seq_first = base;
     for (int r = 0; r < batch; ++r)
       if ((rc = launch_round(m, d, buf, sweep, tail_m, tail_sort, pw, window, base + r))) return rc;
     rounds += batch;
