@@ -1090,7 +1090,7 @@ static int model_sync(gg_model* m) {
     }
     // A scan stalled: the sweeps enqueued behind it ran as no-ops and must be enqueued again.  A chain that keeps
     // changing labels stalls every sweep, so stop running ahead (depth 1) until batches come back clean.
-    m->depth = 1;
+    if (!m->pipe) m->depth = 1;   // (the pipelined form keeps its own look-ahead discipline)
     // ctl[5] scans completed before the flag went up.  pos != 0: the next one is stuck mid-scan.
     const int done = scan ? m->h_rs[5] : m->pending;
     const bool mid = m->h_rs[0] != 0;
@@ -1187,6 +1187,8 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   int rc = check_data(m, d);
   if (rc) return rc;
   if ((m->pending || m->todo) && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
+  // pipelined form: statistics computed ahead belong to the data (and labels) of the previous call
+  if (m->pipe && m->pend_data != d && (rc = drain_pipe(m))) return rc;
   if (m->pending == 0 && m->todo == 0) {
     begin_call(m);
     m->cur0 = m->cur; m->pcur0 = m->pcur;
