@@ -1,6 +1,7 @@
 // gg_latent.h — scalar arithmetic of the latent-distance model (adjacency.py:191-437), shared by the HIP engine
 // and the CPU oracle: numerically stable Bernoulli-logit terms and the step-size adaptation of the HMC update.
 #pragma once
+#include <math.h>
 #include "gg_math.h"
 
 // log(1 + e^x) and 1 / (1 + e^-x) without overflow (the reference writes log(P), log(1 - P): adjacency.py:262-266)
@@ -13,10 +14,13 @@ GG_HD double gg_sigmoid(double x) {
 
 // Both at once from a single exponential: e = exp(-|x|), softplus = max(x, 0) + log(1 + e), sigmoid = 1 / (1 + e) or
 // e / (1 + e).  (Same values as the two functions above.)
+// (exp / log here are the platform's: libm on the host, ocml on the device, <= 1 ulp apart.  The model's parity is a
+// float tolerance anyway (its sums are ordered differently), and the pass is bound by these two calls: the
+// branch-free ocml versions run about twice as fast as the bit-reproducible gg_exp / gg_log.)
 GG_HD void gg_sigmoid_softplus(double x, double* P, double* sp) {
-  const double e = gg_exp(x > 0.0 ? -x : x);
+  const double e = exp(x > 0.0 ? -x : x);
   const double d = 1.0 + e;
-  *sp = (x > 0.0 ? x : 0.0) + gg_log(d);
+  *sp = (x > 0.0 ? x : 0.0) + log(d);
   *P = x >= 0.0 ? 1.0 / d : e / d;
 }
 
