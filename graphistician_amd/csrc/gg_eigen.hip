@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
         dO[gi] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gi, mu0);
       } else if (I < J || li < lj) {
         const double psi = s_psi[li][lj];
-        double o1 = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gj, psi);
-        double o2 = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gj, (uint32_t)gi, psi);
-        val = o1 + o2;
+        // omega_ij and omega_ji see the same psi: the mixture mass is computed once for the pair
+        const double Z = 0.5 * gg_fabs(psi), ptex = gg_pg_mass_texpon(Z);
+        gg_stream s1, s2;
+        gg_stream_init(&s1, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj);
+        gg_stream_init(&s2, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi);
+        val = gg_pg1_pre(&s1, Z, ptex) + gg_pg1_pre(&s2, Z, ptex);
       }
     }
     if (I < J || li <= lj) s_t[li][lj] = val;

@@ -24,17 +24,24 @@
 #define GG_PG_TRUNC 0.64
 #define GG_PI 3.141592653589793238462643383279502884197
 
+// exp / log of the PG(1, z) sampler: the platform's (libm on the host, ocml on the device, <= 1 ulp apart).  The
+// eigenmodels' parity is a float tolerance, an accept / reject comparison flips only when the two sides agree to
+// ~1e-16, and the branch-free ocml routines are markedly faster on the device than the bit-reproducible gg_exp / gg_log
+// (which the block models need and keep).
+#define GG_PG_EXP(x) exp(x)
+#define GG_PG_LOG(x) log(x)
+
 GG_HD double gg_norm_cdf(double x) { return 0.5 * erfc(-x * 0.70710678118654752440); }
 
-GG_HD double gg_expon(gg_stream* s) { return -gg_log(gg_stream_uniform_pos(s)); }
+GG_HD double gg_expon(gg_stream* s) { return -GG_PG_LOG(gg_stream_uniform_pos(s)); }
 
 // a_n(x): coefficients of the alternating series (Devroye 2009; PSW 2013 eq. 12-13)
 GG_HD double gg_pg_a(int n, double x) {
   const double K = ((double)n + 0.5) * GG_PI;
-  if (x > GG_PG_TRUNC) return K * gg_exp(-0.5 * K * K * x);
+  if (x > GG_PG_TRUNC) return K * GG_PG_EXP(-0.5 * K * K * x);
   if (x > 0.0) {
-    double expnt = -1.5 * (gg_log(0.5 * GG_PI) + gg_log(x)) + gg_log(K) - 2.0 * ((double)n + 0.5) * ((double)n + 0.5) / x;
-    return gg_exp(expnt);
+    double expnt = -1.5 * (GG_PG_LOG(0.5 * GG_PI) + GG_PG_LOG(x)) + GG_PG_LOG(K) - 2.0 * ((double)n + 0.5) * ((double)n + 0.5) / x;
+    return GG_PG_EXP(expnt);
   }
   return 0.0;
 }
@@ -45,10 +52,10 @@ GG_HD double gg_pg_mass_texpon(double Z) {
   const double fz = 0.125 * GG_PI * GG_PI + 0.5 * Z * Z;
   const double b = gg_sqrt(1.0 / t) * (t * Z - 1.0);
   const double a = -gg_sqrt(1.0 / t) * (t * Z + 1.0);
-  const double x0 = gg_log(fz) + fz * t;
-  const double xb = x0 - Z + gg_log(gg_norm_cdf(b));
-  const double xa = x0 + Z + gg_log(gg_norm_cdf(a));
-  const double qdivp = 4.0 / GG_PI * (gg_exp(xb) + gg_exp(xa));
+  const double x0 = GG_PG_LOG(fz) + fz * t;
+  const double xb = x0 - Z + GG_PG_LOG(gg_norm_cdf(b));
+  const double xa = x0 + Z + GG_PG_LOG(gg_norm_cdf(a));
+  const double qdivp = 4.0 / GG_PI * (GG_PG_EXP(xb) + GG_PG_EXP(xa));
   return 1.0 / (1.0 + qdivp);
 }
 
@@ -63,7 +70,7 @@ GG_HD double gg_pg_rtigauss(gg_stream* s, double Z) {
       while (E1 * E1 > 2.0 * E2 / t) { E1 = gg_expon(s); E2 = gg_expon(s); }
       X = 1.0 + E1 * t;
       X = t / (X * X);
-      alpha = gg_exp(-0.5 * Z * Z * X);
+      alpha = GG_PG_EXP(-0.5 * Z * Z * X);
     }
   } else {
     const double mu = 1.0 / Z;
@@ -79,11 +86,10 @@ GG_HD double gg_pg_rtigauss(gg_stream* s, double Z) {
   return X;
 }
 
-// omega ~ PG(1, z)
-GG_HD double gg_pg1(gg_stream* s, double z) {
-  const double Z = 0.5 * gg_fabs(z);
+// omega ~ PG(1, z) given Z = |z| / 2 and the mass of the truncated-exponential component (shared by the two
+// draws omega_ij, omega_ji of a pair: same psi)
+GG_HD double gg_pg1_pre(gg_stream* s, double Z, double ptex) {
   const double fz = 0.125 * GG_PI * GG_PI + 0.5 * Z * Z;
-  const double ptex = gg_pg_mass_texpon(Z);
   for (;;) {
     double X;
     if (gg_stream_uniform(s) < ptex) X = GG_PG_TRUNC + gg_expon(s) / fz;
@@ -103,6 +109,12 @@ GG_HD double gg_pg1(gg_stream* s, double z) {
       if (n > 200) return 0.25 * X;  // numerically converged series
     }
   }
+}
+
+// omega ~ PG(1, z)
+GG_HD double gg_pg1(gg_stream* s, double z) {
+  const double Z = 0.5 * gg_fabs(z);
+  return gg_pg1_pre(s, Z, gg_pg_mass_texpon(Z));
 }
 
 // Stream index of omega_ij: one stream per ordered pair.
