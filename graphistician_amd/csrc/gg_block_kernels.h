@@ -729,11 +729,20 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
   return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i);
 }
 
+// Where the spec-order doubles of (direction d, block j, node i of the workgroup) live in LDS: element t is at
+// base + t * stride.  Normal layout [dir][j][node][NT]; split layout (Kp = 64, tables not staged: gg_lp_split4)
+// [dir][j][NT][node], so that a chain reads its statistic for all four nodes with one wide load.
+__device__ __forceinline__ size_t gg_st_slot(bool split, int dj /* d * K + j */, int i, int per, int NT, int* stride) {
+  *stride = split ? per : 1;
+  return split ? ((size_t)dj * NT) * per + i : ((size_t)dj * per + i) * NT;
+}
+
 // The same conditional for a workgroup of 4 waves that holds 4 nodes with Kp = 64 (33 <= K <= 64), when the
 // coefficient tables do not fit in LDS: the 2 NT independent fma chains (direction, statistic) are dealt
 // out to the waves, each wave running its chains for all 4 nodes, so every table entry is fetched once per
 // workgroup instead of once per node; the chains meet in LDS and wave i combines those of node i in the
-// order of gg_block_lp.  Same chains, same order, same bits.  s_st: [dir][j][4][NT], s_acc: [4][2 NT][64].
+// order of gg_block_lp.  Same chains, same order, same bits.  s_st: [dir][j][NT][4] (gg_st_slot with split = true),
+// s_acc: [4][2 NT][64].
 template <int NT, bool ADJ>
 __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const double* s_st, double* s_acc, int n) {
   constexpr int NCH = 2 * NT;
@@ -769,13 +778,14 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
         const int ch = w + 4 * c;
         if (ch < NCH) {
           const int d = ch / NT, t = ch % NT;
-          const double* sb = s_st + (size_t)d * K * 4 * NT + t;
+          // split layout of the statistics: [dir][j][t][node] - the four nodes of a (j, t) are one 32-byte read
+          const double* sb = s_st + ((size_t)d * K * NT + t) * 4;
 #pragma unroll
           for (int u = 0; u < UJ; ++u) {
             if (j + u < K) {
-              const double* sp = sb + (size_t)(j + u) * 4 * NT;
+              const double* sp = sb + (size_t)(j + u) * NT * 4;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) acc[c][i] = gg_fma(tv[c][u], sp[i * NT], acc[c][i]);
+              for (int i = 0; i < 4; ++i) acc[c][i] = gg_fma(tv[c][u], sp[i], acc[c][i]);
             }
           }
         }
@@ -875,16 +885,17 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
     const size_t gi = (size_t)j * x.Np + n;
     const size_t gd = (size_t)d * K * x.Np + gi;   // direction 1 follows direction 0 in the buffer
     const int gc = x.Gcnt[0][gd];
-    double* dst = s_st + (size_t)idx * NT;
+    int ts;
+    double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
     if (ADJ) {
       const int cx = x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0);
       dst[0] = (double)gc;
-      dst[1] = (double)(cx - gc);
+      dst[ts] = (double)(cx - gc);
     } else {
       constexpr int B = (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
       dst[0] = (double)gc;
 #pragma unroll
-      for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
+      for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
     }
   }
   const int ntab = K * NT * Kp;

@@ -477,15 +477,37 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
   for (int grp = blockIdx.x; grp < nact; grp += gridDim.x) {
     const int n0 = pos + grp * per;
     __syncthreads();   // the previous group's LDS is dead
-    for (int idx = tid; idx < 2 * K * per; idx += 256) {
-      const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
-      const int n = (n0 + i < N) ? n0 + i : N - 1;
-      const size_t gi = d * dstride + (size_t)j * Np + n;
-      s_gc[idx] = Gc0[gi];
-      if (!ADJ)
-        for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = Gs0[gi * NSI + s];
+    {
+      // 2 K per <= 512 entries: at most two per thread; all their loads are issued before the first LDS store
+      int gcv[2];
+      long long gsv[2][NSI > 0 ? NSI : 1];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = tid + u * 256;
+        const bool in = idx < 2 * K * per;
+        const int ii = in ? idx : 0;
+        const int i = ii % per, j = (ii / per) % K, d = ii / (per * K);
+        const int n = (n0 + i < N) ? n0 + i : N - 1;
+        const size_t gi = d * dstride + (size_t)j * Np + n;
+        gcv[u] = Gc0[gi];
+        if (!ADJ)
+#pragma unroll
+          for (int s = 0; s < NSI; ++s) gsv[u][s] = Gs0[gi * NSI + s];
+      }
+      const int apv = (tid < per && n0 + tid < wend) ? ap[n0 + tid] : nL;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = tid + u * 256;
+        if (idx < 2 * K * per) {
+          s_gc[idx] = gcv[u];
+          if (!ADJ)
+#pragma unroll
+            for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = gsv[u][s];
+        }
+      }
+      if (tid < per) s_ap[tid] = apv;
     }
-    if (tid < per) s_ap[tid] = (n0 + tid < wend) ? ap[n0 + tid] : nL;
     if (tid == 0) s_ctl[5] = nL;
     __syncthreads();
     if (tid < per) atomicMin(&s_ctl[5], s_ap[tid]);
@@ -562,18 +584,19 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
       const int gc = s_gc[idx];
       const bool dirty = live && s_ap[i] < nL;
       if (dirty) Gc0[gi] = gc;
-      double* dst = s_st + (size_t)idx * NT;
+      int ts;
+      double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
       if (ADJ) {
         const int cx = x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0);
         dst[0] = (double)gc;
-        dst[1] = (double)(cx - gc);
+        dst[ts] = (double)(cx - gc);
       } else {
         dst[0] = (double)gc;
 #pragma unroll
         for (int s = 0; s < NSI; ++s) {
           const long long v = s_gs[(size_t)idx * NSI + s];
           if (dirty) Gs0[gi * NSI + s] = v;
-          dst[1 + s] = (double)v * (s < B ? sc1 : sc2);
+          dst[(1 + s) * ts] = (double)v * (s < B ? sc1 : sc2);
         }
       }
     }

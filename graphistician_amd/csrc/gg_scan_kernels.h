@@ -206,15 +206,16 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         for (int idx = tid; idx < 2 * K * per; idx += 256) {
           const int i = idx % per, j = (idx / per) % K;
           const int gc = s_gc[idx];
-          double* dst = s_st + (size_t)idx * NT;
+          int ts;
+          double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
           if (ADJ) {
             const int cx = s_cnt[j] - (s_c[i] == j ? 1 : 0);
             dst[0] = (double)gc;
-            dst[1] = (double)(cx - gc);
+            dst[ts] = (double)(cx - gc);
           } else {
             dst[0] = (double)gc;
 #pragma unroll
-            for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)s_gs[(size_t)idx * NSI + s] * (s < B ? sc1 : sc2);
+            for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)s_gs[(size_t)idx * NSI + s] * (s < B ? sc1 : sc2);
           }
         }
       }
