@@ -13,6 +13,7 @@
 // speculatively (kernel k_resolve) without changing a single draw.
 #pragma once
 #include "gg_common.h"
+#include "spec/gg_shcov.h"
 
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ long long gg_shfl_down_ll(long long v, int delta) {
@@ -424,6 +425,9 @@ struct gg_params_args {
   int n0, Nl;           // sharded chain: only nodes [n0, n0 + Nl) are stored locally (tables are then partial)
   int tables_from_tab;  // sharded chain: the all-reduced tables are already in `tab`
   unsigned long long* bar;   // k_scan's barrier counter + first-changer words, re-armed for the scan that follows
+  int shared;                // SBMGaussianWeightSharedCov: draw the means given the shared covariance, leave the
+                             // covariance draw and the coefficient tables to k_shared_cov
+  double* csc;               // [K*K][B*B] centred scatter of every block pair (shared-covariance kind)
 };
 
 template <bool ADJ, int B>
@@ -526,7 +530,20 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         e[1] = gg_log(1.0 - pv);
       } else {
         double mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
-        if (g.do_draw) {
+        if (g.do_draw && g.shared) {
+          // weights.py:529-535: mean of the pair given the shared covariance; its centred scatter for :545-548
+          double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB], C[GG_MAXB * GG_MAXB];
+          gg_unpack_wstats(s_tab + 1, B, g.wh.shift, s1, s2);
+          for (int i = 0; i < B; ++i) s1[i] *= g.beta;
+          for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
+          const double nn = g.beta * (double)s_tab[0];
+          gg_stream s;
+          gg_stream_init(&s, g.seed, GG_SITE_W_NIW, g.sweep, (uint32_t)t);
+          if (gg_fixed_cov_mean_draw(&s, g.wh.niw.mu_0, g.sigma + (size_t)t * B * B, B, nn, s1, mo)) atomicOr(&g.ctl[3], 1);
+          for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
+          gg_centered_scatter(nn, s1, s2, mo, B, C);
+          for (int i = 0; i < B * B; ++i) g.csc[(size_t)t * B * B + i] = C[i];
+        } else if (g.do_draw) {
           double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB];
           gg_unpack_wstats(s_tab + 1, B, g.wh.shift, s1, s2);
           gg_stream s;
@@ -542,12 +559,12 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
           for (int i = 0; i < B; ++i) mo[i] = g.mu[(size_t)t * B + i];
           for (int i = 0; i < B * B; ++i) so[i] = g.sigma[(size_t)t * B * B + i];
         }
-        if (g.do_prep && gg_gauss_table(mo, so, B, e)) {
+        if (g.do_prep && !(g.shared && g.do_draw) && gg_gauss_table(mo, so, B, e)) {
           atomicOr(&g.ctl[3], 1);
           for (int i = 0; i < NT; ++i) e[i] = gg_nan();
         }
       }
-      if (g.do_prep)
+      if (g.do_prep && !(!ADJ && g.shared && g.do_draw))
         for (int i = 0; i < NT; ++i) {
           g.T[(size_t)t * NT + i] = e[i];
           g.Tout[((size_t)b * NT + i) * g.Kp + a] = e[i];
@@ -927,6 +944,49 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
   if (live && k == 0) {
     cand[n] = lab;
     if (ap) ap[n] = 0;   // no entry of this scan's change list is applied to the node yet
+  }
+}
+
+// SBMGaussianWeightSharedCov, second half of resample_mu_and_Sig (weights.py:545-552): the shared covariance
+// Sigma ~ IW(lmbda_0 + sum over pairs of their centred scatter, nu_0 + #off-diagonal edges), summed in pair order by
+// one lane (same order as the oracle: bit-exact), then every pair gets it and its coefficient table.
+template <int B>
+__global__ __launch_bounds__(256) void k_shared_cov(gg_params_args g) {
+  if (g.ctl[4]) return;
+  constexpr int NSI = B + B * (B + 1) / 2;
+  constexpr int NTAB = 1 + 2 * NSI;
+  constexpr int NT = 1 + B + B * (B + 1) / 2;
+  __shared__ double s_sig[B * B];
+  const int K = g.K, KK = K * K;
+  if (threadIdx.x == 0) {
+    double S[B * B], sig[B * B];
+    for (int i = 0; i < B * B; ++i) S[i] = g.wh.niw.sigma_0[i];
+    double ntot = 0.0;
+    for (int ab = 0; ab < KK; ++ab) {
+      for (int i = 0; i < B * B; ++i) S[i] += g.csc[(size_t)ab * B * B + i];
+      ntot += g.beta * (double)g.tab[(size_t)ab * NTAB];
+    }
+    gg_stream s;
+    gg_stream_init(&s, g.seed, GG_SITE_W_SHCOV, g.sweep, 0u);
+    gg_iw_draw(&s, S, g.wh.niw.nu_0 + ntot, B, sig);
+    for (int i = 0; i < B * B; ++i) s_sig[i] = sig[i];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < KK; t += 256) {
+    const int a = t / K, b = t % K;
+    double so[B * B], mo[B], e[GG_MAXNT];
+    for (int i = 0; i < B * B; ++i) { so[i] = s_sig[i]; g.sigma[(size_t)t * B * B + i] = so[i]; }
+    if (!g.do_prep) continue;
+    for (int i = 0; i < B; ++i) mo[i] = g.mu[(size_t)t * B + i];
+    if (gg_gauss_table(mo, so, B, e)) {
+      atomicOr(&g.ctl[3], 1);
+      for (int i = 0; i < NT; ++i) e[i] = gg_nan();
+    }
+    for (int i = 0; i < NT; ++i) {
+      g.T[(size_t)t * NT + i] = e[i];
+      g.Tout[((size_t)b * NT + i) * g.Kp + a] = e[i];
+      g.Tin[((size_t)a * NT + i) * g.Kp + b] = e[i];
+    }
   }
 }
 

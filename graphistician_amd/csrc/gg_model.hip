@@ -86,6 +86,7 @@ struct gg_model {
   int Lmax, Lcap, CH, max_idle;
   long long* dbg;               // GG_ROUND_DBG: phase timestamps of k_round
   unsigned long long* bar;      // k_scan: exchange slots
+  double* csc;                  // shared-covariance kind: centred scatter of every block pair
   int round_hint;               // restart rounds the last unfinished scan needed: size of the first batch next time
   int depth;                    // sweeps enqueued ahead of confirmation: halves to 1 when a scan stalls, doubles on clean batches
   int todo;                     // sweeps requested but not enqueued yet (depth-limited)
@@ -109,7 +110,7 @@ struct gg_model {
 
 static int model_kind_ok(int kind) {
   return kind == GG_SBM_ADJ || kind == GG_BB_ADJ || kind == GG_BERN_ADJ || kind == GG_SBM_GAUSS_W || kind == GG_NIW_W ||
-         kind == GG_FIXED_W;
+         kind == GG_FIXED_W || kind == GG_SBM_GAUSS_SHCOV_W;
 }
 
 template <typename T>
@@ -162,7 +163,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->cfg = *cfg;
   m->kind = cfg->kind;
   m->is_adj = (cfg->kind == GG_SBM_ADJ || cfg->kind == GG_BB_ADJ || cfg->kind == GG_BERN_ADJ);
-  m->sbm = (cfg->kind == GG_SBM_ADJ || cfg->kind == GG_SBM_GAUSS_W);
+  m->sbm = (cfg->kind == GG_SBM_ADJ || cfg->kind == GG_SBM_GAUSS_W || cfg->kind == GG_SBM_GAUSS_SHCOV_W);
   m->is_block = true;
   m->N = cfg->N;
   m->K = m->sbm ? cfg->K : 1;
@@ -185,6 +186,10 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->Np = gg_round_up(m->Nl, 64);
   // NIW / non-SBM weight kinds always keep a separate self Gaussian (weights.py:91-94)
   if (m->kind == GG_NIW_W || m->kind == GG_FIXED_W) m->cfg.special_case_self_conns = 1;
+  if (m->kind == GG_SBM_GAUSS_SHCOV_W && !m->cfg.special_case_self_conns) {
+    delete m;
+    return gg_fail(GG_ERR_UNSUPPORTED, "SBMGaussianWeightSharedCov: special_case_self_conns = False is not built (weights.py:545-548 centres the off-diagonal edges only)");
+  }
   GG_HIP(hipStreamCreate(&m->stream));
   const int N = m->N, K = m->K, B = m->B, NT = m->NT;
   const size_t KK = (size_t)K * K;
@@ -204,7 +209,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     if ((rc = dmalloc(&m->p, KK)) || (rc = dmalloc(&m->p_self, 1))) return rc;
   } else {
     if ((rc = dmalloc(&m->mu, KK * B)) || (rc = dmalloc(&m->sigma, KK * B * B)) || (rc = dmalloc(&m->mu_self, B)) ||
-        (rc = dmalloc(&m->sigma_self, (size_t)B * B)))
+        (rc = dmalloc(&m->sigma_self, (size_t)B * B)) || (rc = dmalloc(&m->csc, KK * B * B)))
       return rc;
   }
   m->beta = 1.0;
@@ -288,7 +293,7 @@ int gg_model_destroy(gg_model* m) {
   if (m->ld) { gg_latent_destroy(m->ld); delete m; return GG_OK; }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
-                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar};
+                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   for (hipEvent_t e : m->ev) hipEventDestroy(e);
@@ -587,12 +592,20 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
     g.zero_words = m->Gbytes / 8;
     m->zeroed[1 - buf] = true;
   }
+  g.shared = (m->kind == GG_SBM_GAUSS_SHCOV_W) ? 1 : 0;
+  g.csc = m->csc;
   const int nwg = m->K * m->K + 1;
   if (m->is_adj) k_params<true, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 1) k_params<false, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 2) k_params<false, 2><<<nwg, 256, 0, m->stream>>>(g);
   else k_params<false, 4><<<nwg, 256, 0, m->stream>>>(g);
   GG_HIP(hipGetLastError());
+  if (g.shared && draw) {   // weights.py:545-552: the shared covariance and, with it, the coefficient tables
+    if (m->B == 1) k_shared_cov<1><<<1, 256, 0, m->stream>>>(g);
+    else if (m->B == 2) k_shared_cov<2><<<1, 256, 0, m->stream>>>(g);
+    else k_shared_cov<4><<<1, 256, 0, m->stream>>>(g);
+    GG_HIP(hipGetLastError());
+  }
   return GG_OK;
 }
 

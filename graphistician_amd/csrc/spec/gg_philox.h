@@ -36,7 +36,8 @@ enum gg_site {
   GG_SITE_INIT = 15,       // prior draws at construction
   GG_SITE_DATA = 16,       // synthetic data generation (rvs)
   GG_SITE_EIG_Z = 17,      // truncated-normal auxiliaries of the probit eigenmodel   eigenmodel.py:291
-  GG_SITE_LD = 18          // latent-distance HMC: momenta and acceptance uniforms       adjacency.py:374-421
+  GG_SITE_LD = 18,         // latent-distance HMC: momenta and acceptance uniforms       adjacency.py:374-421
+  GG_SITE_W_SHCOV = 19     // shared covariance of SBMGaussianWeightSharedCov            weights.py:548
 };
 
 struct gg_u32x4 { uint32_t v[4]; };

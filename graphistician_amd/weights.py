@@ -264,6 +264,8 @@ class LowRankGaussianWeightDistribution(GaussianWeightDistribution, GibbsSamplin
 class SBMGaussianWeightDistribution(_WeightsBase):
     """weights.py:172-498: K x K Gaussians indexed by the blocks of the two endpoints."""
 
+    _kind = _abi.SBM_GAUSS_W
+
     _fields = {"c": (_abi.ST_C, np.int32, lambda s: (s.N,)),
                "m": (_abi.ST_M, np.float64, lambda s: (s.C,)),
                "pi": (_abi.ST_PI, np.float64, lambda s: (s.C,)),
@@ -285,7 +287,7 @@ class SBMGaussianWeightDistribution(_WeightsBase):
         else:
             assert isinstance(pi, np.ndarray) and pi.shape == (C,), "pi must be a sclar or a C-vector"
         self.special_case_self_conns = special_case_self_conns
-        self._init_engine(device=device, seed=seed, kind=_abi.SBM_GAUSS_W, N=N, K=self.C, B=B,
+        self._init_engine(device=device, seed=seed, kind=self._kind, N=N, K=self.C, B=B,
                           special_case_self_conns=1 if special_case_self_conns else 0)
         self.pi = pi
         self.m = np.random.dirichlet(self.pi)
@@ -430,3 +432,51 @@ class SBMGaussianWeightDistribution(_WeightsBase):
 
     def resample_m(self):
         self._run(None, _abi.PART_M)
+
+
+class _SharedCovView(object):
+    """Stand-in for the reference's `_cov_model` (pybasicbayes GaussianFixedMean): sigma, nu_0, lmbda_0."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def sigma(self):
+        return self._o._hget("_sigma")[0, 0].copy()
+
+    @property
+    def nu_0(self):
+        B = self._o.B
+        return float(self._o._hget("_niw")[B + B * B])
+
+    @property
+    def lmbda_0(self):
+        B = self._o.B
+        return self._o._hget("_niw")[B:B + B * B].reshape(B, B).copy()
+
+
+class SBMGaussianWeightSharedCov(SBMGaussianWeightDistribution):
+    """weights.py:501-610: block-pair means with ONE covariance shared by all pairs.  resample_mu_and_Sig draws every
+    pair's mean given the covariance (GaussianFixedCov, prior N(mu_0, I)), the self Gaussian, then the covariance from
+    the centred off-diagonal edges (GaussianFixedMean / inverse Wishart(lmbda_0 = Sigma_0, nu_0)); the engine kind differs,
+    the scan and the likelihood are the parent's.  special_case_self_conns=True only (the reference's default)."""
+
+    _kind = _abi.SBM_GAUSS_SHCOV_W
+
+    def __init__(self, N, B=1, C=3, pi=10.0, mu_0=None, Sigma_0=None, nu_0=None, special_case_self_conns=True,
+                 device=0, seed=None):
+        if not special_case_self_conns:
+            raise NotImplementedError("SBMGaussianWeightSharedCov is built for special_case_self_conns=True only")
+        super(SBMGaussianWeightSharedCov, self).__init__(N, B=B, C=C, pi=pi, mu_0=mu_0, Sigma_0=Sigma_0, nu_0=nu_0,
+                                                         special_case_self_conns=True, device=device, seed=seed)
+        # one covariance for every pair: start from the (0, 0) draw of the parent's constructor
+        sig = self._hget("_sigma").copy()
+        sig[:] = sig[0, 0]
+        self._hset("_sigma", sig)
+        self._cov_model = _SharedCovView(self)
+
+    def log_prior(self):
+        # weights.py:554-577 (the Gaussian terms are commented out in the reference too)
+        lp = _dirichlet(self.pi).logpdf(self.m)
+        lp += (np.log(self.m)[self.c]).sum()
+        return lp

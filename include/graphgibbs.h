@@ -42,6 +42,9 @@ enum gg_status {
  *  GG_FIXED_W       weights.py:9-65       FixedGaussianWeightDistribution
  *  GG_LOGISTIC_EIG  eigenmodel.py:822-965 _GibbsLogisticEigenmodel
  *  GG_PROBIT_EIG    eigenmodel.py:239-379 _GibbsProbitEigenmodel (same state ids; the auxiliaries are Z, not omega)
+ *  GG_SBM_GAUSS_SHCOV_W  weights.py:501-610  SBMGaussianWeightSharedCov (one covariance for all block pairs; GG_ST_NIW packs
+ *                   the mean prior mu_0, the inverse-Wishart scale lmbda_0 and nu_0; GG_ST_SIGMA holds the shared
+ *                   covariance in every pair; special_case_self_conns only)
  *  GG_LATENT_DIST   adjacency.py:191-437  LatentDistanceAdjacencyDistribution (HMC; D = dim, sigma_F = sigma;
  *                   parts: GG_PART_F = L, GG_PART_MU0 = mu_0, GG_PART_LMBDA = mu_self)
  */
@@ -54,7 +57,8 @@ enum gg_kind {
   GG_FIXED_W = 6,
   GG_LOGISTIC_EIG = 7,
   GG_PROBIT_EIG = 8,
-  GG_LATENT_DIST = 9
+  GG_LATENT_DIST = 9,
+  GG_SBM_GAUSS_SHCOV_W = 10
 };
 
 typedef struct gg_config {

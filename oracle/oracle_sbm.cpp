@@ -29,6 +29,7 @@
 #include "../graphistician_amd/csrc/spec/gg_math.h"
 #include "../graphistician_amd/csrc/spec/gg_draws.h"
 #include "../graphistician_amd/csrc/spec/gg_lp.h"
+#include "../graphistician_amd/csrc/spec/gg_shcov.h"
 
 #define ORC_NO_EDGE INT32_MIN
 #define ORC_PART_PARAMS 1
@@ -558,6 +559,79 @@ int orc_niw_w_sweep(int N, int B, const uint8_t* A, const int32_t* q, int shift,
                     double* sigma, double* mu_self, double* sigma_self, const double* niw,
                     const double* niw_self, uint64_t seed, uint32_t sweep) {
   return orc_niw_w_sweep_beta(N, B, A, q, shift, mu, sigma, mu_self, sigma_self, niw, niw_self, seed, sweep, 1.0);
+}
+
+// ---------------------------------------------------------------------------
+// SBMGaussianWeightSharedCov (weights.py:501-552): one covariance for all block pairs.
+// resample_mu_and_Sig: for (c1, c2) row-major: mean | Sigma from the pair's edges (GaussianFixedCov, prior
+// N(mu_0, I)); self Gaussian (NIW, as the parent); then Sigma ~ IW(lmbda_0 + sum over off-diagonal edges of
+// (W - Mu)(W - Mu)^T, nu_0 + #edges) with the NEW means; every pair's sigma is set to it.
+// prior: packed [mu_0 (B), lmbda_0 (B*B), nu_0, (unused)] like the NIW layout.  special_case_self_conns only.
+// ---------------------------------------------------------------------------
+static int sbm_wsh_resample_mu_sig(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, const int32_t* c,
+                                   double* mu, double* sigma, double* mu_self, double* sigma_self, const gg_niw* h,
+                                   const gg_niw* hs, uint64_t seed, uint32_t sweep, double beta) {
+  std::vector<WStat> st((size_t)K * K);
+  for (auto& s : st) wstat_zero(&s);
+  WStat sd;
+  wstat_zero(&sd);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      if (!A[(size_t)i * N + j]) continue;
+      const int32_t* qq = q + ((size_t)i * N + j) * B;
+      if (i == j) { wstat_add(&sd, qq, B); continue; }
+      wstat_add(&st[(size_t)c[i] * K + c[j]], qq, B);
+    }
+  double n, s1[GG_MAXB], s2[GG_MAXB * GG_MAXB], C[GG_MAXB * GG_MAXB], S[GG_MAXB * GG_MAXB];
+  double ntot = 0.0;
+  for (int i = 0; i < B * B; ++i) S[i] = h->sigma_0[i];
+  for (int ab = 0; ab < K * K; ++ab) {
+    wstat_to_double(&st[ab], B, shift, &n, s1, s2);
+    n *= beta;
+    for (int r = 0; r < B; ++r) s1[r] *= beta;
+    for (int r = 0; r < B * B; ++r) s2[r] *= beta;
+    gg_stream s;
+    gg_stream_init(&s, seed, GG_SITE_W_NIW, sweep, (uint32_t)ab);
+    if (gg_fixed_cov_mean_draw(&s, h->mu_0, sigma + (size_t)ab * B * B, B, n, s1, mu + (size_t)ab * B)) return -2;
+    gg_centered_scatter(n, s1, s2, mu + (size_t)ab * B, B, C);
+    for (int i = 0; i < B * B; ++i) S[i] += C[i];
+    ntot += n;
+  }
+  {
+    wstat_to_double(&sd, B, shift, &n, s1, s2);
+    n *= beta;
+    for (int r = 0; r < B; ++r) s1[r] *= beta;
+    for (int r = 0; r < B * B; ++r) s2[r] *= beta;
+    gg_stream s;
+    gg_stream_init(&s, seed, GG_SITE_W_NIW_SELF, sweep, 0u);
+    gg_niw_posterior_draw(&s, hs, B, n, s1, s2, mu_self, sigma_self);
+  }
+  double Sig[GG_MAXB * GG_MAXB];
+  gg_stream s;
+  gg_stream_init(&s, seed, GG_SITE_W_SHCOV, sweep, 0u);
+  gg_iw_draw(&s, S, h->nu_0 + ntot, B, Sig);
+  for (int ab = 0; ab < K * K; ++ab)
+    for (int i = 0; i < B * B; ++i) sigma[(size_t)ab * B * B + i] = Sig[i];
+  return 0;
+}
+
+int orc_sbm_wsh_sweep(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, int32_t* c, double* m, double* mu,
+                      double* sigma, double* mu_self, double* sigma_self, const double* pi, const double* prior,
+                      const double* niw_self, uint64_t seed, uint32_t sweep, int parts, double beta) {
+  if (B > GG_MAXB) return -1;
+  gg_niw h, hs;
+  unpack_niw(prior, B, &h);
+  unpack_niw(niw_self, B, &hs);
+  if (parts & ORC_PART_PARAMS) {
+    int rc = sbm_wsh_resample_mu_sig(N, K, B, A, q, shift, c, mu, sigma, mu_self, sigma_self, &h, &hs, seed, sweep, beta);
+    if (rc) return rc;
+  }
+  if (parts & ORC_PART_C) {
+    int rc = sbm_w_resample_c(N, K, B, A, q, shift, c, m, mu, sigma, 1, seed, sweep, beta);
+    if (rc) return rc;
+  }
+  if (parts & ORC_PART_M) resample_m(N, K, c, pi, m, seed, GG_SITE_W_M, sweep);
+  return 0;
 }
 
 // ---------------------------------------------------------------------------

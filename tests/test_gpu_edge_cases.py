@@ -221,3 +221,51 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
     assert np.array_equal(adj.get(abi.ST_M, (K,)), sa.m)
     assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu)
     assert adj.stats()["label_changes"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,B,beta", [(140, 4, 1, 1.0), (180, 5, 2, 1.0), (120, 3, 2, 0.5)])
+def test_shared_covariance_weights_bitexact(abi, N, K, B, beta):
+    """SBMGaussianWeightSharedCov (weights.py:501-552): means given the shared covariance, then the covariance from the
+    centred edges, then the parent's scan: bit-exact against the oracle over several sweeps."""
+    A, W, _ = planted_sbm(N, K, B=B, seed=41)
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=8)
+    st.sigma[:] = st.sigma[0, 0]
+    prior = O.pack_niw(np.full(B, 0.2), np.eye(B) * 1.3, B + 2, 1.0)
+    d = abi.DeviceData(A, W)
+    w = abi.Model(kind=abi.SBM_GAUSS_SHCOV_W, N=N, K=K, B=B, seed=83, special_case_self_conns=1)
+    w.set(abi.ST_C, st.c, np.int32); w.set(abi.ST_M, st.m); w.set(abi.ST_PI, st.pi)
+    w.set(abi.ST_MU, st.mu); w.set(abi.ST_SIGMA, st.sigma); w.set(abi.ST_NIW, prior); w.set(abi.ST_NIW_SELF, st.niw_self)
+    for s in range(4):
+        w.resample(d, 1, beta)
+        O.sbm_wsh_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, prior, st.niw_self, 83, s, beta=beta)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), st.c), s
+        assert np.array_equal(w.get(abi.ST_MU, (K, K, B)), st.mu)
+        sig = w.get(abi.ST_SIGMA, (K, K, B, B))
+        assert np.array_equal(sig, st.sigma) and np.array_equal(sig, np.broadcast_to(sig[0, 0], sig.shape))
+        assert np.array_equal(w.get(abi.ST_MU_SELF, (B,)), st.mu_self) and np.array_equal(w.get(abi.ST_M, (K,)), st.m)
+    ll = w.log_likelihood(d)
+    ref = O.sbm_w_loglik(A, q, shift, st.c, st.mu, st.sigma, st.mu_self, st.sigma_self, 1)
+    assert abs(ll - ref) <= 1e-9 * abs(ref)
+    with pytest.raises(abi.EngineError):
+        abi.Model(kind=abi.SBM_GAUSS_SHCOV_W, N=N, K=K, B=B, seed=1, special_case_self_conns=0)
+
+
+@pytest.mark.gpu
+def test_shared_covariance_host_class(abi):
+    from graphistician_amd.weights import SBMGaussianWeightSharedCov
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    np.random.seed(6)
+    N, C, B = 60, 3, 2
+    A, W, _ = planted_sbm(N, C, B=B, seed=2)
+    net = FactorizedNetworkDistribution(N, SBMAdjacencyDistribution, {"C": C, "seed": 1},
+                                        SBMGaussianWeightSharedCov, {"C": C, "B": B, "seed": 2})
+    lp0 = net.log_likelihood((A, W))
+    for _ in range(30):
+        net.resample((A, W))
+    sig = net.weights._Sigma
+    assert np.array_equal(sig, np.broadcast_to(sig[0, 0], sig.shape))                    # one covariance for all pairs
+    assert np.allclose(net.weights._cov_model.sigma, sig[0, 0]) and net.weights._cov_model.nu_0 == B + 2
+    assert net.log_likelihood((A, W)) > lp0 and np.isfinite(net.log_prior())

@@ -299,3 +299,45 @@ def test_fast_cpu_flavour_is_the_same_chain(N, K, B, special):
         assert np.array_equal(w1.c, w2.c) and np.array_equal(w1.mu, w2.mu) and np.array_equal(w1.sigma, w2.sigma)
         assert np.array_equal(w1.m, w2.m) and np.array_equal(w1.mu_self, w2.mu_self) and np.array_equal(w1.sigma_self, w2.sigma_self)
     fs.close()
+
+
+# ---------------------------------------------------------------- shared-covariance weights (weights.py:501-552)
+def test_shared_cov_oracle_follows_the_conjugate_algebra():
+    """Means: posterior N(Lambda^-1 (mu_0 + Sigma^-1 sum x), Lambda^-1), Lambda = I + n Sigma^-1 (GaussianFixedCov); covariance:
+    inverse Wishart with scale lmbda_0 + centred scatter and nu_0 + #edges degrees of freedom (GaussianFixedMean): checked by
+    moments over repeated draws."""
+    N, K, B = 120, 3, 2
+    A, W, _ = planted_sbm(N, K, B=B, seed=3)
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=1)
+    Sig = np.array([[1.2, 0.3], [0.3, 0.8]])
+    prior = O.pack_niw(np.array([0.1, -0.2]), np.eye(B) * 1.5, B + 2, 1.0)
+    mus, sigs = [], []
+    for sw in range(600):
+        mu, sg = st.mu.copy(), st.sigma.copy()
+        sg[:] = Sig
+        O.sbm_wsh_sweep(A, q, shift, st.c.copy(), st.m.copy(), mu, sg, st.mu_self.copy(), st.sigma_self.copy(), st.pi, prior,
+                        st.niw_self, 5, sw, parts=O.PART_PARAMS)
+        mus.append(mu[0, 1].copy()); sigs.append(sg[0, 0].copy())
+        assert np.array_equal(sg, np.broadcast_to(sg[0, 0], sg.shape))
+    mus, sigs = np.array(mus), np.array(sigs)
+    Wq = np.ldexp(q.astype(np.float64), -shift)
+    c = st.c
+    off = (A == 1) & ~np.eye(N, dtype=bool)
+    X = Wq[(c[:, None] == 0) & (c[None, :] == 1) & off]
+    P = np.linalg.inv(Sig)
+    Ln = np.eye(B) + len(X) * P
+    mean, cov = np.linalg.solve(Ln, prior[:B] + P.dot(X.sum(0))), np.linalg.inv(Ln)
+    assert np.all(np.abs(mus.mean(0) - mean) < 5 * np.sqrt(np.diag(cov) / len(mus)))
+    assert np.allclose(np.cov(mus.T), cov, rtol=0.25, atol=2e-4)
+    # E[Sigma] of IW(S, nu) = S / (nu - B - 1); S ~ lmbda_0 + scatter around the block means (~ the per-pair sample means here)
+    n_edges = off.sum()
+    scatter = np.zeros((B, B))
+    for a in range(K):
+        for b in range(K):
+            Xab = Wq[(c[:, None] == a) & (c[None, :] == b) & off]
+            if len(Xab):
+                Xc = Xab - Xab.mean(0)
+                scatter += Xc.T.dot(Xc)
+    expect = (np.eye(B) * 1.5 + scatter) / (B + 2 + n_edges - B - 1)
+    assert np.allclose(sigs.mean(0), expect, rtol=0.02)
