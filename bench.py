@@ -256,6 +256,52 @@ def bench_latent(args, abi, device, rank, world, barrier, max_over_ranks):
     print(json.dumps(out))
 
 
+def bench_latent_w(args, abi, device, rank, world, barrier, max_over_ranks):
+    """Latent-distance Gaussian weight model (weights.py:613-903; SURVEY.md 8f rank 3, weight side): one step = resample =
+    HMC on L (11 passes over W and W^T), then one more pass for the conjugate draws of b, sigma, self Gaussian, eta."""
+    N, dim = args.nodes, 2
+    rng = np.random.RandomState(1234)
+    Lt = rng.randn(N, dim) * 0.6
+    A = (rng.rand(N, N) < 0.25).astype(np.uint8)
+    W = (-((Lt[:, None, :] - Lt[None, :, :]) ** 2).sum(2) + 0.5 + 0.3 * rng.randn(N, N))[:, :, None]
+    data = abi.DeviceData(A, W, device=device)
+    m = abi.Model(kind=abi.LATENT_DIST_W, N=N, D=dim, K=1, B=1, seed=1 + rank, device=device)
+    crng = np.random.RandomState(1 + rank)
+    L0 = crng.randn(N, dim) * 0.1
+    m.set(abi.ST_F, L0); m.set(abi.ST_MU0, np.array([0.5])); m.set(abi.ST_LD_AUX, np.array([0.01, 1.0, 0.0, 1.0]))
+    m.resample(data, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    m.resample(data, args.steps)
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return
+    passes = 12
+    sweep_bytes = passes * 8.0 * N * N
+    out = {"metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": world * args.steps / el,
+           "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "Latent-distance Gaussian weight model, HMC (10 leapfrog steps) + conjugate draws, N=%d, dim=%d, "
+                                  "edge density 0.25 (SURVEY.md 8f rank 3)" % (N, dim),
+                      "sweep_algorithmic_bytes": sweep_bytes, "accepted_L_proposals": m.stats()["label_changes"],
+                      "last_resample_device_ms": m.stats()["total_ms"]},
+           "roofline": {"bound": "hbm", "kernel": "k_ldw_pass", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": sweep_bytes * args.steps / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "whole-resample effective rate over %d passes of W and W^T (int32 fixed point, 8 N^2 bytes a pass)" % passes}}
+    if not args.no_cpu and world == 1:
+        from oracle import oracle as O
+        q, shift = O.quantise(A, W)
+        Lo = L0.copy()
+        t0 = time.perf_counter()
+        O.ldw_resample(A, q, shift, Lo, 0.5, 0.01, 1.0, 0.0, 1.0, [1.0, 3.0], [0.0, 1.0, 3.0, 1.0], 1, 0)
+        el1 = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / el1, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                               "sample": "1 resample of the same N=%d network, oracle/ C++ -O2, 1 thread" % N}
+    print(json.dumps(out))
+
+
 def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     """One Gaussian-SBM chain sharded over the ranks (strong scaling; BASELINE.json configs[3] at --nodes 65536
     --blocks 64): exact — the same chain for any number of ranks (graphistician_amd/sharded.py)."""
@@ -313,7 +359,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shard", action="store_true",
                     help="one chain sharded over the ranks (strong scaling) instead of an independent chain per rank")
-    ap.add_argument("--config", default="sbm", choices=["sbm", "eigen", "probit", "latent"],
+    ap.add_argument("--config", default="sbm", choices=["sbm", "eigen", "probit", "latent", "latentw"],
                     help="sbm = BASELINE.json configs[1] (default, the headline); eigen = configs[2]")
     ap.add_argument("--latent", type=int, default=8)
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,8 +428,9 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if args.config in ("eigen", "probit", "latent"):
-        (bench_latent if args.config == "latent" else bench_eigen)(args, abi, device, rank, world, barrier, max_over_ranks)
+    if args.config in ("eigen", "probit", "latent", "latentw"):
+        fn = {"latent": bench_latent, "latentw": bench_latent_w}.get(args.config, bench_eigen)
+        fn(args, abi, device, rank, world, barrier, max_over_ranks)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

@@ -28,7 +28,8 @@ int gg_latent_destroy(gg_latent* e);
 int gg_latent_set_state(gg_latent* e, int id, const void* buf, size_t nbytes);
 int gg_latent_get_state(gg_latent* e, int id, void* buf, size_t nbytes);
 void gg_latent_set_beta(gg_latent* e, double beta);
-int gg_latent_resample(gg_latent* e, const gg_data* d, int parts);
+int gg_latent_resample(gg_latent* e, const gg_data* d, int parts, int defer);
+int gg_latent_sync(gg_latent* e);
 int gg_latent_log_likelihood(gg_latent* e, const gg_data* d, double* out);
 int gg_latent_stats(gg_latent* e, gg_stats* out);
 
@@ -41,7 +42,7 @@ struct gg_model {
   bool sharded;
   int spos;                             // sharded scan position
   gg_eigen* eig;
-  gg_latent* ld;                // GG_LATENT_DIST: everything lives in gg_latent.hip
+  gg_latent* ld;                // GG_LATENT_DIST, GG_LATENT_DIST_W: everything lives in gg_latent.hip
   // device state
   int32_t *c, *cand, *cnt;
   // label sort, double buffered: a completed scan writes the sort of its final labels into the other
@@ -135,7 +136,7 @@ extern "C" {
 
 int gg_model_create(gg_model** out, const gg_config* cfg) {
   if (!out || !cfg) return gg_fail(GG_ERR_INVALID, "gg_model_create: null argument");
-  if (cfg->kind == GG_LATENT_DIST) {
+  if (cfg->kind == GG_LATENT_DIST || cfg->kind == GG_LATENT_DIST_W) {
     int rc = gg_ensure_device(cfg->device);
     if (rc) return rc;
     gg_model* m = new gg_model();
@@ -1191,10 +1192,10 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   if (m->ld) {
     gg_latent_set_beta(m->ld, beta);
     for (int s = 0; s < n_sweeps; ++s) {
-      int rc = gg_latent_resample(m->ld, d, GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA);
+      int rc = gg_latent_resample(m->ld, d, GG_PART_ALL, 1);
       if (rc) return rc;
     }
-    return GG_OK;
+    return gg_latent_sync(m->ld);
   }
   if (m->sharded) return gg_fail(GG_ERR_INVALID, "this model owns a shard of the nodes: drive it with the gg_shard_* step API");
   int rc = check_data(m, d);
@@ -1283,7 +1284,7 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   if (beta != 1.0 && m->eig)
     return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: block models only (the reference leaves the eigenmodel's undefined, graph_models.py:478)");
   if (m->eig) return gg_eigen_resample(m->eig, d, parts);
-  if (m->ld) { gg_latent_set_beta(m->ld, beta); return gg_latent_resample(m->ld, d, parts); }
+  if (m->ld) { gg_latent_set_beta(m->ld, beta); return gg_latent_resample(m->ld, d, parts, 0); }
   int rc = model_sync(m);
   if (rc) return rc;
   m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)

@@ -37,7 +37,9 @@ enum gg_site {
   GG_SITE_DATA = 16,       // synthetic data generation (rvs)
   GG_SITE_EIG_Z = 17,      // truncated-normal auxiliaries of the probit eigenmodel   eigenmodel.py:291
   GG_SITE_LD = 18,         // latent-distance HMC: momenta and acceptance uniforms       adjacency.py:374-421
-  GG_SITE_W_SHCOV = 19     // shared covariance of SBMGaussianWeightSharedCov            weights.py:548
+  GG_SITE_W_SHCOV = 19,    // shared covariance of SBMGaussianWeightSharedCov            weights.py:548
+  GG_SITE_LDW_HMC = 20,    // latent-distance weights: HMC momenta and acceptance uniform  weights.py:777-792
+  GG_SITE_LDW = 21         // latent-distance weights: b, sigma, self Gaussian, eta draws  weights.py:833-886
 };
 
 struct gg_u32x4 { uint32_t v[4]; };

@@ -480,3 +480,171 @@ class SBMGaussianWeightSharedCov(SBMGaussianWeightDistribution):
         lp = _dirichlet(self.pi).logpdf(self.m)
         lp += (np.log(self.m)[self.c]).sum()
         return lp
+
+
+class _FixedMeanCovView(object):
+    """Stand-in for `cov` of the latent-distance weights (pybasicbayes GaussianFixedMean): mu, sigma, lmbda_0, nu_0."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    mu = property(lambda s: np.zeros(1))
+    sigma = property(lambda s: np.array([[s._o._aux_get(1)]]),
+                     lambda s, v: s._o._aux_set(1, float(np.asarray(v).ravel()[0])))
+    lmbda_0 = property(lambda s: np.array([[s._o._hget("_niw")[1]]]))
+    nu_0 = property(lambda s: float(s._o._hget("_niw")[2]))
+
+    def resample(self, data=[]):
+        assert len(data) == 0, "posterior draws happen inside the engine sweep"
+        self.sigma = np.atleast_2d(_invwishart.rvs(df=self.nu_0, scale=self.lmbda_0))
+
+
+class _AuxGaussianView(_GaussianView):
+    """The self Gaussian of the latent-distance weights: mu, sigma live in slots 2, 3 of the auxiliary state."""
+
+    def __init__(self, owner):
+        super(_AuxGaussianView, self).__init__(owner, None, None, "_niw_self")
+
+    mu = property(lambda s: np.array([s._o._aux_get(2)]), lambda s, v: s._o._aux_set(2, float(np.asarray(v).ravel()[0])))
+    sigma = property(lambda s: np.array([[s._o._aux_get(3)]]), lambda s, v: s._o._aux_set(3, float(np.asarray(v).ravel()[0])))
+
+
+class LatentDistanceGaussianWeightDistribution(_WeightsBase):
+    """weights.py:613-903.
+
+    l_n ~ N(0, eta I);  W_{n',n} ~ N(-||l_{n'} - l_n||^2 + b, sigma) for n' != n, self weights ~ N(mu_self, sigma_self).
+    resample = HMC on L (step 0.005, 10 leapfrog steps), b from its Gaussian conditional, sigma from the inverse-Wishart
+    conditional of the residuals, the self Gaussian from its NIW posterior, eta from its inverse-gamma conditional
+    (:767-886), all on the engine.  B = 1 as in the reference (:711).  Like the adjacency counterpart the gradient is
+    hand-derived and the HMC transition restated (autograd / hips.inference.hmc are not available): parity unpinned,
+    checked against the oracle's same definition.  beta < 1 tempers the likelihood (AIS)."""
+
+    _fields = {"L": (_abi.ST_F, np.float64, lambda s: (s.N, s.dim)),
+               "_b": (_abi.ST_MU0, np.float64, lambda s: (1,)),
+               "_aux": (_abi.ST_LD_AUX, np.float64, lambda s: (4,)),      # eta, sigma, mu_self, sigma_self
+               "_niw": (_abi.ST_NIW, np.float64, lambda s: (4,)),
+               "_niw_self": (_abi.ST_NIW_SELF, np.float64, lambda s: (4,))}
+
+    def __init__(self, N, B=1, dim=2, b=0.5, sigma=None, Sigma_0=None, nu_0=None, mu_self=0.0, eta=0.01,
+                 device=0, seed=None):
+        super(LatentDistanceGaussianWeightDistribution, self).__init__(N)
+        if B != 1:
+            raise NotImplementedError("LatentDistanceGaussianWeightDistribution: B = 1 only (weights.py:711 asserts it too)")
+        self.B = B
+        self.dim = dim
+        if Sigma_0 is None:
+            Sigma_0 = np.eye(B)
+        if nu_0 is None:
+            nu_0 = B + 2
+        self._init_engine(device=device, seed=seed, kind=_abi.LATENT_DIST_W, N=N, D=dim, K=1, B=1)
+        s0 = float(np.asarray(Sigma_0).ravel()[0])
+        self._hset("_niw", np.array([0.0, s0, float(nu_0), 0.0]))
+        self._hset("_niw_self", np.array([float(mu_self), s0, float(nu_0), 1.0]))
+        self._hset("_b", np.array([b]))
+        self._hset("_aux", np.array([eta, 1.0, 0.0, 1.0]))
+        self.L = np.sqrt(eta) * np.random.randn(N, dim)
+        self.cov = _FixedMeanCovView(self)
+        self._self_gaussian = _AuxGaussianView(self)
+        # pybasicbayes: GaussianFixedMean(sigma=None) and Gaussian(mu_0=...) start from prior draws
+        if sigma is None:
+            self.cov.resample()
+        else:
+            self.cov.sigma = sigma
+        self._self_gaussian.resample()
+
+    def _aux_get(self, k):
+        return float(self._hget("_aux")[k])
+
+    def _aux_set(self, k, v):
+        a = self._hget("_aux").copy()
+        a[k] = v
+        self._hset("_aux", a)
+
+    L = property(lambda s: s._hget("L"), lambda s, v: s._hset("L", v))
+    b = property(lambda s: float(s._hget("_b")[0]), lambda s, v: s._hset("_b", np.array([v], dtype=np.float64)))
+    eta = property(lambda s: s._aux_get(0), lambda s, v: s._aux_set(0, v))
+
+    @property
+    def D(self):
+        return ((self.L[:, None, :] - self.L[None, :, :]) ** 2).sum(2)
+
+    @property
+    def Mu(self):
+        # weights.py:653-660
+        Mu = np.tile((-self.D + self.b)[:, :, None], (1, 1, self.B))
+        Mu[np.arange(self.N), np.arange(self.N), :] = self._self_gaussian.mu
+        return Mu
+
+    @property
+    def Sigma(self):
+        # weights.py:662-670
+        Sig = np.tile(self.cov.sigma[None, None, :, :], (self.N, self.N, 1, 1))
+        Sig[np.arange(self.N), np.arange(self.N)] = self._self_gaussian.sigma
+        return Sig
+
+    def initialize_from_prior(self):
+        # weights.py:672-674
+        self.L = np.sqrt(self.eta) * np.random.randn(self.N, self.dim)
+        self.cov.resample()
+
+    def initialize_hypers(self, W):
+        # weights.py:676-678 optimises L by BFGS on the autograd gradient; a few HMC sweeps from the prior draw do
+        # that job here (the optimiser is initialisation only, not part of the sampler)
+        pass
+
+    def log_prior(self):
+        # weights.py:680-701
+        from scipy.stats import norm, invgamma
+        lp = invgamma.logpdf(self.eta, 1, scale=1)
+        lp += norm.logpdf(self.b, 0, 1)
+        lp += norm.logpdf(self.L, 0, 1).sum()
+        lp += _invwishart.logpdf(self.cov.sigma, self.cov.nu_0, self.cov.lmbda_0)
+        g = self._self_gaussian
+        lp += niw_log_prob(g.mu, g.sigma, g.mu_0, g.sigma_0, g.nu_0, g.kappa_0)
+        return lp
+
+    def sample_predictive_parameters(self):
+        # weights.py:735-764
+        Lext = np.vstack((self.L, np.sqrt(self.eta) * np.random.randn(1, self.dim)))
+        D = ((Lext[:, None, :] - Lext[None, :, :]) ** 2).sum(2)
+        Mu = -D + self.b
+        Mu_row = np.tile(Mu[-1, :][:, None], (1, self.B))
+        Mu_row[-1] = self._self_gaussian.mu
+        Mu_col = Mu_row.copy()
+        Lc = np.linalg.cholesky(self.cov.sigma)
+        L_row = np.tile(Lc[None, :, :], (self.N + 1, 1, 1))
+        L_row[-1] = np.linalg.cholesky(self._self_gaussian.sigma)
+        L_col = L_row.copy()
+        return Mu_row, Mu_col, L_row, L_col
+
+    def _run(self, data, parts, beta=1.0):
+        d = self._data(data)
+        assert d.N == self.N and d.B == self.B
+        eng = self._engine()
+        if parts == _abi.PART_ALL:
+            eng.resample(d, 1, beta)
+        else:
+            eng.resample_part(d, parts, beta)
+        self._mark_stale("L", "_b", "_aux")
+
+    def resample(self, data, beta=1.0):
+        """weights.py:767-773: L, b, cov, self Gaussian, eta."""
+        self._run(data, _abi.PART_ALL, beta)
+
+    def _resample_L(self, A, W, beta=1.0):
+        self._run((A, W), _abi.PART_F, beta)
+
+    def _resample_b(self, A, W, beta=1.0):
+        self._run((A, W), _abi.PART_MU0, beta)
+
+    def _resample_cov(self, A, W, beta=1.0):
+        """sigma and (same engine part) the self Gaussian: weights.py:859-868."""
+        self._run((A, W), _abi.PART_PARAMS, beta)
+
+    _resample_self_gaussian = _resample_cov
+
+    def _resample_eta(self, A=None, W=None):
+        # eta | L does not involve the data (weights.py:870-886); the engine part takes a handle all the same
+        if A is None:
+            raise ValueError("pass the (A, W) the model is being fitted to: the engine part needs a data handle")
+        self._run((A, W), _abi.PART_LMBDA, 1.0)

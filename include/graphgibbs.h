@@ -47,6 +47,10 @@ enum gg_status {
  *                   covariance in every pair; special_case_self_conns only)
  *  GG_LATENT_DIST   adjacency.py:191-437  LatentDistanceAdjacencyDistribution (HMC; D = dim, sigma_F = sigma;
  *                   parts: GG_PART_F = L, GG_PART_MU0 = mu_0, GG_PART_LMBDA = mu_self)
+ *  GG_LATENT_DIST_W weights.py:613-903    LatentDistanceGaussianWeightDistribution (B = 1; D = dim; state: GG_ST_F = L,
+ *                   GG_ST_MU0 = b, GG_ST_LD_AUX = {eta, sigma, mu_self, sigma_self}, GG_ST_NIW = {-, lmbda_0, nu_0, -},
+ *                   GG_ST_NIW_SELF = {mu_0, sigma_0, nu_0, kappa_0}; parts: GG_PART_F = L (HMC), GG_PART_MU0 = b,
+ *                   GG_PART_PARAMS = sigma + self Gaussian, GG_PART_LMBDA = eta)
  */
 enum gg_kind {
   GG_SBM_ADJ = 1,
@@ -58,7 +62,8 @@ enum gg_kind {
   GG_LOGISTIC_EIG = 7,
   GG_PROBIT_EIG = 8,
   GG_LATENT_DIST = 9,
-  GG_SBM_GAUSS_SHCOV_W = 10
+  GG_SBM_GAUSS_SHCOV_W = 10,
+  GG_LATENT_DIST_W = 11
 };
 
 typedef struct gg_config {
@@ -96,7 +101,7 @@ enum gg_state_id {
   GG_ST_LMBDA = 14,     /* double (D)                                     eigenmodel.py:64-73 */
   GG_ST_MU0 = 15,       /* double (1)                                     eigenmodel.py:57 */
   GG_ST_MU_LMBDA = 16,  /* double (D)        prior mean of lambda         eigenmodel.py:71 */
-  GG_ST_LD_AUX = 18,    /* double (3)        latent-distance model: mu_self, HMC step size, running acceptance rate (adjacency.py:201-206) */
+  GG_ST_LD_AUX = 18,    /* double (3)        latent-distance model: mu_self, HMC step size, running acceptance rate (adjacency.py:201-206); (4) for GG_LATENT_DIST_W */
   GG_ST_OMEGA_S = 17    /* double (N,N) read-only: omega_ij + omega_ji off the diagonal, omega_ii on it (eigenmodel.py:859-874) */
 };
 

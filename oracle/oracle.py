@@ -417,3 +417,44 @@ def ld_resample(A, L, mu0, mu_self, sigma, step_sz, accept_rate, seed, sweep, pa
     if rc:
         raise RuntimeError("oracle ld_resample failed rc=%d" % rc)
     return m0.value, ms.value, st.value, ar.value, acc.value
+
+
+# ---------------------------------------------------------------- latent-distance Gaussian weights (oracle_latent.cpp)
+LDW_PART_L, LDW_PART_B, LDW_PART_COV, LDW_PART_ETA, LDW_PART_ALL = 1, 2, 4, 8, 15
+
+
+def ldw_logprob(A, q, shift, L, b, sigma, eta, beta=1.0, grad=False):
+    """log p(L | b, A, W) of weights.py:703-733 (likelihood weighted by beta); with grad: (lp, dL)."""
+    N, dim = L.shape
+    A8, pA = _u8(A != 0)
+    lib().orc_ldw_logprob.restype = C.c_double
+    L = np.ascontiguousarray(L, dtype=np.float64)
+    gL = np.zeros_like(L) if grad else None
+    lp = lib().orc_ldw_logprob(N, dim, pA, _i32(q), int(shift), _f64(L), C.c_double(b), C.c_double(sigma), C.c_double(eta),
+                               C.c_double(beta), _f64(gL) if grad else None)
+    return (lp, gL) if grad else lp
+
+
+def ldw_loglik(A, q, shift, L, b, sigma, mu_self, sigma_self):
+    N, dim = L.shape
+    A8, pA = _u8(A != 0)
+    lib().orc_ldw_loglik.restype = C.c_double
+    return lib().orc_ldw_loglik(N, dim, pA, _i32(q), int(shift), _f64(np.ascontiguousarray(L, dtype=np.float64)), C.c_double(b),
+                                C.c_double(sigma), C.c_double(mu_self), C.c_double(sigma_self))
+
+
+def ldw_resample(A, q, shift, L, b, eta, sigma, mu_self, sigma_self, prior, prior_self, seed, sweep, parts=LDW_PART_ALL, beta=1.0):
+    """One resample (weights.py:767-773), L updated in place; returns (b, eta, sigma, mu_self, sigma_self, accepted)."""
+    N, dim = L.shape
+    A8, pA = _u8(A != 0)
+    vb, ve, vs, vm, vss, acc = (C.c_double(b), C.c_double(eta), C.c_double(sigma), C.c_double(mu_self), C.c_double(sigma_self),
+                                C.c_int(0))
+    pr = np.ascontiguousarray(prior, dtype=np.float64)
+    prs = np.ascontiguousarray(prior_self, dtype=np.float64)
+    assert pr.shape == (2,) and prs.shape == (4,)
+    rc = lib().orc_ldw_resample(N, dim, pA, _i32(q), int(shift), _f64(L), C.byref(vb), C.byref(ve), C.byref(vs), C.byref(vm),
+                                C.byref(vss), _f64(pr), _f64(prs), C.c_uint64(seed), C.c_uint32(sweep), int(parts),
+                                C.c_double(beta), C.byref(acc))
+    if rc:
+        raise RuntimeError("oracle ldw_resample failed rc=%d" % rc)
+    return vb.value, ve.value, vs.value, vm.value, vss.value, acc.value

@@ -98,6 +98,28 @@ def latent_case(N, dim, seed, nsweeps):
     return out
 
 
+def latent_w_case(N, dim, seed, nsweeps):
+    """SURVEY 8f rank 3, weight side: latent-distance Gaussian weights (weights.py:613-903) from a fixed start."""
+    rng = np.random.RandomState(seed)
+    Lt = rng.randn(N, dim) * 0.6
+    A = (rng.rand(N, N) < 0.5).astype(np.uint8)
+    W = -((Lt[:, None, :] - Lt[None, :, :]) ** 2).sum(2) + 0.5 + 0.3 * rng.randn(N, N)
+    W[np.arange(N), np.arange(N)] = 1.5 + 0.2 * rng.randn(N)
+    W = np.ascontiguousarray(W[:, :, None])
+    q, shift = O.quantise(A, W)
+    L = np.ascontiguousarray(rng.randn(N, dim) * 0.3)
+    prior, prior_self = np.array([1.0, 3.0]), np.array([0.0, 1.0, 3.0, 1.0])
+    state = dict(b=0.2, eta=0.3, sigma=0.8, mu_self=0.1, sigma_self=1.1)
+    out = dict(N=N, dim=dim, nsweeps=nsweeps, seed=7000 + seed, A=A, W=W, init_L=L.copy(), prior=prior, prior_self=prior_self)
+    out.update({"init_" + k: v for k, v in state.items()})
+    b, eta, sg, ms, ss = (state[k] for k in ("b", "eta", "sigma", "mu_self", "sigma_self"))
+    for s in range(nsweeps):
+        b, eta, sg, ms, ss, _ = O.ldw_resample(A, q, shift, L, b, eta, sg, ms, ss, prior, prior_self, 7000 + seed, s)
+    out.update(out_L=L, out_b=b, out_eta=eta, out_sigma=sg, out_mu_self=ms, out_sigma_self=ss,
+               ll=O.ldw_loglik(A, q, shift, L, b, sg, ms, ss))
+    return out
+
+
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "sbm_n64_k4_b1.npz"), **sbm_case(64, 4, 1, 7, 6, 1))
     np.savez_compressed(os.path.join(HERE, "sbm_n48_k3_b2_nospecial.npz"), **sbm_case(48, 3, 2, 9, 4, 0))
@@ -105,4 +127,5 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "eigen_logistic_n40_d3.npz"), **eigen_case(40, 3, 11, 3, False))
     np.savez_compressed(os.path.join(HERE, "eigen_probit_n40_d3.npz"), **eigen_case(40, 3, 12, 3, True))
     np.savez_compressed(os.path.join(HERE, "latent_n40_dim2.npz"), **latent_case(40, 2, 13, 4))
+    np.savez_compressed(os.path.join(HERE, "latentw_n40_dim2.npz"), **latent_w_case(40, 2, 14, 4))
     print("golden fixtures written to", HERE)

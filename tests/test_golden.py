@@ -137,6 +137,40 @@ def test_oracle_reproduces_latent_golden():
     assert abs(st - float(g["out_step"])) < 1e-15 and abs(ar - float(g["out_rate"])) < 1e-15
 
 
+def _ldw_state(g, pre):
+    return [float(g[pre + k]) for k in ("b", "eta", "sigma", "mu_self", "sigma_self")]
+
+
+def test_oracle_reproduces_latent_weights_golden():
+    g = np.load(os.path.join(G, "latentw_n40_dim2.npz"))
+    q, shift = O.quantise(g["A"], g["W"])
+    L = g["init_L"].copy()
+    b, eta, sg, ms, ss = _ldw_state(g, "init_")
+    for s in range(int(g["nsweeps"])):
+        b, eta, sg, ms, ss, _ = O.ldw_resample(g["A"], q, shift, L, b, eta, sg, ms, ss, g["prior"], g["prior_self"], int(g["seed"]), s)
+    assert np.allclose(L, g["out_L"], rtol=1e-12, atol=1e-13)
+    assert np.allclose([b, eta, sg, ms, ss], _ldw_state(g, "out_"), rtol=1e-12)
+    assert abs(O.ldw_loglik(g["A"], q, shift, L, b, sg, ms, ss) - float(g["ll"])) <= 1e-10 * abs(float(g["ll"]))
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_latent_weights_golden():
+    from graphistician_amd import _abi as abi
+    g = np.load(os.path.join(G, "latentw_n40_dim2.npz"))
+    N, dim = int(g["N"]), int(g["dim"])
+    d = abi.DeviceData(g["A"], g["W"])
+    m = abi.Model(kind=abi.LATENT_DIST_W, N=N, D=dim, K=1, B=1, seed=int(g["seed"]))
+    b, eta, sg, ms, ss = _ldw_state(g, "init_")
+    m.set(abi.ST_F, g["init_L"]); m.set(abi.ST_MU0, np.array([b])); m.set(abi.ST_LD_AUX, np.array([eta, sg, ms, ss]))
+    m.set(abi.ST_NIW, np.array([0.0, g["prior"][0], g["prior"][1], 0.0])); m.set(abi.ST_NIW_SELF, g["prior_self"])
+    m.resample(d, int(g["nsweeps"]))
+    assert np.allclose(m.get(abi.ST_F, (N, dim)), g["out_L"], rtol=1e-7, atol=1e-9)
+    out = _ldw_state(g, "out_")
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - out[0]) < 1e-8
+    assert np.allclose(m.get(abi.ST_LD_AUX, (4,)), out[1:], rtol=1e-8)
+    assert abs(m.log_likelihood(d) - float(g["ll"])) <= 1e-8 * abs(float(g["ll"]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", EIG_FIXTURES)
 def test_engine_reproduces_eigen_golden(name):
