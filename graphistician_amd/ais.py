@@ -36,7 +36,7 @@ def prior_draw(model):
         # a whole network (networks.py:9-75): both halves from their priors; the tempered path raises the JOINT
         # likelihood p(A | .) p(W | A, .) to beta (weights: build-defined, see weights.py)
         prior_draw(model.adjacency)
-        model.weights.initialize_from_prior()
+        getattr(model.weights, "prior_draw", model.weights.initialize_from_prior)()
     else:
         raise NotImplementedError("AIS is defined for the Beta-Bernoulli (Erdos-Renyi), SBM and latent-distance adjacency models and for whole networks")
 

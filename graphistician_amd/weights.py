@@ -587,6 +587,15 @@ class LatentDistanceGaussianWeightDistribution(_WeightsBase):
         self.L = np.sqrt(self.eta) * np.random.randn(self.N, self.dim)
         self.cov.resample()
 
+    def prior_draw(self):
+        """Every parameter from its prior (weights.py:680-701), for AIS: initialize_from_prior leaves b, eta and the
+        self Gaussian where they are."""
+        from scipy.stats import invgamma
+        self.eta = float(invgamma.rvs(1.0, scale=1.0))
+        self.b = float(np.random.randn())
+        self.initialize_from_prior()
+        self._self_gaussian.resample()
+
     def initialize_hypers(self, W):
         # weights.py:676-678 optimises L by BFGS on the autograd gradient; a few HMC sweeps from the prior draw do
         # that job here (the optimiser is initialisation only, not part of the sampler)

@@ -191,3 +191,27 @@ def test_engine_ais_latent_distance_vs_er():
     er = BetaBernoulliAdjacencyDistribution(N, seed=78)
     lz_er = estimate_marginal_likelihood(er, A, N_samples=16, B=40, steps_per_B=1)
     assert np.isfinite(lz_ld) and lz_ld > lz_er + 3.0, (lz_ld, lz_er)
+
+
+@pytest.mark.gpu
+def test_engine_ais_latent_distance_weights_vs_niw():
+    """Whole-network AIS with the latent-distance weight model (weights.py:613-903) tempered on the engine: on weights
+    with a planted distance structure its evidence beats the single-Gaussian (NIW) network's."""
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import BetaBernoulliAdjacencyDistribution
+    from graphistician_amd.weights import NIWGaussianWeightDistribution, LatentDistanceGaussianWeightDistribution
+    from graphistician_amd.ais import estimate_marginal_likelihood
+    rng = np.random.RandomState(8)
+    N = 14
+    Lt = rng.randn(N, 2) * 1.2
+    A = (rng.rand(N, N) < 0.7).astype(np.uint8)
+    W = (-((Lt[:, None, :] - Lt[None, :, :]) ** 2).sum(2) + 0.5 + 0.2 * rng.randn(N, N))[:, :, None]
+    np.random.seed(2)
+    ld = FactorizedNetworkDistribution(N, BetaBernoulliAdjacencyDistribution, dict(tau1=1.0, tau0=1.0, seed=3),
+                                       LatentDistanceGaussianWeightDistribution, dict(B=1, dim=2, seed=4))
+    er = FactorizedNetworkDistribution(N, BetaBernoulliAdjacencyDistribution, dict(tau1=1.0, tau0=1.0, seed=3),
+                                       NIWGaussianWeightDistribution, dict(B=1, seed=5))
+    lz_ld = estimate_marginal_likelihood(ld, (A, W), N_samples=12, B=150, steps_per_B=4)
+    lz_er = estimate_marginal_likelihood(er, (A, W), N_samples=12, B=60, steps_per_B=1)
+    assert np.isfinite(lz_ld) and np.isfinite(lz_er)
+    assert lz_ld > lz_er + 5.0, (lz_ld, lz_er)      # measured: -561 vs -575 (the fixed HMC step mixes slowly: biased low)
