@@ -431,39 +431,55 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
   const double inv_sigma_F = 1.0 / sigma_F;
   if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(clock64() - c_start));
   if (wave == 0) {
-    if (lane == 0) {   // the critical path is one lane's dependent arithmetic; the rest of the wave stays out of it
-      long long c_wait = 0, c_solve = 0;
-      double dPp[NEGM], dFp[DM];   // the previous node's rank-one change (registers)
+    // The solver wave.  The per-node critical path (Cholesky + two triangular solves: ~200 dependent fp64 operations)
+    // runs on lane 0; everything that is one independent operation per matrix entry -- folding the previous node's
+    // rank-one change into the statistics, the new outer-product change -- is spread over the lanes, lane l owning
+    // entry (l / DM, l % DM), and handed over through a small LDS scratch (same wave: program order, no barrier).
+    // A wave instruction costs the same for 1 or 64 active lanes, so this takes ~250 instructions off the path.
+    double* s_scr = s_stat;                        // [NEGM + DM] precision + mean term, then [2 DM] fn, fo
+    const int li = lane / DM, lj = lane % DM;
+    const int la = li < lj ? li : lj, lb = li < lj ? lj : li;
+    const bool lact = lane < DM * DM && (FULL || lb < D);
+    const int le = lact ? la * D - la * (la - 1) / 2 + (lb - la) : 0;   // compact upper-triangle index of (la, lb)
+    const bool lup = lact && li <= lj;             // the lanes that write their entry
+    const bool lvec = lane < D;                    // lanes that own a component of the mean term / of f
+    long long c_wait = 0, c_solve = 0;
+    double dPl = 0.0, dFl = 0.0;                   // the previous node's rank-one change, this lane's entry
+    bool ready = true;                             // "every updater has applied change nl-2", checked one node ahead
+    for (int nl = 0; nl < T; ++nl) {
+      const int n = t0 + nl;
+      const double* s_st = s_part + nl * (NEGM + DM);
+      const long long c0 = dbg ? clock64() : 0;
+      if (!ready) {
+        for (int spin = 0;; ++spin) {
+          const unsigned long long q = *s_progq;   // one load: the seven progress bytes
+          int mn = 255;
 #pragma unroll
-      for (int e = 0; e < NEGM; ++e) dPp[e] = 0.0;
-#pragma unroll
-      for (int a1 = 0; a1 < DM; ++a1) dFp[a1] = 0.0;
-      bool ready = true;           // "every updater has applied change nl-2", checked one node ahead
-      for (int nl = 0; nl < T; ++nl) {
-        const int n = t0 + nl;
-        const double* s_stat = s_part + nl * (NEGM + DM);
-        const long long c0 = dbg ? clock64() : 0;
-        if (!ready) {
-          for (int spin = 0;; ++spin) {
-            const unsigned long long q = *s_progq;   // one load: the seven progress bytes
-            int mn = 255;
-#pragma unroll
-            for (int w = 1; w <= 7; ++w) { const int v = (int)((q >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
-            if (mn >= nl - 1) break;
-            if (spin > (1 << 22)) { atomicOr(status, 2); break; }   // never spin forever
-            __builtin_amdgcn_s_sleep(1);
-          }
+          for (int w = 1; w <= 7; ++w) { const int v = (int)((q >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
+          if (mn >= nl - 1) break;
+          if (spin > (1 << 22)) { if (lane == 0) atomicOr(status, 2); break; }   // never spin forever
+          __builtin_amdgcn_s_sleep(1);
         }
-        __threadfence_block();
-        const long long c1 = dbg ? clock64() : 0;
-        // statistics of this node with the previous node's change folded in (same order as the updaters':
-        // earlier changes first, the previous node's last)
-        double svp = 0.0, cfp = 0.0;
-        if (nl >= 1) {
-          const double raw = s_S[nl * (EIG_T + 1) + nl - 1];
-          svp = probit ? 2.0 : raw;
-          cfp = gg_fma(-mu0, svp, probit ? raw : (double)s_a[nl * EIG_T + nl - 1]);
-        }
+      }
+      __threadfence_block();
+      const long long c1 = dbg ? clock64() : 0;
+      // statistics of this node with the previous node's change folded in (same order as the updaters':
+      // earlier changes first, the previous node's last), one entry per lane
+      double svp = 0.0, cfp = 0.0;
+      if (nl >= 1) {
+        const double raw = s_S[nl * (EIG_T + 1) + nl - 1];
+        svp = probit ? 2.0 : raw;
+        cfp = gg_fma(-mu0, svp, probit ? raw : (double)s_a[nl * EIG_T + nl - 1]);
+      }
+      if (lup) {
+        double v = gg_fma(svp, dPl, s_st[le]);
+        if (li == lj) v += inv_sigma_F;
+        s_scr[le] = v;
+      }
+      if (lvec) s_scr[NEG + lane] = gg_fma(cfp, dFl, s_st[NEG + lane]);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      if (lane == 0) {
         // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
         double L[DM][DM], hh[DM], x[DM];
         {
@@ -473,21 +489,27 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
 #pragma unroll
             for (int b1 = a1; b1 < DM; ++b1) {
               double v = 0.0;
-              if (FULL || b1 < D) { v = gg_fma(svp, dPp[e], s_stat[e]); ++e; if (a1 == b1) v += inv_sigma_F; }
+              if (FULL || b1 < D) { v = s_scr[e]; ++e; }
               else if (a1 == b1) v = 1.0;
               L[b1][a1] = v;   // lower triangle holds the precision
             }
         }
 #pragma unroll
-        for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? gg_fma(cfp, dFp[a1], s_stat[NEG + a1]) : 0.0;
-        bool ok = true;
+        for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? s_scr[NEG + a1] : 0.0;
+        double zz[DM], fo[DM];
+#pragma unroll
+        for (int i = 0; i < DM; ++i) {
+          zz[i] = (FULL || i < D) ? s_Z[nl * DM + i] : 0.0;
+          fo[i] = (FULL || i < D) ? s_Fo[nl * DM + i] : 0.0;
+        }
+        double dmin = 1.0;           // smallest pivot: a non-positive one voids the node (checked once, off the path)
         // Cholesky (left-looking, same order as gg_chol_d)
 #pragma unroll
         for (int j = 0; j < DM; ++j) {
           double dsum = L[j][j];
 #pragma unroll
           for (int k = 0; k < j; ++k) dsum = gg_fma(-L[j][k], L[j][k], dsum);
-          if (!(dsum > 0.0)) { ok = false; dsum = 1.0; }
+          dmin = __builtin_fmin(dmin, dsum);
           // one reciprocal square root per column instead of D divisions (float-tolerance path)
           double inv = __builtin_amdgcn_rsq(dsum);               // hardware estimate, then two Newton steps
           inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
@@ -502,9 +524,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           }
         }
         // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision)
-        double y[DM], zz[DM];
-#pragma unroll
-        for (int i = 0; i < DM; ++i) zz[i] = (FULL || i < D) ? s_Z[nl * DM + i] : 0.0;
+        double y[DM];
 #pragma unroll
         for (int i = 0; i < DM; ++i) {
           double v = hh[i];
@@ -512,9 +532,6 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           for (int k = 0; k < i; ++k) v = gg_fma(-L[i][k], y[k] - zz[k], v);
           y[i] = gg_fma(v, L[i][i], zz[i]);
         }
-        // progress of the updaters, read now for the NEXT node (needs change nl-1 applied everywhere): the
-        // words arrive while the back substitution runs
-        const unsigned long long pq = *s_progq;   // one load: the seven progress bytes
 #pragma unroll
         for (int i = DM - 1; i >= 0; --i) {
           double v = y[i];
@@ -522,42 +539,45 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           for (int k = i + 1; k < DM; ++k) v = gg_fma(-L[k][i], x[k], v);
           x[i] = v * L[i][i];
         }
-        {
-          int mn = 255;
-#pragma unroll
-          for (int w = 1; w <= 7; ++w) { const int v = (int)((pq >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
-          ready = (nl + 1 < 2) || (mn >= nl);
-        }
-        double fo[DM], fn[DM];
+        const bool ok = dmin > 0.0 && x[0] == x[0];   // x[0] closes the back substitution: NaN anywhere reaches it
+        if (!ok) atomicOr(status, 1);
 #pragma unroll
         for (int a1 = 0; a1 < DM; ++a1) {
-          const double old = (FULL || a1 < D) ? s_Fo[nl * DM + a1] : 0.0;
-          if (!ok) x[a1] = old;
-          fo[a1] = old * lam[a1];
-          fn[a1] = x[a1] * lam[a1];
-        }
-        if (!ok) atomicOr(status, 1);
-        // rank-one change of this node's outer product, seen by the later nodes of the tile
-        {
-          int e = 0;
-#pragma unroll
-          for (int a1 = 0; a1 < DM; ++a1) {
-            dFp[a1] = fn[a1] - fo[a1];
-            if (FULL || a1 < D) s_dF[nl * DM + a1] = dFp[a1];
-#pragma unroll
-            for (int b1 = a1; b1 < DM; ++b1)
-              if (FULL || b1 < D) { dPp[e] = fn[a1] * fn[b1] - fo[a1] * fo[b1]; s_dP[nl * NEGM + e] = dPp[e]; ++e; }
+          if (!ok) x[a1] = fo[a1];
+          if (FULL || a1 < D) {
+            F[(size_t)n * D + a1] = x[a1];
+            s_scr[a1] = x[a1] * lam[a1];            // fn
+            s_scr[DM + a1] = fo[a1] * lam[a1];      // fo
           }
         }
-#pragma unroll
-        for (int a1 = 0; a1 < DM; ++a1)
-          if (FULL || a1 < D) F[(size_t)n * D + a1] = x[a1];
-        __threadfence_block();
-        s_prog[0] = nl + 1;   // change nl is published
-        if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_solve += c3 - c1; }
       }
-      if (dbg) { atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)c_wait); atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)c_solve); atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T); }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      // progress of the updaters for the NEXT node (needs change nl-1 applied everywhere): the words arrive while the
+      // outer product below is formed
+      const unsigned long long pq = *s_progq;
+      // rank-one change of this node's outer product, seen by the later nodes of the tile: one entry per lane
+      if (lact) {
+        const double fna = s_scr[la], fnb = s_scr[lb], foa = s_scr[DM + la], fob = s_scr[DM + lb];
+        dPl = fna * fnb - foa * fob;
+        if (lup) s_dP[nl * NEGM + le] = dPl;
+      }
+      if (lvec) {
+        dFl = s_scr[lane] - s_scr[DM + lane];
+        s_dF[nl * DM + lane] = dFl;
+      }
+      {
+        int mn = 255;
+#pragma unroll
+        for (int w = 1; w <= 7; ++w) { const int v = (int)((pq >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
+        ready = (nl + 1 < 2) || (mn >= nl);
+      }
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) s_prog[0] = nl + 1;   // change nl is published
+      if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_solve += c3 - c1; }
     }
+    if (dbg && lane == 0) { atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)c_wait); atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)c_solve); atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T); }
   } else {
     // updaters: every lane owns up to RU fixed (node, entry) pairs and keeps their running values in registers;
     // per change it needs two or three independent LDS reads per pair (issued as one batch), one fma, one store
