@@ -427,7 +427,7 @@ struct gg_params_args {
   unsigned long long* bar;   // k_scan's barrier counter + first-changer words, re-armed for the scan that follows
   int shared;                // SBMGaussianWeightSharedCov: draw the means given the shared covariance, leave the
                              // covariance draw and the coefficient tables to k_shared_cov
-  double* csc;               // [K*K][B*B] centred scatter of every block pair (shared-covariance kind)
+  double* csc;               // [K*K][B*B + 1] centred scatter and tempered count of every block pair's off-diagonal edges (shared-covariance kind)
 };
 
 template <bool ADJ, int B>
@@ -454,14 +454,22 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
   }
   __shared__ long long s_red[4][NTAB];
   __shared__ long long s_tab[NTAB];
+  __shared__ long long s_tabd[NTAB];   // diagonal edges of pair (a, a), shared-covariance kind without the special case
+  if (threadIdx.x < NTAB) s_tabd[threadIdx.x] = 0;
   const int t = blockIdx.x;
   if (t < K * K) {
     const int a = t / K, b = t % K;
     if (g.do_tables) {
       const int s0 = g.lab_start[a], s1 = g.lab_start[a + 1];
       long long acc[NTAB];
+      // shared-covariance kind without the self-connection special case: the covariance is centred on the
+      // off-diagonal edges only (weights.py:545-548), so the diagonal's share of pair (a, a) is also kept apart
+      const bool keep_diag = !ADJ && g.shared && g.add_diag && a == b;
+      long long accd[ADJ ? 1 : NTAB];
 #pragma unroll
       for (int q = 0; q < NTAB; ++q) acc[q] = 0;
+#pragma unroll
+      for (int q = 0; q < (ADJ ? 1 : NTAB); ++q) accd[q] = 0;
       for (int r = s0 + threadIdx.x; r < s1; r += blockDim.x) {
         int n = g.perm[r] - g.n0;
         if (n < 0 || n >= g.Nl) continue;   // not an owned node
@@ -476,18 +484,23 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         if (g.add_diag && a == b && g.dA[n]) {
           acc[0] += 1;
           if (!ADJ) {
+            accd[0] += 1;
             const int32_t* q = g.dWq + (size_t)n * B;
             int tt = 0;
             for (int r1 = 0; r1 < B; ++r1, ++tt) {
               long long v = q[r1];
               acc[1 + 2 * tt] += (v >> 32);
               acc[2 + 2 * tt] += (v & 0xffffffffll);
+              accd[1 + 2 * tt] += (v >> 32);
+              accd[2 + 2 * tt] += (v & 0xffffffffll);
             }
             for (int r1 = 0; r1 < B; ++r1)
               for (int r2 = r1; r2 < B; ++r2, ++tt) {
                 long long v = (long long)q[r1] * (long long)q[r2];
                 acc[1 + 2 * tt] += (v >> 32);
                 acc[2 + 2 * tt] += (v & 0xffffffffll);
+                accd[1 + 2 * tt] += (v >> 32);
+                accd[2 + 2 * tt] += (v & 0xffffffffll);
               }
           }
         }
@@ -506,6 +519,20 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
         g.tab[(size_t)t * NTAB + threadIdx.x] = v;
       }
       __syncthreads();
+      if (!ADJ && keep_diag) {     // the diagonal's share, reduced the same way (workgroup-uniform branch)
+#pragma unroll
+        for (int q = 0; q < NTAB; ++q) {
+          long long v = gg_wave_sum_ll(accd[q]);
+          if (lane == 0) s_red[wave][q] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < NTAB) {
+          long long v = 0;
+          for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_red[w][threadIdx.x];
+          s_tabd[threadIdx.x] = v;
+        }
+        __syncthreads();
+      }
     } else if (g.tables_from_tab) {
       if (threadIdx.x < NTAB) s_tab[threadIdx.x] = g.tab[(size_t)t * NTAB + threadIdx.x];
       __syncthreads();
@@ -541,8 +568,17 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
           gg_stream_init(&s, g.seed, GG_SITE_W_NIW, g.sweep, (uint32_t)t);
           if (gg_fixed_cov_mean_draw(&s, g.wh.niw.mu_0, g.sigma + (size_t)t * B * B, B, nn, s1, mo)) atomicOr(&g.ctl[3], 1);
           for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
-          gg_centered_scatter(nn, s1, s2, mo, B, C);
-          for (int i = 0; i < B * B; ++i) g.csc[(size_t)t * B * B + i] = C[i];
+          // centred scatter of the pair's OFF-DIAGONAL edges (weights.py:545-548): their statistics are the exact
+          // integer difference of the pair's and its diagonal's (zero when self connections are special-cased)
+          long long off[NTAB];
+          for (int q = 0; q < NTAB; ++q) off[q] = s_tab[q] - s_tabd[q];
+          gg_unpack_wstats(off + 1, B, g.wh.shift, s1, s2);
+          for (int i = 0; i < B; ++i) s1[i] *= g.beta;
+          for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
+          const double noff = g.beta * (double)off[0];
+          gg_centered_scatter(noff, s1, s2, mo, B, C);
+          for (int i = 0; i < B * B; ++i) g.csc[(size_t)t * (B * B + 1) + i] = C[i];
+          g.csc[(size_t)t * (B * B + 1) + B * B] = noff;
         } else if (g.do_draw) {
           double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB];
           gg_unpack_wstats(s_tab + 1, B, g.wh.shift, s1, s2);
@@ -963,8 +999,8 @@ __global__ __launch_bounds__(256) void k_shared_cov(gg_params_args g) {
     for (int i = 0; i < B * B; ++i) S[i] = g.wh.niw.sigma_0[i];
     double ntot = 0.0;
     for (int ab = 0; ab < KK; ++ab) {
-      for (int i = 0; i < B * B; ++i) S[i] += g.csc[(size_t)ab * B * B + i];
-      ntot += g.beta * (double)g.tab[(size_t)ab * NTAB];
+      for (int i = 0; i < B * B; ++i) S[i] += g.csc[(size_t)ab * (B * B + 1) + i];
+      ntot += g.csc[(size_t)ab * (B * B + 1) + B * B];      // tempered number of off-diagonal edges of the pair
     }
     gg_stream s;
     gg_stream_init(&s, g.seed, GG_SITE_W_SHCOV, g.sweep, 0u);

@@ -187,9 +187,9 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->Np = gg_round_up(m->Nl, 64);
   // NIW / non-SBM weight kinds always keep a separate self Gaussian (weights.py:91-94)
   if (m->kind == GG_NIW_W || m->kind == GG_FIXED_W) m->cfg.special_case_self_conns = 1;
-  if (m->kind == GG_SBM_GAUSS_SHCOV_W && !m->cfg.special_case_self_conns) {
+  if (m->kind == GG_SBM_GAUSS_SHCOV_W && !m->cfg.special_case_self_conns && m->sharded) {
     delete m;
-    return gg_fail(GG_ERR_UNSUPPORTED, "SBMGaussianWeightSharedCov: special_case_self_conns = False is not built (weights.py:545-548 centres the off-diagonal edges only)");
+    return gg_fail(GG_ERR_UNSUPPORTED, "SBMGaussianWeightSharedCov without special_case_self_conns: the node-sharded chain does not carry the diagonal's share of the pair tables");
   }
   GG_HIP(hipStreamCreate(&m->stream));
   const int N = m->N, K = m->K, B = m->B, NT = m->NT;
@@ -210,7 +210,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     if ((rc = dmalloc(&m->p, KK)) || (rc = dmalloc(&m->p_self, 1))) return rc;
   } else {
     if ((rc = dmalloc(&m->mu, KK * B)) || (rc = dmalloc(&m->sigma, KK * B * B)) || (rc = dmalloc(&m->mu_self, B)) ||
-        (rc = dmalloc(&m->sigma_self, (size_t)B * B)) || (rc = dmalloc(&m->csc, KK * B * B)))
+        (rc = dmalloc(&m->sigma_self, (size_t)B * B)) || (rc = dmalloc(&m->csc, KK * (B * B + 1))))
       return rc;
   }
   m->beta = 1.0;

@@ -459,16 +459,16 @@ class SBMGaussianWeightSharedCov(SBMGaussianWeightDistribution):
     """weights.py:501-610: block-pair means with ONE covariance shared by all pairs.  resample_mu_and_Sig draws every
     pair's mean given the covariance (GaussianFixedCov, prior N(mu_0, I)), the self Gaussian, then the covariance from
     the centred off-diagonal edges (GaussianFixedMean / inverse Wishart(lmbda_0 = Sigma_0, nu_0)); the engine kind differs,
-    the scan and the likelihood are the parent's.  special_case_self_conns=True only (the reference's default)."""
+    the scan and the likelihood are the parent's.  Without special_case_self_conns the diagonal belongs to pair (c_i, c_i) for
+    the means and stays out of the covariance's centred scatter, as in the reference (:545-548)."""
 
     _kind = _abi.SBM_GAUSS_SHCOV_W
 
     def __init__(self, N, B=1, C=3, pi=10.0, mu_0=None, Sigma_0=None, nu_0=None, special_case_self_conns=True,
                  device=0, seed=None):
-        if not special_case_self_conns:
-            raise NotImplementedError("SBMGaussianWeightSharedCov is built for special_case_self_conns=True only")
         super(SBMGaussianWeightSharedCov, self).__init__(N, B=B, C=C, pi=pi, mu_0=mu_0, Sigma_0=Sigma_0, nu_0=nu_0,
-                                                         special_case_self_conns=True, device=device, seed=seed)
+                                                         special_case_self_conns=special_case_self_conns, device=device,
+                                                         seed=seed)
         # one covariance for every pair: start from the (0, 0) draw of the parent's constructor
         sig = self._hget("_sigma").copy()
         sig[:] = sig[0, 0]

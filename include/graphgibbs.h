@@ -44,7 +44,7 @@ enum gg_status {
  *  GG_PROBIT_EIG    eigenmodel.py:239-379 _GibbsProbitEigenmodel (same state ids; the auxiliaries are Z, not omega)
  *  GG_SBM_GAUSS_SHCOV_W  weights.py:501-610  SBMGaussianWeightSharedCov (one covariance for all block pairs; GG_ST_NIW packs
  *                   the mean prior mu_0, the inverse-Wishart scale lmbda_0 and nu_0; GG_ST_SIGMA holds the shared
- *                   covariance in every pair; special_case_self_conns only)
+ *                   covariance in every pair)
  *  GG_LATENT_DIST   adjacency.py:191-437  LatentDistanceAdjacencyDistribution (HMC; D = dim, sigma_F = sigma;
  *                   parts: GG_PART_F = L, GG_PART_MU0 = mu_0, GG_PART_LMBDA = mu_self)
  *  GG_LATENT_DIST_W weights.py:613-903    LatentDistanceGaussianWeightDistribution (B = 1; D = dim; state: GG_ST_F = L,

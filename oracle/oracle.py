@@ -146,14 +146,15 @@ def sbm_w_sweep(A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, niw, niw_
         raise RuntimeError("oracle sbm_w_sweep failed rc=%d" % rc)
 
 
-def sbm_wsh_sweep(A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, prior, niw_self, seed, sweep, parts=PART_ALL, beta=1.0):
+def sbm_wsh_sweep(A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, prior, niw_self, seed, sweep, parts=PART_ALL, beta=1.0,
+                  special=True):
     """SBMGaussianWeightSharedCov (weights.py:501-552); sigma (K,K,B,B) holds the shared covariance in every pair;
     prior = pack_niw(mu_0, lmbda_0, nu_0, unused)."""
     N, K, B = A.shape[0], m.shape[0], q.shape[2]
     A8, pA = _u8(A != 0)
     rc = lib().orc_sbm_wsh_sweep(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma), _f64(mu_self),
                                  _f64(sigma_self), _f64(np.ascontiguousarray(pi, dtype=np.float64)), _f64(prior), _f64(niw_self),
-                                 C.c_uint64(seed), C.c_uint32(sweep), int(parts), C.c_double(beta))
+                                 int(bool(special)), C.c_uint64(seed), C.c_uint32(sweep), int(parts), C.c_double(beta))
     if rc:
         raise RuntimeError("oracle sbm_wsh_sweep failed rc=%d" % rc)
 

@@ -570,17 +570,26 @@ int orc_niw_w_sweep(int N, int B, const uint8_t* A, const int32_t* q, int shift,
 // ---------------------------------------------------------------------------
 static int sbm_wsh_resample_mu_sig(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, const int32_t* c,
                                    double* mu, double* sigma, double* mu_self, double* sigma_self, const gg_niw* h,
-                                   const gg_niw* hs, uint64_t seed, uint32_t sweep, double beta) {
-  std::vector<WStat> st((size_t)K * K);
+                                   const gg_niw* hs, int special, uint64_t seed, uint32_t sweep, double beta) {
+  // st: the edges each pair's mean is drawn from (_get_mask, weights.py:308-314: the diagonal belongs to pair
+  // (c_i, c_i) unless self connections are special-cased); so: the off-diagonal edges only, which is what the
+  // covariance is centred on (:545-548)
+  std::vector<WStat> st((size_t)K * K), so((size_t)K * K);
   for (auto& s : st) wstat_zero(&s);
+  for (auto& s : so) wstat_zero(&s);
   WStat sd;
   wstat_zero(&sd);
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
       if (!A[(size_t)i * N + j]) continue;
       const int32_t* qq = q + ((size_t)i * N + j) * B;
-      if (i == j) { wstat_add(&sd, qq, B); continue; }
+      if (i == j) {
+        if (special) wstat_add(&sd, qq, B);
+        else wstat_add(&st[(size_t)c[i] * K + c[i]], qq, B);
+        continue;
+      }
       wstat_add(&st[(size_t)c[i] * K + c[j]], qq, B);
+      wstat_add(&so[(size_t)c[i] * K + c[j]], qq, B);
     }
   double n, s1[GG_MAXB], s2[GG_MAXB * GG_MAXB], C[GG_MAXB * GG_MAXB], S[GG_MAXB * GG_MAXB];
   double ntot = 0.0;
@@ -593,11 +602,15 @@ static int sbm_wsh_resample_mu_sig(int N, int K, int B, const uint8_t* A, const 
     gg_stream s;
     gg_stream_init(&s, seed, GG_SITE_W_NIW, sweep, (uint32_t)ab);
     if (gg_fixed_cov_mean_draw(&s, h->mu_0, sigma + (size_t)ab * B * B, B, n, s1, mu + (size_t)ab * B)) return -2;
+    wstat_to_double(&so[ab], B, shift, &n, s1, s2);
+    n *= beta;
+    for (int r = 0; r < B; ++r) s1[r] *= beta;
+    for (int r = 0; r < B * B; ++r) s2[r] *= beta;
     gg_centered_scatter(n, s1, s2, mu + (size_t)ab * B, B, C);
     for (int i = 0; i < B * B; ++i) S[i] += C[i];
     ntot += n;
   }
-  {
+  if (special) {
     wstat_to_double(&sd, B, shift, &n, s1, s2);
     n *= beta;
     for (int r = 0; r < B; ++r) s1[r] *= beta;
@@ -617,17 +630,17 @@ static int sbm_wsh_resample_mu_sig(int N, int K, int B, const uint8_t* A, const 
 
 int orc_sbm_wsh_sweep(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, int32_t* c, double* m, double* mu,
                       double* sigma, double* mu_self, double* sigma_self, const double* pi, const double* prior,
-                      const double* niw_self, uint64_t seed, uint32_t sweep, int parts, double beta) {
+                      const double* niw_self, int special, uint64_t seed, uint32_t sweep, int parts, double beta) {
   if (B > GG_MAXB) return -1;
   gg_niw h, hs;
   unpack_niw(prior, B, &h);
   unpack_niw(niw_self, B, &hs);
   if (parts & ORC_PART_PARAMS) {
-    int rc = sbm_wsh_resample_mu_sig(N, K, B, A, q, shift, c, mu, sigma, mu_self, sigma_self, &h, &hs, seed, sweep, beta);
+    int rc = sbm_wsh_resample_mu_sig(N, K, B, A, q, shift, c, mu, sigma, mu_self, sigma_self, &h, &hs, special, seed, sweep, beta);
     if (rc) return rc;
   }
   if (parts & ORC_PART_C) {
-    int rc = sbm_w_resample_c(N, K, B, A, q, shift, c, m, mu, sigma, 1, seed, sweep, beta);
+    int rc = sbm_w_resample_c(N, K, B, A, q, shift, c, m, mu, sigma, special, seed, sweep, beta);
     if (rc) return rc;
   }
   if (parts & ORC_PART_M) resample_m(N, K, c, pi, m, seed, GG_SITE_W_M, sweep);

@@ -224,32 +224,34 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K,B,beta", [(140, 4, 1, 1.0), (180, 5, 2, 1.0), (120, 3, 2, 0.5)])
-def test_shared_covariance_weights_bitexact(abi, N, K, B, beta):
+@pytest.mark.parametrize("N,K,B,beta,special", [(140, 4, 1, 1.0, 1), (180, 5, 2, 1.0, 1), (120, 3, 2, 0.5, 1),
+                                                (150, 4, 1, 1.0, 0), (130, 3, 2, 0.6, 0)])
+def test_shared_covariance_weights_bitexact(abi, N, K, B, beta, special):
     """SBMGaussianWeightSharedCov (weights.py:501-552): means given the shared covariance, then the covariance from the
     centred edges, then the parent's scan: bit-exact against the oracle over several sweeps."""
     A, W, _ = planted_sbm(N, K, B=B, seed=41)
+    assert np.diag(A).sum() > 3        # self edges present: the two settings differ
     q, shift = O.quantise(A, W)
     st = WState(N, K, B, seed=8)
     st.sigma[:] = st.sigma[0, 0]
     prior = O.pack_niw(np.full(B, 0.2), np.eye(B) * 1.3, B + 2, 1.0)
     d = abi.DeviceData(A, W)
-    w = abi.Model(kind=abi.SBM_GAUSS_SHCOV_W, N=N, K=K, B=B, seed=83, special_case_self_conns=1)
+    w = abi.Model(kind=abi.SBM_GAUSS_SHCOV_W, N=N, K=K, B=B, seed=83, special_case_self_conns=special)
     w.set(abi.ST_C, st.c, np.int32); w.set(abi.ST_M, st.m); w.set(abi.ST_PI, st.pi)
     w.set(abi.ST_MU, st.mu); w.set(abi.ST_SIGMA, st.sigma); w.set(abi.ST_NIW, prior); w.set(abi.ST_NIW_SELF, st.niw_self)
+    w.set(abi.ST_MU_SELF, st.mu_self); w.set(abi.ST_SIGMA_SELF, st.sigma_self)   # (left alone without the special case)
     for s in range(4):
         w.resample(d, 1, beta)
-        O.sbm_wsh_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, prior, st.niw_self, 83, s, beta=beta)
+        O.sbm_wsh_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, prior, st.niw_self, 83, s, beta=beta,
+                        special=special)
         assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), st.c), s
         assert np.array_equal(w.get(abi.ST_MU, (K, K, B)), st.mu)
         sig = w.get(abi.ST_SIGMA, (K, K, B, B))
         assert np.array_equal(sig, st.sigma) and np.array_equal(sig, np.broadcast_to(sig[0, 0], sig.shape))
         assert np.array_equal(w.get(abi.ST_MU_SELF, (B,)), st.mu_self) and np.array_equal(w.get(abi.ST_M, (K,)), st.m)
     ll = w.log_likelihood(d)
-    ref = O.sbm_w_loglik(A, q, shift, st.c, st.mu, st.sigma, st.mu_self, st.sigma_self, 1)
+    ref = O.sbm_w_loglik(A, q, shift, st.c, st.mu, st.sigma, st.mu_self, st.sigma_self, special)
     assert abs(ll - ref) <= 1e-9 * abs(ref)
-    with pytest.raises(abi.EngineError):
-        abi.Model(kind=abi.SBM_GAUSS_SHCOV_W, N=N, K=K, B=B, seed=1, special_case_self_conns=0)
 
 
 @pytest.mark.gpu

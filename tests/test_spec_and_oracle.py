@@ -341,3 +341,36 @@ def test_shared_cov_oracle_follows_the_conjugate_algebra():
                 scatter += Xc.T.dot(Xc)
     expect = (np.eye(B) * 1.5 + scatter) / (B + 2 + n_edges - B - 1)
     assert np.allclose(sigs.mean(0), expect, rtol=0.02)
+
+
+def test_shared_cov_oracle_without_the_self_connection_special_case():
+    """special_case_self_conns=False: self edges join pair (c_i, c_i) for the means (_get_mask, weights.py:308-314), the self
+    Gaussian is left alone (:410-413) and the covariance still sees the off-diagonal edges only (:545-548)."""
+    N, K, B = 90, 2, 1
+    A, W, _ = planted_sbm(N, K, B=B, seed=4)
+    A[np.arange(N), np.arange(N)] = 1                  # plenty of self edges, far from the block means
+    W[np.arange(N), np.arange(N), 0] = 6.0 + 0.1 * np.arange(N) / N
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=2)
+    Sig = np.array([[0.9]])
+    prior = O.pack_niw(np.array([0.0]), np.eye(B), B + 2, 1.0)
+    mus, sigs = [], []
+    for sw in range(500):
+        mu, sg, ms, ss = st.mu.copy(), st.sigma.copy(), st.mu_self.copy(), st.sigma_self.copy()
+        sg[:] = Sig
+        O.sbm_wsh_sweep(A, q, shift, st.c.copy(), st.m.copy(), mu, sg, ms, ss, st.pi, prior, st.niw_self, 9, sw,
+                        parts=O.PART_PARAMS, special=False)
+        assert np.array_equal(ms, st.mu_self) and np.array_equal(ss, st.sigma_self)
+        mus.append(mu[0, 0, 0]); sigs.append(sg[0, 0, 0, 0])
+    Wq = np.ldexp(q.astype(np.float64), -shift)[:, :, 0]
+    c = st.c
+    in00 = (c[:, None] == 0) & (c[None, :] == 0) & (A == 1)
+    X = Wq[in00]                                        # with the diagonal
+    prec = 1.0 + len(X) / Sig[0, 0]
+    mean = (X.sum() / Sig[0, 0]) / prec
+    assert abs(np.mean(mus) - mean) < 5 * np.sqrt(1.0 / prec / len(mus))
+    assert mean > 0.2 + Wq[in00 & ~np.eye(N, dtype=bool)].mean()      # the self edges pulled it up
+    # covariance: off-diagonal edges only, centred on the drawn means (~ the pair means, the (0,0) and (1,1) ones shifted)
+    off = (A == 1) & ~np.eye(N, dtype=bool)
+    assert np.mean(sigs) < 3.0          # had the diagonal (6 +- 0.1 against means near 0-2) been included it would be far larger
+    assert abs(len(sigs) - 500) == 0 and off.sum() > 1000
