@@ -234,7 +234,7 @@ def bench_latent(args, abi, device, rank, world, barrier, max_over_ranks):
     if rank != 0:
         return
     passes = 22
-    sweep_bytes = passes * 2.0 * N * N
+    sweep_bytes = (11 * 2.0 + 11 * 1.0) * N * N      # the L update reads A and A^T, the mu_0 update only A
     out = {"metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": world * args.steps / el,
            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -243,8 +243,9 @@ def bench_latent(args, abi, device, rank, world, barrier, max_over_ranks):
                       "sweep_algorithmic_bytes": sweep_bytes, "accepted_L_proposals": m.stats()["label_changes"]},
            "roofline": {"bound": "hbm", "kernel": "k_ld_pass", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": sweep_bytes * args.steps / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "whole-resample effective rate over %d passes of A and A^T (uint8); each pass also evaluates N^2 "
-                                "fp64 exp + log (sigmoid, softplus), which is what bounds it at this size" % passes}}
+                        "note": "whole-resample effective rate over %d passes (11 of A and A^T, 11 of A; uint8); each pass also evaluates N^2 "
+                                "fp64 exp (sigmoid) and, at the two ends of a trajectory, log (softplus), which is what bounds it "
+                                "at this size" % passes}}
     if not args.no_cpu and world == 1:
         from oracle import oracle as O
         Lo = L0.copy()

@@ -27,7 +27,7 @@ struct gg_latent {
   int N, dim, Np;
   double sigma;
   double *L, *Q, *Pm;      // positions, proposal, momenta  [N][dim]
-  double* Q2;              // wmode: second proposal buffer (the pass kernel drifts into the other one)
+  double* Q2;              // second proposal buffer (the pass kernel drifts into the other one)
   double* row;             // per node: dim gradient sums, ll, s  [N][dim + 2]
   double* scal;            // LS_COUNT scalars
   int* acc;                // bit mask of accepted proposals of the last resample
@@ -45,13 +45,18 @@ struct gg_latent {
 
 // One pass: for node i, over all j != i,
 //   x = -|q_i - q_j|^2 + mu_0,  P = sigmoid(x):
-//   ll_i  = sum_j A_ij x - softplus(x)            (the directed terms of row i)
+//   ll_i  = sum_j A_ij x - softplus(x)            (the directed terms of row i; LL = 1 only)
 //   s_i   = sum_j A_ij - P
 //   g_i   = sum_j (A_ij + A_ji - 2 P) (q_i - q_j) (times -2 later: d x / d q_i = -2 (q_i - q_j), P symmetric)
-template <int DIM>
+// The log probability is needed only at the two ends of a trajectory: the passes in between (LL = 0) skip the
+// logarithm (the pass is bound by its fp64 exp + log) and, in the L update, the reduction too - with kick != 0 the
+// workgroup finishes the leapfrog step of its own node (p_i += f eps grad_i, drift into the other proposal buffer).
+// GRAD = 0 (the mu_0 update: only ll and s are wanted): A^T is not read and the position gradient not formed.
+template <int DIM, int LL, int GRAD>
 __global__ __launch_bounds__(256) void k_ld_pass(int N, int Np, const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                  const double* __restrict__ Q, const double* __restrict__ scal, int mu0_slot,
-                                                 double* __restrict__ row) {
+                                                 double* __restrict__ row, int kick, double* __restrict__ Qdst,
+                                                 double* __restrict__ Pm, double f, int drift, double sigma, double beta) {
   const int i = blockIdx.x;
   const double mu0 = scal[mu0_slot];
   double qi[DIM], g[DIM], ll = 0.0, s = 0.0;
@@ -63,14 +68,21 @@ __global__ __launch_bounds__(256) void k_ld_pass(int N, int Np, const uint8_t* _
 #pragma unroll
     for (int d = 0; d < DIM; ++d) { t[d] = qi[d] - Q[(size_t)j * DIM + d]; d2 += t[d] * t[d]; }
     const double x = -d2 + mu0;
-    const double a1 = A[(size_t)i * Np + j] ? 1.0 : 0.0, a2 = AT[(size_t)i * Np + j] ? 1.0 : 0.0;
+    const double a1 = A[(size_t)i * Np + j] ? 1.0 : 0.0;
     double P, sp;
-    gg_sigmoid_softplus(x, &P, &sp);
-    ll += a1 * x - sp;
+    if (LL) {
+      gg_sigmoid_softplus(x, &P, &sp);
+      ll += a1 * x - sp;
+    } else {
+      P = gg_sigmoid_only(x);
+    }
     s += a1 - P;
-    const double c = a1 + a2 - 2.0 * P;
+    if (GRAD) {
+      const double a2 = AT[(size_t)i * Np + j] ? 1.0 : 0.0;
+      const double c = a1 + a2 - 2.0 * P;
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) g[d] += c * t[d];
+      for (int d = 0; d < DIM; ++d) g[d] += c * t[d];
+    }
   }
   __shared__ double s_red[4][DIM + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,16 +93,55 @@ __global__ __launch_bounds__(256) void k_ld_pass(int N, int Np, const uint8_t* _
     if (lane == 0) s_red[wave][e] = v;
   }
   __syncthreads();
-  if (threadIdx.x < DIM + 2)
-    row[(size_t)i * (DIM + 2) + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+  if (threadIdx.x < DIM + 2) {
+    const int e = threadIdx.x;
+    const double tot = (s_red[0][e] + s_red[1][e]) + (s_red[2][e] + s_red[3][e]);
+    row[(size_t)i * (DIM + 2) + e] = tot;
+    if (kick && e < DIM) {
+      const int idx = i * DIM + e;
+      const double eps = scal[LS_STEP];
+      const double q = Q[idx];
+      const double grad = beta * (-2.0 * tot) - q / sigma;
+      const double p = Pm[idx] + f * eps * grad;
+      Pm[idx] = p;
+      if (drift) Qdst[idx] = q + eps * p;
+    }
+  }
+}
+
+// Scalar leapfrog bookkeeping of the mu_0 update (one thread): phase 0 = start (draw p, half kick, drift),
+// phase 1 = middle step (full kick, drift), phase 2 = last (half kick, Metropolis test).
+// Runs on the one thread that has just finished the reduction of the pass (k_ld_reduce).
+__device__ __forceinline__ void ld_mu0_step(double* scal, int* acc, int phase, double beta, uint64_t seed, uint32_t sweep,
+                                            uint32_t base) {
+  const double eps = 0.005;
+  if (phase == 0) {
+    const double p = gg_normal_at(seed, GG_SITE_LD, sweep, base + 1u);
+    scal[LS_K0] = 0.5 * p * p;
+    scal[LS_QMU0] = scal[LS_MU0];
+    const double g = beta * scal[LS_SALL] - scal[LS_QMU0];
+    const double p1 = p + 0.5 * eps * g;
+    scal[LS_P] = p1;
+    scal[LS_QMU0] += eps * p1;
+  } else {
+    const double g = beta * scal[LS_SALL] - scal[LS_QMU0];
+    const double p1 = scal[LS_P] + (phase == 1 ? 1.0 : 0.5) * eps * g;
+    scal[LS_P] = p1;
+    if (phase == 1) scal[LS_QMU0] += eps * p1;
+    else {
+      const double u = gg_uniform_at(seed, GG_SITE_LD, sweep, base + 2u);
+      if (gg_log(u) < (scal[LS_LP1] - scal[LS_LP0]) + (scal[LS_K0] - 0.5 * p1 * p1)) { scal[LS_MU0] = scal[LS_QMU0]; atomicOr(acc, 2); }
+    }
+  }
 }
 
 // Sums over nodes (fixed order), the diagonal terms, the prior: ll, d ll / d mu_0, d ll / d mu_self, and the
 // log probability beta ll + log prior into scal[lp_slot].  One workgroup.
 template <int DIM>
 __global__ __launch_bounds__(256) void k_ld_reduce(int N, const double* __restrict__ row, const uint8_t* __restrict__ dA,
-                                                   const double* __restrict__ Q, double* __restrict__ scal, int mu0_slot,
-                                                   int muself_slot, double sigma, double beta, int lp_slot) {
+                                                   const double* __restrict__ Q, double* scal, int mu0_slot,
+                                                   int muself_slot, double sigma, double beta, int lp_slot, int mu0_phase,
+                                                   int* acc, uint64_t seed, uint32_t sweep, uint32_t base) {
   const double mu0 = scal[mu0_slot], mus = scal[muself_slot];
   const double xd = mu0 + mus;
   const double Pd = gg_sigmoid(xd), spd = gg_softplus(xd);
@@ -120,6 +171,7 @@ __global__ __launch_bounds__(256) void k_ld_reduce(int N, const double* __restri
     scal[LS_SALL] = t[1];
     scal[LS_SDIAG] = t[2];
     scal[lp_slot] = beta * t[0] - 0.5 * t[3] / sigma - 0.5 * mu0 * mu0 - 0.5 * mus * mus;
+    if (mu0_phase >= 0) ld_mu0_step(scal, acc, mu0_phase, beta, seed, sweep, base);   // the mu_0 update's leapfrog step, fused
   }
 }
 
@@ -161,23 +213,6 @@ __global__ __launch_bounds__(256) void k_ld_momenta(int n, double* __restrict__ 
   }
 }
 
-// p += f eps (beta (-2 g) - q / sigma);  then (drift) q += eps p.   q = Qsrc on the first call (copy of L).
-template <int DIM>
-__global__ __launch_bounds__(256) void k_ld_kick_drift(int N, const double* __restrict__ row, const double* Qsrc,
-                                                       double* Q, double* __restrict__ Pm,
-                                                       const double* __restrict__ scal, double f, double sigma, double beta,
-                                                       int drift) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * DIM) return;
-  const int i = idx / DIM, d = idx % DIM;
-  const double eps = scal[LS_STEP];
-  const double q = Qsrc[idx];
-  const double grad = beta * (-2.0 * row[(size_t)i * (DIM + 2) + d]) - q / sigma;
-  const double p = Pm[idx] + f * eps * grad;
-  Pm[idx] = p;
-  Q[idx] = drift ? q + eps * p : q;
-}
-
 // Kinetic energy at the end, Metropolis test (adjacency.py:386-389 -> hips hmc), step adaptation, acceptance.
 __global__ __launch_bounds__(256) void k_ld_accept_L(int n, double* __restrict__ L, const double* __restrict__ Q,
                                                      const double* __restrict__ Pm, double* __restrict__ scal,
@@ -207,32 +242,6 @@ __global__ __launch_bounds__(256) void k_ld_accept_L(int n, double* __restrict__
   __syncthreads();
   if (s_ok)
     for (int i = threadIdx.x; i < n; i += 256) L[i] = Q[i];
-}
-
-// Scalar leapfrog bookkeeping of the mu_0 update (one thread): phase 0 = start (draw p, half kick, drift),
-// phase 1 = middle step (full kick, drift), phase 2 = last (half kick, Metropolis test).
-__global__ void k_ld_mu0_step(double* __restrict__ scal, int* __restrict__ acc, int phase, double beta, uint64_t seed,
-                              uint32_t sweep, uint32_t base) {
-  if (threadIdx.x || blockIdx.x) return;
-  const double eps = 0.005;
-  if (phase == 0) {
-    const double p = gg_normal_at(seed, GG_SITE_LD, sweep, base + 1u);
-    scal[LS_K0] = 0.5 * p * p;
-    scal[LS_QMU0] = scal[LS_MU0];
-    const double g = beta * scal[LS_SALL] - scal[LS_QMU0];
-    const double p1 = p + 0.5 * eps * g;
-    scal[LS_P] = p1;
-    scal[LS_QMU0] += eps * p1;
-  } else {
-    const double g = beta * scal[LS_SALL] - scal[LS_QMU0];
-    const double p1 = scal[LS_P] + (phase == 1 ? 1.0 : 0.5) * eps * g;
-    scal[LS_P] = p1;
-    if (phase == 1) scal[LS_QMU0] += eps * p1;
-    else {
-      const double u = gg_uniform_at(seed, GG_SITE_LD, sweep, base + 2u);
-      if (gg_log(u) < (scal[LS_LP1] - scal[LS_LP0]) + (scal[LS_K0] - 0.5 * p1 * p1)) { scal[LS_MU0] = scal[LS_QMU0]; atomicOr(acc, 2); }
-    }
-  }
 }
 
 // The whole mu_self update in one workgroup: only the diagonal depends on mu_self (adjacency.py:404-421); the
@@ -568,16 +577,34 @@ static int ldw_reduce(gg_latent* e, const double* Qsrc, int lp_slot) {
   return GG_OK;
 }
 
+// adjacency model: one pass at positions Qsrc (ll: with the log-likelihood terms; kick: the fused leapfrog step)
+static int ld_pass(gg_latent* e, const gg_data* d, const double* Qsrc, int mu0_slot, int ll, int kick, double* Qdst, double f,
+                   int drift, int grad = 1) {
+  const int N = e->N;
+#define ARGS N, e->Np, d->A, d->AT, Qsrc, e->scal, mu0_slot, e->row, kick, Qdst, e->Pm, f, drift, e->sigma, e->beta
+#define CALL(DV)                                                                                                       \
+  if (!grad) { if (ll) k_ld_pass<DV, 1, 0><<<N, 256, 0, e->stream>>>(ARGS); else k_ld_pass<DV, 0, 0><<<N, 256, 0, e->stream>>>(ARGS); } \
+  else { if (ll) k_ld_pass<DV, 1, 1><<<N, 256, 0, e->stream>>>(ARGS); else k_ld_pass<DV, 0, 1><<<N, 256, 0, e->stream>>>(ARGS); }
+  LD_DISPATCH(CALL);
+#undef CALL
+#undef ARGS
+  GG_HIP(hipGetLastError());
+  return GG_OK;
+}
+
 // pass + reduce at positions Qp with (mu_0, mu_self) taken from the given scalar slots; log p -> scal[lp_slot]
-static int ld_eval(gg_latent* e, const gg_data* d, const double* Qp, int mu0_slot, int lp_slot) {
+// (need_ll = 0: only the gradient sums are wanted - the logarithm is skipped and scal[lp_slot], LS_LL are not meaningful)
+static int ld_eval(gg_latent* e, const gg_data* d, const double* Qp, int mu0_slot, int lp_slot, int need_ll = 1, int grad = 1,
+                   int mu0_phase = -1) {
   const int N = e->N;
   if (e->wmode) {
     int rc = ldw_pass(e, d, Qp, 1, 0, nullptr, 0.0, 0);
     return rc ? rc : ldw_reduce(e, Qp, lp_slot);
   }
-#define CALL(DV)                                                                                                       \
-  k_ld_pass<DV><<<N, 256, 0, e->stream>>>(N, e->Np, d->A, d->AT, Qp, e->scal, mu0_slot, e->row);                        \
-  k_ld_reduce<DV><<<1, 256, 0, e->stream>>>(N, e->row, d->dA, Qp, e->scal, mu0_slot, LS_MUSELF, e->sigma, e->beta, lp_slot)
+  int rc = ld_pass(e, d, Qp, mu0_slot, need_ll, 0, nullptr, 0.0, 0, grad);
+  if (rc) return rc;
+#define CALL(DV) k_ld_reduce<DV><<<1, 256, 0, e->stream>>>(N, e->row, d->dA, Qp, e->scal, mu0_slot, LS_MUSELF, e->sigma, e->beta, lp_slot, \
+                                                           mu0_phase, e->acc, e->cfg.seed, e->sweep, (uint32_t)(e->N * e->dim))
   LD_DISPATCH(CALL);
 #undef CALL
   GG_HIP(hipGetLastError());
@@ -593,7 +620,6 @@ static int ld_hmc_L(gg_latent* e, const gg_data* d) {
   const uint32_t site = e->wmode ? GG_SITE_LDW_HMC : GG_SITE_LD;
   int rc;
   k_ld_momenta<<<(n + 255) / 256, 256, 0, st>>>(n, e->Pm, e->scal, e->cfg.seed, e->sweep, site, e->kpart, e->tick);
-  const int nb = (n + 255) / 256;
   if (e->wmode) {
     // trajectory: L -> Q -> Q2 -> Q -> ...; each pass kicks the momenta and drifts into the other buffer; log p at the two ends
     const double* src = e->L;
@@ -609,23 +635,30 @@ static int ld_hmc_L(gg_latent* e, const gg_data* d) {
     k_ld_accept_L<<<1, 256, 0, st>>>(n, e->L, src, e->Pm, e->scal, e->acc, e->cfg.seed, e->sweep, site, 0);
     GG_HIP(hipGetLastError());
     return GG_OK;
-  } else {
-    if ((rc = ld_eval(e, d, e->L, LS_MU0, LS_LP0))) return rc;
-#define CALL(DV) k_ld_kick_drift<DV><<<nb, 256, 0, st>>>(N, e->row, e->L, e->Q, e->Pm, e->scal, 0.5, e->sigma, e->beta, 1)
+  }
+  {
+    // same trajectory bookkeeping as above: L -> Q -> Q2 -> Q -> ...; reductions (log p) at the two ends only
+    const double* src = e->L;
+    double* dst = e->Q;
+    if ((rc = ld_pass(e, d, src, LS_MU0, 1, 1, dst, 0.5, 1))) return rc;
+#define RED(DV, LPS) k_ld_reduce<DV><<<1, 256, 0, st>>>(N, e->row, d->dA, src, e->scal, LS_MU0, LS_MUSELF, e->sigma, e->beta, LPS, -1, nullptr, 0, 0, 0)
+#define CALL(DV) RED(DV, LS_LP0)
     LD_DISPATCH(CALL);
 #undef CALL
     for (int s = 0; s < LD_NSTEPS; ++s) {
-      if ((rc = ld_eval(e, d, e->Q, LS_MU0, LS_LP1))) return rc;
-      const double f = (s < LD_NSTEPS - 1) ? 1.0 : 0.5;
-      const int drift = (s < LD_NSTEPS - 1) ? 1 : 0;
-#define CALL(DV) k_ld_kick_drift<DV><<<nb, 256, 0, st>>>(N, e->row, e->Q, e->Q, e->Pm, e->scal, f, e->sigma, e->beta, drift)
-      LD_DISPATCH(CALL);
-#undef CALL
+      const int last = s == LD_NSTEPS - 1;
+      src = dst;
+      dst = (src == e->Q) ? e->Q2 : e->Q;
+      if ((rc = ld_pass(e, d, src, LS_MU0, last, 1, dst, last ? 0.5 : 1.0, last ? 0 : 1))) return rc;
     }
+#define CALL(DV) RED(DV, LS_LP1)
+    LD_DISPATCH(CALL);
+#undef CALL
+#undef RED
+    k_ld_accept_L<<<1, 256, 0, st>>>(n, e->L, src, e->Pm, e->scal, e->acc, e->cfg.seed, e->sweep, site, 1);
+    GG_HIP(hipGetLastError());
+    return GG_OK;
   }
-  k_ld_accept_L<<<1, 256, 0, st>>>(n, e->L, e->Q, e->Pm, e->scal, e->acc, e->cfg.seed, e->sweep, site, e->wmode ? 0 : 1);
-  GG_HIP(hipGetLastError());
-  return GG_OK;
 }
 
 // parts, adjacency model: GG_PART_F = latent positions, GG_PART_MU0 = mu_0, GG_PART_LMBDA = mu_self (adjacency.py:360-372);
@@ -669,13 +702,12 @@ int gg_latent_resample(gg_latent* e, const gg_data* d, int parts, int defer) {
   } else {
     full = GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA;
     if (parts & GG_PART_MU0) {
-      if ((rc = ld_eval(e, d, e->L, LS_MU0, LS_LP0))) return rc;
-      k_ld_mu0_step<<<1, 64, 0, st>>>(e->scal, e->acc, 0, e->beta, e->cfg.seed, e->sweep, base);
+      // every pass is followed by the reduction, which also runs the scalar leapfrog step of mu_0 (phase 0: start, 1: middle, 2: last + test)
+      if ((rc = ld_eval(e, d, e->L, LS_MU0, LS_LP0, 1, 0, 0))) return rc;
       for (int s = 0; s < LD_NSTEPS; ++s) {
-        if ((rc = ld_eval(e, d, e->L, LS_QMU0, LS_LP1))) return rc;
-        k_ld_mu0_step<<<1, 64, 0, st>>>(e->scal, e->acc, (s < LD_NSTEPS - 1) ? 1 : 2, e->beta, e->cfg.seed, e->sweep, base);
+        const int last = s == LD_NSTEPS - 1;
+        if ((rc = ld_eval(e, d, e->L, LS_QMU0, LS_LP1, last, 0, last ? 2 : 1))) return rc;   // log p at the end only
       }
-      GG_HIP(hipGetLastError());
     }
     if (parts & GG_PART_LMBDA) {
       k_ld_muself<<<1, 256, 0, st>>>(N, d->dA, e->scal, e->acc, e->beta, e->cfg.seed, e->sweep, base);

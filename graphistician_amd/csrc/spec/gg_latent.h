@@ -24,6 +24,13 @@ GG_HD void gg_sigmoid_softplus(double x, double* P, double* sp) {
   *P = x >= 0.0 ? 1.0 / d : e / d;
 }
 
+// The sigmoid alone, same arithmetic as in gg_sigmoid_softplus (gradient-only passes skip the logarithm).
+GG_HD double gg_sigmoid_only(double x) {
+  const double e = exp(x > 0.0 ? -x : x);
+  const double d = 1.0 + e;
+  return x >= 0.0 ? 1.0 / d : e / d;
+}
+
 // hips.inference.hmc, adaptive_step_sz=True, as recollected (the package is not in the image: parity unpinned):
 // running acceptance rate smoothed with constant 0.95; the step grows 2 % while the rate is above the 0.9
 // target and shrinks 2 % otherwise, clipped to [1e-3, 1].
