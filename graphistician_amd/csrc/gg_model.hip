@@ -72,6 +72,7 @@ struct gg_model {
   // host mirrors / hypers
   gg_niw niw, niw_self;
   int32_t* h_rs;  // pinned copy of the control block
+  long long* h_tab;   // pinned staging of the K x K tables + block counts (gg_log_likelihood)
   hipStream_t stream;
   hipStream_t sb;               // bulk statistics of the NEXT sweep run here, concurrently with the scan
   hipEvent_t ev_bulk[2], ev_scan;
@@ -226,6 +227,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if ((rc = dmalloc(&m->bar, (size_t)512))) return rc;
   if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
+  GG_HIP(hipHostMalloc((void**)&m->h_tab, ((size_t)m->K * m->K * m->NTAB + m->K) * sizeof(long long)));
   // resolve chunk: one Kp-lane group per node, LDS budget 96 KiB
   int CH = 1024 / m->Kp;
   if (CH > 64) CH = 64;
@@ -297,6 +299,7 @@ int gg_model_destroy(gg_model* m) {
                   m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
+  if (m->h_tab) hipHostFree(m->h_tab);
   for (hipEvent_t e : m->ev) hipEventDestroy(e);
   if (m->ev_call0) hipEventDestroy(m->ev_call0);
   if (m->ev_call1) hipEventDestroy(m->ev_call1);
@@ -1451,14 +1454,15 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
   if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
   const int K = m->K, B = m->B;
   const size_t KK = (size_t)K * K;
-  std::vector<long long> tab(KK * m->NTAB);
-  std::vector<int32_t> cnt(K);
-  GG_HIP(hipMemcpyAsync(tab.data(), m->tab, tab.size() * 8, hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipMemcpyAsync(cnt.data(), m->cnt, K * 4, hipMemcpyDeviceToHost, m->stream));
+  // tables and block counts through pinned staging (a copy into pageable memory costs tens of microseconds)
+  long long* tab = m->h_tab;
+  int32_t* cnt = reinterpret_cast<int32_t*>(m->h_tab + KK * m->NTAB);
+  GG_HIP(hipMemcpyAsync(tab, m->tab, KK * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipMemcpyAsync(cnt, m->cnt, K * 4, hipMemcpyDeviceToHost, m->stream));
   GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));
   if ((rc = collect_timing(m))) return rc;
-  return loglik_from_tables(m, d, tab.data(), cnt.data(), out);
+  return loglik_from_tables(m, d, tab, cnt, out);
 }
 
 // Microbenchmark of the bulk statistics kernel alone (both directions, current labels): average
