@@ -556,17 +556,17 @@ def main():
             _progress("log-likelihood sweeps")
             try:
                 nll = 50
-                adj.log_likelihood(data); w.log_likelihood(data)
+                abi.log_likelihood_many([adj, w], data)
                 t0l = time.perf_counter()
                 for _ in range(nll):
-                    adj.log_likelihood(data); w.log_likelihood(data)
+                    abi.log_likelihood_many([adj, w], data)
                 ell = time.perf_counter() - t0l
                 ll_bytes = float(N) * N * (1 + 4)
                 out["log_likelihood_sweep"] = {
                     "value": nll / ell, "unit": "evaluations/s", "ms": ell / nll * 1e3, "algorithmic_bytes": ll_bytes,
                     "effective_GBs": ll_bytes * nll / ell / 1e9,
-                    "note": "log p(A | .) + log p(W | A, .) of the whole network (networks.py:28-31), one synchronous call per "
-                            "half: a bulk pass over A and over W plus the K x K closed form; not part of `value`"}
+                    "note": "log p(A | .) + log p(W | A, .) of the whole network (networks.py:28-31), both halves at once "
+                            "(gg_log_likelihood_many): a bulk pass over A and over W plus the K x K closed form; not part of `value`"}
             except Exception as exc:
                 out["log_likelihood_sweep"] = {"error": str(exc)}
         _progress("stream probe")

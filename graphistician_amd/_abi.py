@@ -47,7 +47,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_shard_sizes", "gg_shard_tables",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_shard_sizes", "gg_shard_tables",
            "gg_shard_params", "gg_shard_next", "gg_shard_apply", "gg_shard_finish", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws"]
 
@@ -92,6 +92,7 @@ def lib():
         L.gg_sync_many.argtypes = [C.POINTER(vp), C.c_int32]
         L.gg_bench_stream.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
         L.gg_resample_many.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int32, C.c_int32, C.c_double]
+        L.gg_log_likelihood_many.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int32, C.POINTER(C.c_double)]
         L.gg_log_likelihood.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gg_node_lp.argtypes = [vp, vp, C.c_int32, vp]
         L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -339,6 +340,17 @@ def bench_stream(nbytes, reps=20, mode=0, device=0):
     ms = C.c_double(0)
     check(lib().gg_bench_stream(device, int(nbytes), reps, mode, C.byref(ms)))
     return (2 if mode == 1 else 1) * float(nbytes) / ms.value / 1e6
+
+
+def log_likelihood_many(models, datas):
+    """log_likelihood of several independent models at once (enqueued together, then collected); returns the list of values."""
+    if not isinstance(datas, (list, tuple)):
+        datas = [datas] * len(models)
+    marr = (C.c_void_p * len(models))(*[m._h for m in models])
+    darr = (C.c_void_p * len(models))(*[d.handle for d in datas])
+    out = (C.c_double * len(models))()
+    check(lib().gg_log_likelihood_many(marr, darr, len(models), out))
+    return [float(v) for v in out]
 
 
 def resample_many(models, datas, n_sweeps=1, beta=1.0):

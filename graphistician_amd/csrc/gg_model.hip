@@ -1433,11 +1433,8 @@ static int loglik_from_tables(gg_model* m, const gg_data* d, const long long* ta
 // Closed forms from the K x K tables:
 //   adjacency (abstractions.py:111-115): sum_ab n1 log p + n0 log(1 - clip(p)) + diagonal terms;
 //   weights (weights.py:316-331): sum_ab [ n g + h.s1 + Q.s2 ] + self Gaussian on the diagonal edges.
-int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
-  if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood: null argument");
-  GG_HIP(hipSetDevice(m->cfg.device));
-  if (m->eig) return gg_eigen_log_likelihood(m->eig, d, out);
-  if (m->ld) return gg_latent_log_likelihood(m->ld, d, out);
+// Block kinds: enqueue the statistics pass, the K x K tables and their copy to pinned staging ...
+static int ll_enqueue(gg_model* m, const gg_data* d) {
   int rc = model_sync(m);
   if (rc) return rc;
   m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
@@ -1452,17 +1449,50 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
     if ((rc = enqueue_bulk(m, d, buf, 1, false))) return rc;
   }
   if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
-  const int K = m->K, B = m->B;
-  const size_t KK = (size_t)K * K;
+  const size_t KK = (size_t)m->K * m->K;
   // tables and block counts through pinned staging (a copy into pageable memory costs tens of microseconds)
-  long long* tab = m->h_tab;
-  int32_t* cnt = reinterpret_cast<int32_t*>(m->h_tab + KK * m->NTAB);
-  GG_HIP(hipMemcpyAsync(tab, m->tab, KK * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipMemcpyAsync(cnt, m->cnt, K * 4, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipMemcpyAsync(m->h_tab, m->tab, KK * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipMemcpyAsync(m->h_tab + KK * m->NTAB, m->cnt, m->K * 4, hipMemcpyDeviceToHost, m->stream));
   GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  return GG_OK;
+}
+
+// ... and, once they have arrived, the closed form on the host.
+static int ll_finish(gg_model* m, const gg_data* d, double* out) {
   GG_HIP(hipStreamSynchronize(m->stream));
-  if ((rc = collect_timing(m))) return rc;
-  return loglik_from_tables(m, d, tab, cnt, out);
+  int rc = collect_timing(m);
+  if (rc) return rc;
+  const size_t KK = (size_t)m->K * m->K;
+  return loglik_from_tables(m, d, m->h_tab, reinterpret_cast<const int32_t*>(m->h_tab + KK * m->NTAB), out);
+}
+
+int gg_log_likelihood(gg_model* m, const gg_data* d, double* out) {
+  if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood: null argument");
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (m->eig) return gg_eigen_log_likelihood(m->eig, d, out);
+  if (m->ld) return gg_latent_log_likelihood(m->ld, d, out);
+  int rc = ll_enqueue(m, d);
+  return rc ? rc : ll_finish(m, d, out);
+}
+
+// gg_log_likelihood for n independent models at once: the block models' passes are all enqueued (each on its own
+// stream) before the first is waited for, so that the two halves of FactorizedNetworkDistribution.log_likelihood
+// (networks.py:28-31) stream A and W concurrently; the other kinds follow one after the other.
+int gg_log_likelihood_many(gg_model** ms, const gg_data* const* ds, int32_t n, double* out) {
+  if (n < 0 || (n > 0 && (!ms || !ds || !out))) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood_many: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    if (!ms[i]) return gg_fail(GG_ERR_INVALID, "gg_log_likelihood_many: null model");
+    if (ms[i]->eig || ms[i]->ld) continue;
+    GG_HIP(hipSetDevice(ms[i]->cfg.device));
+    int rc = ll_enqueue(ms[i], ds[i]);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    GG_HIP(hipSetDevice(ms[i]->cfg.device));
+    int rc = (ms[i]->eig || ms[i]->ld) ? gg_log_likelihood(ms[i], ds[i], out + i) : ll_finish(ms[i], ds[i], out + i);
+    if (rc) return rc;
+  }
+  return GG_OK;
 }
 
 // Microbenchmark of the bulk statistics kernel alone (both directions, current labels): average

@@ -41,6 +41,10 @@ class FactorizedNetworkDistribution(NetworkDistribution, GibbsSampling):
     def log_likelihood(self, data):
         # networks.py:28-31
         d = self._device_data(data)
+        if all(hasattr(part, "_engine") for part in (self.adjacency, self.weights)):
+            # both halves on the engine: evaluated concurrently (gg_log_likelihood_many)
+            assert d.N == self.N
+            return sum(_abi.log_likelihood_many([self.adjacency._engine(), self.weights._engine()], d))
         lls = self.adjacency.log_likelihood(d if hasattr(self.adjacency, "_engine") else data[0])
         lls += self.weights.log_likelihood(d)
         return lls

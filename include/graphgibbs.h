@@ -184,6 +184,10 @@ int gg_resample_many(gg_model** models, const gg_data* const* data, int32_t n, i
 /* abstractions.py:111-115 (adjacency kinds), weights.py:316-331 /
  * abstractions.py:257-274 (weight kinds), eigenmodel.py:110-129. */
 int gg_log_likelihood(gg_model* m, const gg_data* d, double* out);
+/* the same for n independent models (models[i] on data[i] -> out[i]); the block models' passes are all enqueued
+ * before the first is waited for: the two halves of FactorizedNetworkDistribution.log_likelihood (networks.py:28-31)
+ * run concurrently. */
+int gg_log_likelihood_many(gg_model** models, const gg_data* const* data, int32_t n, double* out);
 
 /* Conditional log-probabilities lp[K] of node n under the current state
  * (the vector handed to sample_discrete_from_log at adjacency.py:695 /
