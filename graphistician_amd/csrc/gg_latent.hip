@@ -441,6 +441,9 @@ static int lmalloc(T** p, size_t n) {
   return GG_OK;
 }
 
+static int ld_init(gg_latent* e, const gg_config* cfg, int wmode);
+int gg_latent_destroy(gg_latent* e);
+
 int gg_latent_create(gg_latent** out, const gg_config* cfg) {
   if (cfg->N <= 0 || cfg->D < 1 || cfg->D > LD_MAXDIM)
     return gg_fail(GG_ERR_UNSUPPORTED, "latent-distance model: need N > 0 and 1 <= dim <= %d (got N=%d dim=%d)", LD_MAXDIM, cfg->N, cfg->D);
@@ -448,7 +451,14 @@ int gg_latent_create(gg_latent** out, const gg_config* cfg) {
   if (!wmode && !(cfg->sigma_F > 0.0)) return gg_fail(GG_ERR_INVALID, "latent-distance model: sigma must be positive");
   if (wmode && cfg->B != 1)
     return gg_fail(GG_ERR_UNSUPPORTED, "latent-distance weights: B = 1 only, as in the reference (weights.py:711), got B=%d", cfg->B);
-  gg_latent* e = new gg_latent();
+  gg_latent* e = new gg_latent();   // (value-initialised: every pointer starts null)
+  const int rc0 = ld_init(e, cfg, wmode);
+  if (rc0) { gg_latent_destroy(e); return rc0; }
+  *out = e;
+  return GG_OK;
+}
+
+static int ld_init(gg_latent* e, const gg_config* cfg, int wmode) {
   e->cfg = *cfg;
   e->wmode = wmode;
   e->N = cfg->N; e->dim = cfg->D; e->Np = gg_round_up(cfg->N, 64);
@@ -472,7 +482,6 @@ int gg_latent_create(gg_latent** out, const gg_config* cfg) {
   memcpy(e->prior, pr, sizeof(pr));
   memcpy(e->prior_self, pr, sizeof(pr));
   GG_HIP(hipMemcpy(e->scal, init, sizeof(init), hipMemcpyHostToDevice));
-  *out = e;
   return GG_OK;
 }
 
