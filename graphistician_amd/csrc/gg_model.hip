@@ -93,6 +93,11 @@ struct gg_model {
   int depth;                    // sweeps enqueued ahead of confirmation: halves to 1 when a scan stalls, doubles on clean batches
   int todo;                     // sweeps requested but not enqueued yet (depth-limited)
   bool use_scan;                // the scan runs as one resident-grid launch (k_scan) instead of speculate + resolve (+ rounds)
+  int scan_pref;                // GG_SCAN: 1 always, 0 never, unset (-1): adaptive - k_scan while the chain keeps changing labels
+  long long chg_seen;           // label changes (control word 2) at the last decision
+  long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
+  long long scan_hold;          // clean sweeps required before leaving k_scan mode (doubles when the chain stalls again soon after)
+  long long since_revert;       // sweeps completed in speculate + resolve mode since the last switch back
   bool incr;                    // GG_INCREMENTAL=1: G is carried from sweep to sweep (changes flushed in), no bulk pass
   bool G_valid;                 // incr: Gbuf[cur] is the exact histogram of G_data under the current labels
   const gg_data* G_data;
@@ -256,14 +261,21 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     // at N=4096 (11-13k sweeps/s against 17.5k serial); opt-in until launches get cheaper or N is large
     m->pipe = m->sbm && m->K > 1 && (e && atoi(e) == 1);
     // incremental statistics (opt-in, see enqueue_sweep_incr): not combined with the pipelined or sharded forms
-    // GG_SCAN=1 (experiment): the whole scan as one resident-grid launch (k_scan).  Exact, never stalls the sweep
-    // pipeline, but every accepted change costs a grid-wide exchange whose floor is the cross-XCD visibility
-    // latency (measured 8-9 us per exchange on MI355X): 25 us for a quiet scan against 13 us for speculate +
-    // resolve, 15-20 us per change against 17-24 us for a restart round.  Not faster anywhere yet: opt-in.
+    // The scan as one resident-grid launch (k_scan): exact, never stalls the sweep pipeline, ~6.5 us per accepted change
+    // (evaluate 3.3 + fence-free exchange 2.3 + apply 0.7) against ~17 us for a restart round, but a quiet scan costs
+    // 15 us in situ against 9 + 8.5 for k_speculate + k_resolve with more interference on the other model's bulk pass.
+    // Default: adaptive - k_scan while the chain keeps changing labels, speculate + resolve once it has been quiet for
+    // a while (model_sync decides batch by batch; both give the same chain bit for bit).  GG_SCAN=1 / 0 force either.
     const char* es = getenv("GG_SCAN");
-    m->use_scan = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (es && atoi(es) == 1);
+    const bool can_scan = m->sbm && m->K > 1 && !m->pipe && !m->sharded;
+    m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
+    m->use_scan = m->scan_pref == 1;
+    m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 8; m->since_revert = 1 << 30;
     const char* ei = getenv("GG_INCREMENTAL");
     m->incr = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (ei && atoi(ei) == 1);
+    // (carried statistics: the two scan forms keep different books on what of the change list is already in G, so the
+    // form is not switched from sweep to sweep there)
+    if (m->incr && m->scan_pref < 0) m->scan_pref = 0;
   }
   // defaults: uniform m, pi = 1, p = 0.5, standard NIW
   std::vector<double> ones(K, 1.0), um(K, 1.0 / K), half(KK, 0.5);
@@ -777,12 +789,13 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = m->dbg;
   g.keep_L = m->incr ? 1 : 0;
-  a.ap = m->ap; a.Gc0 = gcnt(m, buf, 0); a.Gs0 = gs(m, buf, 0); a.bar = m->bar; a.Lcap = m->Lcap;
+  a.ap = m->ap; a.Gc0 = gcnt(m, buf, 0); a.Gs0 = gs(m, buf, 0); a.bar = m->bar;
+  a.Lcap = m->Lcap < 1024 ? m->Lcap : 1024;   // every workgroup keeps its own copy of the list in LDS (12 KB)
   const int K = m->K, per = 256 / m->Kp;
   const int ngroups = (m->Nl + per - 1) / per;
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
-               (size_t)(per + K + 8) * sizeof(int) + 64;
+               (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)a.Lcap * 3 * sizeof(int);
   if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
@@ -1089,6 +1102,15 @@ static int model_sync(gg_model* m) {
       return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
     }
     if (!m->h_rs[4]) {  // nothing stalled or flushed: every enqueued sweep completed
+      if (m->scan_pref < 0) {
+        // adaptive scan form: stay with the resident-grid scan while labels keep changing, go back to speculate +
+        // resolve after scan_hold sweeps in a row without a change
+        const long long chg = (long long)m->h_rs[2] - m->chg_seen;
+        m->chg_seen = (long long)m->h_rs[2];
+        if (chg != 0) { m->use_scan = true; m->clean_run = 0; }
+        else if (m->use_scan && (m->clean_run += m->pending) >= m->scan_hold) { m->use_scan = false; m->clean_run = 0; m->since_revert = 0; }
+        else if (!m->use_scan) m->since_revert += m->pending;
+      }
       m->sweep += (uint32_t)m->pending;
       m->st.sweeps += (uint64_t)m->pending;
       m->pending = 0;
@@ -1108,6 +1130,11 @@ static int model_sync(gg_model* m) {
     // A scan stalled: the sweeps enqueued behind it ran as no-ops and must be enqueued again.  A chain that keeps
     // changing labels stalls every sweep, so stop running ahead (depth 1) until batches come back clean.
     if (!m->pipe) m->depth = 1;   // (the pipelined form keeps its own look-ahead discipline)
+    if (m->scan_pref < 0) {   // the chain is changing labels: k_scan from the next sweep on
+      // (a stall soon after the last switch back: the chain changes labels now and then - hold the resident form longer)
+      if (!m->use_scan && m->since_revert < 4 * m->scan_hold && m->scan_hold < 1024) m->scan_hold *= 2;
+      m->use_scan = true; m->clean_run = 0; m->chg_seen = (long long)m->h_rs[2];
+    }
     // ctl[5] scans completed before the flag went up.  pos != 0: the next one is stuck mid-scan.
     const int done = scan ? m->h_rs[5] : m->pending;
     const bool mid = m->h_rs[0] != 0;

@@ -22,6 +22,9 @@
 
 #define GG_SCAN_MAXWG 256
 #define GG_BAR_SPIN_LIMIT (1 << 22)
+#ifndef GG_SCAN_POLL_SLEEP
+#define GG_SCAN_POLL_SLEEP 4
+#endif
 
 struct gg_scan_args {
   gg_resolve_args r;          // labels, tables, data rows, RNG addressing, tail outputs (perm / lab_start)
@@ -39,8 +42,12 @@ struct gg_scan_args {
 // counter to reset; the slots (2 x GG_SCAN_MAXWG) are zeroed (tag 0 = never) by k_params before every scan.
 // Returns false on timeout.
 #define GG_SLOT_NONE 0xffffffffffffull
+// fenced = false (the common case): nothing but the slots themselves crosses workgroups - every change travels in the
+// payload - so no release / acquire fence is needed (an agent-scope fence pair costs 6-18 us with 64-256 workgroups, the
+// bare exchange 1-3 us: tools/probe/xcd_barrier.hip).  fenced = true: plain global writes made before the exchange
+// (statistics flushed into G) must be visible to the other workgroups after it.
 __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int G, unsigned tag, unsigned long long mine,
-                                                 bool release, unsigned long long* s_min, int32_t* rs, unsigned long long* best) {
+                                                 bool fenced, unsigned long long* s_min, int32_t* rs, unsigned long long* best) {
   const int tid = threadIdx.x;
   // two slot arrays, alternating by round: a workgroup can be one round ahead of the slowest one (never two), and
   // must not overwrite the value the slow ones are still polling for
@@ -48,7 +55,7 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
   __syncthreads();
   if (tid == 0) {
     *s_min = GG_SLOT_NONE;
-    if (release) __threadfence();   // plain global writes of this workgroup (labels, change list) come first
+    if (fenced) __threadfence();   // plain global writes of this workgroup come first
     __hip_atomic_store(&slots[blockIdx.x], ((unsigned long long)(tag & 0xffffu) << 48) | (mine & GG_SLOT_NONE), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -67,10 +74,10 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
       okall = true;
       break;
     }
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(GG_SCAN_POLL_SLEEP);   // the polls are memory-side loads: keep them off the other model's bulk pass
   }
   if (!okall && tid == 0) atomicOr(&rs[3], 2);
-  __threadfence();
+  if (fenced) __threadfence();
   __syncthreads();
   *best = *s_min;
   __syncthreads();
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);
   off = (off + 7) & ~(size_t)7;
   unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_raw + off); off += 2 * sizeof(unsigned long long);
+  int* s_L = reinterpret_cast<int*>(s_raw + off);   // [Lcap][3]: this workgroup's own copy of the change list
 
   for (int k = tid; k < K; k += 256) s_cnt[k] = g.cnt[k];
   if (stage_tables) {
@@ -170,8 +178,8 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
           const int d = idx & 1, i = (idx >> 1) % per, e = (idx >> 1) / per;
           ok[u] = idx < nitems && n0 + i < N;
           const int ee = ok[u] ? e : 0;
-          const int n2 = g.L[ee * 3];
-          ia[u] = g.L[ee * 3 + 1]; ib[u] = g.L[ee * 3 + 2];
+          const int n2 = s_L[ee * 3];
+          ia[u] = s_L[ee * 3 + 1]; ib[u] = s_L[ee * 3 + 2];
           ii[u] = i; dd[u] = d;
           at[u] = ok[u] ? (size_t)n2 * Np + n0 + i : 0;
         }
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       unsigned long long best;
       {
         const unsigned long long mine = *s_min;   // this workgroup's first changer (48-bit payload) or none
-        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, b == 0, s_min, g.rs, &best)) {
+        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, false, s_min, g.rs, &best)) {
           alive = false;
           break;
         }
@@ -261,7 +269,8 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       if (tid == 0) {
         s_cnt[ca] -= 1; s_cnt[cb] += 1;
         if (has && f >= n0 && f < n0 + per) s_c[f - n0] = cb;
-        if (b == 0) {
+        if (nL < a.Lcap) { s_L[nL * 3] = f; s_L[nL * 3 + 1] = ca; s_L[nL * 3 + 2] = cb; }
+        if (b == 0) {   // for what runs after this kernel (labels; the list, when the statistics are carried over)
           g.c[f] = cb;
           if (nL < a.Lcap) { g.L[nL * 3] = f; g.L[nL * 3 + 1] = ca; g.L[nL * 3 + 2] = cb; }
         }
@@ -289,12 +298,17 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         // the list is full: bring the statistics of every node that is not in LDS right now up to date in G
         // (earlier bands: written back with ap entries applied; later bands: as the bulk pass left them), then
         // start a fresh list.  Grid-wide, followed by a barrier.
-        __syncthreads();
+        {
+          // (earlier bands' write-backs and ap entries were plain stores of other workgroups: fenced meeting first)
+          unsigned long long dummy;
+          if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), GG_SLOT_NONE, true, s_min, g.rs, &dummy)) { alive = false; break; }
+          ++it;
+        }
         for (int n = b * 256 + tid; n < N; n += G * 256) {
           const int ng = n / per;
           if (ng >= band * G && ng < (band + 1) * G) { a.ap[n] = 0; continue; }   // in some workgroup's LDS
           for (int e = a.ap[n]; e < nL; ++e) {
-            const int n2 = g.L[e * 3], ba = g.L[e * 3 + 1], bb = g.L[e * 3 + 2];
+            const int n2 = s_L[e * 3], ba = s_L[e * 3 + 1], bb = s_L[e * 3 + 2];
             const size_t at = (size_t)n2 * Np + n;
             for (int d = 0; d < 2; ++d) {
               if (ADJ) {

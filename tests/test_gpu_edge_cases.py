@@ -224,6 +224,42 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_adaptive_scan_form_is_the_same_chain(abi, monkeypatch):
+    """Default (GG_SCAN unset): the engine runs the scan as k_scan while the chain keeps changing labels and as
+    k_speculate + k_resolve after a run of quiet sweeps (8 at first), deciding batch by batch.  A strongly planted network burns in within a
+    few sweeps and then stays quiet, so 240 sweeps in uneven chunks cross both switches: same chain as the oracle bit for
+    bit at every checkpoint."""
+    monkeypatch.delenv("GG_SCAN", raising=False)
+    N, K = 260, 4
+    A, W, _ = planted_sbm(N, K, seed=77)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=15), WState(N, K, 1, seed=16)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=91, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=92, special_case_self_conns=1)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    fs = O.FastSweeper(A, q, shift, threads=4)
+    ps, done = sa.p_self, 0
+    changes = []
+    for chunk in (1, 2, 5, 40, 100, 3, 89):
+        abi.resample_many([adj, w], d, chunk)
+        for s in range(done, done + chunk):
+            ps = fs.adj_sweep(sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 91, s)
+            fs.w_sweep(sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 92, s)
+        done += chunk
+        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), done
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), done
+        assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu), done
+        changes.append(adj.stats()["label_changes"] + w.stats()["label_changes"])
+    fs.close()
+    assert changes[0] > 0                       # burn-in changed labels (k_scan from the second sweep on)
+    assert changes[-1] == changes[-3]           # ... and the last 92 sweeps none: back on speculate + resolve by then
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,K,B,beta,special", [(140, 4, 1, 1.0, 1), (180, 5, 2, 1.0, 1), (120, 3, 2, 0.5, 1),
                                                 (150, 4, 1, 1.0, 0), (130, 3, 2, 0.6, 0)])
 def test_shared_covariance_weights_bitexact(abi, N, K, B, beta, special):

@@ -9,7 +9,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int SCOPE>   // 0: workgroup scope (sc0), 1: agent scope
+template <int SCOPE, int PAD, int FENCE>   // SCOPE 0: workgroup scope (sc0), 1: agent scope; PAD: slot stride in 8-byte words; FENCE: __threadfence around the exchange
 __global__ __launch_bounds__(256) void k_exchange(unsigned long long* slots, int G, int stride, int rounds, long long* out, int* xcc) {
   if (blockIdx.x % stride) return;
   const int me = blockIdx.x / stride;
@@ -22,11 +22,12 @@ __global__ __launch_bounds__(256) void k_exchange(unsigned long long* slots, int
   int fail = 0;
   for (int r = 1; r <= rounds; ++r) {
     if (r == 2 && tid == 0) t0 = wall_clock64();
-    unsigned long long* s = slots + (r & 1) * 256;
+    unsigned long long* s = slots + (size_t)(r & 1) * 256 * PAD;
     __syncthreads();
     if (tid == 0) {
-      if (SCOPE) __hip_atomic_store(&s[me], (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else __hip_atomic_store(&s[me], (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (FENCE) __threadfence();
+      if (SCOPE) __hip_atomic_store(&s[(size_t)me * PAD], (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(&s[(size_t)me * PAD], (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     int done = 0;
@@ -34,36 +35,44 @@ __global__ __launch_bounds__(256) void k_exchange(unsigned long long* slots, int
       int ok = 1;
       if (tid < G) {
         unsigned long long w;
-        if (SCOPE) w = __hip_atomic_load(&s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else w = __hip_atomic_load(&s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (SCOPE) w = __hip_atomic_load(&s[(size_t)tid * PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else w = __hip_atomic_load(&s[(size_t)tid * PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ok = w == (unsigned long long)r;
       }
       if (__syncthreads_and(ok)) { done = 1; break; }
     }
     if (!done) { fail = 1; break; }
+    if (FENCE) { __threadfence(); __syncthreads(); }
   }
   if (tid == 0) { out[me * 2] = wall_clock64() - t0; out[me * 2 + 1] = fail; }
 }
 
 int main() {
   unsigned long long* slots; long long* out; int* xcc;
-  CHECK(hipMalloc(&slots, 512 * 8)); CHECK(hipMalloc(&out, 512 * 8)); CHECK(hipMalloc(&xcc, 256 * 4));
+  CHECK(hipMalloc(&slots, 2 * 256 * 16 * 8)); CHECK(hipMalloc(&out, 512 * 8)); CHECK(hipMalloc(&xcc, 256 * 4));
   const int rounds = 2001;
-  for (int G : {16, 32, 64}) {
-    for (int mode = 0; mode < 3; ++mode) {     // 0: same XCD + workgroup scope, 1: same XCD + agent scope, 2: spread + agent scope
-      CHECK(hipMemset(slots, 0, 512 * 8));
-      const int stride = mode == 2 ? 1 : 8;
-      if (mode == 0) k_exchange<0><<<G * stride, 256>>>(slots, G, stride, rounds, out, xcc);
-      else k_exchange<1><<<G * stride, 256>>>(slots, G, stride, rounds, out, xcc);
+  const char* names[] = {"same XCD, workgroup scope", "same XCD, agent scope", "spread, agent scope", "spread, agent, padded slots", "spread, agent, fences", "spread, agent, padded, fences"};
+  for (int G : {16, 32, 64, 128, 256}) {
+    for (int mode = 0; mode < 6; ++mode) {
+      if (mode < 2 && G > 32) continue;          // one XCD holds 32 CUs
+      if (mode == 0 && G > 16) continue;         // (times out: stale L1 lines)
+      CHECK(hipMemset(slots, 0, 2 * 256 * 16 * 8));
+      const int stride = mode >= 2 ? 1 : 8;
+      switch (mode) {
+        case 0: k_exchange<0, 1, 0><<<G * stride, 256>>>(slots, G, stride, rounds, out, xcc); break;
+        case 1: case 2: k_exchange<1, 1, 0><<<G * stride, 256>>>(slots, G, stride, rounds, out, xcc); break;
+        case 3: k_exchange<1, 16, 0><<<G * stride, 256>>>(slots, G, stride, rounds, out, xcc); break;
+        case 4: k_exchange<1, 1, 1><<<G * stride, 256>>>(slots, G, stride, rounds, out, xcc); break;
+        default: k_exchange<1, 16, 1><<<G * stride, 256>>>(slots, G, stride, rounds, out, xcc); break;
+      }
       CHECK(hipDeviceSynchronize());
       long long h[512]; int hx[256];
       CHECK(hipMemcpy(h, out, 512 * 8, hipMemcpyDeviceToHost));
       CHECK(hipMemcpy(hx, xcc, 256 * 4, hipMemcpyDeviceToHost));
       int same = 1, fail = 0;
       for (int i = 0; i < G; ++i) { if (hx[i] != hx[0]) same = 0; fail |= (int)h[i * 2 + 1]; }
-      printf("G=%2d %-28s: %.2f us per exchange   all on XCC %d: %s   %s\n", G,
-             mode == 0 ? "same XCD, workgroup scope" : (mode == 1 ? "same XCD, agent scope" : "spread, agent scope"),
-             h[0] * 0.01 / (rounds - 1), hx[0], same ? "yes" : "no", fail ? "TIMEOUT" : "ok");
+      printf("G=%3d %-32s: %6.2f us per exchange   one XCC: %-3s %s\n", G, names[mode], h[0] * 0.01 / (rounds - 1), same ? "yes" : "no",
+             fail ? "TIMEOUT" : "ok");
     }
   }
   return 0;
