@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   if (stage_tables) {
     for (int idx = tid; idx < ntab; idx += 256) { s_T[idx] = x.Tout[idx]; s_T[ntab + idx] = x.Tin[idx]; }
   }
-  for (int n = b * 256 + tid; n < N; n += G * 256) a.ap[n] = 0;   // nothing of this scan's list is in G yet
+  // nothing of this scan's list is in G yet.  Every node's entry is zeroed by the workgroup that OWNS the node's group -
+  // the one that writes it again at the end of the band - so that no address has two unordered writers (the common
+  // exchange carries no fence; the flush path, which reads and writes other workgroups' entries, is fenced on both sides).
+  for (int grp = b; grp < ngroups; grp += G)
+    if (tid < per && grp * per + tid < N) a.ap[grp * per + tid] = 0;
   const size_t dstride = (size_t)K * Np;
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
 
