@@ -270,7 +270,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     const bool can_scan = m->sbm && m->K > 1 && !m->pipe && !m->sharded;
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
     m->use_scan = m->scan_pref == 1;
-    m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 8; m->since_revert = 1 << 30;
+    m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
     const char* ei = getenv("GG_INCREMENTAL");
     m->incr = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (ei && atoi(ei) == 1);
     // (carried statistics: the two scan forms keep different books on what of the change list is already in G, so the
@@ -774,8 +774,9 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
 }
 
 // The whole scan in one launch (k_scan: resident grid, one barrier round per accepted change).
-static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw) {
+static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw, bool resume = false) {
   gg_scan_args a;
+  a.resume = resume ? 1 : 0;
   gg_resolve_args& g = a.r;
   g.x = node_ctx(m, d, buf);
   g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
@@ -827,6 +828,21 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
 // The round that completes the scan sorts the labels into perm buffer `pw`.
 static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort, int pw) {
   int rc;
+  if (m->scan_pref != 0 && !tail_m) {
+    // The resident-grid scan finishes it (6.5 us per further change instead of a launch per change): flush the changes
+    // accepted so far into G (exact statistics under the current labels, empty list), then k_scan from the position
+    // the scan stalled at.
+    if ((rc = read_ctl(m))) return rc;
+    if (m->h_rs[4] && m->h_rs[0] != 0) {
+      if ((rc = launch_apply_L(m, d, buf))) return rc;
+      if ((rc = launch_scan(m, d, buf, sweep, tail_sort, pw, true))) return rc;
+      m->st.resolve_rounds += 1;
+      if ((rc = read_ctl(m))) return rc;
+      if (m->h_rs[3]) return GG_OK;          // (status: reported by the caller's next control-block check)
+    }
+    if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
+    return GG_OK;
+  }
   // at most 512 node groups per round (two workgroups per CU): beyond that a round's latency grows with the window
   int window = m->N < 4096 ? m->N : 4096;
   if (window > 512 * (256 / m->Kp)) window = 512 * (256 / m->Kp);
@@ -1117,7 +1133,10 @@ static int model_sync(gg_model* m) {
       if (m->todo == 0) break;
       // a clean batch: look further ahead again
       if (m->depth < (1 << 20)) m->depth *= 2;
-      const int take = m->todo < m->depth ? m->todo : m->depth;
+      // (adaptive form, speculate + resolve: a stall turns everything enqueued behind it into no-op launches, ~15 us per
+      // sweep - do not run further ahead than a stall costs anyway; the resident scan cannot stall)
+      int take = m->todo < m->depth ? m->todo : m->depth;
+      if (m->scan_pref < 0 && !m->use_scan && take > 64) take = 64;
       m->cur0 = m->cur; m->pcur0 = m->pcur;
       if (scan && (rc = write_ctl_word(m, 5, 0))) return rc;
       for (int i = 0; i < take; ++i)
@@ -1129,10 +1148,18 @@ static int model_sync(gg_model* m) {
     }
     // A scan stalled: the sweeps enqueued behind it ran as no-ops and must be enqueued again.  A chain that keeps
     // changing labels stalls every sweep, so stop running ahead (depth 1) until batches come back clean.
-    if (!m->pipe) m->depth = 1;   // (the pipelined form keeps its own look-ahead discipline)
+    if (!m->pipe && m->scan_pref >= 0) m->depth = 1;   // (the pipelined form keeps its own look-ahead discipline; the adaptive
+                                                       // form switches to the resident scan below, which cannot stall)
     if (m->scan_pref < 0) {   // the chain is changing labels: k_scan from the next sweep on
       // (a stall soon after the last switch back: the chain changes labels now and then - hold the resident form longer)
-      if (!m->use_scan && m->since_revert < 4 * m->scan_hold && m->scan_hold < 1024) m->scan_hold *= 2;
+      // Break-even: a quiet sweep costs ~4 us more in the resident form, a stall ~400 us in the other one (slow path,
+      // host round trips, the no-op launches behind it) = ~100 quiet sweeps.  So once a chain has surprised the
+      // speculative form after a switch back, the resident form is held for 4 x the quiet run that preceded the surprise
+      // (at least 64, at most 4096 sweeps); the first stall of all (burn-in) leaves the short initial hold alone.
+      if (!m->use_scan && m->since_revert < (1 << 29)) {
+        long long h = 4 * m->since_revert;
+        m->scan_hold = h < 64 ? 64 : (h > 4096 ? 4096 : h);
+      }
       m->use_scan = true; m->clean_run = 0; m->chg_seen = (long long)m->h_rs[2];
     }
     // ctl[5] scans completed before the flag went up.  pos != 0: the next one is stuck mid-scan.

@@ -34,6 +34,7 @@ struct gg_scan_args {
   unsigned long long* bar;    // G exchange slots (tag << 48 | payload), zeroed by k_params before every scan
   int Lcap;
   int G;                      // workgroups in the grid
+  int resume;                 // 1: finish a scan that k_resolve left stalled at rs[0] (G is exact for the current labels, L empty)
 };
 
 // Grid-wide exchange that doubles as the barrier: workgroup b publishes (round tag << 48 | payload) in its own
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   constexpr int U = 4;
   const gg_resolve_args& g = a.r;
   const gg_node_ctx& x = g.x;
-  if (g.rs[4]) return;   // an earlier scan of this pipeline is unfinished (uniform: set by a previous launch)
+  if (!a.resume && g.rs[4]) return;   // an earlier scan of this pipeline is unfinished (uniform: set by a previous launch)
   const int N = x.N, K = x.K, Kp = x.Kp, Np = x.Np;
   const int per = 256 / Kp;
   const int tid = threadIdx.x, b = blockIdx.x, G = a.G;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   const size_t dstride = (size_t)K * Np;
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
 
-  int pos = 0, nL = 0, nchg = 0;
+  int pos = a.resume ? g.rs[0] : 0, nL = 0, nchg = 0;   // (resume: uniform, written by an earlier launch)
   unsigned long long it = 0;     // barrier rounds so far (identical in every workgroup)
   int wi = 0;                    // evaluation rounds so far: selects the rotating first-changer word
   bool alive = true;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     }
   };
 
-  for (int band = 0; band * G < ngroups && alive; ++band) {
+  for (int band = (pos / per) / G; band * G < ngroups && alive; ++band) {
     const int grp = band * G + b;
     const bool has = grp < ngroups;
     const int n0 = grp * per;

@@ -226,7 +226,7 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
 @pytest.mark.gpu
 def test_adaptive_scan_form_is_the_same_chain(abi, monkeypatch):
     """Default (GG_SCAN unset): the engine runs the scan as k_scan while the chain keeps changing labels and as
-    k_speculate + k_resolve after a run of quiet sweeps (8 at first), deciding batch by batch.  A strongly planted network burns in within a
+    k_speculate + k_resolve after a run of quiet sweeps (4 at first), deciding batch by batch.  A strongly planted network burns in within a
     few sweeps and then stays quiet, so 240 sweeps in uneven chunks cross both switches: same chain as the oracle bit for
     bit at every checkpoint."""
     monkeypatch.delenv("GG_SCAN", raising=False)
