@@ -96,6 +96,7 @@ struct gg_model {
   int scan_pref;                // GG_SCAN: 1 always, 0 never, unset (-1): adaptive - k_scan while the chain keeps changing labels
   long long chg_seen;           // label changes (control word 2) at the last decision
   long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
+  int scan_spin;                // polls before a k_scan exchange gives up (GG_SCAN_SPIN overrides the default for tests)
   long long scan_hold;          // clean sweeps required before leaving k_scan mode (doubles when the chain stalls again soon after)
   long long since_revert;       // sweeps completed in speculate + resolve mode since the last switch back
   bool incr;                    // GG_INCREMENTAL=1: G is carried from sweep to sweep (changes flushed in), no bulk pass
@@ -271,6 +272,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
     m->use_scan = m->scan_pref == 1;
     m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
+    { const char* esp = getenv("GG_SCAN_SPIN"); m->scan_spin = esp && atoi(esp) > 0 ? atoi(esp) : GG_BAR_SPIN_LIMIT; }
     const char* ei = getenv("GG_INCREMENTAL");
     m->incr = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (ei && atoi(ei) == 1);
     // (carried statistics: the two scan forms keep different books on what of the change list is already in G, so the
@@ -777,6 +779,7 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
 static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw, bool resume = false) {
   gg_scan_args a;
   a.resume = resume ? 1 : 0;
+  a.spin_limit = m->scan_spin;
   gg_resolve_args& g = a.r;
   g.x = node_ctx(m, d, buf);
   g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
@@ -838,10 +841,17 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
       if ((rc = launch_scan(m, d, buf, sweep, tail_sort, pw, true))) return rc;
       m->st.resolve_rounds += 1;
       if ((rc = read_ctl(m))) return rc;
-      if (m->h_rs[3]) return GG_OK;          // (status: reported by the caller's next control-block check)
     }
-    if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
-    return GG_OK;
+    if (m->h_rs[3] == 2 && !m->incr) {
+      // the resident grid timed out and left a consistent stalled scan: restart rounds from here on (see model_sync)
+      if ((rc = write_ctl_word(m, 3, 0))) return rc;
+      fprintf(stderr, "graphgibbs: the resident-grid scan timed out; this model continues with restart rounds (GG_SCAN=0)\n");
+      m->scan_pref = 0; m->use_scan = false;
+    } else {
+      if (m->h_rs[3]) return GG_OK;          // (status: reported by the caller's next control-block check)
+      if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
+      return GG_OK;
+    }
   }
   // at most 512 node groups per round (two workgroups per CU): beyond that a round's latency grows with the window
   int window = m->N < 4096 ? m->N : 4096;
@@ -1104,8 +1114,18 @@ static int model_sync(gg_model* m) {
   const bool scan = m->sbm && m->K > 1;
   GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   for (;;) {
+    bool abort0 = false;
     if (m->pipe) GG_HIP(hipStreamSynchronize(m->sb));
     if ((rc = read_ctl(m))) return rc;
+    if (m->h_rs[3] == 2 && !m->incr) {
+      // A k_scan exchange timed out (the resident grid could not assemble - a device shared with other processes, say)
+      // and left the scan as a stalled one at a consistent position: carry on with the launch-per-change form, for good.
+      if ((rc = write_ctl_word(m, 3, 0))) return rc;
+      if (m->scan_pref != 0) fprintf(stderr, "graphgibbs: the resident-grid scan timed out at node %d (%d changes in its list); this model continues with restart rounds (GG_SCAN=0)\n", m->h_rs[0], m->h_rs[1]);
+      m->scan_pref = 0; m->use_scan = false;
+      m->h_rs[3] = 0;
+      abort0 = m->h_rs[4] && m->h_rs[0] == 0;   // it gave up before its first decision: still a stalled scan, at node 0
+    }
     if (m->h_rs[3]) {
       const int st3 = m->h_rs[3];
       write_ctl_word(m, 3, 0);
@@ -1115,6 +1135,7 @@ static int model_sync(gg_model* m) {
       m->zeroed[0] = m->zeroed[1] = false;
       m->G_valid = false;
       if (st3 & 2) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out (the resident grid did not assemble); set GG_SCAN=0");
+      if (st3 & 4) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out inside the statistics flush; set GG_SCAN=0");
       return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
     }
     if (!m->h_rs[4]) {  // nothing stalled or flushed: every enqueued sweep completed
@@ -1164,11 +1185,18 @@ static int model_sync(gg_model* m) {
     }
     // ctl[5] scans completed before the flag went up.  pos != 0: the next one is stuck mid-scan.
     const int done = scan ? m->h_rs[5] : m->pending;
-    const bool mid = m->h_rs[0] != 0;
+    const bool mid = m->h_rs[0] != 0 || abort0;
     const int completed = mid ? done + 1 : done;       // after the slow path below
     if (mid) {
       const int s_idx = done;                          // index of the stalled sweep within the batch
       const int buf_s = (m->cur0 + s_idx) & 1, P_s = (m->pcur0 + s_idx) & 1;
+      if (abort0) {
+        // nothing of this scan is decided yet (statistics, parameters and tables of the sweep are in place): run it in
+        // the speculative form; what that leaves unfinished is finished below like any other stalled scan
+        if ((rc = write_ctl_word(m, 4, 0))) return rc;
+        if ((rc = launch_speculate(m, d, buf_s, 0, -1, m->sweep + (uint32_t)s_idx, true))) return rc;
+        if ((rc = launch_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s, false))) return rc;
+      }
       if ((rc = finish_scan(m, d, m->incr ? m->cur0 : buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
       if (m->incr && (rc = launch_apply_L(m, d, m->cur0, 2))) return rc;   // what the rounds applied lazily -> all of G
     } else {

@@ -21,7 +21,7 @@
 #include "gg_resolve_kernels.h"
 
 #define GG_SCAN_MAXWG 256
-#define GG_BAR_SPIN_LIMIT (1 << 22)
+#define GG_BAR_SPIN_LIMIT (1 << 19)   // about a quarter of a second of polling: far beyond any kernel the grid may have to wait behind
 #ifndef GG_SCAN_POLL_SLEEP
 #define GG_SCAN_POLL_SLEEP 4
 #endif
@@ -35,6 +35,7 @@ struct gg_scan_args {
   int Lcap;
   int G;                      // workgroups in the grid
   int resume;                 // 1: finish a scan that k_resolve left stalled at rs[0] (G is exact for the current labels, L empty)
+  int spin_limit;             // polls before an exchange gives up (GG_BAR_SPIN_LIMIT; GG_SCAN_SPIN overrides it for tests)
 };
 
 // Grid-wide exchange that doubles as the barrier: workgroup b publishes (round tag << 48 | payload) in its own
@@ -48,7 +49,8 @@ struct gg_scan_args {
 // bare exchange 1-3 us: tools/probe/xcd_barrier.hip).  fenced = true: plain global writes made before the exchange
 // (statistics flushed into G) must be visible to the other workgroups after it.
 __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int G, unsigned tag, unsigned long long mine,
-                                                 bool fenced, unsigned long long* s_min, int32_t* rs, unsigned long long* best) {
+                                                 bool fenced, unsigned long long* s_min, int32_t* rs, unsigned long long* best,
+                                                 int spin_limit) {
   const int tid = threadIdx.x;
   // two slot arrays, alternating by round: a workgroup can be one round ahead of the slowest one (never two), and
   // must not overwrite the value the slow ones are still polling for
@@ -62,7 +64,7 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
   }
   __syncthreads();
   bool okall = false;
-  for (int spin = 0; spin < GG_BAR_SPIN_LIMIT; ++spin) {
+  for (int spin = 0; spin < spin_limit; ++spin) {
     int ok = 1;
     unsigned long long v = GG_SLOT_NONE;
     if (tid < G) {
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   int pos = a.resume ? g.rs[0] : 0, nL = 0, nchg = 0;   // (resume: uniform, written by an earlier launch)
   unsigned long long it = 0;     // barrier rounds so far (identical in every workgroup)
   int wi = 0;                    // evaluation rounds so far: selects the rotating first-changer word
-  bool alive = true;
+  bool alive = true, fatal = false;   // fatal: gave up inside the chip-wide flush (G half updated: not resumable)
   long long t_eval = 0, t_xchg = 0, t_apply = 0, t_load = 0;
   const long long t_begin = g.dbg ? wall_clock64() : 0;
 
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       unsigned long long best;
       {
         const unsigned long long mine = *s_min;   // this workgroup's first changer (48-bit payload) or none
-        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, false, s_min, g.rs, &best)) {
+        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, false, s_min, g.rs, &best, a.spin_limit)) {
           alive = false;
           break;
         }
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         {
           // (earlier bands' write-backs and ap entries were plain stores of other workgroups: fenced meeting first)
           unsigned long long dummy;
-          if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), GG_SLOT_NONE, true, s_min, g.rs, &dummy)) { alive = false; break; }
+          if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), GG_SLOT_NONE, true, s_min, g.rs, &dummy, a.spin_limit)) { alive = false; break; }
           ++it;
         }
         for (int n = b * 256 + tid; n < N; n += G * 256) {
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         }
         {
           unsigned long long dummy;
-          if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), GG_SLOT_NONE, true, s_min, g.rs, &dummy)) { alive = false; break; }
+          if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), GG_SLOT_NONE, true, s_min, g.rs, &dummy, a.spin_limit)) { alive = false; fatal = true; break; }
         }
         ++it;
         nL = 0;
@@ -361,7 +363,29 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     }
   }
   // ---- tail: workgroup 0 publishes the result of the scan
-  if (b != 0 || !alive) return;
+  if (b != 0) return;
+  if (!alive) {
+    // An exchange timed out (the grid could not assemble: the device is shared with other processes, say).  What
+    // workgroup 0 has recorded - labels, change list, position - is a valid prefix of the scan whoever gave up first:
+    // a change is only recorded after every workgroup has published its candidate for it.  Leave the scan as a STALLED
+    // one at that position (the state the restart rounds resume from: G as the bulk pass left it or as written back,
+    // ap entries, L) and let the host carry on with the launch-per-change form.  Status bit 2 tells it why.
+    if (fatal) { if (tid == 0) atomicOr(&g.rs[3], 4); return; }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) g.cnt[k] = s_cnt[k];
+    if (tid == 0) {
+      g.rs[0] = pos;
+      g.rs[1] = nL;
+      g.rs[2] += nchg;
+      g.rs[9] += nchg;
+      g.rs[4] = 1;
+      // round state for the restart rounds, exactly as k_resolve leaves it for an incomplete scan
+      *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(pos, nL, 0, 0, 0);
+      *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]) = GG_NO_CHANGE;
+      g.rs[10] = 0;
+    }
+    return;
+  }
   __syncthreads();
   for (int k = tid; k < K; k += 256) g.cnt[k] = s_cnt[k];
   __threadfence();

@@ -224,6 +224,37 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spin", [1, 3, 9])
+def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin):
+    """A k_scan exchange that times out (GG_SCAN_SPIN: a handful of polls instead of 4 million - what a device shared
+    with other processes would do to the resident grid) leaves the scan as a consistent stalled one; the engine carries
+    on with restart rounds for good and the chain stays the oracle's bit for bit."""
+    monkeypatch.setenv("GG_SCAN", "1")
+    monkeypatch.setenv("GG_SCAN_SPIN", str(spin))
+    N, K = 400, 16
+    A, W, _ = planted_sbm(N, K, seed=19)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=25), WState(N, K, 1, seed=26)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=81, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=82, special_case_self_conns=1)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    ps = sa.p_self
+    nsw = 5
+    abi.resample_many([adj, w], d, nsw)
+    for s in range(nsw):
+        ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 81, s)
+        O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 82, s)
+    assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p)
+    assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu)
+    if spin == 1:      # (with a few more polls the 25 workgroups sometimes do meet in time: then nothing is printed)
+        assert "timed out" in capfd.readouterr().err
+
+
+@pytest.mark.gpu
 def test_adaptive_scan_form_is_the_same_chain(abi, monkeypatch):
     """Default (GG_SCAN unset): the engine runs the scan as k_scan while the chain keeps changing labels and as
     k_speculate + k_resolve after a run of quiet sweeps (4 at first), deciding batch by batch.  A strongly planted network burns in within a
