@@ -35,6 +35,31 @@ def niw_log_prob(mu, sigma, mu_0, sigma_0, nu_0, kappa_0):
     return lp
 
 
+def niw_log_prob_many(mu, sigma, mu_0, sigma_0, nu_0, kappa_0):
+    """Sum of niw_log_prob over a batch of (mu, sigma) pairs that share one prior - mu (..., B), sigma (..., B, B) - in
+    closed form (the K^2 scipy calls of the loop in weights.py:343-352 cost milliseconds per log_prior at K = 8):
+      log IW(S; nu, Psi) = nu/2 log|Psi| - nu B/2 log 2 - log Gamma_B(nu/2) - (nu + B + 1)/2 log|S| - tr(Psi S^-1)/2
+      log N(mu; mu_0, S/kappa) = -B/2 log(2 pi) - log|S/kappa|/2 - kappa/2 (mu - mu_0)' S^-1 (mu - mu_0)."""
+    from scipy.special import multigammaln
+    mu = np.asarray(mu, dtype=np.float64)
+    sigma = np.asarray(sigma, dtype=np.float64)
+    B = mu.shape[-1]
+    mu = mu.reshape(-1, B)
+    sigma = sigma.reshape(-1, B, B)
+    n = mu.shape[0]
+    psi = np.asarray(sigma_0, dtype=np.float64).reshape(B, B)
+    _, logdet = np.linalg.slogdet(sigma)
+    _, logdet_psi = np.linalg.slogdet(psi)
+    sinv = np.linalg.inv(sigma)
+    tr = np.einsum("ij,nji->n", psi, sinv)
+    lp_iw = n * (0.5 * nu_0 * logdet_psi - 0.5 * nu_0 * B * np.log(2.0) - multigammaln(0.5 * nu_0, B)) \
+        - 0.5 * (nu_0 + B + 1) * logdet.sum() - 0.5 * tr.sum()
+    dmu = mu - np.asarray(mu_0, dtype=np.float64).reshape(1, B)
+    quad = np.einsum("ni,nij,nj->n", dmu, sinv, dmu)
+    lp_n = -0.5 * n * B * np.log(2.0 * np.pi) - 0.5 * (logdet - B * np.log(kappa_0)).sum() - 0.5 * kappa_0 * quad.sum()
+    return float(lp_iw + lp_n)
+
+
 class _GaussianView(object):
     """The slice of a pybasicbayes `Gaussian` the reference touches, backed by the owner's state arrays."""
 
@@ -380,9 +405,8 @@ class SBMGaussianWeightDistribution(_WeightsBase):
         # weights.py:333-357
         lp = 0
         lp += _dirichlet(self.pi).logpdf(self.m)
-        for row in self._gaussians:
-            for g in row:
-                lp += niw_log_prob(g.mu, g.sigma, g.mu_0, g.sigma_0, g.nu_0, g.kappa_0)
+        g0 = self._gaussians[0][0]                      # (every pair shares the one NIW prior)
+        lp += niw_log_prob_many(self._hget("_mu"), self._hget("_sigma"), g0.mu_0, g0.sigma_0, g0.nu_0, g0.kappa_0)
         if self.special_case_self_conns:
             g = self._self_gaussian
             lp += niw_log_prob(g.mu, g.sigma, g.mu_0, g.sigma_0, g.nu_0, g.kappa_0)

@@ -147,3 +147,21 @@ def test_network_composition_and_errors():
     assert EmptyAdjacencyDistribution(4).log_likelihood(np.ones((4, 4))) == -np.inf
     Arow, Acol, Wrow, Wcol = net.sample_predictive_distribution()
     assert np.isfinite(net.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=4))
+
+
+def test_vectorised_niw_log_prior_matches_the_scipy_loop():
+    """SBMGaussianWeightDistribution.log_prior sums K^2 NIW log densities (weights.py:343-352): the closed form over the
+    whole batch equals the reference's loop of scipy calls."""
+    from graphistician_amd.weights import niw_log_prob, niw_log_prob_many
+    rng = np.random.RandomState(3)
+    for B in (1, 2, 3):
+        K = 4
+        mu = rng.randn(K, K, B)
+        a = rng.randn(K, K, B, B + 2)
+        sigma = np.einsum("...ik,...jk->...ij", a, a) + 0.1 * np.eye(B)
+        mu_0, nu_0, kappa_0 = rng.randn(B), B + 2.5, 0.7
+        s0 = rng.randn(B, B + 1)
+        sigma_0 = s0.dot(s0.T) + 0.2 * np.eye(B)
+        ref = sum(niw_log_prob(mu[i, j], sigma[i, j], mu_0, sigma_0, nu_0, kappa_0) for i in range(K) for j in range(K))
+        got = niw_log_prob_many(mu, sigma, mu_0, sigma_0, nu_0, kappa_0)
+        assert abs(got - ref) <= 1e-9 * abs(ref)
