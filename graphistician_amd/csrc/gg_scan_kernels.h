@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   constexpr int U = 4;
   const gg_resolve_args& g = a.r;
   const gg_node_ctx& x = g.x;
+  const long long t_kernel0 = g.dbg ? wall_clock64() : 0;
   if (!a.resume && g.rs[4]) return;   // an earlier scan of this pipeline is unfinished (uniform: set by a previous launch)
   const int N = x.N, K = x.K, Kp = x.Kp, Np = x.Np;
   const int per = 256 / Kp;
@@ -116,6 +117,29 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_raw + off); off += 2 * sizeof(unsigned long long);
   int* s_L = reinterpret_cast<int*>(s_raw + off);   // [Lcap][3]: this workgroup's own copy of the change list
 
+  const size_t dstride = (size_t)K * Np;
+  // The first band's statistics: 2 K per <= 512 entries, at most two per thread.  Their loads are issued before the
+  // tables are staged (all of a thread's loads in flight together) and stored to LDS when the band loop starts.
+  const int band_first = ((a.resume ? g.rs[0] : 0) / per) / G;
+  int pf_gc[2];
+  long long pf_gs[2][NSI > 0 ? NSI : 1];
+  {
+    const int grp0 = band_first * G + b;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + u * 256;
+      const bool in = idx < 2 * K * per && grp0 < ngroups;
+      const int ii = in ? idx : 0;
+      const int i = ii % per, j = (ii / per) % K, d = ii / (per * K);
+      int n = (in ? grp0 * per : 0) + i;
+      n = n < N ? n : N - 1;
+      const size_t gi = d * dstride + (size_t)j * Np + n;
+      pf_gc[u] = a.Gc0[gi];
+      if (!ADJ)
+#pragma unroll
+        for (int s2 = 0; s2 < NSI; ++s2) pf_gs[u][s2] = a.Gs0[gi * NSI + s2];
+    }
+  }
   for (int k = tid; k < K; k += 256) s_cnt[k] = g.cnt[k];
   if (stage_tables) {
     for (int idx = tid; idx < ntab; idx += 256) { s_T[idx] = x.Tout[idx]; s_T[ntab + idx] = x.Tin[idx]; }
@@ -125,10 +149,10 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   // exchange carries no fence; the flush path, which reads and writes other workgroups' entries, is fenced on both sides).
   for (int grp = b; grp < ngroups; grp += G)
     if (tid < per && grp * per + tid < N) a.ap[grp * per + tid] = 0;
-  const size_t dstride = (size_t)K * Np;
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
 
   int pos = a.resume ? g.rs[0] : 0, nL = 0, nchg = 0;   // (resume: uniform, written by an earlier launch)
+  const long long t_init0 = g.dbg ? wall_clock64() : 0;
   unsigned long long it = 0;     // barrier rounds so far (identical in every workgroup)
   int wi = 0;                    // evaluation rounds so far: selects the rotating first-changer word
   bool alive = true, fatal = false;   // fatal: gave up inside the chip-wide flush (G half updated: not resumable)
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     }
   };
 
-  for (int band = (pos / per) / G; band * G < ngroups && alive; ++band) {
+  for (int band = band_first; band * G < ngroups && alive; ++band) {
     const int grp = band * G + b;
     const bool has = grp < ngroups;
     const int n0 = grp * per;
@@ -164,13 +188,26 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     __syncthreads();
     if (has) {
       // the group's statistics as the bulk pass left them, plus every change accepted so far
-      for (int idx = tid; idx < 2 * K * per; idx += 256) {
-        const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
-        const int n = (n0 + i < N) ? n0 + i : N - 1;
-        const size_t gi = d * dstride + (size_t)j * Np + n;
-        s_gc[idx] = a.Gc0[gi];
-        if (!ADJ)
-          for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = a.Gs0[gi * NSI + s];
+      if (band == band_first) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {        // prefetched at kernel start
+          const int idx = tid + u * 256;
+          if (idx < 2 * K * per) {
+            s_gc[idx] = pf_gc[u];
+            if (!ADJ)
+#pragma unroll
+              for (int s2 = 0; s2 < NSI; ++s2) s_gs[(size_t)idx * NSI + s2] = pf_gs[u][s2];
+          }
+        }
+      } else {
+        for (int idx = tid; idx < 2 * K * per; idx += 256) {
+          const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
+          const int n = (n0 + i < N) ? n0 + i : N - 1;
+          const size_t gi = d * dstride + (size_t)j * Np + n;
+          s_gc[idx] = a.Gc0[gi];
+          if (!ADJ)
+            for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = a.Gs0[gi * NSI + s];
+        }
       }
       if (tid < per) s_c[tid] = (n0 + tid < N) ? g.c[n0 + tid] : 0;
       __syncthreads();
@@ -363,6 +400,11 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     }
   }
   // ---- tail: workgroup 0 publishes the result of the scan
+  // An unchanged scan keeps its sort: every workgroup copies its share of perm (the tail's longest part, 16 loads deep
+  // when workgroup 0 does it alone); workgroup 0 then only publishes.  (nchg is the same in every workgroup.)
+  const bool unchanged = alive && g.tail_sort && g.rs[9] + nchg == 0;
+  if (unchanged)
+    for (int n = b * 256 + tid; n < N; n += G * 256) g.perm[n] = g.perm_prev[n];
   if (b != 0) return;
   if (!alive) {
     // An exchange timed out (the grid could not assemble: the device is shared with other processes, say).  What
@@ -390,10 +432,19 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   for (int k = tid; k < K; k += 256) g.cnt[k] = s_cnt[k];
   __threadfence();
   __syncthreads();
-  gg_scan_tail(g, s_cnt, s_raw, g.rs[9] + nchg == 0);
+  const long long t_tail0 = g.dbg ? wall_clock64() : 0;
+  if (unchanged) {
+    for (int k = tid; k <= K; k += 256) g.lab_start[k] = g.lab_start_prev[k];
+    if (g.tail_m) { gg_resolve_args gm = g; gm.tail_sort = 0; gg_scan_tail(gm, s_cnt, s_raw, true); }
+  } else {
+    gg_scan_tail(g, s_cnt, s_raw, g.rs[9] + nchg == 0);
+  }
+  if (g.dbg) __syncthreads();
   if (g.dbg && tid == 0) {
     g.dbg[0] = t_eval; g.dbg[1] = t_xchg; g.dbg[2] = t_apply; g.dbg[3] = (long long)it; g.dbg[4] = t_load;
     g.dbg[5] = wall_clock64() - t_begin;
+    g.dbg[6] = wall_clock64() - t_tail0;
+    g.dbg[7] = t_init0 - t_kernel0;
   }
   if (tid == 0) {
     g.rs[0] = 0;

@@ -1,5 +1,7 @@
 """GPU edge cases: ragged sizes, empty / complete graphs, empty blocks, single block, tiny N,
 self-connection conventions, B=4, model reuse across data sets, the Python-level data cache."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,9 @@ def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin)
     """A k_scan exchange that times out (GG_SCAN_SPIN: a handful of polls instead of 4 million - what a device shared
     with other processes would do to the resident grid) leaves the scan as a consistent stalled one; the engine carries
     on with restart rounds for good and the chain stays the oracle's bit for bit."""
+    if os.environ.get("GG_INCREMENTAL") == "1":
+        pytest.skip("with carried statistics a timed-out resident scan is a hard error (the written-back statistics of a "
+                    "half-finished round cannot be trusted)")
     monkeypatch.setenv("GG_SCAN", "1")
     monkeypatch.setenv("GG_SCAN_SPIN", str(spin))
     N, K = 400, 16
