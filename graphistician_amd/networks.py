@@ -5,112 +5,92 @@ engine; the (A, W) pair is uploaded once and cached by identity (engine.py)."""
 import numpy as np
 
 from . import _abi
-
 from . import adjacency
 from . import weights
 from .abstractions import NetworkDistribution, AdjacencyDistribution, WeightDistribution, GibbsSampling
 from .engine import as_device_data
 
 
+def _on_engine(part):
+    return hasattr(part, "_engine")
+
+
 class FactorizedNetworkDistribution(NetworkDistribution, GibbsSampling):
-    """networks.py:9-75."""
+    """networks.py:9-75: p(A, W) = p(A | adjacency model) p(W | A, weight model).  The two halves share nothing but the
+    data, so the engine runs them on separate streams and this class only pairs them up."""
 
     def __init__(self, N, adjacency_class, adjacency_kwargs, weight_class, weight_kwargs):
         super(FactorizedNetworkDistribution, self).__init__()
+        assert issubclass(adjacency_class, AdjacencyDistribution) and issubclass(weight_class, WeightDistribution)
         self.N = N
-        assert issubclass(adjacency_class, AdjacencyDistribution)
-        self._adjacency = adjacency_class(N, **adjacency_kwargs)
-        assert issubclass(weight_class, WeightDistribution)
-        self._weights = weight_class(N, **weight_kwargs)
+        self._halves = (adjacency_class(N, **adjacency_kwargs), weight_class(N, **weight_kwargs))
 
-    @property
-    def adjacency(self):
-        return self._adjacency
+    adjacency = property(lambda self: self._halves[0])
+    weights = property(lambda self: self._halves[1])
 
-    @property
-    def weights(self):
-        return self._weights
-
+    # -- engine plumbing ---------------------------------------------------------------------------------------
     def _device_data(self, data):
-        if isinstance(data, _abi.DeviceData):   # already resident
+        """The (A, W) pair as a device handle (uploaded once, cached by identity); handles pass through."""
+        if isinstance(data, _abi.DeviceData):
             return data
         A, W = data
-        dev = getattr(self._weights, "_device", getattr(self._adjacency, "_device", 0))
-        return as_device_data(A, W, device=dev)
+        adj, wts = self._halves
+        return as_device_data(A, W, device=getattr(wts, "_device", getattr(adj, "_device", 0)))
 
+    def _adjacency_arg(self, d, data):
+        # host-only adjacency classes (Fixed / Complete / Empty) take the matrix itself
+        return d if _on_engine(self.adjacency) else data[0]
+
+    # -- densities (networks.py:28-37) ---------------------------------------------------------------------------
     def log_likelihood(self, data):
-        # networks.py:28-31
         d = self._device_data(data)
-        if all(hasattr(part, "_engine") for part in (self.adjacency, self.weights)):
-            # both halves on the engine: evaluated concurrently (gg_log_likelihood_many)
+        adj, wts = self._halves
+        if _on_engine(adj) and _on_engine(wts):
             assert d.N == self.N
-            return sum(_abi.log_likelihood_many([self.adjacency._engine(), self.weights._engine()], d))
-        lls = self.adjacency.log_likelihood(d if hasattr(self.adjacency, "_engine") else data[0])
-        lls += self.weights.log_likelihood(d)
-        return lls
+            # both halves' passes are enqueued before either is waited for (gg_log_likelihood_many)
+            return sum(_abi.log_likelihood_many([adj._engine(), wts._engine()], d))
+        return adj.log_likelihood(self._adjacency_arg(d, data)) + wts.log_likelihood(d)
 
     def log_prior(self):
-        # networks.py:33-37
-        lp = 0
-        lp += self.adjacency.log_prior()
-        lp += self.weights.log_prior()
-        return lp
+        return sum(half.log_prior() for half in self._halves)
 
+    # -- sampling (networks.py:39-58) ------------------------------------------------------------------------------
     def rvs(self, *args, **kwargs):
-        # networks.py:39-42
-        A = self.adjacency.rvs()
-        W = self.weights.rvs()
-        return A, W
+        return self.adjacency.rvs(), self.weights.rvs()
 
     def sample_predictive_parameters(self):
-        # networks.py:44-50 (the reference asks the adjacency twice; the weight parameters are what is meant)
-        Aprms = self.adjacency.sample_predictive_parameters()
-        Wprms = self.weights.sample_predictive_parameters()
-        return Aprms, Wprms
+        # (the reference asks the adjacency model twice at :47-48; the weight parameters are what is meant)
+        return tuple(half.sample_predictive_parameters() for half in self._halves)
 
     def sample_predictive_distribution(self):
-        # networks.py:52-58
-        Arow, Acol = self.adjacency.sample_predictive_distribution()
-        Wrow, Wcol = self.weights.sample_predictive_distribution()
-        return Arow, Acol, Wrow, Wcol
+        return tuple(self.adjacency.sample_predictive_distribution()) + tuple(self.weights.sample_predictive_distribution())
 
     def approx_predictive_ll(self, Arow, Acol, Wrow, Wcol, M=100):
         # networks.py:60-67
-        pll = 0
-        pll += self.adjacency.approx_predictive_ll(Arow, Acol, M=M)
-        pll += self.weights.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=M)
-        return pll
+        return (self.adjacency.approx_predictive_ll(Arow, Acol, M=M) +
+                self.weights.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=M))
 
+    # -- one Gibbs sweep (networks.py:69-71) -----------------------------------------------------------------------
     def resample(self, data, beta=1.0):
-        # networks.py:69-71; beta < 1 tempers both halves' likelihoods (AIS over whole networks)
+        """Adjacency half, then weight half; beta < 1 tempers both likelihoods (AIS over whole networks)."""
         d = self._device_data(data)
-        if beta == 1.0:
-            self.adjacency.resample(d if hasattr(self.adjacency, "_engine") else data[0])
-            self.weights.resample(d)
-        else:
-            self.adjacency.resample(d if hasattr(self.adjacency, "_engine") else data[0], beta=beta)
-            self.weights.resample(d, beta=beta)
-        # both halves are enqueued stream-ordered on their own models; finishing them together lets the
-        # engine overlap whatever it still has to do for either (gg_sync_many)
-        engines = [getattr(part, "_model", None) for part in (self.adjacency, self.weights)]
-        engines = [e for e in engines if e is not None]
-        if len(engines) > 1:
-            _abi.sync_many(engines)
+        kw = {} if beta == 1.0 else {"beta": beta}
+        self.adjacency.resample(self._adjacency_arg(d, data), **kw)
+        self.weights.resample(d, **kw)
+        # each half was enqueued stream-ordered on its own model: finishing them together lets the engine overlap
+        # whatever either still has to do (gg_sync_many)
+        models = [m for m in (getattr(half, "_model", None) for half in self._halves) if m is not None]
+        if len(models) > 1:
+            _abi.sync_many(models)
 
     def meanfieldupdate(self, expected_suff_stats):
-        # networks.py:73-75 (a stub in the reference as well)
-        pass
+        pass   # a stub in the reference as well (networks.py:73-75)
 
 
 class GaussianBernoulliNetwork(FactorizedNetworkDistribution):
-    """networks.py:78-88."""
+    """networks.py:78-88: Bernoulli(p) edges with N(mu, sigma) weights, nothing to learn."""
 
     def __init__(self, N, B, p=0.5, mu=None, sigma=None):
-        if mu is None:
-            mu = np.zeros(B)
-        if sigma is None:
-            sigma = np.eye(B)
-        super(GaussianBernoulliNetwork, self).__init__(
-            N,
-            adjacency.BernoulliAdjacencyDistribution, {"p": p},
-            weights.FixedGaussianWeightDistribution, {"B": B, "mu": mu, "sigma": sigma})
+        gauss = {"B": B, "mu": np.zeros(B) if mu is None else mu, "sigma": np.eye(B) if sigma is None else sigma}
+        super(GaussianBernoulliNetwork, self).__init__(N, adjacency.BernoulliAdjacencyDistribution, {"p": p},
+                                                       weights.FixedGaussianWeightDistribution, gauss)
