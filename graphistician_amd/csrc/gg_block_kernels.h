@@ -395,6 +395,7 @@ __global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restri
 //   3. and writes the pair's coefficient-table entries (k_prep_tables);
 // every thread also zeroes a slice of the *other* statistics buffer, which the
 // next half-sweep's bulk kernel accumulates into.
+#define GG_SLOT_PAD 16   // 8-byte words between two exchange slots of k_scan: every slot on its own 128-byte line
 struct gg_params_args {
   int is_adj, K, Kp, B, NSI, Np, N;
   int do_tables, do_draw, do_prep;
@@ -442,7 +443,9 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
     g.ctl[8] = 0;
     g.ctl[9] = 0;
   }
-  if (g.do_prep && g.bar && blockIdx.x == 0) { g.bar[threadIdx.x] = 0ull; g.bar[256 + threadIdx.x] = 0ull; }   // k_scan's exchange slots: tag 0 = never written
+  // k_scan's exchange slots (2 x 256, one per 128-byte line): tag 0 = never written
+  if (g.do_prep && g.bar)
+    for (unsigned sl = blockIdx.x * blockDim.x + threadIdx.x; sl < 512u; sl += gridDim.x * blockDim.x) g.bar[(size_t)sl * GG_SLOT_PAD] = 0ull;
   const int K = g.K;
   constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
   constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;

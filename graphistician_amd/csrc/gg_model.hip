@@ -230,7 +230,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->incr = false; m->G_valid = false; m->G_data = nullptr;
   m->bar = nullptr; m->use_scan = false;
   m->depth = 1 << 20; m->todo = 0; m->round_hint = 0;
-  if ((rc = dmalloc(&m->bar, (size_t)512))) return rc;
+  if ((rc = dmalloc(&m->bar, (size_t)512 * GG_SLOT_PAD))) return rc;
   if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
   GG_HIP(hipHostMalloc((void**)&m->h_tab, ((size_t)m->K * m->K * m->NTAB + m->K) * sizeof(long long)));

@@ -54,12 +54,12 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
   const int tid = threadIdx.x;
   // two slot arrays, alternating by round: a workgroup can be one round ahead of the slowest one (never two), and
   // must not overwrite the value the slow ones are still polling for
-  slots += (tag & 1u) * GG_SCAN_MAXWG;
+  slots += (size_t)(tag & 1u) * GG_SCAN_MAXWG * GG_SLOT_PAD;
   __syncthreads();
   if (tid == 0) {
     *s_min = GG_SLOT_NONE;
     if (fenced) __threadfence();   // plain global writes of this workgroup come first
-    __hip_atomic_store(&slots[blockIdx.x], ((unsigned long long)(tag & 0xffffu) << 48) | (mine & GG_SLOT_NONE), __ATOMIC_RELAXED,
+    __hip_atomic_store(&slots[(size_t)blockIdx.x * GG_SLOT_PAD], ((unsigned long long)(tag & 0xffffu) << 48) | (mine & GG_SLOT_NONE), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
@@ -68,7 +68,7 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
     int ok = 1;
     unsigned long long v = GG_SLOT_NONE;
     if (tid < G) {
-      const unsigned long long w = __hip_atomic_load(&slots[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long w = __hip_atomic_load(&slots[(size_t)tid * GG_SLOT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ok = (unsigned)(w >> 48) == (tag & 0xffffu);
       v = w & GG_SLOT_NONE;
     }
