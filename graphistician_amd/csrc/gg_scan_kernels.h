@@ -64,20 +64,21 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
   }
   __syncthreads();
   bool okall = false;
+  // lane t watches slot t and stops loading it once its tag has arrived: the polls are memory-side loads that compete
+  // with the other model's bulk pass, and most slots are ready long before the last one
+  bool seen = tid >= G;
+  unsigned long long v = GG_SLOT_NONE;
   for (int spin = 0; spin < spin_limit; ++spin) {
-    int ok = 1;
-    unsigned long long v = GG_SLOT_NONE;
-    if (tid < G) {
+    if (!seen) {
       const unsigned long long w = __hip_atomic_load(&slots[(size_t)tid * GG_SLOT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ok = (unsigned)(w >> 48) == (tag & 0xffffu);
-      v = w & GG_SLOT_NONE;
+      if ((unsigned)(w >> 48) == (tag & 0xffffu)) { seen = true; v = w & GG_SLOT_NONE; }
     }
-    if (__syncthreads_and(ok)) {
+    if (__syncthreads_and(seen ? 1 : 0)) {
       if (v != GG_SLOT_NONE) atomicMin(s_min, v);
       okall = true;
       break;
     }
-    __builtin_amdgcn_s_sleep(GG_SCAN_POLL_SLEEP);   // the polls are memory-side loads: keep them off the other model's bulk pass
+    __builtin_amdgcn_s_sleep(GG_SCAN_POLL_SLEEP);
   }
   if (!okall && tid == 0) atomicOr(&rs[3], 2);
   if (fenced) __threadfence();
