@@ -22,6 +22,7 @@ import numpy as np
 from scipy.special import logsumexp
 
 from .adjacency import SBMAdjacencyDistribution, BetaBernoulliAdjacencyDistribution, LatentDistanceAdjacencyDistribution
+from .eigenmodel import LogisticEigenmodel, ProbitEigenmodel
 
 
 def prior_draw(model):
@@ -30,7 +31,9 @@ def prior_draw(model):
         model.m = np.random.dirichlet(model.pi)
         model.c = np.random.choice(model.C, p=model.m, size=model.N)
         model.initialize_from_prior()
-    elif isinstance(model, (BetaBernoulliAdjacencyDistribution, LatentDistanceAdjacencyDistribution)):
+    elif isinstance(model, ProbitEigenmodel):
+        raise NotImplementedError("AIS: the probit eigenmodel has no tempered conditionals")
+    elif isinstance(model, (BetaBernoulliAdjacencyDistribution, LatentDistanceAdjacencyDistribution, LogisticEigenmodel)):
         model.initialize_from_prior()
     elif hasattr(model, "adjacency") and hasattr(model, "weights"):
         # a whole network (networks.py:9-75): both halves from their priors; the tempered path raises the JOINT

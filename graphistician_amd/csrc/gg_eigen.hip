@@ -31,6 +31,7 @@ struct gg_eigen {
   gg_config cfg;
   int N, D, Np, DM;
   int probit;            // GG_PROBIT_EIG: buffer S holds Z_ij + Z_ji, the pair weight is the constant 2
+  double beta;           // AIS inverse temperature (logistic link only): omega ~ PG(beta, psi), kappa = beta (A - 1/2)
   int NEG, NE, NG;        // D(D+1)/2, NEG + D, 2 + 2D + NEG
   int NCH;
   double *F, *lmbda, *mu0, *mu_lmbda;
@@ -86,7 +87,7 @@ template <int DM>
 __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const double* __restrict__ F,
                                                    const double* __restrict__ lmbda, const double* __restrict__ mu0p,
                                                    uint64_t seed, uint32_t sweep, double* __restrict__ S,
-                                                   double* __restrict__ dO) {
+                                                   double* __restrict__ dO, double beta) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
   __shared__ double s_t[32][33];
   __shared__ double s_psi[32][33];
@@ -109,7 +110,20 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
     const int gi = I * 32 + li, gj = J * 32 + lj;
     double val = 0.0;
     if (gi < N && gj < N) {
-      if (I == J && li == lj) {
+      if (beta != 1.0) {
+        // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
+        if (I == J && li == lj) {
+          gg_stream s0;
+          gg_stream_init(&s0, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gi);
+          dO[gi] = beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0;
+        } else if (I < J || li < lj) {
+          const double psi = s_psi[li][lj];
+          gg_stream s1, s2;
+          gg_stream_init(&s1, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj);
+          gg_stream_init(&s2, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi);
+          val = beta > 0.0 ? gg_pg_frac(&s1, beta, psi) + gg_pg_frac(&s2, beta, psi) : 0.0;
+        }
+      } else if (I == J && li == lj) {
         dO[gi] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gi, mu0);
       } else if (I < J || li < lj) {
         const double psi = s_psi[li][lj];
@@ -214,7 +228,7 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
                                                         const double* __restrict__ F, const double* __restrict__ lmbda,
                                                         const double* __restrict__ mu0p, int NCH,
                                                         double* __restrict__ part, int ex_lo, int ex_hi, int node, int c,
-                                                        int probit) {
+                                                        int probit, double ka) {
   // nodes [ex_lo, ex_hi) (the previous tile, whose scan is still running) are left out: the chain adds them
   constexpr int NEGM = DM * (DM + 1) / 2;
   const int n = t0 + node;
@@ -232,7 +246,7 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
     // logistic: s = omega_ij + omega_ji, a = kappa_ij + kappa_ji; probit (eigenmodel.py:312-321): s = 2, a = Z_ij + Z_ji
     const double raw = S[(size_t)n * Np + nn];
     const double s = probit ? 2.0 : raw;
-    const double a = probit ? raw : (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
+    const double a = probit ? raw : ka * (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
     const double v = a - mu0 * s;
     double ft[DM];
 #pragma unroll
@@ -283,8 +297,8 @@ __global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, i
                                                         const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                         const double* __restrict__ F, const double* __restrict__ lmbda,
                                                         const double* __restrict__ mu0p, int NCH,
-                                                        double* __restrict__ part, int ex_lo, int ex_hi, int probit) {
-  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, ex_hi, blockIdx.x, blockIdx.y, probit);
+                                                        double* __restrict__ part, int ex_lo, int ex_hi, int probit, double ka) {
+  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, ex_hi, blockIdx.x, blockIdx.y, probit, ka);
 }
 
 template <int DM, bool FULL>
@@ -294,13 +308,13 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
                                                    const double* __restrict__ mu0p, double sigma_F, int NCH,
                                                    const double* __restrict__ part, const double* __restrict__ Z,
                                                    int* __restrict__ status, long long* __restrict__ dbg,
-                                                   double* __restrict__ part_next, int probit) {
+                                                   double* __restrict__ part_next, int probit, double ka) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   if (blockIdx.x > 0) {
     // riders: the statistics of the NEXT tile (all nodes outside this tile and the next), computed while
     // workgroup 0 scans this one; the next launch's chain adds this tile's nodes with their new features
     const int idx = blockIdx.x - 1;
-    eig_tile_stats_body<DM>(N, Np, Drt, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, t0 + EIG_T, idx / NCH, idx % NCH, probit);
+    eig_tile_stats_body<DM>(N, Np, Drt, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, t0 + EIG_T, idx / NCH, idx % NCH, probit, ka);
     return;
   }
   extern __shared__ __align__(16) unsigned char s_chain[];
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           const int m = kk * 4 + (l >> 4);
           const double raw = s_S[row * (EIG_T + 1) + m];
           const double sv = probit ? 2.0 : raw;
-          const double xa = mean ? gg_fma(-mu0, sv, probit ? raw : (double)s_a[row * EIG_T + m]) : sv;
+          const double xa = mean ? gg_fma(-mu0, sv, probit ? raw : ka * (double)s_a[row * EIG_T + m]) : sv;
           double yb = 0.0;
           if (cvalid) yb = mean ? s_dF[m * DM + a1] : s_dF[m * DM + a1] * s_dF[m * DM + b1];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
       if (nl >= 1) {
         const double raw = s_S[nl * (EIG_T + 1) + nl - 1];
         svp = probit ? 2.0 : raw;
-        cfp = gg_fma(-mu0, svp, probit ? raw : (double)s_a[nl * EIG_T + nl - 1]);
+        cfp = gg_fma(-mu0, svp, probit ? raw : ka * (double)s_a[nl * EIG_T + nl - 1]);
       }
       if (lup) {
         double v = gg_fma(svp, dPl, s_st[le]);
@@ -607,7 +621,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
         const int i = act ? ui[r] : 0, e = ue[r];
         sv[r] = s_S[i * (EIG_T + 1) + k];
         dd[r] = (e < NEG) ? s_dP[k * NEGM + e] : s_dF[k * DM + (e - NEG)];
-        aa[r] = (double)s_a[i * EIG_T + k];
+        aa[r] = ka * (double)s_a[i * EIG_T + k];
       }
       asm volatile("" ::: "memory");
 #pragma unroll
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
 template <int DM>
 __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const double* __restrict__ S,
                                                     const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
-                                                    const double* __restrict__ F, double* __restrict__ gpart, int probit) {
+                                                    const double* __restrict__ F, double* __restrict__ gpart, int probit, double ka) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   constexpr int NGM = 2 + 2 * DM + NEGM;
   double acc[NGM];
@@ -644,7 +658,7 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
   for (int j = i + 1 + threadIdx.x; j < N; j += 256) {
     const double raw = S[(size_t)i * Np + j];
     const double s = probit ? 2.0 : raw;
-    const double a = probit ? raw : (double)((int)A[(size_t)i * Np + j] + (int)AT[(size_t)i * Np + j] - 1);
+    const double a = probit ? raw : ka * (double)((int)A[(size_t)i * Np + j] + (int)AT[(size_t)i * Np + j] - 1);
     double g[DM];
 #pragma unroll
     for (int d = 0; d < DM; ++d) g[d] = d < D ? fi[d] * F[(size_t)j * D + d] : 0.0;
@@ -682,7 +696,7 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, 
                                                           double* __restrict__ lmbda, double* __restrict__ mu0p,
                                                           const double* __restrict__ mu_lmbda, double mu_mu_0,
                                                           double sigma_mu0, double sigma_lmbda, int do_mu0, int do_lmbda,
-                                                          uint64_t seed, uint32_t sweep, int* __restrict__ status, int probit) {
+                                                          uint64_t seed, uint32_t sweep, int* __restrict__ status, int probit, double ka) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   constexpr int NGM = 2 + 2 * DM + NEGM;
   __shared__ double s_tot[NGM + 2];
@@ -704,7 +718,7 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, 
   // diagonal: sum omega_ii and sum (A_ii - 1/2)
   double so = 0.0, sk = 0.0;
   if (!probit)   // (the probit bias update leaves the diagonal out altogether: eigenmodel.py:339-346)
-    for (int i = tid; i < N; i += 256) { so += dO[i]; sk += (dA[i] ? 1.0 : 0.0) - 0.5; }
+    for (int i = tid; i < N; i += 256) { so += dO[i]; sk += ka * ((dA[i] ? 1.0 : 0.0) - 0.5); }
   for (int dl = 32; dl >= 1; dl >>= 1) { so += __shfl_down(so, dl); sk += __shfl_down(sk, dl); }
   if ((tid & 63) == 0) { s_w[tid >> 6][0] = so; s_w[tid >> 6][1] = sk; }
   __syncthreads();
@@ -807,6 +821,7 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   e->cfg = *cfg;
   e->N = cfg->N; e->D = cfg->D; e->Np = gg_round_up(cfg->N, 64);
   e->probit = cfg->kind == GG_PROBIT_EIG ? 1 : 0;
+  e->beta = 1.0;
   e->DM = cfg->D <= 4 ? 4 : 8;
   e->NEG = e->D * (e->D + 1) / 2; e->NE = e->NEG + e->D;
   e->NG = 2 + 2 * e->DM + e->DM * (e->DM + 1) / 2;
@@ -896,6 +911,8 @@ int gg_eigen_get_state(gg_eigen* e, int id, void* buf, size_t nbytes) {
     else { CALL(8); }                      \
   } while (0)
 
+void gg_eigen_set_beta(gg_eigen* e, double beta) { e->beta = beta; }
+
 int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   if (!d) return gg_fail(GG_ERR_INVALID, "null data handle");
   if (d->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, e->N);
@@ -912,7 +929,7 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
       EIG_DISPATCH(CALL);
 #undef CALL
     } else {
-#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO)
+#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -945,7 +962,7 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     const size_t part_stride = (size_t)EIG_T * e->NCH * e->NE;
     {
       dim3 grd(N < EIG_T ? N : EIG_T, e->NCH);
-#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, 0, e->probit)
+#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, 0, e->probit, e->beta)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -958,10 +975,10 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
 #define CALL(DMV)                                                                                                      \
   if (D == DMV)                                                                                                        \
     k_eig_chain<DMV, true><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,       \
-                                                         e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit); \
+                                                         e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit, e->beta); \
   else                                                                                                                 \
     k_eig_chain<DMV, false><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,      \
-                                                          e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit)
+                                                          e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit, e->beta)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -970,10 +987,10 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   const int do_lm = ((parts & GG_PART_LMBDA) && !e->cfg.lmbda_given) ? 1 : 0;
   if (do_mu0 || do_lm) {
 #define CALL(DMV)                                                                                                   \
-  k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart, e->probit);    \
+  k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart, e->probit, e->beta);    \
   k_eig_draw_globals<DMV><<<1, 256, 0, st>>>(N, (N < 512 ? N : 512), D, e->gpart, e->dO, d->dA, e->lmbda, e->mu0, e->mu_lmbda,            \
                                              e->cfg.mu_mu_0, e->cfg.sigma_mu0, e->cfg.sigma_lmbda, do_mu0, do_lm,   \
-                                             e->cfg.seed, e->sweep, e->status, e->probit)
+                                             e->cfg.seed, e->sweep, e->status, e->probit, e->beta)
     EIG_DISPATCH(CALL);
 #undef CALL
   }

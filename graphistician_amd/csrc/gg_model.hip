@@ -20,6 +20,7 @@ int gg_eigen_destroy(gg_eigen* e);
 int gg_eigen_set_state(gg_eigen* e, int id, const void* buf, size_t nbytes);
 int gg_eigen_get_state(gg_eigen* e, int id, void* buf, size_t nbytes);
 int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts);
+void gg_eigen_set_beta(gg_eigen* e, double beta);
 int gg_eigen_log_likelihood(gg_eigen* e, const gg_data* d, double* out);
 int gg_eigen_stats(gg_eigen* e, gg_stats* out);
 struct gg_latent;  // gg_latent.hip
@@ -1266,9 +1267,10 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
-  if (beta != 1.0 && m->eig)
-    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: block models only (the reference leaves the eigenmodel's undefined, graph_models.py:478)");
+  if (beta != 1.0 && m->eig && m->kind == GG_PROBIT_EIG)
+    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: not defined for the probit eigenmodel (the truncated-normal augmentation has no tempered counterpart)");
   if (m->eig) {
+    gg_eigen_set_beta(m->eig, beta);   // logistic link: PG(beta, psi) augmentation (build-defined; the reference leaves it a TODO, graph_models.py:478)
     for (int s = 0; s < n_sweeps; ++s) {
       int rc = gg_eigen_resample(m->eig, d, GG_PART_ALL);
       if (rc) return rc;
@@ -1367,9 +1369,9 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
-  if (beta != 1.0 && m->eig)
-    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: block models only (the reference leaves the eigenmodel's undefined, graph_models.py:478)");
-  if (m->eig) return gg_eigen_resample(m->eig, d, parts);
+  if (beta != 1.0 && m->eig && m->kind == GG_PROBIT_EIG)
+    return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: not defined for the probit eigenmodel (the truncated-normal augmentation has no tempered counterpart)");
+  if (m->eig) { gg_eigen_set_beta(m->eig, beta); return gg_eigen_resample(m->eig, d, parts); }
   if (m->ld) { gg_latent_set_beta(m->ld, beta); return gg_latent_resample(m->ld, d, parts, 0); }
   int rc = model_sync(m);
   if (rc) return rc;

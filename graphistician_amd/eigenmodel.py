@@ -119,31 +119,33 @@ class LogisticEigenmodel(AdjacencyDistribution, GibbsSampling, EngineBacked):
         P = np.clip(1.0 / (1.0 + np.exp(-Mu)), 1e-16, 1 - 1e-16)
         return P[-1, :], P[:, -1]
 
-    def _run(self, A, parts):
+    def _run(self, A, parts, beta=1.0):
         d = self._data(A)
         assert d.N == self.N
         eng = self._engine()
         if parts == _abi.PART_ALL:
-            eng.resample(d, 1)
+            eng.resample(d, 1, beta)
         else:
-            eng.resample_part(d, parts)
+            eng.resample_part(d, parts, beta)
         self._mark_stale("F", "lmbda", "_mu0")
 
-    def resample(self, A):
-        """eigenmodel.py:836-857: Omega -> F -> mu_0 -> lambda."""
-        self._run(A, _abi.PART_ALL)
+    def resample(self, A, beta=1.0):
+        """eigenmodel.py:836-857: Omega -> F -> mu_0 -> lambda.  beta < 1 tempers the likelihood for AIS: BUILD-DEFINED (the
+        reference leaves it a TODO, graph_models.py:478) - omega ~ PG(beta, psi), kappa = beta (A - 1/2); the PG(beta, .)
+        draw for a real shape is the truncated gamma-sum representation (csrc/spec/gg_pg.h), approximate by construction."""
+        self._run(A, _abi.PART_ALL, beta)
 
-    def _resample_Omega(self, A):
-        self._run(A, _abi.PART_OMEGA)
+    def _resample_Omega(self, A, beta=1.0):
+        self._run(A, _abi.PART_OMEGA, beta)
 
-    def _resample_F(self, A):
-        self._run(A, _abi.PART_F)
+    def _resample_F(self, A, beta=1.0):
+        self._run(A, _abi.PART_F, beta)
 
-    def _resample_mu_0(self, A):
-        self._run(A, _abi.PART_MU0)
+    def _resample_mu_0(self, A, beta=1.0):
+        self._run(A, _abi.PART_MU0, beta)
 
-    def _resample_lmbda(self, A):
-        self._run(A, _abi.PART_LMBDA)
+    def _resample_lmbda(self, A, beta=1.0):
+        self._run(A, _abi.PART_LMBDA, beta)
 
 
 class ProbitEigenmodel(LogisticEigenmodel):

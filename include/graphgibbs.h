@@ -166,7 +166,9 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes);
 
 /* n_sweeps x resample(data): adjacency.py:615-618 / weights.py:394-397 /
  * adjacency.py:153-181 / weights.py:154-162 / eigenmodel.py:836-857.
- * beta is the AIS inverse temperature (graph_models.py:50-64); 1.0 = plain Gibbs. */
+ * beta is the AIS inverse temperature (graph_models.py:50-64); 1.0 = plain Gibbs.  Defined by the reference for the
+ * ER / SBM adjacency models; build-defined for the weight kinds (statistics x beta), the latent-distance models (likelihood
+ * term x beta) and GG_LOGISTIC_EIG (omega ~ PG(beta, psi), kappa x beta); GG_PROBIT_EIG returns GG_ERR_UNSUPPORTED for beta != 1. */
 int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta);
 int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta);
 /* Stream-ordered form: gg_resample_async enqueues n_sweeps sweeps on the model's HIP stream and

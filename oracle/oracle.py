@@ -268,8 +268,8 @@ PART_EIG_ALL = 120
 
 
 def eig_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given, seed, sweep,
-              parts=PART_EIG_ALL, Omega=None):
-    """In-place sweep of (F, lmbda); returns (mu_0, Omega)."""
+              parts=PART_EIG_ALL, Omega=None, beta=1.0):
+    """In-place sweep of (F, lmbda); returns (mu_0, Omega).  beta < 1: tempered likelihood (build-defined, PG(beta, psi))."""
     N, D = F.shape
     A8, pA = _u8(A != 0)
     if Omega is None:
@@ -278,7 +278,7 @@ def eig_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lm
     rc = lib().orc_eig_sweep(N, D, pA, _f64(F), _f64(lmbda), C.byref(mu), _f64(Omega),
                              _f64(np.ascontiguousarray(mu_lmbda, dtype=np.float64)), C.c_double(mu_mu_0),
                              C.c_double(sigma_mu0), C.c_double(sigma_F), C.c_double(sigma_lmbda), int(lmbda_given),
-                             C.c_uint64(seed), C.c_uint32(sweep), int(parts))
+                             C.c_uint64(seed), C.c_uint32(sweep), int(parts), C.c_double(beta))
     if rc:
         raise RuntimeError("oracle eig_sweep failed rc=%d" % rc)
     return mu.value, Omega
@@ -328,6 +328,12 @@ def truncnorm_vec(u, mu, a):
     a = np.ascontiguousarray(a, dtype=np.int32)
     out = np.empty_like(u)
     lib().orc_truncnorm_vec(_f64(u), _f64(mu), _i32(a), _f64(out), C.c_longlong(u.size))
+    return out
+
+
+def pg_frac_vec(seed, b, z, n):
+    out = np.empty(n)
+    lib().orc_pg_frac_vec(C.c_uint64(seed), C.c_double(b), C.c_double(z), _f64(out), C.c_longlong(n))
     return out
 
 

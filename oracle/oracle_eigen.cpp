@@ -34,16 +34,26 @@ static double eig_psi(int N, int D, const double* F, const double* lmbda, double
 }
 
 // eigenmodel.py:859-874 _resample_Omega: omega_ij ~ PG(1, Mu_ij) for all N^2 entries.
+// beta != 1 (AIS; build-defined, the reference leaves it a TODO at graph_models.py:478): the likelihood to the power beta
+// is augmented with omega_ij ~ PG(beta, Mu_ij) and kappa = beta (A - 1/2) (spec/gg_pg.h: gg_pg_frac).
 void orc_eig_resample_omega(int N, int D, const double* F, const double* lmbda, double mu_0, uint64_t seed,
-                            uint32_t sweep, double* Omega) {
+                            uint32_t sweep, double* Omega, double beta) {
   for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j)
-      Omega[(size_t)i * N + j] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)i, (uint32_t)j, eig_psi(N, D, F, lmbda, mu_0, i, j));
+    for (int j = 0; j < N; ++j) {
+      const double psi = eig_psi(N, D, F, lmbda, mu_0, i, j);
+      if (beta == 1.0) Omega[(size_t)i * N + j] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)i, (uint32_t)j, psi);
+      else if (beta == 0.0) Omega[(size_t)i * N + j] = 0.0;
+      else {
+        gg_stream s;
+        gg_stream_init(&s, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j);
+        Omega[(size_t)i * N + j] = gg_pg_frac(&s, beta, psi);
+      }
+    }
 }
 
 // eigenmodel.py:876-908 _resample_F: sequential over nodes, F[n] updated in place.
 int orc_eig_resample_F(int N, int D, const uint8_t* A, const double* Omega, double* F, const double* lmbda,
-                       double mu_0, double sigma_F, uint64_t seed, uint32_t sweep) {
+                       double mu_0, double sigma_F, uint64_t seed, uint32_t sweep, double beta) {
   std::vector<double> prec((size_t)D * D), h(D), z(D), x(D);
   for (int n = 0; n < N; ++n) {
     for (int a = 0; a < D * D; ++a) prec[a] = 0.0;
@@ -52,8 +62,8 @@ int orc_eig_resample_F(int N, int D, const uint8_t* A, const double* Omega, doub
       if (nn == n) continue;
       const double o1 = Omega[(size_t)n * N + nn], o2 = Omega[(size_t)nn * N + n];
       // O * zcent = kappa - O mu_0 with kappa = A - 1/2 (eigenmodel.py:813-820,892)
-      const double k1 = (A[(size_t)n * N + nn] ? 1.0 : 0.0) - 0.5 - o1 * mu_0;
-      const double k2 = (A[(size_t)nn * N + n] ? 1.0 : 0.0) - 0.5 - o2 * mu_0;
+      const double k1 = beta * ((A[(size_t)n * N + nn] ? 1.0 : 0.0) - 0.5) - o1 * mu_0;
+      const double k2 = beta * ((A[(size_t)nn * N + n] ? 1.0 : 0.0) - 0.5) - o2 * mu_0;
       const double* f = F + (size_t)nn * D;
       for (int a = 0; a < D; ++a) {
         for (int b = 0; b < D; ++b) prec[a * D + b] += f[a] * f[b] * lmbda[a] * lmbda[b] * (o1 + o2);
@@ -69,14 +79,14 @@ int orc_eig_resample_F(int N, int D, const uint8_t* A, const double* Omega, doub
 
 // eigenmodel.py:910-932 _resample_mu_0.
 double orc_eig_resample_mu0(int N, int D, const uint8_t* A, const double* Omega, const double* F,
-                            const double* lmbda, double mu_mu_0, double sigma_mu0, uint64_t seed, uint32_t sweep) {
+                            const double* lmbda, double mu_mu_0, double sigma_mu0, uint64_t seed, uint32_t sweep, double beta) {
   double prec = 1.0 / sigma_mu0, h = mu_mu_0 / sigma_mu0;
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
       const double o = Omega[(size_t)i * N + j];
       prec += o;
       const double fdf = (i == j) ? 0.0 : eig_psi(N, D, F, lmbda, 0.0, i, j);
-      h += ((A[(size_t)i * N + j] ? 1.0 : 0.0) - 0.5) - o * fdf;
+      h += beta * ((A[(size_t)i * N + j] ? 1.0 : 0.0) - 0.5) - o * fdf;
     }
   const double var = 1.0 / prec;
   return var * h + gg_sqrt(var) * gg_normal_at(seed, GG_SITE_EIG_MU0, sweep, 0u);
@@ -84,14 +94,14 @@ double orc_eig_resample_mu0(int N, int D, const uint8_t* A, const double* Omega,
 
 // eigenmodel.py:934-965 _resample_lmbda.
 int orc_eig_resample_lmbda(int N, int D, const uint8_t* A, const double* Omega, const double* F, double* lmbda,
-                           double mu_0, const double* mu_lmbda, double sigma_lmbda, uint64_t seed, uint32_t sweep) {
+                           double mu_0, const double* mu_lmbda, double sigma_lmbda, uint64_t seed, uint32_t sweep, double beta) {
   std::vector<double> prec((size_t)D * D, 0.0), h(D), z(D), x(D);
   for (int a = 0; a < D; ++a) { prec[a * D + a] = 1.0 / sigma_lmbda; h[a] = mu_lmbda[a] / sigma_lmbda; }
   for (int n1 = 0; n1 < N; ++n1)
     for (int n2 = n1 + 1; n2 < N; ++n2) {
       const double o12 = Omega[(size_t)n1 * N + n2], o21 = Omega[(size_t)n2 * N + n1];
-      const double k12 = (A[(size_t)n1 * N + n2] ? 1.0 : 0.0) - 0.5 - o12 * mu_0;
-      const double k21 = (A[(size_t)n2 * N + n1] ? 1.0 : 0.0) - 0.5 - o21 * mu_0;
+      const double k12 = beta * ((A[(size_t)n1 * N + n2] ? 1.0 : 0.0) - 0.5) - o12 * mu_0;
+      const double k21 = beta * ((A[(size_t)n2 * N + n1] ? 1.0 : 0.0) - 0.5) - o21 * mu_0;
       const double* f1 = F + (size_t)n1 * D;
       const double* f2 = F + (size_t)n2 * D;
       for (int a = 0; a < D; ++a) {
@@ -109,16 +119,16 @@ int orc_eig_resample_lmbda(int N, int D, const uint8_t* A, const double* Omega, 
 // (N x N) so that tests can inspect it.
 int orc_eig_sweep(int N, int D, const uint8_t* A, double* F, double* lmbda, double* mu_0, double* Omega,
                   const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
-                  int lmbda_given, uint64_t seed, uint32_t sweep, int parts) {
+                  int lmbda_given, uint64_t seed, uint32_t sweep, int parts, double beta) {
   if (D > GG_MAXD) return -1;
-  if (parts & ORC_PART_OMEGA) orc_eig_resample_omega(N, D, F, lmbda, *mu_0, seed, sweep, Omega);
+  if (parts & ORC_PART_OMEGA) orc_eig_resample_omega(N, D, F, lmbda, *mu_0, seed, sweep, Omega, beta);
   if (parts & ORC_PART_F) {
-    int rc = orc_eig_resample_F(N, D, A, Omega, F, lmbda, *mu_0, sigma_F, seed, sweep);
+    int rc = orc_eig_resample_F(N, D, A, Omega, F, lmbda, *mu_0, sigma_F, seed, sweep, beta);
     if (rc) return rc;
   }
-  if (parts & ORC_PART_MU0) *mu_0 = orc_eig_resample_mu0(N, D, A, Omega, F, lmbda, mu_mu_0, sigma_mu0, seed, sweep);
+  if (parts & ORC_PART_MU0) *mu_0 = orc_eig_resample_mu0(N, D, A, Omega, F, lmbda, mu_mu_0, sigma_mu0, seed, sweep, beta);
   if ((parts & ORC_PART_LMBDA) && !lmbda_given) {
-    int rc = orc_eig_resample_lmbda(N, D, A, Omega, F, lmbda, *mu_0, mu_lmbda, sigma_lmbda, seed, sweep);
+    int rc = orc_eig_resample_lmbda(N, D, A, Omega, F, lmbda, *mu_0, mu_lmbda, sigma_lmbda, seed, sweep, beta);
     if (rc) return rc;
   }
   return 0;
@@ -134,6 +144,15 @@ double orc_eig_loglik(int N, int D, const uint8_t* A, const double* F, const dou
       ll += A[(size_t)i * N + j] ? log(P) : log(1.0 - P);
     }
   return ll;
+}
+
+// PG(b, z) draws with a real shape 0 < b < 1 (gg_pg_frac) for distributional tests.
+void orc_pg_frac_vec(uint64_t seed, double b, double z, double* out, long long n) {
+  for (long long i = 0; i < n; ++i) {
+    gg_stream s;
+    gg_stream_init(&s, seed, GG_SITE_EIG_OMEGA, 1u, (uint32_t)i);
+    out[i] = gg_pg_frac(&s, b, z);
+  }
 }
 
 // PG(1, z) draws for distributional tests: n draws, stream index = i.

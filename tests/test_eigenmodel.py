@@ -170,6 +170,91 @@ def test_engine_chain_matches_oracle():
     assert np.isfinite(m.log_probability(A))
 
 
+# ================================================================ tempered logistic eigenmodel (AIS; build-defined)
+def test_pg_fractional_shape_sampler():
+    """PG(b, z) for a real shape 0 < b <= 1 (spec/gg_pg.h gg_pg_frac: truncated gamma-sum representation + mean of the
+    remainder): first two moments E = b tanh(z/2) / (2z), Var = b (sinh z - z) / (4 z^3 cosh^2(z/2)) (PSW 2013), and at
+    b = 1 the same law as the exact Devroye sampler."""
+    n = 40000
+    for b, z in [(0.5, 0.0), (0.3, 1.5), (0.9, 4.0), (0.05, 0.7)]:
+        x = O.pg_frac_vec(5, b, z, n)
+        if z == 0.0:
+            mean, var = b / 4.0, b / 24.0
+        else:
+            mean, var = b / (2 * z) * np.tanh(z / 2), b * (np.sinh(z) - z) / (4 * z ** 3 * np.cosh(z / 2) ** 2)
+        assert np.all(x > 0)
+        assert abs(x.mean() - mean) < 5 * np.sqrt(var / n)
+        assert abs(x.var() - var) < 0.06 * var
+    assert stats.ks_2samp(O.pg1_vec(7, 2.0, n), O.pg_frac_vec(9, 1.0, 2.0, n)).pvalue > 1e-3
+
+
+def test_tempered_oracle_limits():
+    """beta = 1 is the plain sweep bit for bit; beta = 0 targets the prior whatever the data (F ~ N(0, sigma_F I),
+    mu_0 ~ N(mu_mu_0, sigma_mu0), lambda ~ N(mu_lambda, sigma_lambda I))."""
+    N, D = 12, 2
+    A, F, lmbda, mu_0 = make_case(N, D, 5)
+    F1, l1 = F.copy(), lmbda.copy()
+    F2, l2 = F.copy(), lmbda.copy()
+    m1, _ = O.eig_sweep(A, F1, l1, mu_0, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 11, 0)
+    m2, _ = O.eig_sweep(A, F2, l2, mu_0, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 11, 0, beta=1.0)
+    assert np.array_equal(F1, F2) and np.array_equal(l1, l2) and m1 == m2
+    fs, ms, ls = [], [], []
+    for sw in range(1500):
+        mu_0, Om = O.eig_sweep(A, F, lmbda, mu_0, np.zeros(D), -0.3, 2.0, 1.5, 0.5, 0, 12, sw, beta=0.0)
+        assert not Om.any()
+        fs.append(F[3, 1]); ms.append(mu_0); ls.append(lmbda[0])
+    assert stats.kstest(np.array(fs) / np.sqrt(1.5), "norm").pvalue > 1e-3
+    assert stats.kstest((np.array(ms) + 0.3) / np.sqrt(2.0), "norm").pvalue > 1e-3
+    assert stats.kstest(np.array(ls) / np.sqrt(0.5), "norm").pvalue > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,beta", [(70, 3, 0.4), (130, 8, 0.75), (40, 2, 0.0)])
+def test_engine_tempered_sweeps_match_oracle(N, D, beta):
+    """Tempered sweeps of the engine against the oracle's same (build-defined) definition, part by part and as a chain."""
+    from graphistician_amd import _abi as abi
+    A, F, lmbda, mu_0 = make_case(N, D, 31 + N)
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=313, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=-0.3,
+                  lmbda_given=0)
+    m.set(abi.ST_F, F); m.set(abi.ST_LMBDA, lmbda); m.set(abi.ST_MU0, np.array([mu_0])); m.set(abi.ST_MU_LMBDA, np.zeros(D))
+    Fo, lo, mo = F.copy(), lmbda.copy(), mu_0
+    # the auxiliaries alone: S = Omega + Omega^T off the diagonal, Omega_ii on it
+    m.resample_part(d, abi.PART_OMEGA, beta)
+    _, Om = O.eig_sweep(A, Fo, lo, mo, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 313, 0, parts=O.PART_OMEGA, beta=beta)
+    S = m.get(abi.ST_OMEGA_S, (N, N))
+    ref = Om + Om.T
+    ref[np.arange(N), np.arange(N)] = np.diag(Om)
+    assert np.allclose(S, ref, rtol=1e-9, atol=1e-14)
+    # the rest of the sweep, then two more full ones
+    for part in (abi.PART_F, abi.PART_MU0, abi.PART_LMBDA):
+        m.resample_part(d, part, beta)
+    mo, _ = O.eig_sweep(A, Fo, lo, mo, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 313, 0, Omega=Om,
+                        parts=O.PART_F | O.PART_MU0 | O.PART_LMBDA, beta=beta)
+    assert np.allclose(m.get(abi.ST_F, (N, D)), Fo, rtol=1e-7, atol=1e-9)
+    assert np.allclose(m.get(abi.ST_LMBDA, (D,)), lo, rtol=1e-7, atol=1e-9) and abs(m.get(abi.ST_MU0, (1,))[0] - mo) < 1e-8
+
+
+@pytest.mark.gpu
+def test_engine_ais_logistic_eigenmodel_vs_er():
+    """AIS with the tempered logistic eigenmodel: on a network with latent-feature structure its evidence beats the
+    Erdos-Renyi model's closed-form evidence; on a structureless network it does not beat it by much."""
+    from graphistician_amd.eigenmodel import LogisticEigenmodel
+    from graphistician_amd.ais import estimate_marginal_likelihood
+    from scipy.special import betaln
+    rng = np.random.RandomState(4)
+    N, D = 24, 2
+    F = rng.randn(N, D) * 1.6
+    psi = F.dot(F.T) * 1.0 - 0.5
+    A = (rng.rand(N, N) < 1 / (1 + np.exp(-psi))).astype(np.uint8)
+    n1 = int(A.sum())
+    er = betaln(1 + n1, 1 + N * N - n1) - betaln(1, 1)
+    np.random.seed(3)
+    m = LogisticEigenmodel(N, D, p=0.4, lmbda=np.ones(D), seed=77)
+    lz = estimate_marginal_likelihood(m, A, N_samples=8, B=60, steps_per_B=2)
+    assert np.isfinite(lz) and lz > er + 10.0, (lz, er)
+
+
 # ================================================================ probit eigenmodel (eigenmodel.py:223-379)
 def probit_F_conditional(Z, F, lmbda, mu_0, sigma_F, n):
     """eigenmodel.py:301-321 written out with numpy."""
