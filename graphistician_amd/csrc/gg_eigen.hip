@@ -463,6 +463,13 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
     for (int nl = 0; nl < T; ++nl) {
       const int n = t0 + nl;
       const double* s_st = s_part + nl * (NEGM + DM);
+      // pair weight and centred pair value of (this node, the previous one): tile constants, read before the wait
+      double svp = 0.0, cfp = 0.0;
+      if (nl >= 1) {
+        const double raw = s_S[nl * (EIG_T + 1) + nl - 1];
+        svp = probit ? 2.0 : raw;
+        cfp = gg_fma(-mu0, svp, probit ? raw : ka * (double)s_a[nl * EIG_T + nl - 1]);
+      }
       const long long c0 = dbg ? clock64() : 0;
       if (!ready) {
         for (int spin = 0;; ++spin) {
@@ -479,12 +486,6 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
       const long long c1 = dbg ? clock64() : 0;
       // statistics of this node with the previous node's change folded in (same order as the updaters':
       // earlier changes first, the previous node's last), one entry per lane
-      double svp = 0.0, cfp = 0.0;
-      if (nl >= 1) {
-        const double raw = s_S[nl * (EIG_T + 1) + nl - 1];
-        svp = probit ? 2.0 : raw;
-        cfp = gg_fma(-mu0, svp, probit ? raw : ka * (double)s_a[nl * EIG_T + nl - 1]);
-      }
       if (lup) {
         double v = gg_fma(svp, dPl, s_st[le]);
         if (li == lj) v += inv_sigma_F;
