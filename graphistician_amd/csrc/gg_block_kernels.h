@@ -910,21 +910,11 @@ __device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n,
 // nodes per workgroup.  The workgroup first stages its nodes' statistics (one
 // coalesced round of loads) and, when they fit, the coefficient tables in LDS:
 // the per-j loop then never waits on global memory.
+// The evaluation itself (all 256 threads of the workgroup): returns the drawn label of node *n_out for lane (i, k).
 template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
-                                                   uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
-                                                   double* __restrict__ lp_out, const int32_t* __restrict__ ctl,
-                                                   int stage_tables, int sweep_from_ctl, int round_mode, int32_t* __restrict__ ap) {
-  if (round_mode) {            // device-driven restart round: start where the scan stands, unless it is done
-    if (ctl[7]) return;
-    n_begin = ctl[0];
-    const int first = (int)blockIdx.x * (256 / x.Kp);
-    if (n_begin + first >= x.N) return;
-    if (ctl[8] > 0 && first >= ctl[8]) return;   // adaptive window chosen by the last resolve
-  } else if (ctl && ctl[4]) {
-    return;
-  }
-  if (sweep_from_ctl) sweep = (uint32_t)ctl[6];
+__device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, uint64_t seed, uint32_t site, uint32_t sweep,
+                                            int lp_node, double* __restrict__ lp_out, int stage_tables, int* n_out,
+                                            bool* live_out) {
   constexpr int NSI = ADJ ? 0 : NT - 1;
   extern __shared__ __align__(16) unsigned char s_spec[];
   const int K = x.K, Kp = x.Kp;
@@ -979,8 +969,30 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
   else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
   if (lp_out && nn == lp_node && live && k < K) lp_out[k] = lp;
   double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
-  int lab = gg_group_categorical(lp, k, K, Kp, u);
-  if (live && k == 0) {
+  *n_out = n;
+  *live_out = live;
+  return gg_group_categorical(lp, k, K, Kp, u);
+}
+
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
+                                                   uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
+                                                   double* __restrict__ lp_out, const int32_t* __restrict__ ctl,
+                                                   int stage_tables, int sweep_from_ctl, int round_mode, int32_t* __restrict__ ap) {
+  if (round_mode) {            // device-driven restart round: start where the scan stands, unless it is done
+    if (ctl[7]) return;
+    n_begin = ctl[0];
+    const int first = (int)blockIdx.x * (256 / x.Kp);
+    if (n_begin + first >= x.N) return;
+    if (ctl[8] > 0 && first >= ctl[8]) return;   // adaptive window chosen by the last resolve
+  } else if (ctl && ctl[4]) {
+    return;
+  }
+  if (sweep_from_ctl) sweep = (uint32_t)ctl[6];
+  int n;
+  bool live;
+  const int lab = gg_spec_eval<NT, ADJ>(x, n_begin, seed, site, sweep, lp_node, lp_out, stage_tables, &n, &live);
+  if (live && threadIdx.x % x.Kp == 0) {
     cand[n] = lab;
     if (ap) ap[n] = 0;   // no entry of this scan's change list is applied to the node yet
   }

@@ -209,6 +209,11 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
       (rc = dmalloc(&m->Tout, (size_t)K * NT * m->Kp)) || (rc = dmalloc(&m->Tin, (size_t)K * NT * m->Kp)) ||
       (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 32)) || (rc = dmalloc(&m->lp_out, K)))
     return rc;
+  {
+    // the 64-bit word the workgroups report their first changer to starts (and is always left) at "none"
+    const unsigned long long none = GG_NO_CHANGE;
+    GG_HIP(hipMemcpy(m->rs + GG_RS_MIN, &none, sizeof(none), hipMemcpyHostToDevice));
+  }
   m->Gbytes = (size_t)2 * K * m->Np * (sizeof(int32_t) + (size_t)m->NSI * sizeof(long long));
   for (int b = 0; b < 2; ++b) {
     if ((rc = dmalloc(&m->Gbuf[b], m->Gbytes))) return rc;
@@ -661,6 +666,45 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
   return GG_OK;
 }
 
+// k_speculate + the common case of k_resolve in one launch (k_spec_resolve): the speculative form of the adaptive scan.
+static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, int pw) {
+  gg_resolve_args g;
+  g.x = node_ctx(m, d, buf);
+  g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
+  g.tail_m = 0; g.tail_sort = 1;
+  g.m = m->m; g.pi = m->pi; g.perm = m->permb[pw]; g.lab_start = m->labb[pw];
+  g.perm_prev = m->permb[1 - pw]; g.lab_start_prev = m->labb[1 - pw];
+  g.flush_on_change = 0; g.sweep_from_ctl = 0; g.round_mode = 0; g.window = 0; g.stage_tables = 0;
+  g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
+  g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
+  g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
+  g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
+  g.dbg = nullptr;
+  g.keep_L = 0;
+  const int K = m->K, per = 256 / m->Kp;
+  const int nb = (m->Nl + per - 1) / per;
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
+  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += table_bytes(m);
+  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+#define SPR(NTV, ADJV)                                                                                                     \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set && lds > 48 * 1024) {                                                                                    \
+      GG_HIP(hipFuncSetAttribute((const void*)k_spec_resolve<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    k_spec_resolve<NTV, ADJV><<<nb, 256, lds, m->stream>>>(g, stage, m->ap);                                                \
+  } while (0)
+  if (m->is_adj) SPR(2, true);
+  else if (m->B == 1) SPR(3, false);
+  else if (m->B == 2) SPR(6, false);
+  else SPR(15, false);
+#undef SPR
+  GG_HIP(hipGetLastError());
+  return GG_OK;
+}
+
 // The tail of a completed scan sorts the final labels into perm buffer `pw` (default: the other one).
 static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort,
                           int pw = -1, bool flush_on_change = false, bool from_ctl = false, int round_window = 0) {
@@ -926,6 +970,10 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
   if (scan) {
     if (m->use_scan) {
       if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P))) return rc;
+    } else if (m->scan_pref < 0 && !getenv("GG_NO_FUSED_SPEC")) {
+      // adaptive form, quiet phase: speculation and the resolution of the common case in one launch; a scan that does
+      // change a label is left stalled behind its first change for the resident grid (finish_scan)
+      if ((rc = launch_spec_resolve(m, d, buf, sweep, 1 - P))) return rc;
     } else {
       if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
       if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
