@@ -255,7 +255,9 @@ def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin)
         O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 82, s)
     assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p)
     assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu)
-    if spin == 1:      # (with a few more polls the 25 workgroups sometimes do meet in time: then nothing is printed)
+    # (with a few more polls the 25 workgroups sometimes do meet in time, and the pipelined form never runs the resident
+    # scan: then nothing is printed)
+    if spin == 1 and os.environ.get("GG_PIPELINE") != "1":
         assert "timed out" in capfd.readouterr().err
 
 
