@@ -364,8 +364,8 @@ def main():
                     help="sbm = BASELINE.json configs[1] (default, the headline); eigen = configs[2]")
     ap.add_argument("--latent", type=int, default=8)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nodes", type=int, default=4096)
     ap.add_argument("--blocks", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
