@@ -369,6 +369,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=4096)
     ap.add_argument("--blocks", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
+    ap.add_argument("--burnin", type=int, default=30,
+                    help="sweeps run as part of chain set-up, before the W warm-up steps: the chain starts from a prior draw "
+                         "and relabels thousands of nodes in its first few sweeps; the metric is the sampler's steady state")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the multi-process protocol (rendezvous, barrier, max-over-ranks) without the engine")
@@ -445,6 +448,8 @@ def main():
     chain_seed = int(os.environ.get("GG_BENCH_CHAIN_SEED", "1"))
     adj, w = build_models(abi, N, K, chain_seed=chain_seed, device=device)
 
+    if args.burnin > 0:          # set-up: out of the prior draw's transient (SBM config: --burnin)
+        abi.resample_many([adj, w], data, args.burnin)
     for _ in range(args.warmup):
         adj.resample(data, 1)
         w.resample(data, 1)
@@ -500,7 +505,7 @@ def main():
                     N, K, "BASELINE.json configs[1]" if (N, K) == (4096, 16) else
                     ("BASELINE.json configs[3] on one GPU" if (N, K) == (65536, 64) else "same recipe, other size")),
                 "parallelism": "one replica of the chain per GPU, no collective" if world > 1 else "single GPU",
-                "chain_seed": chain_seed,
+                "chain_seed": chain_seed, "burn_in_sweeps": args.burnin,
                 "label_changes_in_timed_region": int(chg),
                 "sweep_algorithmic_bytes": sweep_bytes,
                 "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9,
@@ -537,6 +542,8 @@ def main():
             try:
                 os.environ["GG_INCREMENTAL"] = "1"
                 adj_i, w_i = build_models(abi, N, K, chain_seed=chain_seed, device=device)
+                if args.burnin > 0:
+                    abi.resample_many([adj_i, w_i], data, args.burnin)
                 for _ in range(args.warmup):
                     adj_i.resample(data, 1); w_i.resample(data, 1)
                 t0i = time.perf_counter()
