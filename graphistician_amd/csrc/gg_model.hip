@@ -350,7 +350,7 @@ static int state_ptr(gg_model* m, int id, void** p, size_t* nbytes) {
   return *p ? GG_OK : GG_ERR_INVALID;
 }
 
-static int model_sync(gg_model* m);
+static int model_sync(gg_model* m, bool ctl_fresh = false);
 static int drain_pipe(gg_model* m);
 
 int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
@@ -1156,16 +1156,19 @@ static int collect_timing(gg_model* m) {
 
 // Confirm the optimistic sweeps: if a scan stalled (or flushed the pipeline), finish it on the slow
 // path and re-enqueue the sweeps that became no-ops behind it.
-static int model_sync(gg_model* m) {
+// ctl_fresh: the caller has already recorded ev_call1, copied the control block to h_rs and waited for it
+// (gg_sync_many overlaps that round trip over all its models).
+static int model_sync(gg_model* m, bool ctl_fresh) {
   if (m->eig || m->ld || (m->pending == 0 && m->todo == 0)) return GG_OK;
   int rc;
   const gg_data* d = m->pend_data;
   const bool scan = m->sbm && m->K > 1;
-  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  if (!ctl_fresh) GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   for (;;) {
     bool abort0 = false;
     if (m->pipe) GG_HIP(hipStreamSynchronize(m->sb));
-    if ((rc = read_ctl(m))) return rc;
+    if (ctl_fresh) ctl_fresh = false;
+    else if ((rc = read_ctl(m))) return rc;
     if (m->h_rs[3] == 2 && !m->incr) {
       // A k_scan exchange timed out (the resident grid could not assemble - a device shared with other processes, say)
       // and left the scan as a stalled one at a consistent position: carry on with the launch-per-change form, for good.
@@ -1286,8 +1289,10 @@ static int model_sync(gg_model* m) {
     m->m_pending = false;
   }
   if (scan) {
-    if ((rc = write_ctl_word(m, 5, 0))) return rc;
-    if ((rc = read_ctl(m))) return rc;
+    // the count of completed scans restarts for the next batch: a stream-ordered copy from pinned staging, no round trip
+    // (everything this function has to know is in the control block it read last)
+    m->h_rs[26] = 0;
+    GG_HIP(hipMemcpyAsync(m->rs + 5, m->h_rs + 26, sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
   }
   m->st.label_changes = (uint64_t)m->h_rs[2];
   if (m->dbg && m->use_scan) {
@@ -1367,16 +1372,46 @@ int gg_sync_many(gg_model** ms, int32_t n) {
   if (n < 0 || (n > 0 && !ms)) return gg_fail(GG_ERR_INVALID, "gg_sync_many: bad arguments");
   if (n == 0) return GG_OK;
   if (n == 1) return gg_sync(ms[0]);
+  // First the common case without threads: the control blocks of all models are fetched with one overlapped round trip;
+  // if no scan stalled and nothing is left to enqueue, finishing a model is bookkeeping (a thread costs more than that).
+  std::vector<char> fresh((size_t)n, 0);
+  bool slow = false;
+  for (int i = 0; i < n; ++i) {
+    gg_model* m = ms[i];
+    if (!m) return gg_fail(GG_ERR_INVALID, "null model");
+    if (m->eig || m->ld || m->pipe || (m->pending == 0 && m->todo == 0)) continue;
+    GG_HIP(hipSetDevice(m->cfg.device));
+    GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+    GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 24 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    fresh[(size_t)i] = 1;
+  }
+  for (int i = 0; i < n; ++i) {
+    gg_model* m = ms[i];
+    if (!fresh[(size_t)i]) { if (m->pipe) slow = true; continue; }
+    GG_HIP(hipSetDevice(m->cfg.device));
+    GG_HIP(hipStreamSynchronize(m->stream));
+    if (m->h_rs[4] || m->h_rs[3] || m->todo > 0) slow = true;
+  }
+  if (!slow) {
+    for (int i = 0; i < n; ++i) {
+      GG_HIP(hipSetDevice(ms[i]->cfg.device));
+      const int rc = model_sync(ms[i], fresh[(size_t)i] != 0);
+      if (rc) return rc;
+    }
+    return GG_OK;
+  }
   std::vector<int> rcs((size_t)n, GG_OK);
   std::vector<std::string> errs((size_t)n);
   std::vector<std::thread> th;
-  for (int i = 1; i < n; ++i)
-    th.emplace_back([&, i]() {
-      rcs[(size_t)i] = gg_sync(ms[i]);
-      if (rcs[(size_t)i]) errs[(size_t)i] = gg_err_text;   // the error text is thread-local
-    });
-  rcs[0] = gg_sync(ms[0]);
-  if (rcs[0]) errs[0] = gg_err_text;
+  auto one = [&](int i) {
+    int rc = GG_OK;
+    if (hipSetDevice(ms[i]->cfg.device) != hipSuccess) rc = gg_fail(GG_ERR_HIP, "hipSetDevice failed");
+    else if (!(ms[i]->eig || ms[i]->ld)) rc = model_sync(ms[i], fresh[(size_t)i] != 0);
+    rcs[(size_t)i] = rc;
+    if (rc) errs[(size_t)i] = gg_err_text;   // the error text is thread-local
+  };
+  for (int i = 1; i < n; ++i) th.emplace_back(one, i);
+  one(0);
   for (auto& t : th) t.join();
   for (int i = 0; i < n; ++i)
     if (rcs[(size_t)i]) { gg_err_text = errs[(size_t)i]; return rcs[(size_t)i]; }
@@ -1389,6 +1424,18 @@ int gg_sync_many(gg_model** ms, int32_t n) {
 int gg_resample_many(gg_model** ms, const gg_data* const* ds, int32_t n, int32_t n_sweeps, double beta) {
   if (n < 0 || (n > 0 && (!ms || !ds))) return gg_fail(GG_ERR_INVALID, "gg_resample_many: bad arguments");
   if (n == 0) return GG_OK;
+  static int thr = -1;
+  if (thr < 0) { const char* et = getenv("GG_MANY_INTERLEAVE"); thr = et ? atoi(et) : 32; }
+  if (n_sweeps <= thr) {
+    // short runs: enqueueing from this thread costs less than starting one per model - sweep by sweep, alternating
+    // between the models, so that none of them waits for another's whole batch; completion is shared (gg_sync_many)
+    for (int s = 0; s < n_sweeps; ++s)
+      for (int i = 0; i < n; ++i) {
+        const int rc = gg_resample_async(ms[i], ds[i], 1, beta);
+        if (rc) return rc;
+      }
+    return gg_sync_many(ms, n);
+  }
   std::vector<int> rcs((size_t)n, GG_OK);
   std::vector<std::string> errs((size_t)n);
   auto run = [&](int i) {
