@@ -22,8 +22,10 @@ int gg_fail(int code, const char* fmt, ...);
 #define GG_HIP(call)                                                                          \
   do {                                                                                        \
     hipError_t e__ = (call);                                                                  \
-    if (e__ != hipSuccess)                                                                    \
+    if (e__ != hipSuccess) {                                                                  \
+      (void)hipGetLastError();   /* the error is reported here: do not leave it sticking to the next, unrelated call */ \
       return gg_fail(GG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    }                                                                                         \
   } while (0)
 
 static inline int gg_round_up(int x, int m) { return (x + m - 1) / m * m; }

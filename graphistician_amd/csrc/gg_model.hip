@@ -140,6 +140,46 @@ static size_t resolve_lds_bytes(const gg_model* m, int CH) {
 
 static size_t table_bytes(const gg_model* m) { return (size_t)2 * m->K * m->NT * m->Kp * sizeof(double); }
 
+// Dynamic LDS of the scan kernels (bytes) and whether the coefficient tables are staged in it.  One place for the
+// launch sites and for the capacity check at model creation: 150 KB is what a workgroup may ask for next to the few
+// static words these kernels keep.
+#define GG_LDS_LIMIT ((size_t)150 * 1024)
+static size_t lds_spec(const gg_model* m, int* stage_out) {
+  const int K = m->K, per = 256 / m->Kp;
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
+  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += table_bytes(m);
+  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+  if (stage_out) *stage_out = stage;
+  return lds;
+}
+static size_t lds_round(const gg_model* m, int* stage_out) {
+  const int K = m->K, per = 256 / m->Kp;
+  const size_t gsb = m->is_adj ? 0 : (size_t)2 * K * per * m->NSI * sizeof(long long);
+  const size_t meet = (size_t)4 * 2 * m->NT * 64 * sizeof(double);
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
+               (size_t)(per + 8 + K) * sizeof(int) + 64;
+  const int stage = (lds + gsb + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += gsb + table_bytes(m);
+  else if (m->Kp == 64 && !m->is_adj) lds += gsb > meet ? gsb : meet;   // k_round: the meeting place reuses the dead integer statistics
+  else if (m->Kp == 64) lds += gsb + meet;
+  else lds += gsb;
+  if (stage_out) *stage_out = stage;
+  return lds;
+}
+static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
+  const int K = m->K, per = 256 / m->Kp;
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
+               (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)lcap * 3 * sizeof(int);
+  if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
+  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += table_bytes(m);
+  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);
+  if (stage_out) *stage_out = stage;
+  return lds;
+}
+
+
 extern "C" {
 
 int gg_model_create(gg_model** out, const gg_config* cfg) {
@@ -284,6 +324,18 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     // (carried statistics: the two scan forms keep different books on what of the change list is already in G, so the
     // form is not switched from sweep to sweep there)
     if (m->incr && m->scan_pref < 0) m->scan_pref = 0;
+    if (can_scan) {
+      // what fits in LDS decides which scan forms this shape (K, B) can run
+      const bool fit_scan = lds_scan(m, m->Lcap < 1024 ? m->Lcap : 1024, nullptr) <= GG_LDS_LIMIT;
+      const bool fit_round = lds_round(m, nullptr) <= GG_LDS_LIMIT;
+      if (lds_spec(m, nullptr) > GG_LDS_LIMIT || (!fit_scan && !fit_round)) {
+        const size_t need = lds_round(m, nullptr);
+        gg_model_destroy(m);
+        return gg_fail(GG_ERR_UNSUPPORTED, "K=%d with B=%d needs %zu KB of LDS per workgroup for the node scan (150 KB available)",
+                       cfg->K, cfg->B, need / 1024);
+      }
+      if (!fit_scan) { m->scan_pref = 0; m->use_scan = false; }   // restart rounds only (their meeting place reuses dead statistics)
+    }
   }
   // defaults: uniform m, pi = 1, p = 0.5, standard NIW
   std::vector<double> ones(K, 1.0), um(K, 1.0 / K), half(KK, 0.5);
@@ -681,17 +733,15 @@ static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t 
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = nullptr;
   g.keep_L = 0;
-  const int K = m->K, per = 256 / m->Kp;
+  const int per = 256 / m->Kp;
   const int nb = (m->Nl + per - 1) / per;
-  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
-  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
-  if (stage) lds += table_bytes(m);
-  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+  int stage;
+  const size_t lds = lds_spec(m, &stage);
 #define SPR(NTV, ADJV)                                                                                                     \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
     if (!attr_set && lds > 48 * 1024) {                                                                                    \
-      GG_HIP(hipFuncSetAttribute((const void*)k_spec_resolve<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      GG_HIP(hipFuncSetAttribute((const void*)k_spec_resolve<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
     k_spec_resolve<NTV, ADJV><<<nb, 256, lds, m->stream>>>(g, stage, m->ap);                                                \
@@ -780,20 +830,18 @@ static int launch_round(gg_model* m, const gg_data* d, int buf, uint32_t sweep, 
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = m->dbg;
   g.keep_L = m->incr ? 1 : 0;
-  const int K = m->K, per = 256 / m->Kp;
+  const int per = 256 / m->Kp;
   int nb = (window + per - 1) / per;
   if (nb > 512) nb = 512;   // groups beyond the grid are strided over
-  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
-               (size_t)(per + 8 + K) * sizeof(int) + 64;
-  if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
-  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
-  if (stage) lds += table_bytes(m);
-  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+  int stage;
+  const size_t lds = lds_round(m, &stage);
+  if (lds > GG_LDS_LIMIT)
+    return gg_fail(GG_ERR_UNSUPPORTED, "restart rounds need %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
 #define RND(NTV, ADJV)                                                                                            \
   do {                                                                                                            \
     static bool attr_set = false;                                                                                 \
     if (!attr_set && lds > 48 * 1024) {                                                                           \
-      GG_HIP(hipFuncSetAttribute((const void*)k_round<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      GG_HIP(hipFuncSetAttribute((const void*)k_round<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
       attr_set = true;                                                                                            \
     }                                                                                                             \
     k_round<NTV, ADJV><<<nb, 256, lds, m->stream>>>(g, m->ap, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0),      \
@@ -840,15 +888,13 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   g.keep_L = m->incr ? 1 : 0;
   a.ap = m->ap; a.Gc0 = gcnt(m, buf, 0); a.Gs0 = gs(m, buf, 0); a.bar = m->bar;
   a.Lcap = m->Lcap < 1024 ? m->Lcap : 1024;   // every workgroup keeps its own copy of the list in LDS (12 KB)
-  const int K = m->K, per = 256 / m->Kp;
+  const int per = 256 / m->Kp;
   const int ngroups = (m->Nl + per - 1) / per;
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
-  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
-               (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)a.Lcap * 3 * sizeof(int);
-  if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
-  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
-  if (stage) lds += table_bytes(m);
-  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);
+  int stage;
+  const size_t lds = lds_scan(m, a.Lcap, &stage);
+  if (lds > GG_LDS_LIMIT)
+    return gg_fail(GG_ERR_UNSUPPORTED, "the resident-grid scan needs %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
   g.stage_tables = stage;
 #define SCN(NTV, ADJV)                                                                                            \
   do {                                                                                                            \

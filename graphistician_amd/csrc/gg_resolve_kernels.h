@@ -499,12 +499,18 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
   extern __shared__ __align__(16) unsigned char s_raw[];
   // [dir][j][i] integer statistics, then their spec-order doubles [dir][j][i][NT], then tables when staged
   long long* s_gs = reinterpret_cast<long long*>(s_raw);
-  size_t off = ADJ ? 0 : (size_t)2 * K * per * NSI * sizeof(long long);
+  // Weights with Kp = 64 and unstaged tables: the integer statistics are dead once they are converted and written back,
+  // which is before the split chains need their meeting place (gg_lp_split4) - the two share one region, or B = 4 with
+  // K > 40 would not fit in 160 KB of LDS.
+  const size_t gs_bytes = ADJ ? 0 : (size_t)2 * K * per * NSI * sizeof(long long);
+  const size_t meet_bytes = (size_t)4 * 2 * NT * 64 * sizeof(double);
+  const bool alias_meet = !ADJ && !stage_tables && Kp == 64;
+  size_t off = alias_meet ? (gs_bytes > meet_bytes ? gs_bytes : meet_bytes) : gs_bytes;
   double* s_st = reinterpret_cast<double*>(s_raw + off); off += (size_t)2 * K * per * NT * sizeof(double);
-  double* s_T = reinterpret_cast<double*>(s_raw + off);
+  double* s_T = alias_meet ? reinterpret_cast<double*>(s_raw) : reinterpret_cast<double*>(s_raw + off);
   const int ntab = K * NT * Kp;
   if (stage_tables) off += (size_t)2 * ntab * sizeof(double);
-  else if (Kp == 64) off += (size_t)4 * 2 * NT * 64 * sizeof(double);   // the split chains meet here (gg_lp_split4)
+  else if (Kp == 64 && !alias_meet) off += meet_bytes;   // the split chains meet here (gg_lp_split4)
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_ap = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
   int* s_ctl = reinterpret_cast<int*>(s_raw + off); off += 8 * sizeof(int);

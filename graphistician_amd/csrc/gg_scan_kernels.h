@@ -417,13 +417,17 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     __syncthreads();
     for (int k = tid; k < K; k += 256) g.cnt[k] = s_cnt[k];
     if (tid == 0) {
-      g.rs[0] = pos;
+      // (the last node itself changed and the confirming exchange gave up: stand on that node again - its conditional
+      // does not depend on its own label, so the restart round redraws the same label, finds the window final and runs
+      // the tail; a stalled scan at pos == N would give the rounds nothing to do)
+      const int rpos = pos < N ? pos : N - 1;
+      g.rs[0] = rpos;
       g.rs[1] = nL;
       g.rs[2] += nchg;
       g.rs[9] += nchg;
       g.rs[4] = 1;
       // round state for the restart rounds, exactly as k_resolve leaves it for an incomplete scan
-      *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(pos, nL, 0, 0, 0);
+      *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(rpos, nL, 0, 0, 0);
       *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]) = GG_NO_CHANGE;
       g.rs[10] = 0;
     }

@@ -1,0 +1,55 @@
+"""Randomised parity stress: small Gaussian-SBM networks of random shape (N, K, B, density, self-connection conventions),
+a few sweeps each in uneven chunks, engine against the oracle, labels and parameters bit for bit.  Run it under the
+scan-form switches as well (GG_SCAN=0 / 1, GG_SCAN_SPIN=2, GG_INCREMENTAL=1).
+
+    python tools/fuzz_parity.py [cases] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+from tests.helpers import planted_sbm, AdjState, WState  # noqa: E402
+from graphistician_amd import _abi as abi  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+for case in range(cases):
+    N = int(rng.choice([5, 17, 33, 64, 65, 100, 129, 200, 257, 300]))
+    K = int(rng.choice([2, 3, 4, 7, 16, 17, 33, 40, 64]))
+    K = min(K, N)
+    B = int(rng.choice([1, 1, 1, 2, 4]))
+    special = int(rng.rand() < 0.7)
+    seed = int(rng.randint(1, 1 << 30))
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case %d: N=%d K=%d B=%d special=%d seed=%d" % (case, N, K, B, special, seed), flush=True)
+    A, W, _ = planted_sbm(N, K, B=B, seed=seed % 1000)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=seed % 977), WState(N, K, B, seed=seed % 991)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=seed, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                    special_case_self_conns=special)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=seed + 1, special_case_self_conns=special)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    w.set(abi.ST_MU_SELF, sw.mu_self); w.set(abi.ST_SIGMA_SELF, sw.sigma_self)
+    ps, done = sa.p_self, 0
+    for chunk in (1, int(rng.randint(1, 4)), int(rng.randint(1, 12))):
+        abi.resample_many([adj, w], d, chunk)
+        for s in range(done, done + chunk):
+            ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, special, seed, s)
+            O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self,
+                          special, seed + 1, s)
+        done += chunk
+        ok = (np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p) and
+              np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, B)), sw.mu) and
+              np.array_equal(w.get(abi.ST_SIGMA, (K, K, B, B)), sw.sigma) and np.array_equal(w.get(abi.ST_M, (K,)), sw.m))
+        if not ok:
+            print("MISMATCH case %d: N=%d K=%d B=%d special=%d seed=%d after %d sweeps" % (case, N, K, B, special, seed, done))
+            sys.exit(1)
+    del adj, w, d
+print("fuzz ok: %d cases" % cases)
