@@ -2,7 +2,9 @@
 a few sweeps each in uneven chunks, engine against the oracle, labels and parameters bit for bit.  Run it under the
 scan-form switches as well (GG_SCAN=0 / 1, GG_SCAN_SPIN=2, GG_INCREMENTAL=1).
 
-    python tools/fuzz_parity.py [cases] [seed]
+    python tests/fuzz_parity.py [cases] [seed]        (FUZZ_VERBOSE=1 prints every configuration)
+
+Test infrastructure (it checks against oracle/): tests/test_gpu_edge_cases.py runs a short stream of it.
 """
 import os
 import sys
@@ -14,17 +16,9 @@ from oracle import oracle as O  # noqa: E402
 from tests.helpers import planted_sbm, AdjState, WState  # noqa: E402
 from graphistician_amd import _abi as abi  # noqa: E402
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-for case in range(cases):
-    N = int(rng.choice([5, 17, 33, 64, 65, 100, 129, 200, 257, 300]))
-    K = int(rng.choice([2, 3, 4, 7, 16, 17, 33, 40, 64]))
-    K = min(K, N)
-    B = int(rng.choice([1, 1, 1, 2, 4]))
-    special = int(rng.rand() < 0.7)
-    seed = int(rng.randint(1, 1 << 30))
-    if os.environ.get("FUZZ_VERBOSE"):
-        print("case %d: N=%d K=%d B=%d special=%d seed=%d" % (case, N, K, B, special, seed), flush=True)
+
+def one_case(N, K, B, special, seed, chunks):
+    """Adjacency and weight models of one random network, advanced in the given chunks; None or a mismatch message."""
     A, W, _ = planted_sbm(N, K, B=B, seed=seed % 1000)
     q, shift = O.quantise(A, W)
     sa, sw = AdjState(N, K, seed=seed % 977), WState(N, K, B, seed=seed % 991)
@@ -38,7 +32,7 @@ for case in range(cases):
     w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
     w.set(abi.ST_MU_SELF, sw.mu_self); w.set(abi.ST_SIGMA_SELF, sw.sigma_self)
     ps, done = sa.p_self, 0
-    for chunk in (1, int(rng.randint(1, 4)), int(rng.randint(1, 12))):
+    for chunk in chunks:
         abi.resample_many([adj, w], d, chunk)
         for s in range(done, done + chunk):
             ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, special, seed, s)
@@ -49,7 +43,34 @@ for case in range(cases):
               np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, B)), sw.mu) and
               np.array_equal(w.get(abi.ST_SIGMA, (K, K, B, B)), sw.sigma) and np.array_equal(w.get(abi.ST_M, (K,)), sw.m))
         if not ok:
-            print("MISMATCH case %d: N=%d K=%d B=%d special=%d seed=%d after %d sweeps" % (case, N, K, B, special, seed, done))
-            sys.exit(1)
-    del adj, w, d
-print("fuzz ok: %d cases" % cases)
+            return "N=%d K=%d B=%d special=%d seed=%d after %d sweeps" % (N, K, B, special, seed, done)
+    return None
+
+
+def run(cases, seed0, verbose=False):
+    """`cases` random configurations from the stream seeded with `seed0`; returns the list of mismatch messages."""
+    rng = np.random.RandomState(seed0)
+    bad = []
+    for case in range(cases):
+        N = int(rng.choice([5, 17, 33, 64, 65, 100, 129, 200, 257, 300]))
+        K = min(int(rng.choice([2, 3, 4, 7, 16, 17, 33, 40, 64])), N)
+        B = int(rng.choice([1, 1, 1, 2, 4]))
+        special = int(rng.rand() < 0.7)
+        seed = int(rng.randint(1, 1 << 30))
+        chunks = (1, int(rng.randint(1, 4)), int(rng.randint(1, 12)))
+        if verbose:
+            print("case %d: N=%d K=%d B=%d special=%d seed=%d chunks=%s" % (case, N, K, B, special, seed, chunks), flush=True)
+        msg = one_case(N, K, B, special, seed, chunks)
+        if msg:
+            bad.append("case %d: %s" % (case, msg))
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0, verbose=bool(os.environ.get("FUZZ_VERBOSE")))
+    for b in bad:
+        print("MISMATCH", b)
+    if bad:
+        sys.exit(1)
+    print("fuzz ok: %d cases" % n)
