@@ -397,3 +397,4 @@ def test_short_parity_fuzz(abi):
     streams under every scan-form switch are part of the release soak, profiles/README.md)."""
     from tests.fuzz_parity import run
     assert run(30, 20261003) == []
+    assert run(20, 20261004, extended=True) == []     # tempered sweeps and shared-covariance weights as well
