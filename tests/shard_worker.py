@@ -17,16 +17,18 @@ def main():
     from oracle import oracle as O
     from tests.helpers import planted_sbm, AdjState, WState
     comm = S.TorchComm()
-    N, K, B, nsweeps = int(sys.argv[1]), int(sys.argv[2]), 1, int(sys.argv[3])
+    N, K, nsweeps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    special = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     A, W, _ = planted_sbm(N, K, B=B, seed=77)
     n0, n1 = S.shard_range(N, comm.rank, comm.world)
     data = abi.DeviceData.shard(A, W, n0, n1, device=0)
     a, w = AdjState(N, K, seed=5), WState(N, K, B, seed=6)
     adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=901, tau1=1.0, tau0=1.0, allow_self_connections=1,
-                    special_case_self_conns=1, shard_begin=n0, shard_end=n1)
+                    special_case_self_conns=special, shard_begin=n0, shard_end=n1)
     adj.set(abi.ST_C, a.c, np.int32); adj.set(abi.ST_M, a.m); adj.set(abi.ST_PI, a.pi); adj.set(abi.ST_P, a.p)
     adj.set(abi.ST_P_SELF, np.array([a.p_self]))
-    wm = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=902, special_case_self_conns=1, shard_begin=n0, shard_end=n1)
+    wm = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=902, special_case_self_conns=special, shard_begin=n0, shard_end=n1)
     for sid, v, dt in ((abi.ST_C, w.c, np.int32), (abi.ST_M, w.m, np.float64), (abi.ST_PI, w.pi, np.float64),
                        (abi.ST_MU, w.mu, np.float64), (abi.ST_SIGMA, w.sigma, np.float64),
                        (abi.ST_MU_SELF, w.mu_self, np.float64), (abi.ST_SIGMA_SELF, w.sigma_self, np.float64),
@@ -40,17 +42,18 @@ def main():
         q, shift = O.quantise(A, W)
         ps = a.p_self
         for s in range(nsweeps):
-            ps = O.sbm_adj_sweep(A, a.c, a.m, a.p, ps, a.pi, 1.0, 1.0, 1, 901, s)
-            O.sbm_w_sweep(A, q, shift, w.c, w.m, w.mu, w.sigma, w.mu_self, w.sigma_self, w.pi, w.niw, w.niw_self, 1, 902, s)
+            ps = O.sbm_adj_sweep(A, a.c, a.m, a.p, ps, a.pi, 1.0, 1.0, special, 901, s)
+            O.sbm_w_sweep(A, q, shift, w.c, w.m, w.mu, w.sigma, w.mu_self, w.sigma_self, w.pi, w.niw, w.niw_self, special, 902, s)
         assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), a.c), "adjacency labels differ"
         assert np.array_equal(adj.get(abi.ST_P, (K, K)), a.p) and np.array_equal(adj.get(abi.ST_M, (K,)), a.m)
         assert adj.get(abi.ST_P_SELF, (1,))[0] == ps
         assert np.array_equal(wm.get(abi.ST_C, (N,), np.int32), w.c), "weight labels differ"
         assert np.array_equal(wm.get(abi.ST_MU, (K, K, B)), w.mu) and np.array_equal(wm.get(abi.ST_SIGMA, (K, K, B, B)), w.sigma)
         assert np.array_equal(wm.get(abi.ST_M, (K,)), w.m)
-        ref = O.sbm_adj_loglik(A, a.c, a.p, ps) + O.sbm_w_loglik(A, q, shift, w.c, w.mu, w.sigma, w.mu_self, w.sigma_self, 1)
+        ref = (O.sbm_adj_loglik(A, a.c, a.p, ps, True, bool(special)) +
+               O.sbm_w_loglik(A, q, shift, w.c, w.mu, w.sigma, w.mu_self, w.sigma_self, bool(special)))
         assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
-        print("SHARD-OK world=%d N=%d K=%d sweeps=%d changes=%d" % (comm.world, N, K, nsweeps,
+        print("SHARD-OK world=%d N=%d K=%d B=%d special=%d sweeps=%d changes=%d" % (comm.world, N, K, B, special, nsweeps,
               adj.stats()["label_changes"] + wm.stats()["label_changes"]))
     dist.barrier()
     dist.destroy_process_group()

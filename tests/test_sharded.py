@@ -10,10 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,N,K", [(1, 150, 4), (2, 200, 5), (3, 330, 7)])
-def test_sharded_chain_equals_single_chain(world, N, K):
+@pytest.mark.parametrize("world,N,K,B,special", [(1, 150, 4, 1, 1), (2, 200, 5, 1, 1), (3, 330, 7, 1, 1), (2, 257, 33, 2, 0),
+                                                 (3, 160, 64, 4, 1), (2, 129, 17, 1, 0)])
+def test_sharded_chain_equals_single_chain(world, N, K, B, special):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(29540 + world), os.path.join(ROOT, "tests", "shard_worker.py"), str(N), str(K), "3"]
+           "127.0.0.1", "--master-port", str(29600 + world + 4 * B + 16 * special), os.path.join(ROOT, "tests", "shard_worker.py"),
+           str(N), str(K), "3", str(B), str(special)]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "SHARD-OK world=%d" % world in out.stdout, out.stdout[-1500:]
