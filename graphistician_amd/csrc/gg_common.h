@@ -29,6 +29,37 @@ int gg_fail(int code, const char* fmt, ...);
   } while (0)
 
 static inline int gg_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Host-side validation of double-valued state handed over the C ABI: a NaN or an infinity would reach samplers whose
+// rejection loops only end on comparisons that succeed (gamma, Polya-gamma, truncated normal): a hung GPU, not an error.
+static inline long long gg_first_nonfinite(const double* v, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!(v[i] - v[i] == 0.0)) return (long long)i;
+  return -1;
+}
+// Symmetric positive definite B x B (row-major)?  Plain Cholesky pivots.
+static inline bool gg_is_spd(const double* S, int B) {
+  double L[16] = {0};
+  if (B > 4) return false;
+  for (int j = 0; j < B; ++j) {
+    double d = S[j * B + j];
+    for (int k = 0; k < j; ++k) d -= L[j * B + k] * L[j * B + k];
+    if (!(d > 0.0)) return false;
+    const double dj = __builtin_sqrt(d);
+    L[j * B + j] = dj;
+    for (int i = j + 1; i < B; ++i) {
+      {
+        const double lo = S[i * B + j], up = S[j * B + i], df = lo > up ? lo - up : up - lo;
+        const double mag = (lo < 0 ? -lo : lo) + (up < 0 ? -up : up);
+        if (df > 1e-8 * mag) return false;   // (the kernels read the lower triangle; rounding-level asymmetry is let through)
+      }
+      double v = S[i * B + j];
+      for (int k = 0; k < j; ++k) v -= L[i * B + k] * L[j * B + k];
+      L[i * B + j] = v / dj;
+    }
+  }
+  return true;
+}
 static inline int gg_ceil_log2(long long n) { int b = 0; while ((1LL << b) < n) ++b; return b; }
 static inline int gg_qbits(int N) { int b = (62 - gg_ceil_log2(N)) / 2; return b > 23 ? 23 : b; }
 

@@ -818,6 +818,11 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
     return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: need N > 0 and 1 <= D <= 8 (got N=%d D=%d)", cfg->N, cfg->D);
   if ((long long)cfg->N * cfg->N >= (1LL << 32) + 1)
     return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: N*N must fit the 32-bit Philox index");
+  {
+    const double v[4] = {cfg->sigma_mu0, cfg->sigma_F, cfg->sigma_lmbda, cfg->mu_mu_0};
+    if (gg_first_nonfinite(v, 4) >= 0 || !(v[0] > 0.0 && v[1] > 0.0 && v[2] > 0.0))
+      return gg_fail(GG_ERR_INVALID, "eigenmodel: prior variances (sigma_mu0, sigma_F, sigma_lmbda) = (%g, %g, %g) must be positive and finite, mu_mu_0 finite", v[0], v[1], v[2]);
+  }
   gg_eigen* e = new gg_eigen();
   e->cfg = *cfg;
   e->N = cfg->N; e->D = cfg->D; e->Np = gg_round_up(cfg->N, 64);
@@ -875,6 +880,10 @@ int gg_eigen_set_state(gg_eigen* e, int id, const void* buf, size_t nbytes) {
   void* p; size_t need;
   if (eig_state_ptr(e, id, &p, &need)) return gg_fail(GG_ERR_INVALID, "state id %d not valid for the eigenmodel", id);
   if (nbytes != need) return gg_fail(GG_ERR_INVALID, "state id %d: expected %zu bytes, got %zu", id, need, nbytes);
+  {
+    const long long bad = gg_first_nonfinite((const double*)buf, nbytes / sizeof(double));   // (all eigenmodel state is doubles)
+    if (bad >= 0) return gg_fail(GG_ERR_INVALID, "state id %d: non-finite value at index %lld", id, bad);
+  }
   GG_HIP(hipMemcpyAsync(p, buf, nbytes, hipMemcpyHostToDevice, e->stream));
   GG_HIP(hipStreamSynchronize(e->stream));
   return GG_OK;

@@ -521,6 +521,10 @@ int gg_latent_set_state(gg_latent* e, int id, const void* buf, size_t nbytes) {
   int rc = ld_state_slot(e, id, &p, &hp, &need);
   if (rc) return rc;
   if (nbytes != need) return gg_fail(GG_ERR_INVALID, "state id %d: expected %zu bytes, got %zu", id, need, nbytes);
+  {
+    const long long bad = gg_first_nonfinite((const double*)buf, nbytes / sizeof(double));   // (all of this model's state is doubles)
+    if (bad >= 0) return gg_fail(GG_ERR_INVALID, "state id %d: non-finite value at index %lld", id, bad);
+  }
   if (hp) { memcpy(hp, buf, nbytes); return GG_OK; }
   GG_HIP(hipMemcpyAsync(p, buf, nbytes, hipMemcpyHostToDevice, e->stream));
   GG_HIP(hipStreamSynchronize(e->stream));

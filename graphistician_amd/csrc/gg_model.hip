@@ -222,6 +222,11 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d: the HIP engine supports B in {1,2,4}", cfg->B);
   }
+  if ((cfg->kind == GG_SBM_ADJ || cfg->kind == GG_BB_ADJ) &&
+      !(cfg->tau1 > 0.0 && cfg->tau0 > 0.0 && cfg->tau1 - cfg->tau1 == 0.0 && cfg->tau0 - cfg->tau0 == 0.0)) {
+    delete m;
+    return gg_fail(GG_ERR_INVALID, "Beta prior (tau1, tau0) = (%g, %g) must be positive and finite", cfg->tau1, cfg->tau0);
+  }
   m->Kp = gg_next_pow2(m->K < 2 ? 2 : m->K);
   m->NT = m->is_adj ? 2 : gg_nt_gauss(m->B);
   m->NSI = m->is_adj ? 0 : gg_nsi(m->B);
@@ -427,6 +432,10 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
       for (int b = 0; b < 2; ++b)
         if (m->gexec[a][b]) { hipGraphExecDestroy(m->gexec[a][b]); m->gexec[a][b] = nullptr; }
     const double* d = (const double*)buf;
+    if (gg_first_nonfinite(d, B + B * B + 2) >= 0) return gg_fail(GG_ERR_INVALID, "NIW hypers: non-finite value");
+    if (!gg_is_spd(d + B, (int)B)) return gg_fail(GG_ERR_INVALID, "NIW hypers: Sigma_0 is not symmetric positive definite");
+    if (!(d[B + B * B] > (double)B - 1.0)) return gg_fail(GG_ERR_INVALID, "NIW hypers: nu_0 = %g must exceed B - 1 = %d", d[B + B * B], (int)B - 1);
+    if (!(d[B + B * B + 1] > 0.0)) return gg_fail(GG_ERR_INVALID, "NIW hypers: kappa_0 = %g must be positive", d[B + B * B + 1]);
     gg_niw* h = id == GG_ST_NIW ? &m->niw : &m->niw_self;
     memset(h, 0, sizeof(gg_niw));
     for (size_t i = 0; i < B; ++i) h->mu_0[i] = d[i];
@@ -445,6 +454,22 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
     m->perm_valid = false;
     m->G_valid = false;
     { int rc1 = drain_pipe(m); if (rc1) return rc1; }
+  } else {
+    // every other state is doubles: values the samplers cannot digest are refused here (gg_common.h)
+    const double* v = (const double*)buf;
+    const size_t n = nbytes / sizeof(double);
+    const long long bad = gg_first_nonfinite(v, n);
+    if (bad >= 0) return gg_fail(GG_ERR_INVALID, "state id %d: non-finite value at index %lld", id, bad);
+    if (id == GG_ST_PI || id == GG_ST_M || id == GG_ST_P || id == GG_ST_P_SELF) {
+      for (size_t i = 0; i < n; ++i) {
+        if (id == GG_ST_PI && !(v[i] > 0.0)) return gg_fail(GG_ERR_INVALID, "Dirichlet parameter pi[%zu] = %g must be positive", i, v[i]);
+        if (id != GG_ST_PI && !(v[i] >= 0.0 && v[i] <= 1.0)) return gg_fail(GG_ERR_INVALID, "state id %d: probability %g at index %zu outside [0, 1]", id, v[i], i);
+      }
+    }
+    if (id == GG_ST_SIGMA || id == GG_ST_SIGMA_SELF) {
+      for (size_t i = 0; i < n; i += B * B)
+        if (!gg_is_spd(v + i, (int)B)) return gg_fail(GG_ERR_INVALID, "state id %d: covariance %zu is not symmetric positive definite", id, i / (B * B));
+    }
   }
   GG_HIP(hipMemcpyAsync(p, buf, nbytes, hipMemcpyHostToDevice, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));

@@ -32,6 +32,7 @@ GG_HD double gg_normal(gg_stream* s) {
 
 // Gamma(shape a, scale 1), Marsaglia & Tsang (2000).
 GG_HD double gg_gamma(gg_stream* s, double a) {
+  if (!(a > 0.0)) return __builtin_nan("");   // (a shape that is not positive - or NaN - would never leave the loop below)
   double boost = 1.0;
   if (a < 1.0) {
     double u = gg_stream_uniform_pos(s);

@@ -398,3 +398,61 @@ def test_short_parity_fuzz(abi):
     from tests.fuzz_parity import run
     assert run(30, 20261003) == []
     assert run(20, 20261004, extended=True) == []     # tempered sweeps and shared-covariance weights as well
+
+
+@pytest.mark.gpu
+def test_invalid_arguments_are_errors_not_hangs(abi):
+    """Values the samplers cannot digest (a NaN or a non-positive shape never leaves a rejection loop: a hung GPU) and
+    mismatched shapes are refused at the C ABI with GG_ERR_INVALID / UNSUPPORTED; the library stays usable."""
+    N, K = 50, 3
+    A, W, _ = planted_sbm(N, K, seed=1)
+    d, dA = abi.DeviceData(A, W), abi.DeviceData(A, None)
+    A2, W2, _ = planted_sbm(60, K, seed=1)
+    d2 = abi.DeviceData(A2, W2)
+
+    def adj(**kw):
+        cfg = dict(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=1, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+        cfg.update(kw)
+        return abi.Model(**cfg)
+
+    m = adj()
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=2, seed=2, special_case_self_conns=1)
+    eye = np.eye(2)
+    bad_calls = [
+        lambda: m.resample(d2, 1),                                          # data of another size
+        lambda: m.log_likelihood(d2),
+        lambda: m.resample(d, 1, -0.5), lambda: m.resample(d, 1, 1.5), lambda: m.resample(d, 1, float("nan")),
+        lambda: m.set(abi.ST_C, np.full(N, K), np.int32), lambda: m.set(abi.ST_C, np.full(N, -1), np.int32),
+        lambda: m.set(abi.ST_P, np.full((K, K), 1.5)), lambda: m.set(abi.ST_P, np.full((K, K), np.nan)),
+        lambda: m.set(abi.ST_PI, np.array([-1.0, 1.0, 1.0])), lambda: m.set(abi.ST_PI, np.array([0.0, 1.0, 1.0])),
+        lambda: m.set(abi.ST_M, np.array([np.inf, 0.0, 0.0])),
+        lambda: m.set(abi.ST_P, np.zeros(2)), lambda: m.set(999, np.zeros(2)), lambda: m.get(999, (2,)),
+        lambda: adj(tau1=0.0), lambda: adj(tau0=-1.0), lambda: adj(tau1=float("nan")),
+        lambda: adj(K=0), lambda: adj(K=65), lambda: adj(N=0), lambda: adj(device=99),
+        lambda: w.resample(dA, 1),                                          # weight model, data without W
+        lambda: w.set(abi.ST_SIGMA, -np.tile(eye, (K, K, 1, 1))),
+        lambda: w.set(abi.ST_SIGMA, np.tile(np.array([[1.0, 2.0], [2.0, 1.0]]), (K, K, 1, 1))),   # indefinite
+        lambda: w.set(abi.ST_MU, np.full((K, K, 2), np.nan)),
+        lambda: w.set(abi.ST_NIW, O.pack_niw(np.zeros(2), eye, 0.5, 1.0)),  # nu_0 <= B - 1
+        lambda: w.set(abi.ST_NIW, O.pack_niw(np.zeros(2), eye, 4.0, 0.0)),  # kappa_0 = 0
+        lambda: w.set(abi.ST_NIW, O.pack_niw(np.zeros(2), -eye, 4.0, 1.0)),
+        lambda: abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=2, K=1, B=1, seed=1, sigma_mu0=1.0, sigma_F=0.0, sigma_lmbda=1.0, mu_mu_0=0.0),
+        lambda: abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=9, K=1, B=1, seed=1, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=0.0),
+        lambda: abi.Model(kind=abi.LATENT_DIST, N=N, D=2, K=1, B=1, seed=1, sigma_F=-1.0),
+    ]
+    for i, call in enumerate(bad_calls):
+        with pytest.raises(abi.EngineError):
+            call()
+            pytest.fail("bad call %d was accepted" % i)
+    e = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=2, K=1, B=1, seed=1, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=0.0)
+    with pytest.raises(abi.EngineError):
+        e.set(abi.ST_F, np.full((N, 2), np.nan))
+    Wn, An = W.copy(), A.copy()
+    An[0, 1] = 1; Wn[0, 1] = np.nan
+    with pytest.raises(abi.EngineError):
+        abi.DeviceData(An, Wn)
+    # zero sweeps, a sync without work and a zero entry in m are fine; the handles are still usable after all that
+    m.resample(d, 0); m.sync()
+    m.set(abi.ST_M, np.array([0.5, 0.5, 0.0]))
+    m.resample(d, 2)
+    assert m.get(abi.ST_C, (N,), np.int32).max() < K
