@@ -562,10 +562,19 @@ static int bulk_rw(const gg_model* m, int strips, int ndirs) {
   static int override_rw = -1;
   if (override_rw < 0) { const char* e = getenv("GG_BULK_RW"); override_rw = e ? atoi(e) : 0; }
   if (override_rw > 0) return override_rw > 1020 ? 1020 : (override_rw + 3) / 4 * 4;
+  {
+    static int rw_a = -1, rw_w = -1;   // per-half overrides (tuning)
+    if (rw_a < 0) { const char* e = getenv("GG_BULK_RW_A"); rw_a = e ? atoi(e) : 0; }
+    if (rw_w < 0) { const char* e = getenv("GG_BULK_RW_W"); rw_w = e ? atoi(e) : 0; }
+    const int o = m->is_adj ? rw_a : rw_w;
+    if (o > 0) return o > 1020 ? 1020 : (o + 3) / 4 * 4;
+  }
   (void)strips; (void)ndirs;
-  // measured on MI355X at N=4096 (tools/tune_bulk.py): weights best at 128 rows per workgroup,
-  // adjacency at 64; larger N keeps the same number of row slots per label
-  long long rw = m->is_adj ? m->N / 64 : m->N / 32;
+  // Rows per workgroup, measured on MI355X inside the whole sweep (both halves' passes share the chip): at N=4096 the
+  // weight pass is fastest at 160-192 rows (5.45 TB/s alone against 5.2 at 128), and the adjacency pass, which has slack,
+  // disturbs it least at 192-256 rows (fewer, longer workgroups: its own rate falls from 4.0 to 3.1 TB/s, the sweep gains
+  // 4 %); N=16384 prefers 512-768 for both.  Larger N keeps the same number of row slots per label.
+  long long rw = (long long)m->N * 3 / 64;
   rw = (rw + 3) / 4 * 4;
   if (rw < 16) rw = 16;
   if (rw > 1020) rw = 1020;

@@ -456,3 +456,11 @@ def test_invalid_arguments_are_errors_not_hangs(abi):
     m.set(abi.ST_M, np.array([0.5, 0.5, 0.0]))
     m.resample(d, 2)
     assert m.get(abi.ST_C, (N,), np.int32).max() < K
+
+
+@pytest.mark.gpu
+def test_every_adjacency_and_weight_class_combination_runs(abi):
+    """9 adjacency classes x 4-5 weight classes x B in {1, 2} through FactorizedNetworkDistribution: rvs, three sweeps,
+    log_likelihood / log_prior / log_probability finite, predictive parameters (tests/combo_smoke.py)."""
+    from tests.combo_smoke import main
+    assert main() == 0
