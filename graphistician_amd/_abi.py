@@ -31,9 +31,10 @@ class EngineError(RuntimeError):
 
 
 class Config(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("B", C.c_int32), ("D", C.c_int32),
-                ("allow_self_connections", C.c_int32), ("special_case_self_conns", C.c_int32), ("device", C.c_int32),
-                ("seed", C.c_uint64), ("tau1", C.c_double), ("tau0", C.c_double), ("sigma_mu0", C.c_double),
+    # field for field include/graphgibbs.h `gg_config` (tests/test_abi_and_host.py parses the header and compares)
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("B", C.c_int32),
+                ("D", C.c_int32), ("allow_self_connections", C.c_int32), ("special_case_self_conns", C.c_int32),
+                ("device", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64), ("tau1", C.c_double), ("tau0", C.c_double), ("sigma_mu0", C.c_double),
                 ("sigma_F", C.c_double), ("sigma_lmbda", C.c_double), ("mu_mu_0", C.c_double),
                 ("lmbda_given", C.c_int32), ("reserved", C.c_int32), ("shard_begin", C.c_int32),
                 ("shard_end", C.c_int32)]
@@ -129,6 +130,15 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _adjacency_u8(A):
+    """(N, N) adjacency as uint8 {0, 1}.  NaN is refused: `NaN != 0` would silently upload a missing entry as an edge
+    (the reference's eigenmodel treats NaN as missing data, eigenmodel.py:121-127; the engine has no missing-data mask)."""
+    A = np.asarray(A)
+    if A.dtype.kind == "f" and np.isnan(A).any():
+        raise ValueError("the adjacency matrix contains NaN: missing entries are not supported by the engine")
+    return np.ascontiguousarray(A != 0, dtype=np.uint8)
+
+
 class DeviceData(object):
     """Device-resident (A, W): replaces the ndarray pair of networks.py:28,69."""
 
@@ -137,7 +147,7 @@ class DeviceData(object):
         if handle is not None:
             self._h = handle
         else:
-            A = np.ascontiguousarray(np.asarray(A) != 0, dtype=np.uint8)
+            A = _adjacency_u8(A)
             assert A.ndim == 2 and A.shape[0] == A.shape[1]
             N = A.shape[0]
             if W is not None:
@@ -156,7 +166,7 @@ class DeviceData(object):
     @classmethod
     def shard(cls, A, W, n0, n1, device=0):
         """Column shard [n0, n1) of the network for a chain sharded over several GPUs."""
-        A = np.ascontiguousarray(np.asarray(A) != 0, dtype=np.uint8)
+        A = _adjacency_u8(A)
         N = A.shape[0]
         h = C.c_void_p()
         if W is not None:
@@ -224,6 +234,7 @@ class Model(object):
         c = Config()
         for k, v in cfg.items():
             setattr(c, k, v)
+        c.struct_size = C.sizeof(Config)
         self.cfg = c
         self._h = C.c_void_p()
         check(lib().gg_model_create(C.byref(self._h), C.byref(c)))

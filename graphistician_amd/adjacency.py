@@ -457,9 +457,7 @@ class SBMAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacke
         if parts == _abi.PART_ALL:
             eng.resample_async(d, 1, beta)   # stream-ordered: the next state read (or log_likelihood) waits for it
         else:
-            eng.resample_part(d, parts, beta)
-            if parts == _abi.PART_M:
-                eng.sweep = eng.sweep + 1   # resample_m closes a sweep: advance the Philox sweep counter
+            eng.resample_part(d, parts, beta)   # (the engine advances its Philox sweep index: graphgibbs.h, gg_resample_part)
         self._mark_stale("c", "m", "p", "p_self")
 
     def resample(self, A, beta=1.0):

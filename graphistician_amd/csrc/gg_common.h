@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -29,6 +30,14 @@ int gg_fail(int code, const char* fmt, ...);
   } while (0)
 
 static inline int gg_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Bytes a streaming pass may touch before its loads become non-temporal (beyond what the 256 MiB Infinity Cache keeps
+// from sweep to sweep, see gg_stream_load).  GG_NT_BYTES overrides the threshold: 0 forces the non-temporal
+// instantiations at any size, which is how the parity tests reach them with small networks.  Read at every launch.
+static inline double gg_nt_threshold() {
+  const char* e = getenv("GG_NT_BYTES");
+  return e ? atof(e) : 200e6;
+}
 
 // Host-side validation of double-valued state handed over the C ABI: a NaN or an infinity would reach samplers whose
 // rejection loops only end on comparisons that succeed (gamma, Polya-gamma, truncated normal): a hung GPU, not an error.
@@ -83,6 +92,13 @@ struct gg_data {
   long long d1;                              // number of self edges
   long long dS[GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];  // sum q, sum q q^T over self edges (fits: N * 2^46)
   hipStream_t stream;
+  // Lifetime: a model with sweeps enqueued on this network (gg_resample_async) holds a reference until it has been
+  // synchronised; gg_data_destroy on a referenced handle only marks it, the last release frees it.  uid is unique per
+  // created network (a new allocation at a recycled address is never mistaken for the old one).
+  int refs, dead;
+  unsigned long long uid;
 };
 
 int gg_ensure_device(int device);
+void gg_data_retain(const gg_data* d);
+void gg_data_release(const gg_data* d);

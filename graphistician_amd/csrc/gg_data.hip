@@ -13,6 +13,11 @@
 
 thread_local std::string gg_err_text;
 
+static unsigned long long gg_next_data_uid() {
+  static unsigned long long next = 0;
+  return __atomic_add_fetch(&next, 1ULL, __ATOMIC_RELAXED);
+}
+
 int gg_fail(int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -214,6 +219,7 @@ int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const 
   if (rc) return rc;
   gg_data* d = new gg_data();
   memset(d, 0, sizeof(*d));
+  d->uid = gg_next_data_uid();
   d->device = device;
   d->N = N;
   d->n0 = 0; d->n1 = N;
@@ -303,6 +309,7 @@ static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c
   const int Nl = n1 - n0;
   gg_data* d = new gg_data();
   memset(d, 0, sizeof(*d));
+  d->uid = gg_next_data_uid();
   d->device = device; d->N = N; d->n0 = n0; d->n1 = n1; d->B = 1; d->Np = gg_round_up(Nl, 64); d->has_w = 1;
   GG_HIP(hipStreamCreate(&d->stream));
   rc = alloc_data(d);
@@ -367,6 +374,7 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
   if (rc) return rc;
   gg_data* d = new gg_data();
   memset(d, 0, sizeof(*d));
+  d->uid = gg_next_data_uid();
   d->device = device;
   d->N = N; d->n0 = n0; d->n1 = n1;
   d->B = W ? B : 1;
@@ -437,8 +445,31 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
   return GG_OK;
 }
 
+static void data_free(gg_data* d);
+
 int gg_data_destroy(gg_data* d) {
   if (!d) return GG_OK;
+  if (__atomic_load_n(&d->refs, __ATOMIC_ACQUIRE) > 0) {   // sweeps are still enqueued on it: freed by the last release
+    __atomic_store_n(&d->dead, 1, __ATOMIC_RELEASE);
+    if (__atomic_load_n(&d->refs, __ATOMIC_ACQUIRE) > 0) return GG_OK;
+  }
+  data_free(d);
+  return GG_OK;
+}
+
+}  // extern "C"
+
+void gg_data_retain(const gg_data* d) {
+  if (d) __atomic_add_fetch(&const_cast<gg_data*>(d)->refs, 1, __ATOMIC_ACQ_REL);
+}
+void gg_data_release(const gg_data* d) {
+  if (!d) return;
+  gg_data* w = const_cast<gg_data*>(d);
+  if (__atomic_sub_fetch(&w->refs, 1, __ATOMIC_ACQ_REL) == 0 && __atomic_load_n(&w->dead, __ATOMIC_ACQUIRE)) data_free(w);
+}
+
+static void data_free(gg_data* d) {
+  if (__atomic_exchange_n(&d->dead, 2, __ATOMIC_ACQ_REL) == 2) return;   // (destroy and the last release met: free once)
   hipSetDevice(d->device);
   if (d->A) hipFree(d->A);
   if (d->AT) hipFree(d->AT);
@@ -448,8 +479,9 @@ int gg_data_destroy(gg_data* d) {
   if (d->dWq) hipFree(d->dWq);
   if (d->stream) hipStreamDestroy(d->stream);
   delete d;
-  return GG_OK;
 }
+
+extern "C" {
 
 int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64_t* n_edges) {
   if (!d) return gg_fail(GG_ERR_INVALID, "null data");

@@ -41,6 +41,7 @@ struct gg_eigen {
   long long* dbgbuf;   // GG_EIG_DBG: cycle counters of the chain's solver wave
   hipStream_t stream;
   uint32_t sweep;
+  int parts_done;          // parts already drawn under the current sweep index (step-wise calls, see gg_resample_part)
   bool have_omega;
   hipEvent_t e0, e1;
   gg_stats st;
@@ -875,6 +876,7 @@ int gg_eigen_set_state(gg_eigen* e, int id, const void* buf, size_t nbytes) {
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
     e->sweep = *(const uint32_t*)buf;
+    e->parts_done = 0;
     return GG_OK;
   }
   void* p; size_t need;
@@ -928,6 +930,8 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   if (d->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, e->N);
   const int N = e->N, D = e->D, Np = e->Np;
   hipStream_t st = e->stream;
+  // a part asked for a second time under the same sweep index starts a new one: fresh Philox counters (graphgibbs.h)
+  if (parts & e->parts_done) { e->sweep += 1; e->parts_done = 0; }
   GG_HIP(hipEventRecord(e->e0, st));
   const bool full = (parts & (GG_PART_OMEGA | GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) ==
                     (GG_PART_OMEGA | GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA);
@@ -1022,7 +1026,8 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     (void)hipMemcpy(e->status, &z, sizeof(int), hipMemcpyHostToDevice);
     return gg_fail(GG_ERR_NUMERIC, "eigenmodel: a posterior precision is not positive definite");
   }
-  if (full) { e->sweep += 1; e->st.sweeps += 1; }
+  if (full) { e->sweep += 1; e->st.sweeps += 1; e->parts_done = 0; }
+  else e->parts_done |= parts;
   return GG_OK;
 }
 

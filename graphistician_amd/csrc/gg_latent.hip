@@ -36,6 +36,7 @@ struct gg_latent {
   hipStream_t stream;
   hipEvent_t e0, e1;
   uint32_t sweep;
+  int parts_done;          // parts already drawn under the current sweep index (step-wise calls, see gg_resample_part)
   double beta;
   gg_stats st;
   int wmode;               // 1: GG_LATENT_DIST_W (weights.py:613-903)
@@ -515,6 +516,7 @@ int gg_latent_set_state(gg_latent* e, int id, const void* buf, size_t nbytes) {
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
     e->sweep = *(const uint32_t*)buf;
+    e->parts_done = 0;
     return GG_OK;
   }
   void *p, *hp; size_t need = 0;
@@ -570,7 +572,7 @@ static int ld_check_data(gg_latent* e, const gg_data* d) {
 static int ldw_pass(gg_latent* e, const gg_data* d, const double* Qsrc, int stats, int kick, double* Qdst, double f, int drift) {
   const int N = e->N;
   const double inv_q = ldexp(1.0, -d->shift);
-  const int ntl = 8.0 * N * e->Np > 200e6;
+  const int ntl = 8.0 * N * e->Np > gg_nt_threshold();
 #define ARGS N, e->Np, d->Wq, d->WqT, inv_q, Qsrc, e->scal, e->row, kick, Qdst, e->Pm, f, drift, e->beta
 #define CALL(DV)                                                                         \
   if (stats) { if (ntl) k_ldw_pass<DV, 1, 1><<<N, 256, 0, e->stream>>>(ARGS); else k_ldw_pass<DV, 1, 0><<<N, 256, 0, e->stream>>>(ARGS); } \
@@ -695,6 +697,8 @@ int gg_latent_resample(gg_latent* e, const gg_data* d, int parts, int defer) {
   if (rc) return rc;
   const int N = e->N, n = N * e->dim;
   hipStream_t st = e->stream;
+  // a part asked for a second time under the same sweep index starts a new one: fresh Philox counters (graphgibbs.h)
+  if (parts & e->parts_done) { e->sweep += 1; e->parts_done = 0; }
   GG_HIP(hipEventRecord(e->e0, st));
   GG_HIP(hipMemsetAsync(e->acc, 0, sizeof(int), st));
   const uint32_t base = (uint32_t)n;
@@ -728,7 +732,8 @@ int gg_latent_resample(gg_latent* e, const gg_data* d, int parts, int defer) {
     }
   }
   GG_HIP(hipEventRecord(e->e1, st));
-  if ((parts & full) == full) { e->sweep += 1; e->st.sweeps += 1; }
+  if ((parts & full) == full) { e->sweep += 1; e->st.sweeps += 1; e->parts_done = 0; }
+  else e->parts_done |= (parts & full);
   return defer ? GG_OK : gg_latent_sync(e);
 }
 

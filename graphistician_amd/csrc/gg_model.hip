@@ -81,11 +81,12 @@ struct gg_model {
   bool use_graph;               // replay pipelined sweeps from a captured hipGraph (one per buffer parity)
   bool capturing;
   hipGraphExec_t gexec[2][2];   // [cur][pcur]
-  const gg_data* gdata[2][2];
+  unsigned long long gdata_uid[2][2];
   hipEvent_t ev_join;
   bool next_bulk;               // Gbuf[cur] already holds (is receiving) the next sweep's statistics
   int cur0, pcur0;              // buffer indices when the pending batch started
   uint32_t sweep;
+  int parts_done;               // step-wise calls: parts already drawn under the current sweep index (gg_resample_part)
   int Lmax, Lcap, CH, max_idle;
   long long* dbg;               // GG_ROUND_DBG: phase timestamps of k_round
   unsigned long long* bar;      // k_scan: exchange slots
@@ -101,8 +102,8 @@ struct gg_model {
   long long scan_hold;          // clean sweeps required before leaving k_scan mode (doubles when the chain stalls again soon after)
   long long since_revert;       // sweeps completed in speculate + resolve mode since the last switch back
   bool incr;                    // GG_INCREMENTAL=1: G is carried from sweep to sweep (changes flushed in), no bulk pass
-  bool G_valid;                 // incr: Gbuf[cur] is the exact histogram of G_data under the current labels
-  const gg_data* G_data;
+  bool G_valid;                 // incr: Gbuf[cur] is the exact histogram of network G_uid under the current labels
+  unsigned long long G_uid;
   int32_t* ap;                  // restart rounds: entries of L already applied to node n's statistics
   size_t resolve_lds;
   bool resolve_stage;          // coefficient tables staged in the resolver's LDS
@@ -116,6 +117,14 @@ struct gg_model {
   hipEvent_t ev_call0, ev_call1;
   gg_stats st;
 };
+
+// The network a model has sweeps enqueued on is held by reference until they are confirmed (gg_common.h).
+static void set_pend_data(gg_model* m, const gg_data* d) {
+  if (m->pend_data == d) return;
+  if (d) gg_data_retain(d);
+  if (m->pend_data) gg_data_release(m->pend_data);
+  m->pend_data = d;
+}
 
 static int model_kind_ok(int kind) {
   return kind == GG_SBM_ADJ || kind == GG_BB_ADJ || kind == GG_BERN_ADJ || kind == GG_SBM_GAUSS_W || kind == GG_NIW_W ||
@@ -184,6 +193,9 @@ extern "C" {
 
 int gg_model_create(gg_model** out, const gg_config* cfg) {
   if (!out || !cfg) return gg_fail(GG_ERR_INVALID, "gg_model_create: null argument");
+  if (cfg->struct_size != (uint32_t)sizeof(gg_config))
+    return gg_fail(GG_ERR_INVALID, "gg_config.struct_size = %u but this library's gg_config has %zu bytes: the caller's binding of "
+                   "include/graphgibbs.h is out of date (or struct_size was not set)", cfg->struct_size, sizeof(gg_config));
   if (cfg->kind == GG_LATENT_DIST || cfg->kind == GG_LATENT_DIST_W) {
     int rc = gg_ensure_device(cfg->device);
     if (rc) return rc;
@@ -278,7 +290,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if ((rc = dmalloc(&m->L, (size_t)m->Lcap * 3))) return rc;
   if ((rc = dmalloc(&m->ap, (size_t)m->Nl + 1))) return rc;
   m->dbg = nullptr;
-  m->incr = false; m->G_valid = false; m->G_data = nullptr;
+  m->incr = false; m->G_valid = false; m->G_uid = 0;
   m->bar = nullptr; m->use_scan = false;
   m->depth = 1 << 20; m->todo = 0; m->round_hint = 0;
   if ((rc = dmalloc(&m->bar, (size_t)512 * GG_SLOT_PAD))) return rc;
@@ -371,6 +383,7 @@ int gg_model_destroy(gg_model* m) {
   hipSetDevice(m->cfg.device);
   if (m->eig) { gg_eigen_destroy(m->eig); delete m; return GG_OK; }
   if (m->ld) { gg_latent_destroy(m->ld); delete m; return GG_OK; }
+  if (m->pend_data) { hipStreamSynchronize(m->stream); set_pend_data(m, nullptr); }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
                   m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc};
@@ -420,6 +433,7 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
     m->sweep = *(const uint32_t*)buf;
+    m->parts_done = 0;
     GG_HIP(hipMemcpy(m->rs + 6, &m->sweep, 4, hipMemcpyHostToDevice));   // device-side copy read by replayed sweeps
     return GG_OK;
   }
@@ -621,7 +635,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
     int RW = bulk_rw(m, strips, ndirs);
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
     // non-temporal loads once a pass streams more than the Infinity Cache holds (see gg_stream_load)
-    if ((double)ndirs * N * (double)Np > 200e6)
+    if ((double)ndirs * N * (double)Np > gg_nt_threshold())
       k_bulk_adj<true><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
     else
       k_bulk_adj<false><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
@@ -633,7 +647,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
     dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
     static int unroll = -1;
     if (unroll < 0) { const char* e = getenv("GG_BULK_UNROLL"); unroll = e ? atoi(e) : 4; }
-    const bool ntl = (double)ndirs * N * (double)Np * 4.0 * m->B > 200e6;   // beyond the Infinity Cache: see gg_stream_load
+    const bool ntl = (double)ndirs * N * (double)Np * 4.0 * m->B > gg_nt_threshold();   // beyond the Infinity Cache: see gg_stream_load
 #define BULKW(BV, UV)                                                                                                 \
   do {                                                                                                                \
     if (ntl) k_bulk_w<BV, UV, true><<<grd, 256, 0, st>>>(d->WqT, d->Wq, Np, perm, lab_start, K, RW, gcnt(m, buf, 0),    \
@@ -1080,11 +1094,11 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
 static int enqueue_sweep_incr(gg_model* m, const gg_data* d, uint32_t sweep) {
   int rc;
   const int buf = m->cur, P = m->pcur;
-  if (!m->G_valid || m->G_data != d) {
+  if (!m->G_valid || m->G_uid != d->uid) {
     m->zeroed[buf] = false;
     if ((rc = enqueue_bulk(m, d, buf, 3, true, sweep))) return rc;
     m->G_valid = true;
-    m->G_data = d;
+    m->G_uid = d->uid;
   }
   if ((rc = enqueue_params(m, d, buf, true, true, true, false, sweep, P))) return rc;
   if (m->use_scan) {
@@ -1159,7 +1173,7 @@ static int enqueue_sweep_pipe(gg_model* m, const gg_data* d, uint32_t sweep) {
 static int launch_sweep_graph(gg_model* m, const gg_data* d, uint32_t sweep) {
   int rc;
   const int g = m->cur, P = m->pcur;
-  if (m->gexec[g][P] && m->gdata[g][P] != d) {
+  if (m->gexec[g][P] && m->gdata_uid[g][P] != d->uid) {
     GG_HIP(hipGraphExecDestroy(m->gexec[g][P]));
     m->gexec[g][P] = nullptr;
   }
@@ -1174,7 +1188,7 @@ static int launch_sweep_graph(gg_model* m, const gg_data* d, uint32_t sweep) {
     if (e != hipSuccess) return gg_fail(GG_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
     GG_HIP(hipGraphInstantiate(&m->gexec[g][P], graph, nullptr, nullptr, 0));
     GG_HIP(hipGraphDestroy(graph));
-    m->gdata[g][P] = d;
+    m->gdata_uid[g][P] = d->uid;
   }
   GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[g], 0));   // this sweep's statistics (enqueued eagerly or by the last replay)
   GG_HIP(hipGraphLaunch(m->gexec[g][P], m->stream));
@@ -1266,6 +1280,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       m->next_bulk = false;
       m->zeroed[0] = m->zeroed[1] = false;
       m->G_valid = false;
+      set_pend_data(m, nullptr);
       if (st3 & 2) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out (the resident grid did not assemble); set GG_SCAN=0");
       if (st3 & 4) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out inside the statistics flush; set GG_SCAN=0");
       return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
@@ -1383,6 +1398,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
                       (h[5] + h[7]) * 0.01);
   }
   GG_HIP(hipEventSynchronize(m->ev_call1));
+  set_pend_data(m, nullptr);   // nothing of this model is in flight on the network any more
   if ((rc = collect_timing(m))) return rc;
   return GG_OK;
 }
@@ -1421,14 +1437,16 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   if (m->sharded) return gg_fail(GG_ERR_INVALID, "this model owns a shard of the nodes: drive it with the gg_shard_* step API");
   int rc = check_data(m, d);
   if (rc) return rc;
+  if (n_sweeps <= 0) return GG_OK;
   if ((m->pending || m->todo) && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
   // pipelined form: statistics computed ahead belong to the data (and labels) of the previous call
   if (m->pipe && m->pend_data != d && (rc = drain_pipe(m))) return rc;
   if (m->pending == 0 && m->todo == 0) {
+    if (m->parts_done) { m->sweep += 1; m->parts_done = 0; }   // step-wise parts were drawn under this index already
     begin_call(m);
     m->cur0 = m->cur; m->pcur0 = m->pcur;
   }
-  m->pend_data = d;
+  set_pend_data(m, d);
   m->beta = beta;
   for (int s = 0; s < n_sweeps; ++s) {
     if (m->todo > 0 || m->pending >= m->depth) { m->todo += 1; continue; }   // not further ahead than `depth`
@@ -1555,6 +1573,10 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
   if (rc) return rc;
   if ((rc = drain_pipe(m))) return rc;
+  // Philox counters are addressed by (seed, site, sweep, index): a part asked for again under the same sweep index
+  // would redraw the very same variates (a deterministic map, not a Markov kernel), so it starts a new sweep index.
+  parts &= (GG_PART_PARAMS | GG_PART_C | GG_PART_M);
+  if (parts & m->parts_done) { m->sweep += 1; m->parts_done = 0; }
   begin_call(m);
   const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
   const bool do_params = (parts & GG_PART_PARAMS) && learn_params;
@@ -1587,6 +1609,9 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
     write_ctl_word(m, 3, 0);
     return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
   }
+  // resample_m is the last step of a sweep (adjacency.py:615-618, weights.py:394-397): it closes the sweep index
+  if (parts & GG_PART_M) { m->sweep += 1; m->parts_done = 0; }
+  else m->parts_done |= parts;
   return collect_timing(m);
 }
 

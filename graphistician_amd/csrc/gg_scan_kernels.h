@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   unsigned long long it = 0;     // barrier rounds so far (identical in every workgroup)
   int wi = 0;                    // evaluation rounds so far: selects the rotating first-changer word
   bool alive = true, fatal = false;   // fatal: gave up inside the chip-wide flush (G half updated: not resumable)
+  bool flushed = false;               // the list was flushed at least once in this scan (same in every workgroup)
   long long t_eval = 0, t_xchg = 0, t_apply = 0, t_load = 0;
   const long long t_begin = g.dbg ? wall_clock64() : 0;
 
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         }
         ++it;
         nL = 0;
+        flushed = true;
       }
     }
     if (!alive) break;
@@ -413,7 +415,11 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     // a change is only recorded after every workgroup has published its candidate for it.  Leave the scan as a STALLED
     // one at that position (the state the restart rounds resume from: G as the bulk pass left it or as written back,
     // ap entries, L) and let the host carry on with the launch-per-change form.  Status bit 2 tells it why.
-    if (fatal) { if (tid == 0) atomicOr(&g.rs[3], 4); return; }
+    // After a flush the statistics of the band that was in LDS at the time are not in G any more (the flush skips them and
+    // restarts the list), and the workgroups that gave up may stand one accepted change apart: there is no consistent
+    // stalled scan to hand to the restart rounds.  Reported as an error instead of resuming from stale statistics
+    // (needs > 1024 changes in one scan AND a grid that cannot assemble).
+    if (fatal || flushed) { if (tid == 0) atomicOr(&g.rs[3], 4); return; }
     __syncthreads();
     for (int k = tid; k < K; k += 256) g.cnt[k] = s_cnt[k];
     if (tid == 0) {

@@ -1,6 +1,8 @@
 // gg_selftest.hip — device-side evaluation of the shared arithmetic spec so that
 // parity tests can compare gfx950 results with the host build bit for bit.
 #include "gg_common.h"
+#include "spec/gg_pg.h"
+#include "spec/gg_probit.h"
 
 __global__ void k_math(int op, const double* x, const double* y, double* out, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,7 +22,10 @@ __global__ void k_math(int op, const double* x, const double* y, double* out, lo
   out[i] = r;
 }
 
-// what: 0 normal, 1 gamma(a), 2 beta(a,b), 3 dirichlet(alpha[K]), 4 NIW posterior draw
+// what: 0 normal, 1 gamma(a), 2 beta(a,b), 3 dirichlet(alpha[K]), 4 NIW posterior draw,
+//       5 truncated normal N(mu, 1) on z > 0 (a != 0) / z < 0 (a == 0): prm = {mu, a} (a < 0: the sign is drawn first,
+//         A ~ Bern(1 - Phi(-mu)), the two-stage construction of test/test_distributions.py:39-56),
+//       6 PG(1, z): prm = {z},  7 categorical draw from prm = lp[K] (one uniform per draw)
 __global__ void k_draws(int what, uint64_t seed, const double* prm, int nprm, double* out, long long n, int stride) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -61,6 +66,20 @@ __global__ void k_draws(int what, uint64_t seed, const double* prm, int nprm, do
       gg_niw_posterior_draw(&s, &h, B, q[0], q + 1, q + 1 + B, mu, sig);
       for (int j = 0; j < B; ++j) out[i * stride + j] = mu[j];
       for (int j = 0; j < B * B; ++j) out[i * stride + B + j] = sig[j];
+    } break;
+    case 5: {
+      const double mu = prm[0];
+      int a = (int)prm[1];
+      if (a < 0) a = gg_uniform_at(seed, GG_SITE_INIT, 6u, (uint32_t)i) < 1.0 - gg_norm_cdf(-mu) ? 1 : 0;
+      out[i] = gg_truncnorm(gg_uniform_at(seed, GG_SITE_INIT, 5u, (uint32_t)i), mu, a);
+    } break;
+    case 6:
+      gg_stream_init(&s, seed, GG_SITE_INIT, 7u, (uint32_t)i);
+      out[i] = gg_pg1(&s, prm[0]);
+      break;
+    case 7: {
+      double scratch[128];
+      out[i] = (double)gg_categorical(prm, nprm, gg_uniform_at(seed, GG_SITE_INIT, 8u, (uint32_t)i), scratch);
     } break;
   }
 }
@@ -116,7 +135,7 @@ int gg_selftest_draws(int32_t device, int32_t what, uint64_t seed, const double*
   if (nparams > 0) GG_HIP(hipMemcpy(dp, params, nparams * 8, hipMemcpyHostToDevice));
   int np = nparams;
   if (what == 4) np = (int)params[0];
-  k_draws<<<(unsigned)((n + 63) / 64), 64>>>(what, seed, dp, what == 3 ? nparams : np, dout, n, stride > 0 ? stride : 1);
+  k_draws<<<(unsigned)((n + 63) / 64), 64>>>(what, seed, dp, (what == 3 || what == 7) ? nparams : np, dout, n, stride > 0 ? stride : 1);
   GG_HIP(hipGetLastError());
   GG_HIP(hipMemcpy(out, dout, no * 8, hipMemcpyDeviceToHost));
   hipFree(dp); hipFree(dout);
@@ -144,7 +163,7 @@ int gg_bench_stream(int32_t device, int64_t bytes, int32_t reps, int32_t mode, d
   GG_HIP(hipEventCreate(&e1));
   const int nb = 256 * 16;   // 16 workgroups per CU, grid-strided
   // the same streaming hint as the bulk kernels: non-temporal loads beyond the Infinity Cache (gg_stream_load)
-  const bool ntl = (double)bytes > 200e6;
+  const bool ntl = (double)bytes > gg_nt_threshold();
   if (ntl) k_stream_probe<true><<<nb, 256>>>(src, dst, n16, sink); else k_stream_probe<false><<<nb, 256>>>(src, dst, n16, sink);   // warm-up
   GG_HIP(hipEventRecord(e0, 0));
   for (int r = 0; r < reps; ++r) {

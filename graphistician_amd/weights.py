@@ -438,9 +438,7 @@ class SBMGaussianWeightDistribution(_WeightsBase):
         if parts == _abi.PART_ALL:
             eng.resample_async(d, 1, beta)    # stream-ordered: the next state read (or log_likelihood) waits for it
         else:
-            eng.resample_part(d, parts, beta)
-            if parts == _abi.PART_M:
-                eng.sweep = eng.sweep + 1
+            eng.resample_part(d, parts, beta)   # (the engine advances its Philox sweep index: graphgibbs.h, gg_resample_part)
         self._mark_stale("c", "m", "_mu", "_sigma", "_mu_self", "_sigma_self")
 
     def resample(self, data, beta=1.0):

@@ -67,6 +67,8 @@ enum gg_kind {
 };
 
 typedef struct gg_config {
+  uint32_t struct_size;           /* = sizeof(gg_config) as the CALLER compiled / declared it; gg_model_create refuses a
+                                     mismatch (a stale binding would otherwise be read past its end) */
   int32_t kind;                   /* gg_kind */
   int32_t N;                      /* nodes */
   int32_t K;                      /* blocks C (1 for non-SBM kinds) */
@@ -75,6 +77,7 @@ typedef struct gg_config {
   int32_t allow_self_connections; /* adjacency.py:461 */
   int32_t special_case_self_conns;/* adjacency.py:462, weights.py:189; BB: self_connection (adjacency.py:119-125) */
   int32_t device;                 /* HIP device ordinal */
+  int32_t reserved0;              /* keeps seed 8-byte aligned without hidden padding; set to 0 */
   uint64_t seed;                  /* Philox key */
   double tau1, tau0;              /* Beta prior (adjacency.py:460) */
   double sigma_mu0, sigma_F, sigma_lmbda, mu_mu_0; /* eigenmodel.py:41-56 */
@@ -170,6 +173,12 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes);
  * ER / SBM adjacency models; build-defined for the weight kinds (statistics x beta), the latent-distance models (likelihood
  * term x beta) and GG_LOGISTIC_EIG (omega ~ PG(beta, psi), kappa x beta); GG_PROBIT_EIG returns GG_ERR_UNSUPPORTED for beta != 1. */
 int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta);
+/* Step-wise parts (the reference's public resample_p / resample_c / resample_m, _resample_Omega / _resample_F / ...).
+ * Sweep-index rule: every draw is addressed by (seed, site, sweep index, element).  Parts called one after the other
+ * share the current sweep index until one of them is asked for a second time (or, for the block models, until
+ * GG_PART_M - the last step of a sweep - has run): then the index advances, so that repeating a part never repeats
+ * its variates.  A full gg_resample after step-wise parts starts at a fresh index as well.  GG_ST_SWEEP reads / sets
+ * the index (setting it forgets which parts were drawn under it). */
 int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta);
 /* Stream-ordered form: gg_resample_async enqueues n_sweeps sweeps on the model's HIP stream and
  * returns; gg_sync (and every call that reads state) waits for them.  gg_resample = async + sync.

@@ -23,6 +23,52 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.gg_version()
 
 
+_CTYPES_OF = {"int32_t": "c_int", "uint32_t": "c_uint", "uint64_t": "c_ulong", "int64_t": "c_long", "double": "c_double"}
+
+
+def _header_struct(hdr, name):
+    """[(c type, field name), ...] of `typedef struct <name> { ... } <name>;` in include/graphgibbs.h."""
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        for n in names.split(","):
+            out.append((ctype, n.strip()))
+    return out
+
+
+def _stub_struct(md, cls):
+    """The ctypes `_fields_` of class `cls` in the stub INTEGRATION.md shows a maintainer."""
+    block = re.search(r"class\s+%s\(C\.Structure\):.*?_fields_\s*=\s*\[(.*?)\]\n" % cls, md, re.S).group(1)
+    return re.findall(r'\("(\w+)",\s*C\.(\w+)\)', block)
+
+
+def test_ctypes_structs_match_the_header_field_for_field():
+    """gg_config / gg_stats as declared in include/graphgibbs.h, as bound in graphistician_amd/_abi.py and as printed in
+    INTEGRATION.md must agree in names, types and order (round 1 shipped a stub that ended two fields early), and
+    gg_config has no hidden padding, so sizeof is the sum of its fields."""
+    import ctypes as C
+    from graphistician_amd import _abi
+    hdr = open(os.path.join(ROOT, "include", "graphgibbs.h")).read()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for cname, cls in (("gg_config", _abi.Config), ("gg_stats", _abi.Stats)):
+        want = _header_struct(hdr, cname)
+        got = [(f[1].__name__, f[0]) for f in cls._fields_]
+        assert [(_CTYPES_OF[t], n) for t, n in want] == got, cname
+    cfg = _header_struct(hdr, "gg_config")
+    assert cfg[0] == ("uint32_t", "struct_size")
+    size = {"int32_t": 4, "uint32_t": 4, "uint64_t": 8, "int64_t": 8, "double": 8}
+    assert C.sizeof(_abi.Config) == sum(size[t] for t, _ in cfg), "hidden padding in gg_config"
+    stub = _stub_struct(md, "Config")
+    assert [n for n, _ in stub] == [n for _, n in cfg], "INTEGRATION.md's Config stub is out of step with gg_config"
+    assert [getattr(C, t).__name__ for _, t in stub] == [_CTYPES_OF[t] for t, _ in cfg]
+    assert "struct_size=C.sizeof(Config)" in md
+
+
 def test_no_cpu_fallback():
     from graphistician_amd import _abi
     if _abi.device_count() > 0:
@@ -165,3 +211,36 @@ def test_vectorised_niw_log_prior_matches_the_scipy_loop():
         ref = sum(niw_log_prob(mu[i, j], sigma[i, j], mu_0, sigma_0, nu_0, kappa_0) for i in range(K) for j in range(K))
         got = niw_log_prob_many(mu, sigma, mu_0, sigma_0, nu_0, kappa_0)
         assert abs(got - ref) <= 1e-9 * abs(ref)
+
+
+def test_stale_config_struct_is_refused_before_anything_else():
+    """gg_model_create checks gg_config.struct_size first (no device needed to see it)."""
+    import ctypes as C
+    from graphistician_amd import _abi
+    cfg = _abi.Config()
+    cfg.kind, cfg.N, cfg.K, cfg.B = _abi.SBM_ADJ, 8, 2, 1
+    h = C.c_void_p()
+    for bad in (0, C.sizeof(_abi.Config) - 8):
+        cfg.struct_size = bad
+        assert _abi.lib().gg_model_create(C.byref(h), C.byref(cfg)) == _abi.ERR_INVALID
+        assert b"struct_size" in _abi.lib().gg_last_error()
+
+
+def test_data_cache_key_sees_in_place_edits():
+    """engine.as_device_data keys its cache on a content sample as well as on identity: refilling a buffer in
+    place or masking a held-out row / column changes the key; NaN in A is refused at upload."""
+    from graphistician_amd import engine, _abi
+    rng = np.random.RandomState(0)
+    A = (rng.rand(512, 512) < 0.5).astype(np.float64)
+    W = rng.randn(512, 512, 2)
+    k0 = (engine._fingerprint(A), engine._fingerprint(W))
+    assert k0 == (engine._fingerprint(A), engine._fingerprint(W))
+    A2 = A.copy()
+    A2[37, :] = 0; A2[:, 37] = 0                       # hold one node out
+    A[:] = A2
+    assert engine._fingerprint(A) != k0[0]
+    W[:] = rng.randn(512, 512, 2)                      # a new rvs() draw into the same buffer
+    assert engine._fingerprint(W) != k0[1]
+    A[3, 4] = np.nan
+    with pytest.raises(ValueError):
+        _abi._adjacency_u8(A)

@@ -1,0 +1,207 @@
+"""GPU parity AT THE SIZES OF BASELINE.json's configs ("configs untested at their size").
+
+The small-N suites exercise every scan form; what they cannot reach is what only exists at size: the bulk launch
+shapes of N >= 4096, more than 1024 label changes in one scan (change-list flushes), the non-temporal instantiations
+of the streaming kernels (chosen above ~200 MB per pass: configs[3] and [4]), K = 64 tables streamed from L2.  Here
+the engine runs the configs' own shapes against the multi-threaded CPU oracle (oracle_fast.cpp: the same chain bit
+for bit as the plain restatement, tests/test_spec_and_oracle.py::test_fast_cpu_flavour_is_the_same_chain):
+
+* configs[1]  N=4096, K=16: 30 sweeps from a prior draw (thousands of label changes) + 100 steady sweeps;
+* the same chain with GG_NT_BYTES=0 (non-temporal bulk instantiations forced) — and a small-N chain under it;
+* configs[4] shape  N=8192, K=16 (one AIS chain's network): 12 sweeps + the tempered sweeps AIS runs;
+* configs[3] shape on what the oracle finishes in seconds: N=16384, K=64, 10 sweeps (non-temporal path by size);
+* configs[2]  logistic eigenmodel N=4096, D=8: one full sweep vs the oracle at the float tolerance of DESIGN.md §7.
+
+Reference lines: adjacency.py:615-702, weights.py:394-498, eigenmodel.py:836-965.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from graphistician_amd import _abi
+    if _abi.device_count() < 1:
+        pytest.fail("no HIP device: the engine has no CPU fallback")
+    return _abi
+
+
+def planted_truth(N, K, seed):
+    rng = np.random.RandomState(seed)
+    m = rng.dirichlet(np.ones(K) * 10.0)
+    c = rng.choice(K, p=m, size=N).astype(np.int32)
+    p = rng.beta(1.0, 1.0, size=(K, K))
+    sigma = 1.0 / rng.gamma(1.5, 2.0, size=(K, K))
+    mu = rng.randn(K, K) * np.sqrt(sigma)
+    return dict(c=c, p=p, p_self=float(rng.beta(1.0, 1.0)), mu=mu, sigma=sigma)
+
+
+class Chain(object):
+    """One Gaussian-SBM chain (adjacency + weights) on the engine and on the oracle, started from the same prior draw."""
+
+    def __init__(self, abi, N, K, data_seed=1234, chain_seed=5):
+        self.abi, self.N, self.K = abi, N, K
+        t = planted_truth(N, K, data_seed)
+        # the network is generated on the device (adjacency.py:558-560, weights.py:360-373) and downloaded for the oracle
+        self.data = abi.DeviceData.synthetic_sbm(N, t["c"], t["p"], t["p_self"], t["mu"], t["sigma"], 0.0, 1.0, seed=data_seed)
+        A, W = self.data.download()
+        q, shift = O.quantise(A, W)
+        del W
+        self.fs = O.FastSweeper(A, q, shift)
+        rng = np.random.RandomState(chain_seed)
+        self.sa, self.sw = chain_seed * 2 + 1, chain_seed * 2 + 2
+        self.pi_a, self.pi_w = np.ones(K), np.ones(K) * 10.0
+        self.c_a = rng.choice(K, size=N).astype(np.int32)
+        self.m_a = rng.dirichlet(self.pi_a)
+        self.p = np.ascontiguousarray(rng.beta(1.0, 1.0, size=(K, K)))
+        self.ps = float(rng.beta(1.0, 1.0))
+        self.c_w = rng.choice(K, size=N).astype(np.int32)
+        self.m_w = rng.dirichlet(self.pi_w)
+        self.mu = np.ascontiguousarray(rng.randn(K, K, 1))
+        self.sig = np.ones((K, K, 1, 1))
+        self.mus, self.sigs = np.zeros(1), np.ones((1, 1))
+        self.niw = O.pack_niw([0.0], [[1.0]], 3.0, 1.0)
+        self.adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=self.sa, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                             special_case_self_conns=1)
+        a = self.adj
+        a.set(abi.ST_C, self.c_a, np.int32); a.set(abi.ST_M, self.m_a); a.set(abi.ST_PI, self.pi_a); a.set(abi.ST_P, self.p)
+        a.set(abi.ST_P_SELF, np.array([self.ps]))
+        self.w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=self.sw, special_case_self_conns=1)
+        w = self.w
+        w.set(abi.ST_C, self.c_w, np.int32); w.set(abi.ST_M, self.m_w); w.set(abi.ST_PI, self.pi_w)
+        w.set(abi.ST_MU, self.mu); w.set(abi.ST_SIGMA, self.sig); w.set(abi.ST_NIW, self.niw); w.set(abi.ST_NIW_SELF, self.niw)
+        self.s = 0
+
+    def run(self, n, chunk=None):
+        """n sweeps on both sides (the engine in chunks of `chunk`), then every piece of state compared bit for bit."""
+        abi, N, K = self.abi, self.N, self.K
+        left = n
+        while left > 0:
+            k = min(left, chunk or left)
+            abi.resample_many([self.adj, self.w], self.data, k)
+            left -= k
+        for _ in range(n):
+            self.ps = self.fs.adj_sweep(self.c_a, self.m_a, self.p, self.ps, self.pi_a, 1.0, 1.0, 1, self.sa, self.s)
+            self.fs.w_sweep(self.c_w, self.m_w, self.mu, self.sig, self.mus, self.sigs, self.pi_w, self.niw, self.niw, 1, self.sw, self.s)
+            self.s += 1
+        a, w = self.adj, self.w
+        assert np.array_equal(a.get(abi.ST_C, (N,), np.int32), self.c_a), "adjacency labels differ after sweep %d" % self.s
+        assert np.array_equal(a.get(abi.ST_P, (K, K)), self.p)
+        assert np.array_equal(a.get(abi.ST_P_SELF, (1,)), np.array([self.ps]))
+        assert np.array_equal(a.get(abi.ST_M, (K,)), self.m_a)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), self.c_w), "weight labels differ after sweep %d" % self.s
+        assert np.array_equal(w.get(abi.ST_MU, (K, K, 1)), self.mu)
+        assert np.array_equal(w.get(abi.ST_SIGMA, (K, K, 1, 1)), self.sig)
+        assert np.array_equal(w.get(abi.ST_MU_SELF, (1,)), self.mus)
+        assert np.array_equal(w.get(abi.ST_M, (K,)), self.m_w)
+
+    def changes(self):
+        return self.adj.stats()["label_changes"], self.w.stats()["label_changes"]
+
+    def loglik_matches(self):
+        ll = sum(self.abi.log_likelihood_many([self.adj, self.w], self.data))
+        A, W = self.data.download()
+        q, shift = O.quantise(A, W)
+        ref = (O.sbm_adj_loglik(A, self.c_a, self.p, self.ps) +
+               O.sbm_w_loglik(A, q, shift, self.c_w, self.mu, self.sig, self.mus, self.sigs, 1))
+        assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
+
+
+@pytest.fixture
+def forced_nt():
+    os.environ["GG_NT_BYTES"] = "0"
+    yield
+    os.environ.pop("GG_NT_BYTES", None)
+
+
+def test_cfg1_n4096_k16_chain_bitexact(abi):
+    """BASELINE.json configs[1]: burn-in from a prior draw (every scan form, list flushes) and the steady state."""
+    ch = Chain(abi, 4096, 16)
+    ch.run(30, chunk=7)
+    ca, cw = ch.changes()
+    assert ca + cw > 2000, "the burn-in was expected to relabel thousands of nodes (%d + %d)" % (ca, cw)
+    ch.run(100)
+    ch.loglik_matches()
+
+
+def test_cfg1_n4096_k16_nontemporal_instantiations_bitexact(abi, forced_nt):
+    """The same chain through k_bulk_adj<true> / k_bulk_w<1,4,true> (what configs[3] and [4] run by size)."""
+    ch = Chain(abi, 4096, 16, chain_seed=6)
+    ch.run(12, chunk=5)
+    ch.run(20)
+    ch.loglik_matches()
+
+
+@pytest.mark.parametrize("N,K", [(300, 5), (1100, 33)])
+def test_small_chains_under_forced_nontemporal_loads(abi, forced_nt, N, K):
+    ch = Chain(abi, N, K, data_seed=N, chain_seed=N + 1)
+    ch.run(8, chunk=3)
+    ch.loglik_matches()
+
+
+def test_cfg4_shape_n8192_k16_chain_and_tempered_sweeps(abi):
+    """configs[4]: the network one AIS chain works on (N=8192; 268 MB of weights per direction: non-temporal by size).
+    Plain sweeps, then sweeps at the inverse temperatures AIS visits (graph_models.py:50-64)."""
+    N, K = 8192, 16
+    ch = Chain(abi, N, K, chain_seed=9)
+    ch.run(12, chunk=4)
+    ch.loglik_matches()
+    # tempered sweeps of the adjacency half (the reference tempers ER / SBM adjacency, demo_ais.py:33-52)
+    A, _ = ch.data.download(with_weights=False)
+    for beta in (0.0, 0.37, 0.99):
+        ch.adj.resample(ch.data, 1, beta=beta)
+        ch.ps = O.sbm_adj_sweep(A, ch.c_a, ch.m_a, ch.p, ch.ps, ch.pi_a, 1.0, 1.0, 1, ch.sa, ch.s, beta=beta)
+        ch.adj.sweep = ch.s + 1
+        ch.s += 1
+        assert np.array_equal(ch.adj.get(abi.ST_C, (N,), np.int32), ch.c_a), "tempered labels differ at beta=%g" % beta
+        assert np.array_equal(ch.adj.get(abi.ST_P, (K, K)), ch.p)
+
+
+def test_cfg3_shape_n16384_k64_chain_bitexact(abi):
+    """configs[3]'s K = 64 (tables streamed from L2, split conditionals) at the largest N the oracle finishes in
+    seconds; 1.07 GB per weight pass: the non-temporal path by size."""
+    ch = Chain(abi, 16384, 64, chain_seed=3)
+    ch.run(10, chunk=4)
+    ca, cw = ch.changes()
+    assert ca + cw > 10000
+    ch.loglik_matches()
+
+
+def test_cfg2_eigenmodel_n4096_d8_one_sweep(abi):
+    """BASELINE.json configs[2]: one full logistic-eigenmodel sweep (Omega, F, mu_0, lambda) at N=4096, D=8 vs the
+    oracle.  Tolerances as DESIGN.md §7: the engine sums in a different order (symmetrised Omega, tiled scan)."""
+    N, D, seed = 4096, 8, 21
+    rng = np.random.RandomState(1234)
+    Ft, lt = rng.randn(N, D), rng.randn(D)
+    mm = -1.2815515655446004
+    mu_t = mm + rng.randn()
+    Mu = mu_t + (Ft * lt).dot(Ft.T)
+    np.fill_diagonal(Mu, mu_t)
+    A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-Mu))).astype(np.uint8)
+    del Mu
+    F0 = np.ascontiguousarray(rng.randn(N, D)); l0 = np.ascontiguousarray(rng.randn(D)); m0 = mm + rng.randn()
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=seed, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=mm)
+    m.set(abi.ST_F, F0); m.set(abi.ST_LMBDA, l0); m.set(abi.ST_MU0, np.array([m0])); m.set(abi.ST_MU_LMBDA, np.zeros(D))
+    m.resample(d, 1)
+    Fo, lo = F0.copy(), l0.copy()
+    mu_o, Om = O.eig_sweep(A, Fo, lo, m0, np.zeros(D), mm, 1.0, 1.0, 1.0, 0, seed, 0)
+    S = m.get(abi.ST_OMEGA_S, (N, N))
+    ref = Om + Om.T
+    np.fill_diagonal(ref, np.diag(Om))
+    assert np.allclose(S, ref, rtol=1e-9, atol=1e-13)
+    del S, ref, Om
+    F1 = m.get(abi.ST_F, (N, D))
+    # 4096 sequential D x D solves, each conditioned on all the earlier ones: rounding differences accumulate along the scan
+    assert np.allclose(F1, Fo, rtol=1e-6, atol=1e-7), np.abs(F1 - Fo).max()
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - mu_o) < 1e-7
+    assert np.allclose(m.get(abi.ST_LMBDA, (D,)), lo, rtol=1e-6, atol=1e-8)
+    ll = m.log_likelihood(d)
+    ref_ll = O.eig_loglik(A, Fo, lo, mu_o)
+    assert abs(ll - ref_ll) <= 1e-6 * abs(ref_ll)
