@@ -107,6 +107,27 @@ def cpu_baseline(abi, data, N, K, budget_s):
                sample="%d full sweeps (adjacency + weights) after %d untimed ones on the same N=%d K=%d network, oracle/oracle_fast.cpp "
                       "(C++ -O2, OpenMP, %d threads)" % (n, n_warm, N, K, fs.threads))
     fs.close()
+    # parity, checked in the same run: the engine runs the very chain the CPU just ran (same start, same Philox keys, same
+    # number of sweeps) and must land on the same labels and parameters bit for bit
+    _progress("parity check: the engine on the CPU baseline's chain (%d sweeps)" % (n_warm + n))
+    f0 = fresh()
+    ea = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=11, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                   special_case_self_conns=1, device=data.device)
+    ea.set(abi.ST_C, f0["c_a"], np.int32); ea.set(abi.ST_M, f0["m_a"]); ea.set(abi.ST_PI, np.ones(K)); ea.set(abi.ST_P, f0["p"])
+    ea.set(abi.ST_P_SELF, np.array([f0["ps"]]))
+    ew = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=12, special_case_self_conns=1, device=data.device)
+    ew.set(abi.ST_C, f0["c_w"], np.int32); ew.set(abi.ST_M, f0["m_w"]); ew.set(abi.ST_PI, np.ones(K) * 10)
+    ew.set(abi.ST_MU, f0["mu"]); ew.set(abi.ST_SIGMA, f0["sig"]); ew.set(abi.ST_NIW, niw); ew.set(abi.ST_NIW_SELF, niw)
+    abi.resample_many([ea, ew], data, n_warm + n)
+    same = dict(adjacency_labels=bool(np.array_equal(ea.get(abi.ST_C, (N,), np.int32), st["c_a"])),
+                weight_labels=bool(np.array_equal(ew.get(abi.ST_C, (N,), np.int32), st["c_w"])),
+                p=bool(np.array_equal(ea.get(abi.ST_P, (K, K)), st["p"])),
+                mu=bool(np.array_equal(ew.get(abi.ST_MU, (K, K, 1)), st["mu"])),
+                sigma=bool(np.array_equal(ew.get(abi.ST_SIGMA, (K, K, 1, 1)), st["sig"])))
+    out["parity"] = dict(checked=True, bit_exact=all(same.values()), sweeps=int(n_warm + n), fields=same,
+                         label_changes=int(ea.stats()["label_changes"] + ew.stats()["label_changes"]),
+                         labels_digest=int(np.bitwise_xor.reduce(st["c_a"].astype(np.int64) * np.arange(1, N + 1))))
+    del ea, ew
     _progress("cpu baseline: scalar flavour")
     # plain scalar restatement
     st = fresh()
@@ -158,6 +179,123 @@ def cpu_literal_extrapolated(N, K, seed=3):
     return dict(value=1.0 / (t_adj + t_w), unit="sweeps/s", cores=1, kind="port",
                 sample="oracle/literal.py (numpy/scipy loops of the reference) timed at N=%d and %d, K=%d, extrapolated to N=%d K=%d "
                        "by operation count: %.0f s adjacency half + %.0f s weight half per sweep" % (Na, Nb, K0, N, K, t_adj, t_w))
+
+
+def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every, barrier=lambda: None, stepwise=False):
+    """One Gaussian-SBM chain (adjacency + weight models) on `data`: set-up burn-in, `warmup` untimed sweeps, `steps`
+    timed sweeps.  One step = one FactorizedNetworkDistribution.resample((A,W)): the two halves are independent models
+    (networks.py:69-71) enqueued stream-ordered on their own HIP streams; the timed region ends when both
+    streams have drained (gg_sync)."""
+    adj, w = build_models(abi, N, K, chain_seed=chain_seed, device=device)
+    if burnin > 0:          # set-up: out of the prior draw's transient (SBM config: --burnin)
+        abi.resample_many([adj, w], data, burnin)
+    for _ in range(warmup):
+        adj.resample(data, 1)
+        w.resample(data, 1)
+    chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
+    adj.set_timing(every)
+    w.set_timing(every)
+    barrier()
+    t0 = time.perf_counter()
+    if stepwise:
+        for _ in range(steps):
+            adj.resample_async(data, 1)
+            w.resample_async(data, 1)
+        abi.sync_many([adj, w])
+    else:
+        abi.resample_many([adj, w], data, steps)
+    barrier()
+    el = time.perf_counter() - t0
+    sa, sw = adj.stats(), w.stats()
+    adj.set_timing(0); w.set_timing(0)
+    return dict(adj=adj, w=w, elapsed=el,
+                bulk=dict(adj_ms=sa["bulk_ms"], adj_n=sa["bulk_launches"], w_ms=sw["bulk_ms"], w_n=sw["bulk_launches"]),
+                changes=sa["label_changes"] + sw["label_changes"] - chg0,
+                changes_adj=sa["label_changes"], changes_w=sw["label_changes"])
+
+
+def extra_mixing_chains(abi, data, N, K, device, burnin, steps=100):
+    """The headline chain (seed 1) settles into zero label changes per sweep; chains 2 and 4 keep mixing (the scan's
+    sequential machinery at work in the timed region).  Same network, same kernels, other prior draws."""
+    out = []
+    for seed in (2, 4):
+        r = run_chain(abi, data, N, K, seed, device, burnin, 10, steps, 0)
+        out.append({"chain_seed": seed, "value": steps / r["elapsed"], "unit": "sweeps/s", "ms_per_step": r["elapsed"] / steps * 1e3,
+                    "label_changes_per_sweep": r["changes"] / float(steps)})
+        del r
+    return out
+
+
+def extra_eigen(abi, device, N=4096, D=8, warmup=5, steps=20):
+    """BASELINE.json configs[2] (logistic eigenmodel Gibbs, eigenmodel.py:836-857) inside the default run."""
+    rng = np.random.RandomState(1234)
+    F = rng.randn(N, D); lam = rng.randn(D); mm = -1.2815515655446004
+    mu0 = mm + rng.randn()
+    Mu = mu0 + (F * lam).dot(F.T)
+    np.fill_diagonal(Mu, mu0)
+    A = (rng.rand(N, N) < 1.0 / (1.0 + np.exp(-Mu))).astype(np.uint8)
+    del Mu
+    data = abi.DeviceData(A, None, device=device)
+    m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=1, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=mm,
+                  device=device)
+    crng = np.random.RandomState(1)
+    m.set(abi.ST_F, crng.randn(N, D)); m.set(abi.ST_LMBDA, crng.randn(D)); m.set(abi.ST_MU0, np.array([mm + crng.randn()]))
+    m.set(abi.ST_MU_LMBDA, np.zeros(D))
+    m.resample(data, warmup)
+    t0 = time.perf_counter()
+    m.resample(data, steps)
+    m.get(abi.ST_MU0, (1,))
+    el = time.perf_counter() - t0
+    sweep_bytes = float(N) * N * (3 * 8 + 2 * 2)
+    return {"workload": "Logistic eigenmodel Gibbs (Polya-gamma), N=%d, D=%d (BASELINE.json configs[2])" % (N, D),
+            "value": steps / el, "unit": "sweeps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+            "sweep_algorithmic_bytes": sweep_bytes, "effective_GBs": sweep_bytes * steps / el / 1e9,
+            "bound": "latency of the sequential latent-feature scan (N dependent D x D solves) + PG(1,z) draws, not HBM (DESIGN.md 7)"}
+
+
+def extra_big(abi, device, N=65536, K=64, burnin=12, warmup=2, steps=20):
+    """BASELINE.json configs[3] on ONE GPU (43 GB resident): every bulk launch of the timed region sampled."""
+    truth = planted_truth(N, K, seed=1234)
+    data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                        truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
+    r = run_chain(abi, data, N, K, 1, device, burnin, warmup, steps, 1)
+    per_ms = r["bulk"]["w_ms"] / max(r["bulk"]["w_n"], 1)
+    alg = 2.0 * float(N) * N * 4.0
+    ach = alg / (per_ms * 1e-3) / 1e9 if per_ms > 0 else 0.0
+    sweep_bytes = 2.0 * N * N * 5.0
+    out = {"workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1 (BASELINE.json configs[3] on one GPU)" % (N, K),
+           "value": steps / r["elapsed"], "unit": "sweeps/s", "ms_per_step": r["elapsed"] / steps * 1e3, "steps": steps,
+           "burn_in_sweeps": burnin, "label_changes_per_sweep": r["changes"] / float(steps),
+           "sweep_algorithmic_bytes": sweep_bytes, "sweep_effective_GBs": sweep_bytes * steps / r["elapsed"] / 1e9,
+           "roofline": {"bound": "hbm", "kernel": "k_bulk_w<1> (non-temporal loads)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "launch_ms": per_ms, "launch_bytes": alg,
+                        "sampled_launches": int(r["bulk"]["w_n"]),
+                        "adj_kernel": {"launch_ms": r["bulk"]["adj_ms"] / max(r["bulk"]["adj_n"], 1), "launch_bytes": 2.0 * float(N) * N}}}
+    del r, data
+    return out
+
+
+def extra_ais(abi, device, N=8192, R=3, B=100, steps_per_B=2):
+    """BASELINE.json configs[4], one of its chains: AIS evidence of the SBM (R=3, b0=b1=1, alpha0=10) on a planted-SBM graph
+    (examples/demo_ais.py:10-62,70-80): B temperatures, steps_per_B tempered sweeps each plus one log-likelihood
+    evaluation per temperature, all through the host classes."""
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd import ais as AIS
+    truth = planted_truth(N, R, seed=99)
+    data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                        truth["mu_self"], truth["sigma_self"], seed=99, device=device)
+    np.random.seed(5)
+    sbm = SBMAdjacencyDistribution(N, C=R, pi=10.0, tau0=1.0, tau1=1.0, device=device, seed=20)
+    AIS.estimate_marginal_likelihood(sbm, data, N_samples=1, B=6, steps_per_B=steps_per_B)      # warm-up
+    t0 = time.perf_counter()
+    logZ = AIS.estimate_marginal_likelihood(sbm, data, N_samples=1, B=B, steps_per_B=steps_per_B)
+    el = time.perf_counter() - t0
+    nsweeps = (B - 2) * steps_per_B
+    return {"workload": "AIS, SBM adjacency R=%d, N=%d, one chain: %d temperatures x %d tempered sweeps + 1 log-likelihood each "
+                        "(BASELINE.json configs[4]; its 8 chains are independent, one per GPU)" % (R, N, B, steps_per_B),
+            "value": nsweeps / el, "unit": "sweeps/s (including the per-temperature log-likelihood)", "seconds_per_chain": el,
+            "tempered_sweeps": nsweeps, "log_likelihood_evaluations": B - 1, "log_Z_one_chain": float(logZ),
+            "sweep_algorithmic_bytes": 2.0 * N * N, "log_likelihood_algorithmic_bytes": 1.0 * N * N}
 
 
 def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
@@ -373,6 +511,8 @@ def main():
                     help="sweeps run as part of chain set-up, before the W warm-up steps: the chain starts from a prior draw "
                          "and relabels thousands of nodes in its first few sweeps; the metric is the sampler's steady state")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra legs of the default run (mixing chains, configs[2], configs[3] on one GPU, one AIS chain)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the multi-process protocol (rendezvous, barrier, max-over-ranks) without the engine")
     args = ap.parse_args()
@@ -446,36 +586,12 @@ def main():
     # much of the scan's slow path it exercises) depends on its prior draw, so every rank runs a replica of the
     # SAME chain (GG_BENCH_CHAIN_SEED, default 1).  Independent chains differ only in this seed.
     chain_seed = int(os.environ.get("GG_BENCH_CHAIN_SEED", "1"))
-    adj, w = build_models(abi, N, K, chain_seed=chain_seed, device=device)
-
-    if args.burnin > 0:          # set-up: out of the prior draw's transient (SBM config: --burnin)
-        abi.resample_many([adj, w], data, args.burnin)
-    for _ in range(args.warmup):
-        adj.resample(data, 1)
-        w.resample(data, 1)
-    chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
-    every = 8 if N <= 8192 else 1
-    adj.set_timing(every)   # HIP events around the bulk kernel of every n-th sweep (on the engine streams)
-    w.set_timing(every)
-    barrier()
-    t0 = time.perf_counter()
-    # One step = one FactorizedNetworkDistribution.resample((A,W)): the two halves are independent
-    # models (networks.py:69-71) and are enqueued stream-ordered on their own HIP
-    # streams; the timed region ends when both streams have drained (gg_sync).
-    if os.environ.get("GG_BENCH_STEPWISE"):
-        for _ in range(args.steps):
-            adj.resample_async(data, 1)
-            w.resample_async(data, 1)
-        abi.sync_many([adj, w])
-    else:
-        abi.resample_many([adj, w], data, args.steps)
-    barrier()
-    el = time.perf_counter() - t0
+    every = 1 if N <= 8192 else 1        # HIP events around EVERY bulk launch of the timed region (on the engine streams)
+    r = run_chain(abi, data, N, K, chain_seed, device, args.burnin, args.warmup, args.steps, every, barrier,
+                  stepwise=bool(os.environ.get("GG_BENCH_STEPWISE")))
+    adj, w, el, bulk, chg = r["adj"], r["w"], r["elapsed"], r["bulk"], r["changes"]
     if rank == 0:
         _progress("timed region done: %d sweeps in %.3f s" % (args.steps, el))
-    sa, sw = adj.stats(), w.stats()
-    bulk = dict(adj_ms=sa["bulk_ms"], adj_n=sa["bulk_launches"], w_ms=sw["bulk_ms"], w_n=sw["bulk_launches"])
-    chg = sa["label_changes"] + sw["label_changes"] - chg0
     el = max_over_ranks(el)
 
     if rank == 0:
@@ -588,8 +704,28 @@ def main():
         if not args.no_cpu and world == 1:   # timed on rank 0 at N=1 only
             _progress("cpu baseline (bounded: about %.0f s)" % args.cpu_seconds)
             out["cpu_baseline"] = cpu_baseline(abi, data, N, K, args.cpu_seconds)
+            out["parity_checked"] = bool(out["cpu_baseline"].get("parity", {}).get("bit_exact", False))
             _progress("literal baseline")
             out["cpu_baseline"]["literal_extrapolated"] = cpu_literal_extrapolated(N, K)
+        else:
+            out["parity_checked"] = False
+        if world == 1 and not args.no_extras:
+            # The other configurations of BASELINE.json and the chains that keep mixing, in the same driver-run line
+            # (extra keys; `value` stays the configs[1] headline).  Each leg is bounded and must never cost the line.
+            _progress("mixing chains (seeds 2 and 4)")
+            try:
+                out["mixing_chains"] = extra_mixing_chains(abi, data, N, K, device, args.burnin)
+            except Exception as exc:
+                out["mixing_chains"] = {"error": str(exc)}
+            del adj, w, r, data
+            legs = {}
+            for name, fn in (("eigen_n4096_d8", extra_eigen), ("ais_sbm_n8192", extra_ais), ("sbm_n65536_k64_one_gpu", extra_big)):
+                _progress("extra config: %s" % name)
+                try:
+                    legs[name] = fn(abi, device)
+                except Exception as exc:
+                    legs[name] = {"error": str(exc)}
+            out["other_configs"] = legs
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -46,7 +46,7 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double)]
 
 
-EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_info",
+EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_update", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
            "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_shard_sizes", "gg_shard_tables",
            "gg_shard_params", "gg_shard_next", "gg_shard_apply", "gg_shard_finish", "gg_shard_log_likelihood",
@@ -77,6 +77,7 @@ def lib():
         vp = C.c_void_p
         L.gg_data_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32]
         L.gg_data_destroy.argtypes = [vp]
+        L.gg_data_update.argtypes = [vp, vp, vp]
         L.gg_data_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int64)]
         L.gg_data_create_sbm.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp, C.c_double,
@@ -199,6 +200,17 @@ class DeviceData(object):
                                                  float(mu_self), float(sigma_self), C.c_uint64(seed), int(shard[0]),
                                                  int(shard[1]), device))
         return cls(handle=h, N=N, B=1, device=device)
+
+    def update(self, A, W=None):
+        """Replace the network in place with another (A, W) of the same shape (gg_data_update)."""
+        A = _adjacency_u8(A)
+        assert A.shape == (self.N, self.N)
+        if W is not None:
+            W = np.ascontiguousarray(W, dtype=np.float64)
+            if W.ndim == 2:
+                W = W[:, :, None].copy()
+            assert W.shape == (self.N, self.N, self.B)
+        check(lib().gg_data_update(self._h, _ptr(A), _ptr(W) if W is not None else None))
 
     @property
     def handle(self):

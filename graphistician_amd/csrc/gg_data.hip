@@ -199,6 +199,61 @@ static void diag_stats_host(gg_data* d, const uint8_t* dA, const int32_t* dWq) {
   }
 }
 
+// Host staging of a whole (A, W) into an allocated handle (gg_data_create, gg_data_update).
+static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
+  const int N = d->N, B = d->B;
+  // host staging: off-diagonal copy, diagonal, quantisation (same arithmetic as the
+  // oracle's orc_quantise: shift = qbits - frexp-exponent of max |w| over edges).
+  size_t nA = (size_t)N * d->Np;
+  std::vector<uint8_t> hA(nA, 0), hdA(N, 0);
+  long long nedges = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      uint8_t a = A[(size_t)i * N + j] ? 1 : 0;
+      nedges += a;
+      if (i == j) hdA[i] = a; else hA[(size_t)i * d->Np + j] = a;
+    }
+  d->n_edges = nedges;
+  GG_HIP(hipMemcpyAsync(d->A, hA.data(), nA, hipMemcpyHostToDevice, d->stream));
+  GG_HIP(hipMemcpyAsync(d->dA, hdA.data(), N, hipMemcpyHostToDevice, d->stream));
+  std::vector<int32_t> hW, hdW;
+  if (W) {
+    double wmax = 0.0;
+    for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
+      if (!A[ij]) continue;
+      for (int b = 0; b < B; ++b) {
+        double a = fabs(W[ij * B + b]);
+        if (!(a <= 1.7e308)) return gg_fail(GG_ERR_NUMERIC, "non-finite weight on an edge");
+        if (a > wmax) wmax = a;
+      }
+    }
+    if (wmax == 0.0) wmax = 1.0;
+    int e;
+    frexp(wmax, &e);
+    d->shift = gg_qbits(N) - e;
+    hW.assign(nA * B, 0);
+    hdW.assign((size_t)N * B, 0);
+    for (size_t x = 0; x < nA; ++x) hW[x * B] = GG_NO_EDGE;
+    for (int i = 0; i < N; ++i) {
+      hdW[(size_t)i * B] = GG_NO_EDGE;
+      for (int j = 0; j < N; ++j) {
+        size_t ij = (size_t)i * N + j;
+        if (!A[ij]) continue;
+        int32_t* dst = (i == j) ? &hdW[(size_t)i * B] : &hW[((size_t)i * d->Np + j) * B];
+        for (int b = 0; b < B; ++b) dst[b] = (int32_t)llrint(ldexp(W[ij * B + b], d->shift));
+      }
+    }
+    GG_HIP(hipMemcpyAsync(d->Wq, hW.data(), hW.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    GG_HIP(hipMemcpyAsync(d->dWq, hdW.data(), hdW.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+  }
+  diag_stats_host(d, hdA.data(), W ? hdW.data() : nullptr);
+  int rc = make_transposes(d);
+  if (rc) return rc;
+  GG_HIP(hipStreamSynchronize(d->stream));
+  return GG_OK;
+}
+
+
 extern "C" {
 
 int gg_device_count(int* count) {
@@ -229,57 +284,25 @@ int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const 
   GG_HIP(hipStreamCreate(&d->stream));
   rc = alloc_data(d);
   if (rc) return rc;
-
-  // host staging: off-diagonal copy, diagonal, quantisation (same arithmetic as the
-  // oracle's orc_quantise: shift = qbits - frexp-exponent of max |w| over edges).
-  size_t nA = (size_t)N * d->Np;
-  std::vector<uint8_t> hA(nA, 0), hdA(N, 0);
-  long long nedges = 0;
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) {
-      uint8_t a = A[(size_t)i * N + j] ? 1 : 0;
-      nedges += a;
-      if (i == j) hdA[i] = a; else hA[(size_t)i * d->Np + j] = a;
-    }
-  d->n_edges = nedges;
-  GG_HIP(hipMemcpyAsync(d->A, hA.data(), nA, hipMemcpyHostToDevice, d->stream));
-  GG_HIP(hipMemcpyAsync(d->dA, hdA.data(), N, hipMemcpyHostToDevice, d->stream));
-  std::vector<int32_t> hW, hdW;
-  if (W) {
-    double wmax = 0.0;
-    for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
-      if (!A[ij]) continue;
-      for (int b = 0; b < B; ++b) {
-        double a = fabs(W[ij * B + b]);
-        if (!(a <= 1.7e308)) { gg_data_destroy(d); return gg_fail(GG_ERR_NUMERIC, "non-finite weight on an edge"); }
-        if (a > wmax) wmax = a;
-      }
-    }
-    if (wmax == 0.0) wmax = 1.0;
-    int e;
-    frexp(wmax, &e);
-    d->shift = gg_qbits(N) - e;
-    hW.assign(nA * B, 0);
-    hdW.assign((size_t)N * B, 0);
-    for (size_t x = 0; x < nA; ++x) hW[x * B] = GG_NO_EDGE;
-    for (int i = 0; i < N; ++i) {
-      hdW[(size_t)i * B] = GG_NO_EDGE;
-      for (int j = 0; j < N; ++j) {
-        size_t ij = (size_t)i * N + j;
-        if (!A[ij]) continue;
-        int32_t* dst = (i == j) ? &hdW[(size_t)i * B] : &hW[((size_t)i * d->Np + j) * B];
-        for (int b = 0; b < B; ++b) dst[b] = (int32_t)llrint(ldexp(W[ij * B + b], d->shift));
-      }
-    }
-    GG_HIP(hipMemcpyAsync(d->Wq, hW.data(), hW.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
-    GG_HIP(hipMemcpyAsync(d->dWq, hdW.data(), hdW.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
-  }
-  diag_stats_host(d, hdA.data(), W ? hdW.data() : nullptr);
-  rc = make_transposes(d);
+  rc = fill_full(d, A, W);
   if (rc) { gg_data_destroy(d); return rc; }
-  GG_HIP(hipStreamSynchronize(d->stream));
   *out = d;
   return GG_OK;
+}
+
+// Re-upload a new (A, W) of the same shape into an existing handle: the reference's loops that draw fresh data every
+// iteration (Geweke tests: test/test_logistic_eigenmodel_geweke.py:35-47 `A = model.rvs()`; AIS / predictive checks
+// with held-out entries) then pay one staging copy instead of allocating and freeing every device buffer.
+int gg_data_update(gg_data* d, const uint8_t* A, const double* W) {
+  if (!d || !A) return gg_fail(GG_ERR_INVALID, "gg_data_update: null argument");
+  if (d->n0 != 0 || d->n1 != d->N) return gg_fail(GG_ERR_INVALID, "gg_data_update: not for column shards");
+  if ((W != nullptr) != (d->has_w != 0)) return gg_fail(GG_ERR_INVALID, "gg_data_update: the handle was created %s weights", d->has_w ? "with" : "without");
+  if (__atomic_load_n(&d->refs, __ATOMIC_ACQUIRE) > 0)
+    return gg_fail(GG_ERR_INVALID, "gg_data_update: a model still has sweeps enqueued on this network (gg_sync it first)");
+  int rc = gg_ensure_device(d->device);
+  if (rc) return rc;
+  d->uid = gg_next_data_uid();   // a different network from here on (statistics carried by a model belong to the old one)
+  return fill_full(d, A, W);
 }
 
 static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,

@@ -59,7 +59,22 @@ def as_device_data(A, W=None, device=0):
     if hit is not None:
         _DATA_CACHE.move_to_end(key)
         return hit[0]
-    d = _abi.DeviceData(A, Wn, device=device)
+    d = None
+    if len(_DATA_CACHE) >= _DATA_CACHE_SIZE:
+        # A loop that draws new data every iteration (`A = model.rvs(); model.resample(A)`, the reference's Geweke tests)
+        # would allocate and free every device buffer each time round: recycle the least recently used handle of the same
+        # shape instead (gg_data_update; refused - and then simply not recycled - while sweeps are still pending on it).
+        old_key, (old, _, oldW) = next(iter(_DATA_CACHE.items()))
+        B = 1 if Wn is None else (1 if Wn.ndim == 2 else Wn.shape[2])
+        if old.N == A.shape[0] and old.device == device and (oldW is None) == (Wn is None) and old.B == B:
+            try:
+                old.update(A, Wn)
+                d = old
+                del _DATA_CACHE[old_key]
+            except _abi.EngineError:
+                d = None
+    if d is None:
+        d = _abi.DeviceData(A, Wn, device=device)
     _DATA_CACHE[key] = (d, A, Wn)  # keep the arrays alive so ids are not reused
     while len(_DATA_CACHE) > _DATA_CACHE_SIZE:
         _DATA_CACHE.popitem(last=False)

@@ -141,7 +141,14 @@ const char* gg_version(void);
  * float64 or NULL for adjacency-only use.  The engine copies; the caller keeps
  * ownership.  Weights are stored as fixed point. */
 int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t device);
+/* A model that has sweeps enqueued on a network (gg_resample_async) holds a reference to it until it is synchronised:
+ * destroying the handle earlier only marks it, the last reference frees it. */
 int gg_data_destroy(gg_data* d);
+/* Replace the network held by an existing handle with another (A, W) of the same N, B (W NULL iff it was created without
+ * weights): one staging copy instead of freeing and allocating every device buffer - for callers that draw fresh data
+ * every iteration (the Geweke loops of test/test_logistic_eigenmodel_geweke.py:35-47).  Refused while a model still has
+ * sweeps enqueued on the handle. */
+int gg_data_update(gg_data* d, const uint8_t* A, const double* W);
 int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64_t* n_edges);
 /* Synthetic planted-SBM network generated on the device (bench / large N):
  * mirrors SBMAdjacencyDistribution.rvs (adjacency.py:558-560) and

@@ -38,7 +38,10 @@ def batch_z(x, mean, nb=25):
     return (bm.mean() - mean) / (bm.std(ddof=1) / np.sqrt(nb))
 
 
-def check_law(x, dist, args=(), thin=4, burn=200, mean=None):
+def check_law(x, dist, args=(), thin=8, burn=200, mean=None):
+    """The data sets are kept tiny on purpose: the more data, the tighter the posterior and the slower a Geweke chain
+    forgets (its autocorrelation is about 1 - prior precision / posterior precision), and a KS test on correlated
+    samples rejects correct samplers."""
     x = np.asarray(x)[burn:]
     assert stats.kstest(x[::thin], dist, args=args).pvalue > 1e-3, (dist, args)
     if mean is not None:
@@ -86,9 +89,9 @@ def _niw_marginals_1d(mu_0, s0, nu0, k0):
 def test_geweke_niw_weights_on_the_engine(abi):
     from graphistician_amd.weights import NIWGaussianWeightDistribution
     np.random.seed(13)
-    N, iters = 6, 4000
-    A = (np.random.rand(N, N) < 0.6).astype(np.uint8)
-    np.fill_diagonal(A, 1)
+    N, iters = 4, 6000
+    A = np.zeros((N, N), dtype=np.uint8)
+    A[0, 1] = A[1, 0] = A[2, 3] = A[3, 1] = A[0, 0] = A[2, 2] = 1          # 4 edges + 2 self edges
     w = NIWGaussianWeightDistribution(N, B=1, mu_0=np.array([0.3]), Sigma_0=np.array([[1.4]]), nu_0=5.0, kappa_0=0.7, seed=5)
     mus, sig, mus_s, sig_s = [], [], [], []
     for it in range(iters):
@@ -107,8 +110,9 @@ def test_geweke_niw_weights_two_dimensional(abi):
     """B = 2 (the Bartlett draw): marginals of the NIW prior — Sigma_11 ~ InvGamma((nu-1)/2, S_11/2), mu_1 Student-t."""
     from graphistician_amd.weights import NIWGaussianWeightDistribution
     np.random.seed(14)
-    N, iters = 5, 4000
-    A = np.ones((N, N), dtype=np.uint8)
+    N, iters = 4, 6000
+    A = np.zeros((N, N), dtype=np.uint8)
+    A[0, 1] = A[1, 2] = A[2, 0] = A[3, 0] = A[1, 3] = 1                     # 5 edges
     S0 = np.array([[1.2, 0.4], [0.4, 0.9]])
     w = NIWGaussianWeightDistribution(N, B=2, mu_0=np.zeros(2), Sigma_0=S0, nu_0=6.0, kappa_0=1.0, seed=6)
     s11, mu1, rho = [], [], []
@@ -125,8 +129,8 @@ def test_geweke_niw_weights_two_dimensional(abi):
 def test_geweke_sbm_gaussian_weights_on_the_engine(abi):
     from graphistician_amd.weights import SBMGaussianWeightDistribution
     np.random.seed(15)
-    N, C, iters = 8, 2, 4000
-    A = (np.random.rand(N, N) < 0.7).astype(np.uint8)
+    N, C, iters = 6, 2, 6000
+    A = (np.random.rand(N, N) < 0.3).astype(np.uint8)
     w = SBMGaussianWeightDistribution(N, B=1, C=C, pi=3.0, mu_0=np.array([0.0]), Sigma_0=np.array([[1.0]]), nu_0=4.0,
                                       kappa_0=0.5, seed=8)
     mu01, s10, m0, c3 = [], [], [], []
@@ -145,16 +149,16 @@ def test_geweke_sbm_gaussian_weights_on_the_engine(abi):
 def test_geweke_eigenmodel_on_the_engine(abi, cls_name):
     from graphistician_amd import eigenmodel as E
     np.random.seed(16)
-    N, D, iters = 6, 2, 4000
+    N, D, iters = 5, 2, 8000
     m = getattr(E, cls_name)(N, D, p=0.3, sigma_mu0=0.8, sigma_F=1.3, sigma_lmbda=0.9, seed=99)
     mu0, lam, f00, f31 = [], [], [], []
     for it in range(iters):
         m.resample(m.rvs())
         mu0.append(m.mu_0); lam.append(m.lmbda[1]); f00.append(m.F[0, 0]); f31.append(m.F[3, 1])
-    check_law(mu0, "norm", (m.mu_mu_0, np.sqrt(0.8)), thin=5, mean=m.mu_mu_0)
-    check_law(lam, "norm", (0.0, np.sqrt(0.9)), thin=5, mean=0.0)
-    check_law(f00, "norm", (0.0, np.sqrt(1.3)), thin=5, mean=0.0)
-    check_law(f31, "norm", (0.0, np.sqrt(1.3)), thin=5, mean=0.0)
+    check_law(mu0, "norm", (m.mu_mu_0, np.sqrt(0.8)), thin=12, mean=m.mu_mu_0)
+    check_law(lam, "norm", (0.0, np.sqrt(0.9)), thin=12, mean=0.0)
+    check_law(f00, "norm", (0.0, np.sqrt(1.3)), thin=12, mean=0.0)
+    check_law(f31, "norm", (0.0, np.sqrt(1.3)), thin=12, mean=0.0)
 
 
 # ------------------------------------------------------------------ the reference's asserted test, on the device
