@@ -209,9 +209,11 @@ def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every,
     sa, sw = adj.stats(), w.stats()
     adj.set_timing(0); w.set_timing(0)
     return dict(adj=adj, w=w, elapsed=el,
-                bulk=dict(adj_ms=sa["bulk_ms"], adj_n=sa["bulk_launches"], w_ms=sw["bulk_ms"], w_n=sw["bulk_launches"]),
+                bulk=dict(adj_ms=sa["bulk_ms"], adj_n=sa["bulk_launches"], adj_bytes=sa["bulk_bytes"],
+                          w_ms=sw["bulk_ms"], w_n=sw["bulk_launches"], w_bytes=sw["bulk_bytes"]),
                 changes=sa["label_changes"] + sw["label_changes"] - chg0,
-                changes_adj=sa["label_changes"], changes_w=sw["label_changes"])
+                changes_adj=sa["label_changes"], changes_w=sw["label_changes"],
+                ahead=bool(sw["bulk_launches"] > steps // max(every, 1) + 2))   # two timed launches per sampled sweep: the ahead form
 
 
 def extra_mixing_chains(abi, data, N, K, device, burnin, steps=100):
@@ -260,8 +262,8 @@ def extra_big(abi, device, N=65536, K=64, burnin=12, warmup=2, steps=20):
                                         truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
     r = run_chain(abi, data, N, K, 1, device, burnin, warmup, steps, 1)
     per_ms = r["bulk"]["w_ms"] / max(r["bulk"]["w_n"], 1)
-    alg = 2.0 * float(N) * N * 4.0
-    ach = alg / (per_ms * 1e-3) / 1e9 if per_ms > 0 else 0.0
+    alg = r["bulk"]["w_bytes"] / max(r["bulk"]["w_n"], 1)
+    ach = r["bulk"]["w_bytes"] / (r["bulk"]["w_ms"] * 1e-3) / 1e9 if r["bulk"]["w_ms"] > 0 else 0.0
     sweep_bytes = 2.0 * N * N * 5.0
     out = {"workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1 (BASELINE.json configs[3] on one GPU)" % (N, K),
            "value": steps / r["elapsed"], "unit": "sweeps/s", "ms_per_step": r["elapsed"] / steps * 1e3, "steps": steps,
@@ -270,7 +272,8 @@ def extra_big(abi, device, N=65536, K=64, burnin=12, warmup=2, steps=20):
            "roofline": {"bound": "hbm", "kernel": "k_bulk_w<1> (non-temporal loads)", "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "launch_ms": per_ms, "launch_bytes": alg,
                         "sampled_launches": int(r["bulk"]["w_n"]),
-                        "adj_kernel": {"launch_ms": r["bulk"]["adj_ms"] / max(r["bulk"]["adj_n"], 1), "launch_bytes": 2.0 * float(N) * N}}}
+                        "adj_kernel": {"launch_ms": r["bulk"]["adj_ms"] / max(r["bulk"]["adj_n"], 1),
+                                       "launch_bytes": r["bulk"]["adj_bytes"] / max(r["bulk"]["adj_n"], 1)}}}
     del r, data
     return out
 
@@ -586,7 +589,9 @@ def main():
     # much of the scan's slow path it exercises) depends on its prior draw, so every rank runs a replica of the
     # SAME chain (GG_BENCH_CHAIN_SEED, default 1).  Independent chains differ only in this seed.
     chain_seed = int(os.environ.get("GG_BENCH_CHAIN_SEED", "1"))
-    every = 1 if N <= 8192 else 1        # HIP events around EVERY bulk launch of the timed region (on the engine streams)
+    # HIP events (on the engine streams) around the launches that stream the data: every one of them for short runs (the
+    # driver's --steps 20), every few for long ones (each record costs the stream a barrier packet, ~1 us of the sweep)
+    every = max(1, args.steps // 64)
     r = run_chain(abi, data, N, K, chain_seed, device, args.burnin, args.warmup, args.steps, every, barrier,
                   stepwise=bool(os.environ.get("GG_BENCH_STEPWISE")))
     adj, w, el, bulk, chg = r["adj"], r["w"], r["elapsed"], r["bulk"], r["changes"]
@@ -595,11 +600,13 @@ def main():
     el = max_over_ranks(el)
 
     if rank == 0:
-        # dominant kernel: k_bulk_w<1> — one launch streams the N x N int32 weight matrix AND its stored
-        # transpose once each (out- and in-statistics of every node): 2 * N^2 * 4 algorithmic bytes
+        # Dominant kernel: the weight model's streaming pass over the N x N int32 weight matrix AND its stored transpose
+        # (out- and in-statistics of every node): 2 * N^2 * 4 algorithmic bytes per sweep.  While the chain is quiet the
+        # pass of sweep s+1 rides in the two launches of sweep s (k_params + riders, k_spec_resolve + riders):
+        # the events bracket exactly those launches, achieved = the bytes their riders stream / their duration.
         per_launch_ms = bulk["w_ms"] / max(bulk["w_n"], 1)
-        alg_bytes = 2.0 * float(N) * N * 4.0
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        alg_bytes = bulk["w_bytes"] / max(bulk["w_n"], 1)
+        achieved = bulk["w_bytes"] / (bulk["w_ms"] * 1e-3) / 1e9 if bulk["w_ms"] > 0 else 0.0
         sweep_bytes = 2.0 * N * N * (1.0 + 4.0)
         sa_ms, sa_b = adj.bench_bulk(data, 20)
         sw_ms, sw_b = w.bench_bulk(data, 20)
@@ -628,7 +635,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_bulk_w<1>",
+                "kernel": "k_params<false,1,1> + k_spec_resolve<3,false,1> (riders = the weight pass k_bulk_w<1> of the next sweep)"
+                          if r["ahead"] else "k_bulk_w<1>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -642,38 +650,15 @@ def main():
                 "launch_bytes": alg_bytes,
                 "sampled_launches": int(bulk["w_n"]),
                 "standalone_GBs": sw_b / sw_ms / 1e6,
-                "note": "achieved = in-situ (HIP events on the engine stream around every n-th launch inside the timed "
+                "note": "achieved = in situ (HIP events on the engine stream around the sampled launches inside the timed "
                         "region, with the adjacency model's kernels running concurrently on another stream); "
-                        "standalone_GBs = the same kernel launched back to back alone",
-                "adj_kernel": {"kernel": "k_bulk_adj", "launch_ms": bulk["adj_ms"] / max(bulk["adj_n"], 1),
-                               "launch_bytes": 2.0 * float(N) * N, "standalone_GBs": sa_b / sa_ms / 1e6},
+                        "standalone_GBs = the plain bulk kernel k_bulk_w<1> launched back to back alone",
+                "adj_kernel": {"kernel": "adjacency pass (k_bulk_adj, or its riders)", "launch_ms": bulk["adj_ms"] / max(bulk["adj_n"], 1),
+                               "launch_bytes": bulk["adj_bytes"] / max(bulk["adj_n"], 1), "standalone_GBs": sa_b / sa_ms / 1e6},
             },
         }
         # measured ceiling beside the nominal peak: a pure read stream of the same number of bytes as one
         # k_bulk_w launch (cache-resident at N=4096, like the kernel's own data) and of 4 GiB (HBM)
-        if world == 1 and not os.environ.get("GG_INCREMENTAL"):
-            # Reported beside the headline, never as it: the same chain with the per-node statistics carried from
-            # sweep to sweep (label changes flushed in) instead of recounted from X and X^T — no N x N streaming.
-            _progress("incremental-statistics variant")
-            try:
-                os.environ["GG_INCREMENTAL"] = "1"
-                adj_i, w_i = build_models(abi, N, K, chain_seed=chain_seed, device=device)
-                if args.burnin > 0:
-                    abi.resample_many([adj_i, w_i], data, args.burnin)
-                for _ in range(args.warmup):
-                    adj_i.resample(data, 1); w_i.resample(data, 1)
-                t0i = time.perf_counter()
-                abi.resample_many([adj_i, w_i], data, args.steps)
-                eli = time.perf_counter() - t0i
-                out["incremental_statistics"] = {
-                    "value": args.steps / eli, "unit": "sweeps/s", "ms_per_step": eli / args.steps * 1e3,
-                    "note": "GG_INCREMENTAL=1 (opt-in): identical chain bit for bit (tests/test_gpu_edge_cases.py); a sweep no "
-                            "longer streams the N x N data, so this figure is NOT comparable with the HBM roofline and is not `value`"}
-                del adj_i, w_i
-            except Exception as exc:
-                out["incremental_statistics"] = {"error": str(exc)}
-            finally:
-                os.environ.pop("GG_INCREMENTAL", None)
         if world == 1:
             # the log-likelihood sweep the reference's demos add after every resample, timed on its own
             _progress("log-likelihood sweeps")

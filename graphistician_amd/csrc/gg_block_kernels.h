@@ -56,14 +56,6 @@ __global__ __launch_bounds__(1024) void k_sort_labels(const int32_t* __restrict_
   }
 }
 
-// Zero a statistics buffer unless the pipeline is stalled (a stalled scan still needs its buffer).
-__global__ void k_zero_if_live(const int32_t* __restrict__ ctl, unsigned long long* __restrict__ p, size_t words) {
-  if (ctl[4]) return;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < words; i += stride) p[i] = 0ull;
-}
-
 // ------------------------------------------------------------------ BULK kernels
 // G[k][n] = sum over rows i with label k of X[i][n]  (column sums grouped by the
 // row's label).  Run on X it yields the in-edge histograms of every node, run on
@@ -93,21 +85,20 @@ __device__ __forceinline__ bool gg_find_slot(const int32_t* __restrict__ lab_sta
 
 // Adjacency: 16 uint8 per lane per row, SWAR byte counters (<= 255 rows per wave).
 // blockIdx.z selects the direction: 0 = out-statistics (reads X^T), 1 = in-statistics (reads X).
+// One (column strip, label slot, direction) work item of the adjacency pass; a workgroup of 256 threads.
 template <bool NTL>
-__global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ XT, const uint8_t* __restrict__ X1,
-                                                  int Np, const int32_t* __restrict__ perm,
-                                                  const int32_t* __restrict__ lab_start, int K, int RW,
-                                                  int32_t* __restrict__ G0, int32_t* __restrict__ G1, int dir0,
-                                                  const int32_t* __restrict__ ctl) {
+__device__ __forceinline__ void gg_bulk_adj_body(const uint8_t* __restrict__ XT, const uint8_t* __restrict__ X1,
+                                                 int Np, const int32_t* __restrict__ perm,
+                                                 const int32_t* __restrict__ lab_start, int K, int RW,
+                                                 int32_t* __restrict__ G0, int32_t* __restrict__ G1, int dir, int strip,
+                                                 int slot) {
   __shared__ unsigned int s_bins[1024];
-  if (ctl && ctl[4]) return;  // pipeline stalled by an earlier scan: leave everything untouched
-  const int dir = dir0 + blockIdx.z;
   const uint8_t* __restrict__ X = dir == 0 ? XT : X1;
   int32_t* __restrict__ G = dir == 0 ? G0 : G1;
   int k, row0, nrows;
-  if (!gg_find_slot(lab_start, K, RW, blockIdx.y, &k, &row0, &nrows)) return;
+  if (!gg_find_slot(lab_start, K, RW, slot, &k, &row0, &nrows)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col0 = blockIdx.x * 1024 + lane * 16;
+  const int col0 = strip * 1024 + lane * 16;
   for (int i = tid; i < 1024; i += 256) s_bins[i] = 0;
   __syncthreads();
   unsigned int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -141,9 +132,19 @@ __global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ XT
   __syncthreads();
   for (int i = tid; i < 1024; i += 256) {
     unsigned int v = s_bins[i];
-    int col = blockIdx.x * 1024 + i;
+    int col = strip * 1024 + i;
     if (v && col < Np) atomicAdd(&G[(size_t)k * Np + col], (int)v);
   }
+}
+
+template <bool NTL>
+__global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ XT, const uint8_t* __restrict__ X1,
+                                                  int Np, const int32_t* __restrict__ perm,
+                                                  const int32_t* __restrict__ lab_start, int K, int RW,
+                                                  int32_t* __restrict__ G0, int32_t* __restrict__ G1, int dir0,
+                                                  const int32_t* __restrict__ ctl) {
+  if (ctl && ctl[4]) return;  // pipeline stalled by an earlier scan: leave everything untouched
+  gg_bulk_adj_body<NTL>(XT, X1, Np, perm, lab_start, K, RW, G0, G1, dir0 + (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // streaming reads of the bulk passes: -DGG_NT_LOADS marks them non-temporal (each byte is used once per pass)
@@ -172,27 +173,26 @@ __device__ __forceinline__ uint4 gg_stream_load(const uint4* p) {
 
 // Weights: 4 int32 per lane per row = 4 / B elements; per element edge count,
 // sum q_r, sum q_r q_s in 64-bit integers.
+// One (column strip, label slot, direction) work item of the weight pass; a workgroup of 256 threads.
 template <int B, int U, bool NTL>
-__global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
-                                                int Np, const int32_t* __restrict__ perm,
-                                                const int32_t* __restrict__ lab_start, int K, int RW,
-                                                int32_t* __restrict__ Gc0, int32_t* __restrict__ Gc1,
-                                                long long* __restrict__ Gs0, long long* __restrict__ Gs1, int dir0,
-                                                const int32_t* __restrict__ ctl) {
+__device__ __forceinline__ void gg_bulk_w_body(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
+                                               int Np, const int32_t* __restrict__ perm,
+                                               const int32_t* __restrict__ lab_start, int K, int RW,
+                                               int32_t* __restrict__ Gc0, int32_t* __restrict__ Gc1,
+                                               long long* __restrict__ Gs0, long long* __restrict__ Gs1, int dir, int strip,
+                                               int slot) {
   constexpr int EPL = 4 / B;               // elements per lane
   constexpr int NSI = B + B * (B + 1) / 2; // integer statistics per element
   constexpr int SC = 64 * EPL;             // strip columns
   __shared__ int s_cnt[SC];
   __shared__ unsigned long long s_s[SC * NSI];
-  if (ctl && ctl[4]) return;
-  const int dir = dir0 + blockIdx.z;
   const int32_t* __restrict__ X = dir == 0 ? XT : X1;
   int32_t* __restrict__ Gcnt = dir == 0 ? Gc0 : Gc1;
   long long* __restrict__ GS = dir == 0 ? Gs0 : Gs1;
   int k, row0, nrows;
-  if (!gg_find_slot(lab_start, K, RW, blockIdx.y, &k, &row0, &nrows)) return;
+  if (!gg_find_slot(lab_start, K, RW, slot, &k, &row0, &nrows)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col0 = blockIdx.x * SC + lane * EPL;
+  const int col0 = strip * SC + lane * EPL;
   for (int i = tid; i < SC; i += 256) s_cnt[i] = 0;
   for (int i = tid; i < SC * NSI; i += 256) s_s[i] = 0ull;
   __syncthreads();
@@ -275,13 +275,65 @@ __global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, 
   }
   __syncthreads();
   for (int i = tid; i < SC; i += 256) {
-    int col = blockIdx.x * SC + i;
+    int col = strip * SC + i;
     int v = s_cnt[i];
     if (v && col < Np) {
       atomicAdd(&Gcnt[(size_t)k * Np + col], v);
       for (int s = 0; s < NSI; ++s)
         atomicAdd(reinterpret_cast<unsigned long long*>(&GS[((size_t)k * Np + col) * NSI + s]), s_s[i * NSI + s]);
     }
+  }
+}
+
+template <int B, int U, bool NTL>
+__global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
+                                                int Np, const int32_t* __restrict__ perm,
+                                                const int32_t* __restrict__ lab_start, int K, int RW,
+                                                int32_t* __restrict__ Gc0, int32_t* __restrict__ Gc1,
+                                                long long* __restrict__ Gs0, long long* __restrict__ Gs1, int dir0,
+                                                const int32_t* __restrict__ ctl) {
+  if (ctl && ctl[4]) return;
+  gg_bulk_w_body<B, U, NTL>(XT, X1, Np, perm, lab_start, K, RW, Gc0, Gc1, Gs0, Gs1, dir0 + (int)blockIdx.z, (int)blockIdx.x,
+                            (int)blockIdx.y);
+}
+
+// ------------------------------------------------------------------ riders
+// The statistics of sweep s+1 are those the bulk pass would count under the labels sweep s STARTS with whenever the scan of
+// sweep s changes no label - the steady state of a converged chain.  While a chain is quiet the engine therefore does not
+// launch the bulk pass of sweep s+1 on its own: its work items ride as extra workgroups ("riders", block indices behind
+// the front workgroups) in the two launches of sweep s's latency chain - k_params and k_spec_resolve - and stream X and
+// X^T while those few hundred workgroups wait on dependent loads.  Every sweep still streams all of the data once; a scan
+// that does change a label stalls the pipeline as before, and the riders' statistics are discarded.
+struct gg_ride_args {
+  const void* XT;            // adjacency: uint8 A^T / A; weights: int32 Wq^T / Wq
+  const void* X1;
+  int Np, K, RW;
+  const int32_t* perm;       // label sort the sweep starts with
+  const int32_t* lab_start;
+  int32_t *Gc0, *Gc1;        // statistics buffer of the NEXT sweep (zeroed by the previous sweep's k_params)
+  long long *Gs0, *Gs1;
+  int strips, nslots;        // work item w = (dir * nslots + slot) * strips + strip
+  int w0, w1;                // this launch carries items [w0, w1)
+  int front;                 // block index of the first rider
+  int nriders;               // rider workgroups in the launch (persistent: item w, w + nriders, ...)
+  long long* dbg;            // GG_SWQ_DBG: [0] first workgroup start, [1] last scan end, [2] last parameter end, [3] last rider end,
+                             //             [4] first rider start, [5] verdict seen by the parameter workgroups (max)
+};
+
+// Riders are persistent: `nriders` workgroups walk the work items with that stride.  Their number bounds the bytes the pass
+// keeps in flight (workgroups x 4 waves x 4 KB), and with it the loaded latency every dependent load of the front
+// workgroups sees: enough in flight to saturate HBM, not four times that (measured: DESIGN.md section 5).
+template <bool ADJ, int B, bool NTL>
+__device__ __forceinline__ void gg_ride(const gg_ride_args& r) {
+  for (int w = r.w0 + ((int)blockIdx.x - r.front); w < r.w1; w += r.nriders) {
+    const int strip = w % r.strips, sl = (w / r.strips) % r.nslots, dir = w / (r.strips * r.nslots);
+    if (ADJ)
+      gg_bulk_adj_body<NTL>(reinterpret_cast<const uint8_t*>(r.XT), reinterpret_cast<const uint8_t*>(r.X1), r.Np, r.perm, r.lab_start,
+                            r.K, r.RW, r.Gc0, r.Gc1, dir, strip, sl);
+    else
+      gg_bulk_w_body<B, 4, NTL>(reinterpret_cast<const int32_t*>(r.XT), reinterpret_cast<const int32_t*>(r.X1), r.Np, r.perm,
+                                r.lab_start, r.K, r.RW, r.Gc0, r.Gc1, r.Gs0, r.Gs1, dir, strip, sl);
+    __syncthreads();   // the body's LDS bins are reused by the next item
   }
 }
 
@@ -414,6 +466,7 @@ struct gg_params_args {
   uint32_t sweep;
   double *m, *logm, *p, *p_self, *mu, *sigma, *mu_self, *sigma_self, *T, *Tout, *Tin;
   int32_t* ctl;
+  unsigned* verdict;              // verdict word of the fused launch (its own cache line)
   unsigned long long* zero_ptr;   // other statistics buffer (8-byte words) or null
   size_t zero_words;
   // deferred resample_m of the PREVIOUS sweep (adjacency.py:697-702): drawn here, off the scan's
@@ -431,35 +484,66 @@ struct gg_params_args {
   double* csc;               // [K*K][B*B + 1] centred scatter and tempered count of every block pair's off-diagonal edges (shared-covariance kind)
 };
 
+#ifndef GG_VERDICT_FIRST_SLEEP
+#define GG_VERDICT_FIRST_SLEEP 2   // x 127 x 64 clocks before the first poll
+#endif
+// Verdict word of the fused quiet-chain launch (k_sweep_q, gg_resolve_kernels.h): the workgroup that resolves the scan of
+// sweep s publishes (launch tag << 1 | scan changed a label); the parameter workgroups of sweep s+1, which ride in the
+// same launch, wait for it before they write anything (an unchanged scan is what makes their input statistics valid).
+// The word lives on a cache line of its own (gg_params_args::verdict / gg_resolve_args::verdict): agent-scope polls of one
+// address are served by ONE memory channel, past the per-XCD L2s - a few hundred workgroups polling the line the scan's
+// atomics live on, or polling at full rate, slow those atomics and every stream that crosses that channel (measured:
+// scan 11 -> 35 us, riders 30 -> 59 us).  So: a first sleep about as long as the scan takes, then a poll every ~1 us.
+// One thread polls (presleep: 127 x 64-clock sleeps before the first poll); true = the scan changed nothing.
+__device__ __forceinline__ bool gg_poll_verdict(int32_t* ctl, unsigned* verdict, unsigned tag, int presleep) {
+  for (int i = 0; i < presleep; ++i) __builtin_amdgcn_s_sleep(127);
+  for (int spin = 0; spin < (1 << 19); ++spin) {
+    // (relaxed polls: an acquire load would invalidate the compute unit's caches, shared with the scan's workgroups, at
+    // every poll; nothing this workgroup reads afterwards was written by the scan)
+    const unsigned v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((v >> 1) == tag) return (v & 1u) == 0u;
+    __builtin_amdgcn_s_sleep(40);
+  }
+  atomicOr(&ctl[3], 8);   // the resolving workgroups are dispatched ahead of this one: only a hung device gets here
+  return false;
+}
+// The same for a whole workgroup (uniform result).
+__device__ __forceinline__ bool gg_wait_verdict(int32_t* ctl, unsigned* verdict, unsigned tag) {
+  __shared__ int s_verdict_ok;
+  if (threadIdx.x == 0) s_verdict_ok = gg_poll_verdict(ctl, verdict, tag, GG_VERDICT_FIRST_SLEEP) ? 1 : 0;
+  __syncthreads();
+  return s_verdict_ok != 0;
+}
+
+// The parameter step of one workgroup (`bid` of `nfront`).  gate_tag != 0: nothing is written before the verdict of the
+// scan that runs in the same launch has arrived, and nothing at all if that scan changed a label.
 template <bool ADJ, int B>
-__global__ __launch_bounds__(256) void k_params(gg_params_args g) {
-  if (g.ctl[4]) return;
-  if (g.sweep_from_ctl) {
-    g.sweep = (uint32_t)g.ctl[6];
-    g.m_sweep = g.sweep - 1u;
-  }
-  if (g.do_prep && blockIdx.x == 0 && threadIdx.x == 0) {   // a new scan follows: reset its per-scan words
-    g.ctl[7] = 0;
-    g.ctl[8] = 0;
-    g.ctl[9] = 0;
-  }
-  // k_scan's exchange slots (2 x 256, one per 128-byte line): tag 0 = never written
-  if (g.do_prep && g.bar)
-    for (unsigned sl = blockIdx.x * blockDim.x + threadIdx.x; sl < 512u; sl += gridDim.x * blockDim.x) g.bar[(size_t)sl * GG_SLOT_PAD] = 0ull;
+__device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid, const unsigned nfront, const unsigned gate_tag) {
   const int K = g.K;
   constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
   constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;
   constexpr int NT = ADJ ? 2 : (1 + B + B * (B + 1) / 2);
-  if (g.zero_ptr) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < g.zero_words; i += stride) g.zero_ptr[i] = 0ull;
-  }
+  auto housekeeping = [&]() {
+    if (g.do_prep && bid == 0 && threadIdx.x == 0) {   // a new scan follows: reset its per-scan words
+      g.ctl[7] = 0;
+      g.ctl[8] = 0;
+      g.ctl[9] = 0;
+    }
+    // k_scan's exchange slots (2 x 256, one per 128-byte line): tag 0 = never written
+    if (g.do_prep && g.bar)
+      for (unsigned sl = bid * blockDim.x + threadIdx.x; sl < 512u; sl += nfront * blockDim.x) g.bar[(size_t)sl * GG_SLOT_PAD] = 0ull;
+    if (g.zero_ptr) {
+      size_t i = (size_t)bid * blockDim.x + threadIdx.x;
+      size_t stride = (size_t)nfront * blockDim.x;
+      for (; i < g.zero_words; i += stride) g.zero_ptr[i] = 0ull;
+    }
+  };
+  if (!gate_tag) housekeeping();
   __shared__ long long s_red[4][NTAB];
   __shared__ long long s_tab[NTAB];
   __shared__ long long s_tabd[NTAB];   // diagonal edges of pair (a, a), shared-covariance kind without the special case
   if (threadIdx.x < NTAB) s_tabd[threadIdx.x] = 0;
-  const int t = blockIdx.x;
+  const int t = bid;
   if (t < K * K) {
     const int a = t / K, b = t % K;
     if (g.do_tables) {
@@ -540,8 +624,17 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
       if (threadIdx.x < NTAB) s_tab[threadIdx.x] = g.tab[(size_t)t * NTAB + threadIdx.x];
       __syncthreads();
     }
+    // Gated form: the draw itself (one lane, a few microseconds of dependent arithmetic) does not wait for the verdict, only
+    // its writes do - except for the shared-covariance kind, whose draw reads state the same step writes.
+    const bool early_gate = gate_tag && !ADJ && g.shared;
+    if (early_gate) {
+      if (!gg_wait_verdict(g.ctl, g.verdict, gate_tag)) return;   // (workgroup-uniform)
+      housekeeping();
+    }
+    __shared__ int s_commit;
     if (threadIdx.x == 0) {
       double e[GG_MAXNT];
+      bool bad = false, commit = true;
       if (ADJ) {
         double pv;
         if (g.do_draw) {
@@ -552,12 +645,13 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
           gg_stream s;
           gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_P : GG_SITE_ADJ_P, g.sweep, (uint32_t)t);
           pv = gg_beta(&s, g.ah.tau1 + g.beta * (double)n1, g.ah.tau0 + g.beta * (double)n0);
-          g.p[t] = pv;
         } else {
           pv = g.p[t];
         }
         e[0] = gg_log(pv);
         e[1] = gg_log(1.0 - pv);
+        if (gate_tag) commit = gg_poll_verdict(g.ctl, g.verdict, gate_tag, 0);
+        if (commit && g.do_draw) g.p[t] = pv;
       } else {
         double mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
         if (g.do_draw && g.shared) {
@@ -592,26 +686,42 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
           for (int i = 0; i < B; ++i) s1[i] *= g.beta;
           for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
           gg_niw_posterior_draw(&s, &g.wh.niw, B, g.beta * (double)s_tab[0], s1, s2, mo, so);
-          for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
-          for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
         } else {
           for (int i = 0; i < B; ++i) mo[i] = g.mu[(size_t)t * B + i];
           for (int i = 0; i < B * B; ++i) so[i] = g.sigma[(size_t)t * B * B + i];
         }
         if (g.do_prep && !(g.shared && g.do_draw) && gg_gauss_table(mo, so, B, e)) {
-          atomicOr(&g.ctl[3], 1);
+          bad = true;
           for (int i = 0; i < NT; ++i) e[i] = gg_nan();
         }
+        if (gate_tag && !early_gate) commit = gg_poll_verdict(g.ctl, g.verdict, gate_tag, 0);
+        if (commit) {
+          if (bad) atomicOr(&g.ctl[3], 1);
+          if (g.do_draw && !g.shared) {
+            for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
+            for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
+          }
+        }
       }
-      if (g.do_prep && !(!ADJ && g.shared && g.do_draw))
+      if (commit && g.do_prep && !(!ADJ && g.shared && g.do_draw))
         for (int i = 0; i < NT; ++i) {
           g.T[(size_t)t * NT + i] = e[i];
           g.Tout[((size_t)b * NT + i) * g.Kp + a] = e[i];
           g.Tin[((size_t)a * NT + i) * g.Kp + b] = e[i];
         }
+      s_commit = commit ? 1 : 0;
+    }
+    if (gate_tag && !early_gate) {
+      __syncthreads();
+      if (!s_commit) return;
+      housekeeping();
     }
   } else {
     // last workgroup: the self parameter and log m
+    if (gate_tag) {
+      if (!gg_wait_verdict(g.ctl, g.verdict, gate_tag)) return;
+      housekeeping();
+    }
     if (threadIdx.x == 0 && g.do_draw) {
       if (ADJ) {
         if (g.ah.special) {
@@ -652,6 +762,17 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g) {
       if (g.do_prep) g.logm[kk] = gg_log(mk);
     }
   }
+}
+
+template <bool ADJ, int B, int RIDE = 0>   // RIDE: 0 none, 1 riders with plain loads, 2 riders with non-temporal loads
+__global__ __launch_bounds__(256) void k_params(gg_params_args g, gg_ride_args ride = gg_ride_args()) {
+  if (g.ctl[4]) return;
+  if (RIDE && (int)blockIdx.x >= ride.front) {
+    gg_ride<ADJ, B, RIDE == 2>(ride);
+    return;
+  }
+  const unsigned nfront = RIDE ? (unsigned)ride.front : gridDim.x;   // the workgroups that do k_params' own work
+  gg_params_body<ADJ, B>(g, (int)blockIdx.x, nfront, 0u);
 }
 
 // ------------------------------------------------------------------ per-node conditional
@@ -911,7 +1032,10 @@ __device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n,
 // coalesced round of loads) and, when they fit, the coefficient tables in LDS:
 // the per-j loop then never waits on global memory.
 // The evaluation itself (all 256 threads of the workgroup): returns the drawn label of node *n_out for lane (i, k).
-template <int NT, bool ADJ>
+// UJ_: table entries fetched per batch (0: the default depth; riding kernels ask for less).  SPLIT: -1 = decide at run time
+// whether the K > 32 form (gg_lp_split4, 128+ registers of table entries in flight) runs; 0 / 1 = compiled for one of the
+// two only, so that the kernel's register allocation is not that of the form it never runs.
+template <int NT, bool ADJ, int UJ_ = 0, int SPLIT = -1>
 __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, uint64_t seed, uint32_t site, uint32_t sweep,
                                             int lp_node, double* __restrict__ lp_out, int stage_tables, int* n_out,
                                             bool* live_out) {
@@ -964,9 +1088,9 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
   };
   // (two call sites: the table pointers keep their address space, LDS or global, instead of becoming flat)
   double lp;
-  if (stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab);
-  else if (Kp == 64) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T /* chains meet here */, nn);
-  else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
+  if (SPLIT != 1 && stage_tables) lp = gg_node_lp_core<NT, ADJ, UJ_>(x, nn, k, ld, s_T, s_T + ntab);
+  else if (SPLIT < 0 ? Kp == 64 : SPLIT == 1) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T /* chains meet here */, nn);
+  else lp = gg_node_lp_core<NT, ADJ, UJ_>(x, nn, k, ld, x.Tout, x.Tin);
   if (lp_out && nn == lp_node && live && k < K) lp_out[k] = lp;
   double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
   *n_out = n;

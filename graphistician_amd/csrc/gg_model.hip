@@ -55,12 +55,14 @@ struct gg_model {
   double *p, *p_self;
   double *mu, *sigma, *mu_self, *sigma_self;
   double *T, *Tout, *Tin;
-  // statistics: two buffers [Gcnt out | Gcnt in | GS out | GS in]; the pipeline alternates between
-  // them so that the next half-sweep's buffer is zeroed inside the current one (k_params)
-  unsigned char* Gbuf[2];
+  // statistics: three buffers [Gcnt out | Gcnt in | GS out | GS in], used in rotation.  Sweep s reads Gbuf[cur]; in the
+  // "ahead" form (quiet chains, enqueue_sweep_ahead) the riders of its two launches count sweep s+1's statistics into
+  // Gbuf[cur+1] while k_params zeroes Gbuf[cur+2] for the riders of sweep s+1; the serial form (enqueue_sweep_serial)
+  // counts into Gbuf[cur] itself and zeroes Gbuf[cur+1].
+  unsigned char* Gbuf[3];
   size_t Gbytes;
   int cur;
-  bool zeroed[2];
+  bool zeroed[3];
   bool perm_valid;
   long long* tab;
   int32_t *rs, *L;   // rs = control block (gg_resolve_kernels.h)
@@ -75,15 +77,14 @@ struct gg_model {
   int32_t* h_rs;  // pinned copy of the control block
   long long* h_tab;   // pinned staging of the K x K tables + block counts (gg_log_likelihood)
   hipStream_t stream;
-  hipStream_t sb;               // bulk statistics of the NEXT sweep run here, concurrently with the scan
-  hipEvent_t ev_bulk[2], ev_scan;
-  bool pipe;                    // cross-sweep pipelining enabled (scan models)
-  bool use_graph;               // replay pipelined sweeps from a captured hipGraph (one per buffer parity)
-  bool capturing;
-  hipGraphExec_t gexec[2][2];   // [cur][pcur]
-  unsigned long long gdata_uid[2][2];
-  hipEvent_t ev_join;
-  bool next_bulk;               // Gbuf[cur] already holds (is receiving) the next sweep's statistics
+  bool can_ahead;               // this model may run the ahead form (scan model, not sharded, GG_AHEAD != 0)
+  bool ahead;                   // Gbuf[cur] holds the exact statistics of network ahead_uid under the CURRENT labels
+  unsigned long long ahead_uid; // (counted by the riders of the last completed sweep, whose scan changed no label)
+  unsigned* verdict;            // verdict word of the fused launch, alone on its cache line
+  long long* swq_dbg;           // GG_SWQ_DBG=1: timestamps of the last fused launch (gg_ride_args::dbg)
+  unsigned vtag;                // tag of the last fused launch's verdict word (k_sweep_q)
+  bool pre;                     // ahead form: the parameter step of the NEXT sweep to enqueue has run already (inside the last k_sweep_q)
+  double ride_split;            // share of the next sweep's bulk work items that rides in the k_params launch (rest: k_spec_resolve)
   int cur0, pcur0;              // buffer indices when the pending batch started
   uint32_t sweep;
   int parts_done;               // step-wise calls: parts already drawn under the current sweep index (gg_resample_part)
@@ -101,9 +102,6 @@ struct gg_model {
   int scan_spin;                // polls before a k_scan exchange gives up (GG_SCAN_SPIN overrides the default for tests)
   long long scan_hold;          // clean sweeps required before leaving k_scan mode (doubles when the chain stalls again soon after)
   long long since_revert;       // sweeps completed in speculate + resolve mode since the last switch back
-  bool incr;                    // GG_INCREMENTAL=1: G is carried from sweep to sweep (changes flushed in), no bulk pass
-  bool G_valid;                 // incr: Gbuf[cur] is the exact histogram of network G_uid under the current labels
-  unsigned long long G_uid;
   int32_t* ap;                  // restart rounds: entries of L already applied to node n's statistics
   size_t resolve_lds;
   bool resolve_stage;          // coefficient tables staged in the resolver's LDS
@@ -272,7 +270,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     GG_HIP(hipMemcpy(m->rs + GG_RS_MIN, &none, sizeof(none), hipMemcpyHostToDevice));
   }
   m->Gbytes = (size_t)2 * K * m->Np * (sizeof(int32_t) + (size_t)m->NSI * sizeof(long long));
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < 3; ++b) {
     if ((rc = dmalloc(&m->Gbuf[b], m->Gbytes))) return rc;
     m->zeroed[b] = true;
   }
@@ -290,11 +288,14 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if ((rc = dmalloc(&m->L, (size_t)m->Lcap * 3))) return rc;
   if ((rc = dmalloc(&m->ap, (size_t)m->Nl + 1))) return rc;
   m->dbg = nullptr;
-  m->incr = false; m->G_valid = false; m->G_uid = 0;
+  m->ahead = false; m->ahead_uid = 0;
   m->bar = nullptr; m->use_scan = false;
   m->depth = 1 << 20; m->todo = 0; m->round_hint = 0;
   if ((rc = dmalloc(&m->bar, (size_t)512 * GG_SLOT_PAD))) return rc;
   if (getenv("GG_ROUND_DBG") && (rc = dmalloc(&m->dbg, (size_t)512 * 8 + 8))) return rc;
+  if ((rc = dmalloc(&m->verdict, 64))) return rc;
+  m->swq_dbg = nullptr;
+  if (getenv("GG_SWQ_DBG") && (rc = dmalloc(&m->swq_dbg, 8))) return rc;
   GG_HIP(hipHostMalloc((void**)&m->h_rs, 32 * sizeof(int32_t)));
   GG_HIP(hipHostMalloc((void**)&m->h_tab, ((size_t)m->K * m->K * m->NTAB + m->K) * sizeof(long long)));
   // resolve chunk: one Kp-lane group per node, LDS budget 96 KiB
@@ -308,39 +309,24 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->max_idle = 1;
   GG_HIP(hipEventCreate(&m->ev_call0));
   GG_HIP(hipEventCreate(&m->ev_call1));
-  GG_HIP(hipStreamCreate(&m->sb));
-  GG_HIP(hipEventCreateWithFlags(&m->ev_bulk[0], hipEventDisableTiming));
-  GG_HIP(hipEventCreateWithFlags(&m->ev_bulk[1], hipEventDisableTiming));
-  GG_HIP(hipEventCreateWithFlags(&m->ev_scan, hipEventDisableTiming));
-  GG_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   {
-    // measured on MI355X / ROCm 7.2 (N=4096, K=16): replaying the two-stream sweep from a hipGraph costs
-    // ~55 us of host time per model-sweep (4.3k sweeps/s) against ~16 us for eager launches: opt-in only
-    const char* eg = getenv("GG_GRAPH");
-    m->use_graph = (eg && atoi(eg) == 1);
-  }
-  {
-    const char* e = getenv("GG_PIPELINE");
-    // eager cross-sweep pipelining: exact, but its extra event records / waits make the host the bottleneck
-    // at N=4096 (11-13k sweeps/s against 17.5k serial); opt-in until launches get cheaper or N is large
-    m->pipe = m->sbm && m->K > 1 && (e && atoi(e) == 1);
-    // incremental statistics (opt-in, see enqueue_sweep_incr): not combined with the pipelined or sharded forms
     // The scan as one resident-grid launch (k_scan): exact, never stalls the sweep pipeline, ~6.5 us per accepted change
     // (evaluate 3.3 + fence-free exchange 2.3 + apply 0.7) against ~17 us for a restart round, but a quiet scan costs
-    // 15 us in situ against 9 + 8.5 for k_speculate + k_resolve with more interference on the other model's bulk pass.
-    // Default: adaptive - k_scan while the chain keeps changing labels, speculate + resolve once it has been quiet for
-    // a while (model_sync decides batch by batch; both give the same chain bit for bit).  GG_SCAN=1 / 0 force either.
+    // 15 us in situ against 11 for k_spec_resolve, with more interference on the other model's streaming.
+    // Default: adaptive - k_scan while the chain keeps changing labels, the speculative one-launch form once it has been
+    // quiet for a while (model_sync decides batch by batch; both give the same chain bit for bit).  GG_SCAN=1 / 0 force either.
     const char* es = getenv("GG_SCAN");
-    const bool can_scan = m->sbm && m->K > 1 && !m->pipe && !m->sharded;
+    const bool can_scan = m->sbm && m->K > 1 && !m->sharded;
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
     m->use_scan = m->scan_pref == 1;
     m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
     { const char* esp = getenv("GG_SCAN_SPIN"); m->scan_spin = esp && atoi(esp) > 0 ? atoi(esp) : GG_BAR_SPIN_LIMIT; }
-    const char* ei = getenv("GG_INCREMENTAL");
-    m->incr = m->sbm && m->K > 1 && !m->pipe && !m->sharded && (ei && atoi(ei) == 1);
-    // (carried statistics: the two scan forms keep different books on what of the change list is already in G, so the
-    // form is not switched from sweep to sweep there)
-    if (m->incr && m->scan_pref < 0) m->scan_pref = 0;
+    // The ahead form (enqueue_sweep_ahead): while the chain is quiet, the next sweep's bulk pass rides in this sweep's
+    // k_params and k_spec_resolve launches.  GG_AHEAD=0 keeps every sweep in the serial form (bulk -> params -> scan).
+    const char* ea = getenv("GG_AHEAD");
+    m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0);
+    const char* ers = getenv("GG_RIDE_SPLIT");
+    m->ride_split = ers ? atof(ers) : -1.0;   // (default chosen below, once the scan forms of this shape are known)
     if (can_scan) {
       // what fits in LDS decides which scan forms this shape (K, B) can run
       const bool fit_scan = lds_scan(m, m->Lcap < 1024 ? m->Lcap : 1024, nullptr) <= GG_LDS_LIMIT;
@@ -351,7 +337,15 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
         return gg_fail(GG_ERR_UNSUPPORTED, "K=%d with B=%d needs %zu KB of LDS per workgroup for the node scan (150 KB available)",
                        cfg->K, cfg->B, need / 1024);
       }
-      if (!fit_scan) { m->scan_pref = 0; m->use_scan = false; }   // restart rounds only (their meeting place reuses dead statistics)
+      if (!fit_scan) { m->scan_pref = 0; m->use_scan = false; m->can_ahead = false; }   // restart rounds only (their meeting place reuses dead statistics)
+    }
+    if (!(m->ride_split >= 0.0 && m->ride_split <= 1.0)) {
+      // Riders get the occupancy of the launch they ride in: k_params and the lean k_spec_resolve (K <= 32, or tables
+      // staged in LDS) leave them what the plain bulk kernel has; the K > 32 conditional with its table entries in
+      // registers does not, so there the whole pass rides with k_params.
+      int stage = 0;
+      lds_spec(m, &stage);
+      m->ride_split = (!stage && m->Kp == 64) ? 1.0 : 0.5;
     }
   }
   // defaults: uniform m, pi = 1, p = 0.5, standard NIW
@@ -385,8 +379,8 @@ int gg_model_destroy(gg_model* m) {
   if (m->ld) { gg_latent_destroy(m->ld); delete m; return GG_OK; }
   if (m->pend_data) { hipStreamSynchronize(m->stream); set_pend_data(m, nullptr); }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
-                  m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->tab,
-                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc};
+                  m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
+                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -394,10 +388,6 @@ int gg_model_destroy(gg_model* m) {
   if (m->ev_call0) hipEventDestroy(m->ev_call0);
   if (m->ev_call1) hipEventDestroy(m->ev_call1);
   if (m->stream) hipStreamDestroy(m->stream);
-  if (m->sb) hipStreamDestroy(m->sb);
-  for (hipEvent_t e : {m->ev_bulk[0], m->ev_bulk[1], m->ev_scan, m->ev_join}) if (e) hipEventDestroy(e);
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b) if (m->gexec[a][b]) hipGraphExecDestroy(m->gexec[a][b]);
   delete m;
   return GG_OK;
 }
@@ -421,7 +411,11 @@ static int state_ptr(gg_model* m, int id, void** p, size_t* nbytes) {
 }
 
 static int model_sync(gg_model* m, bool ctl_fresh = false);
-static int drain_pipe(gg_model* m);
+// Forget statistics counted ahead for the next sweep (labels or data are about to change from outside, or the buffer
+// is about to be reused): Gbuf[cur] then holds stale numbers and must be zeroed before the next bulk pass adds to it.
+static void drop_ahead(gg_model* m) {
+  if (m->ahead) { m->ahead = false; m->zeroed[m->cur] = false; }
+}
 
 int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
   if (!m || !buf) return gg_fail(GG_ERR_INVALID, "gg_set_state: null argument");
@@ -434,17 +428,12 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
     m->sweep = *(const uint32_t*)buf;
     m->parts_done = 0;
-    GG_HIP(hipMemcpy(m->rs + 6, &m->sweep, 4, hipMemcpyHostToDevice));   // device-side copy read by replayed sweeps
     return GG_OK;
   }
   if (id == GG_ST_NIW || id == GG_ST_NIW_SELF) {
     if (m->is_adj) return gg_fail(GG_ERR_INVALID, "NIW hypers on an adjacency model");
     size_t need = (B + B * B + 2) * 8;
     if (nbytes != need) return gg_fail(GG_ERR_INVALID, "NIW hypers: expected %zu bytes, got %zu", need, nbytes);
-    { int rc1 = drain_pipe(m); if (rc1) return rc1; }
-    for (int a = 0; a < 2; ++a)        // hyper-parameters are baked into captured kernel arguments
-      for (int b = 0; b < 2; ++b)
-        if (m->gexec[a][b]) { hipGraphExecDestroy(m->gexec[a][b]); m->gexec[a][b] = nullptr; }
     const double* d = (const double*)buf;
     if (gg_first_nonfinite(d, B + B * B + 2) >= 0) return gg_fail(GG_ERR_INVALID, "NIW hypers: non-finite value");
     if (!gg_is_spd(d + B, (int)B)) return gg_fail(GG_ERR_INVALID, "NIW hypers: Sigma_0 is not symmetric positive definite");
@@ -466,8 +455,7 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
     for (int n = 0; n < m->N; ++n)
       if (c[n] < 0 || c[n] >= m->K) return gg_fail(GG_ERR_INVALID, "label c[%d]=%d out of range [0,%d)", n, c[n], m->K);
     m->perm_valid = false;
-    m->G_valid = false;
-    { int rc1 = drain_pipe(m); if (rc1) return rc1; }
+    drop_ahead(m);          // statistics counted ahead belong to the old labels
   } else {
     // every other state is doubles: values the samplers cannot digest are refused here (gg_common.h)
     const double* v = (const double*)buf;
@@ -543,7 +531,8 @@ static int check_data(const gg_model* m, const gg_data* d) {
 static hipEvent_t next_event(gg_model* m) {
   if (m->ev_used == m->ev.size()) {
     hipEvent_t e;
-    hipEventCreate(&e);
+    // (device-scope release only: a timing sample must not make the launch it brackets write its cache lines back to host-visible memory)
+    if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) { (void)hipGetLastError(); hipEventCreate(&e); }
     m->ev.push_back(e);
   }
   return m->ev[m->ev_used++];
@@ -612,42 +601,44 @@ static int ensure_zero(gg_model* m, int buf) {
   return GG_OK;
 }
 
+// Launch shape of a bulk pass over this model's matrices: column strips, label slots, rows per slot, streaming hint.
+struct bulk_shape { int strips, nslots, RW; bool ntl; };
+static bulk_shape bulk_shape_of(const gg_model* m, int ndirs) {
+  bulk_shape b;
+  const int SC = m->is_adj ? 1024 : 64 * (4 / m->B);
+  b.strips = (m->Np + SC - 1) / SC;
+  b.RW = bulk_rw(m, b.strips, ndirs);
+  b.nslots = (m->N + b.RW - 1) / b.RW + m->K;
+  // non-temporal loads once a pass streams more than the Infinity Cache holds (see gg_stream_load)
+  b.ntl = (double)ndirs * m->N * (double)m->Np * (m->is_adj ? 1.0 : 4.0 * m->B) > gg_nt_threshold();
+  return b;
+}
+
 // BULK statistics under the current labels into buffer `buf`.  dirs: bit 0 = out (reads X^T), bit 1 = in (reads X).
-static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined, uint32_t sweep = 0,
-                        hipStream_t st = nullptr, int pidx = -1) {
+static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined, uint32_t sweep = 0) {
   const int N = m->N, K = m->K, Np = m->Np;
   int rc;
-  if (!st) {
-    st = m->stream;
-    if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, buf))) return rc;
-  }
-  if (pidx < 0) pidx = m->pcur;
-  const int32_t* perm = m->permb[pidx];
-  const int32_t* lab_start = m->labb[pidx];
+  hipStream_t st = m->stream;
+  if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, buf))) return rc;
+  const int32_t* perm = m->permb[m->pcur];
+  const int32_t* lab_start = m->labb[m->pcur];
   const int dir0 = (dirs & 1) ? 0 : 1;
   const int ndirs = (dirs == 3) ? 2 : 1;
   const int32_t* ctl = pipelined ? m->rs : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = !m->capturing && m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+  const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
   if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, st)); }
+  const bulk_shape bs = bulk_shape_of(m, ndirs);
+  dim3 grd(bs.strips, bs.nslots, ndirs);
+  const int RW = bs.RW;
   if (m->is_adj) {
-    int strips = (Np + 1023) / 1024;
-    int RW = bulk_rw(m, strips, ndirs);
-    dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
-    // non-temporal loads once a pass streams more than the Infinity Cache holds (see gg_stream_load)
-    if ((double)ndirs * N * (double)Np > gg_nt_threshold())
+    if (bs.ntl)
       k_bulk_adj<true><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
     else
       k_bulk_adj<false><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
     if (timed) m->ev_bytes.push_back((double)ndirs * N * (double)N);
   } else {
-    int SC = 64 * (4 / m->B);
-    int strips = (Np + SC - 1) / SC;
-    int RW = bulk_rw(m, strips, ndirs);
-    dim3 grd(strips, (N + RW - 1) / RW + K, ndirs);
-    static int unroll = -1;
-    if (unroll < 0) { const char* e = getenv("GG_BULK_UNROLL"); unroll = e ? atoi(e) : 4; }
-    const bool ntl = (double)ndirs * N * (double)Np * 4.0 * m->B > gg_nt_threshold();   // beyond the Infinity Cache: see gg_stream_load
+    const bool ntl = bs.ntl;
 #define BULKW(BV, UV)                                                                                                 \
   do {                                                                                                                \
     if (ntl) k_bulk_w<BV, UV, true><<<grd, 256, 0, st>>>(d->WqT, d->Wq, Np, perm, lab_start, K, RW, gcnt(m, buf, 0),    \
@@ -656,7 +647,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
                                                       gcnt(m, buf, 1), gs(m, buf, 0), gs(m, buf, 1), dir0, ctl);      \
   } while (0)
     switch (m->B) {
-      case 1: if (unroll >= 8) BULKW(1, 8); else if (unroll >= 4) BULKW(1, 4); else BULKW(1, 2); break;
+      case 1: BULKW(1, 4); break;
       case 2: BULKW(2, 4); break;
       case 4: BULKW(4, 4); break;
     }
@@ -672,10 +663,42 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   return GG_OK;
 }
 
+// The next sweep's bulk pass as riders (gg_block_kernels.h): work items [part == 0: the first ride_split share;
+// part == 1: the rest] of the pass over both directions, counted into buffer `nbuf` under the label sort `P`.
+static gg_ride_args make_ride(const gg_model* m, const gg_data* d, int nbuf, int P, int part, int front, int* nriders, int* ntl,
+                              double* bytes) {
+  gg_ride_args r;
+  memset(&r, 0, sizeof(r));
+  const bulk_shape bs = bulk_shape_of(m, 2);
+  r.XT = m->is_adj ? (const void*)d->AT : (const void*)d->WqT;
+  r.X1 = m->is_adj ? (const void*)d->A : (const void*)d->Wq;
+  r.Np = m->Np; r.K = m->K; r.RW = bs.RW;
+  r.perm = m->permb[P]; r.lab_start = m->labb[P];
+  r.Gc0 = gcnt(m, nbuf, 0); r.Gc1 = gcnt(m, nbuf, 1); r.Gs0 = gs(m, nbuf, 0); r.Gs1 = gs(m, nbuf, 1);
+  r.strips = bs.strips; r.nslots = bs.nslots;
+  const long long W = (long long)bs.strips * bs.nslots * 2;
+  long long ws = (long long)((double)W * m->ride_split + 0.5);
+  ws = ws < 0 ? 0 : (ws > W ? W : ws);
+  if (part == 2) ws = W;              // the whole pass in one launch
+  r.w0 = (part == 0 || part == 2) ? 0 : (int)ws;
+  r.w1 = (part == 0 || part == 2) ? (int)ws : (int)W;
+  r.front = front;
+  {
+    static int cap = -1;   // GG_RIDERS: most rider workgroups per launch (a cap below ~512 starves the pass, above it changes nothing: measured)
+    if (cap < 0) { const char* e = getenv("GG_RIDERS"); cap = e && atoi(e) > 0 ? atoi(e) : 2048; }
+    r.nriders = (r.w1 - r.w0) < cap ? (r.w1 - r.w0) : cap;
+  }
+  *nriders = r.nriders;
+  *ntl = bs.ntl ? 1 : 0;
+  if (bytes) *bytes = 2.0 * m->N * (double)m->N * (m->is_adj ? 1.0 : 4.0 * m->B) * (double)(r.w1 - r.w0) / (double)(W > 0 ? W : 1);
+  return r;
+}
+
 // fused: pair tables (from buffer `buf`) -> parameter draw -> coefficient tables; optionally zero the other buffer
-static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, bool draw, bool prep, bool zero_other,
-                          uint32_t sweep, int pidx = -1, bool from_ctl = false) {
-  if (pidx < 0) pidx = m->pcur;
+// zero_buf >= 0: that statistics buffer is zeroed by the kernel's workgroups (unless it is known to be zero already);
+// ride_next >= 0 (ahead form): the first share of the NEXT sweep's bulk pass rides behind them, counting into that buffer.
+static gg_params_args fill_params_args(gg_model* m, const gg_data* d, int buf, bool tables, bool draw, bool prep, int zero_buf,
+                                       uint32_t sweep, int pidx) {
   gg_params_args g;
   memset(&g, 0, sizeof(g));
   g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.Kp = m->Kp; g.B = m->B; g.NSI = m->NSI; g.Np = m->Np; g.N = m->N;
@@ -702,24 +725,51 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   g.m = m->m; g.logm = m->logm; g.p = m->p; g.p_self = m->p_self; g.mu = m->mu; g.sigma = m->sigma;
   g.mu_self = m->mu_self; g.sigma_self = m->sigma_self; g.T = m->T; g.Tout = m->Tout; g.Tin = m->Tin;
   g.ctl = m->rs;
+  g.verdict = m->verdict;
   g.bar = m->bar;
   g.pi = m->pi;
   g.beta = m->beta;
-  g.sweep_from_ctl = from_ctl ? 1 : 0;
+  g.sweep_from_ctl = 0;
   g.tables_from_tab = m->shard_from_tab ? 1 : 0;
   if (m->m_pending && prep) {
     g.draw_m = 1; g.m_site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M; g.m_sweep = m->m_sweep;
     m->m_pending = false;
   }
-  if (zero_other && !m->zeroed[1 - buf]) {
-    g.zero_ptr = reinterpret_cast<unsigned long long*>(m->Gbuf[1 - buf]);
+  if (zero_buf >= 0 && !m->zeroed[zero_buf]) {
+    g.zero_ptr = reinterpret_cast<unsigned long long*>(m->Gbuf[zero_buf]);
     g.zero_words = m->Gbytes / 8;
-    m->zeroed[1 - buf] = true;
+    m->zeroed[zero_buf] = true;
   }
   g.shared = (m->kind == GG_SBM_GAUSS_SHCOV_W) ? 1 : 0;
   g.csc = m->csc;
+  return g;
+}
+
+static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, bool draw, bool prep, int zero_buf,
+                          uint32_t sweep, int pidx = -1, int ride_next = -1, int ride_part = 0) {
+  if (pidx < 0) pidx = m->pcur;
+  gg_params_args g = fill_params_args(m, d, buf, tables, draw, prep, zero_buf, sweep, pidx);
   const int nwg = m->K * m->K + 1;
-  if (m->is_adj) k_params<true, 1><<<nwg, 256, 0, m->stream>>>(g);
+  if (ride_next >= 0) {
+    int nr, ntl;
+    double bytes;
+    const gg_ride_args r = make_ride(m, d, ride_next, pidx, ride_part, nwg, &nr, &ntl, &bytes);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+    if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
+#define PRM(ADJV, BV)                                                                          \
+  do {                                                                                         \
+    if (ntl) k_params<ADJV, BV, 2><<<nwg + nr, 256, 0, m->stream>>>(g, r);                     \
+    else k_params<ADJV, BV, 1><<<nwg + nr, 256, 0, m->stream>>>(g, r);                         \
+  } while (0)
+    if (m->is_adj) PRM(true, 1);
+    else if (m->B == 1) PRM(false, 1);
+    else if (m->B == 2) PRM(false, 2);
+    else PRM(false, 4);
+#undef PRM
+    if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
+    m->zeroed[ride_next] = false;
+  } else if (m->is_adj) k_params<true, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 1) k_params<false, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 2) k_params<false, 2><<<nwg, 256, 0, m->stream>>>(g);
   else k_params<false, 4><<<nwg, 256, 0, m->stream>>>(g);
@@ -734,7 +784,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
 }
 
 static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined,
-                            bool from_ctl = false, int round_window = 0, int explicit_count = 0) {
+                            int round_window = 0, int explicit_count = 0) {
   gg_node_ctx x = node_ctx(m, d, buf);
   const int K = m->K, per = 256 / m->Kp;
   const int count = round_window > 0 ? round_window : (explicit_count > 0 ? explicit_count : (m->Nl - n_begin));
@@ -755,7 +805,7 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
     k_speculate<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl,    \
-                                                        stage, from_ctl ? 1 : 0, round_window > 0 ? 1 : 0, m->ap);        \
+                                                        stage, 0, round_window > 0 ? 1 : 0, m->ap);                       \
   } while (0)
   if (m->is_adj) SPEC(2, true);
   else if (m->B == 1) SPEC(3, false);
@@ -766,9 +816,9 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
   return GG_OK;
 }
 
-// k_speculate + the common case of k_resolve in one launch (k_spec_resolve): the speculative form of the adaptive scan.
-static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, int pw) {
+static gg_resolve_args fill_spec_args(gg_model* m, const gg_data* d, int buf, uint32_t sweep, int pw) {
   gg_resolve_args g;
+  memset(&g, 0, sizeof(g));
   g.x = node_ctx(m, d, buf);
   g.c = m->c; g.cnt = m->cnt; g.cand = m->cand; g.rs = m->rs; g.L = m->L;
   g.tail_m = 0; g.tail_sort = 1;
@@ -781,31 +831,119 @@ static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t 
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = nullptr;
   g.keep_L = 0;
+  g.verdict = m->verdict;
+  return g;
+}
+
+// The quiet chain's sweep in one launch (k_sweep_q): scan of sweep `sweep` on buffer `a` | parameter step of sweep + 1
+// on buffer `b` (gated on the scan's verdict) | riders counting the statistics of sweep + 2 into buffer `c`.
+static int launch_sweep_q(gg_model* m, const gg_data* d, int a, int b, int c, uint32_t sweep, int P) {
+  gg_resolve_args g = fill_spec_args(m, d, a, sweep, 1 - P);
+  // (the parameter step and the riders read the label sort the scan starts from: the one it ends with is being written
+  // by this very launch and is the same iff the scan changes nothing - the only case in which either result is used)
+  gg_params_args pg = fill_params_args(m, d, b, true, true, true, a /* zeroed after the verdict, for the next launch's riders */,
+                                       sweep + 1u, P);
+  const int per = 256 / m->Kp;
+  const int nspec = (m->Nl + per - 1) / per;
+  const int nparams = m->K * m->K + 1;
+  int stage;
+  const size_t lds = lds_spec(m, &stage);
+  int nr = 0, ntl = 0;
+  double bytes = 0;
+  gg_ride_args r = make_ride(m, d, c, P, 2, nspec + nparams, &nr, &ntl, &bytes);
+  if (m->swq_dbg) {
+    const long long init[8] = {0x7fffffffffffffffLL, 0, 0, 0, 0x7fffffffffffffffLL, 0, 0, 0};
+    GG_HIP(hipMemcpyAsync(m->swq_dbg, init, sizeof(init), hipMemcpyHostToDevice, m->stream));
+    r.dbg = m->swq_dbg;
+  }
+  const bool split64 = !stage && m->Kp == 64;
+  m->vtag += 1u;
+  if (m->vtag == 0u || m->vtag >= 0x7fffffffu) m->vtag = 1u;
+  const unsigned vtag = m->vtag;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+  if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
+#define SWQ1(NTV, ADJV, LV, SV)                                                                                            \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set && lds > 40 * 1024) {                                                                                    \
+      GG_HIP(hipFuncSetAttribute((const void*)k_sweep_q<NTV, ADJV, LV, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    k_sweep_q<NTV, ADJV, LV, SV><<<nspec + nparams + nr, 256, lds, m->stream>>>(g, stage, m->ap, pg, r, nspec, vtag);        \
+  } while (0)
+#define SWQ(NTV, ADJV)                                                                                                     \
+  do {                                                                                                                     \
+    if (split64) { if (ntl) SWQ1(NTV, ADJV, 1, 1); else SWQ1(NTV, ADJV, 0, 1); }                                          \
+    else { if (ntl) SWQ1(NTV, ADJV, 1, 0); else SWQ1(NTV, ADJV, 0, 0); }                                                  \
+  } while (0)
+  if (m->is_adj) SWQ(2, true);
+  else if (m->B == 1) SWQ(3, false);
+  else if (m->B == 2) SWQ(6, false);
+  else SWQ(15, false);
+#undef SWQ
+#undef SWQ1
+  if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
+  GG_HIP(hipGetLastError());
+  m->zeroed[c] = false;
+  return GG_OK;
+}
+
+// k_speculate + the common case of k_resolve in one launch (k_spec_resolve): the speculative form of the adaptive scan.
+// ride_next >= 0 (ahead form): the rest of the next sweep's bulk pass rides behind its workgroups (label sort 1 - pw, the
+// one this sweep started with).
+static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, int pw, int ride_next = -1) {
+  gg_resolve_args g = fill_spec_args(m, d, buf, sweep, pw);
   const int per = 256 / m->Kp;
   const int nb = (m->Nl + per - 1) / per;
   int stage;
   const size_t lds = lds_spec(m, &stage);
-#define SPR(NTV, ADJV)                                                                                                     \
+  int nr = 0, ntl = 0;
+  double bytes = 0;
+  gg_ride_args r;
+  memset(&r, 0, sizeof(r));
+  if (ride_next >= 0) r = make_ride(m, d, ride_next, 1 - pw, 1, nb, &nr, &ntl, &bytes);
+  const int ride = ride_next < 0 ? 0 : (ntl ? 2 : 1);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool timed = ride && m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+  if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
+  const bool split64 = !stage && m->Kp == 64;   // the K > 32 conditional (gg_lp_split4): its own instantiation
+#define SPR1(NTV, ADJV, RV, SV)                                                                                            \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
-    if (!attr_set && lds > 48 * 1024) {                                                                                    \
-      GG_HIP(hipFuncSetAttribute((const void*)k_spec_resolve<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+    if (!attr_set && lds > 40 * 1024) {                                                                                    \
+      GG_HIP(hipFuncSetAttribute((const void*)k_spec_resolve<NTV, ADJV, RV, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    k_spec_resolve<NTV, ADJV><<<nb, 256, lds, m->stream>>>(g, stage, m->ap);                                                \
+    k_spec_resolve<NTV, ADJV, RV, SV><<<nb + nr, 256, lds, m->stream>>>(g, stage, m->ap, r);                                \
+  } while (0)
+#define SPR(NTV, ADJV)                                                                                                     \
+  do {                                                                                                                     \
+    if (split64) {                                                                                                         \
+      if (ride == 0) SPR1(NTV, ADJV, 0, 1);                                                                                \
+      else if (ride == 1) SPR1(NTV, ADJV, 1, 1);                                                                           \
+      else SPR1(NTV, ADJV, 2, 1);                                                                                          \
+    } else {                                                                                                               \
+      if (ride == 0) SPR1(NTV, ADJV, 0, 0);                                                                                \
+      else if (ride == 1) SPR1(NTV, ADJV, 1, 0);                                                                           \
+      else SPR1(NTV, ADJV, 2, 0);                                                                                          \
+    }                                                                                                                      \
   } while (0)
   if (m->is_adj) SPR(2, true);
   else if (m->B == 1) SPR(3, false);
   else if (m->B == 2) SPR(6, false);
   else SPR(15, false);
 #undef SPR
+#undef SPR1
+  if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
   GG_HIP(hipGetLastError());
+  if (ride_next >= 0) m->zeroed[ride_next] = false;
   return GG_OK;
 }
 
 // The tail of a completed scan sorts the final labels into perm buffer `pw` (default: the other one).
 static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort,
-                          int pw = -1, bool flush_on_change = false, bool from_ctl = false, int round_window = 0) {
+                          int pw = -1, int round_window = 0) {
   if (pw < 0) pw = 1 - m->pcur;
   gg_resolve_args g;
   g.x = node_ctx(m, d, buf);
@@ -813,8 +951,8 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   g.tail_m = tail_m ? 1 : 0; g.tail_sort = tail_sort ? 1 : 0;
   g.m = m->m; g.pi = m->pi; g.perm = m->permb[pw]; g.lab_start = m->labb[pw];
   g.perm_prev = m->permb[1 - pw]; g.lab_start_prev = m->labb[1 - pw];
-  g.flush_on_change = flush_on_change ? 1 : 0;
-  g.sweep_from_ctl = from_ctl ? 1 : 0;
+  g.flush_on_change = 0;
+  g.sweep_from_ctl = 0;
   g.round_mode = round_window > 0 ? 1 : 0;
   g.window = round_window;
   g.stage_tables = m->resolve_stage ? 1 : 0;
@@ -823,7 +961,7 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = nullptr;
-  g.keep_L = m->incr ? 1 : 0;
+  g.keep_L = 0;
   size_t lds = m->resolve_lds;
 #define RES(NTV, ADJV)                                                                                           \
   do {                                                                                                           \
@@ -877,7 +1015,7 @@ static int launch_round(gg_model* m, const gg_data* d, int buf, uint32_t sweep, 
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = m->dbg;
-  g.keep_L = m->incr ? 1 : 0;
+  g.keep_L = 0;
   const int per = 256 / m->Kp;
   int nb = (window + per - 1) / per;
   if (nb > 512) nb = 512;   // groups beyond the grid are strided over
@@ -933,7 +1071,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = m->dbg;
-  g.keep_L = m->incr ? 1 : 0;
+  g.keep_L = 0;
   a.ap = m->ap; a.Gc0 = gcnt(m, buf, 0); a.Gs0 = gs(m, buf, 0); a.bar = m->bar;
   a.Lcap = m->Lcap < 1024 ? m->Lcap : 1024;   // every workgroup keeps its own copy of the list in LDS (12 KB)
   const int per = 256 / m->Kp;
@@ -981,7 +1119,7 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
       m->st.resolve_rounds += 1;
       if ((rc = read_ctl(m))) return rc;
     }
-    if (m->h_rs[3] == 2 && !m->incr) {
+    if (m->h_rs[3] == 2) {
       // the resident grid timed out and left a consistent stalled scan: restart rounds from here on (see model_sync)
       if ((rc = write_ctl_word(m, 3, 0))) return rc;
       fprintf(stderr, "graphgibbs: the resident-grid scan timed out; this model continues with restart rounds (GG_SCAN=0)\n");
@@ -1053,24 +1191,31 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
 }
 
 // ---- one full sweep, enqueued optimistically (no host sync) ---------------------------------
-// Serial form (K = 1 kinds, or GG_PIPELINE=0), everything on the scan stream:
-//   bulk -> params (+ zero the other buffer) -> speculate -> resolve (+ re-sort)
+// Serial form, everything on the model's stream:
+//   bulk -> params (+ zero the next buffer) -> scan (k_scan, or k_spec_resolve while the chain is quiet and the ahead
+//   form is off) [K = 1 kinds: bulk -> params]
 static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
   int rc;
   const bool scan = m->sbm && m->K > 1;
-  const int buf = m->cur, P = m->pcur;
-  if ((rc = enqueue_bulk(m, d, buf, scan ? 3 : 1, true, sweep))) return rc;
-  if ((rc = enqueue_params(m, d, buf, true, true, scan, true, sweep, P))) return rc;
+  const int buf = m->cur, nxt = (buf + 1) % 3, P = m->pcur;
+  if (m->ahead && m->ahead_uid == d->uid) {
+    // the statistics of this sweep were counted ahead by the riders of the previous one (which changed no label)
+    m->ahead = false;
+  } else {
+    drop_ahead(m);
+    if ((rc = enqueue_bulk(m, d, buf, scan ? 3 : 1, true, sweep))) return rc;
+  }
+  if ((rc = enqueue_params(m, d, buf, true, true, scan, nxt, sweep, P))) return rc;
   if (scan) {
     if (m->use_scan) {
       if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P))) return rc;
-    } else if (m->scan_pref < 0 && !getenv("GG_NO_FUSED_SPEC")) {
+    } else if (m->scan_pref < 0) {
       // adaptive form, quiet phase: speculation and the resolution of the common case in one launch; a scan that does
       // change a label is left stalled behind its first change for the resident grid (finish_scan)
       if ((rc = launch_spec_resolve(m, d, buf, sweep, 1 - P))) return rc;
     } else {
       if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
-      if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
+      if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P))) return rc;
     }
     m->st.resolve_rounds += 1;
     m->m_pending = true;   // drawn by the next sweep's k_params (or at the next sync)
@@ -1082,147 +1227,56 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, sweep, m->m);
     GG_HIP(hipGetLastError());
   }
-  m->cur = 1 - buf;
+  m->cur = nxt;
   return GG_OK;
 }
 
-// Incremental form (GG_INCREMENTAL=1, scan models): the per-node statistics G are exact integers, so instead of
-// recounting them from X and X^T every sweep they are carried over: a scan's accepted changes are flushed
-// into G (k_apply_L: rows of X / X^T of the changed nodes only), and a bulk pass runs only when G is not
-// known to match the labels (first sweep, labels or data replaced from outside).  Same chain bit for bit;
-// the sweep no longer streams the N x N data, so it is reported separately from the default path.
-static int enqueue_sweep_incr(gg_model* m, const gg_data* d, uint32_t sweep) {
+// Ahead form (scan models while the chain is quiet).  A sweep that is followed by another one in the
+// same call runs as ONE launch:
+//   k_sweep_q(s):  scan of sweep s  |  parameter step of sweep s+1 (gated on the scan's verdict)  |  riders: bulk pass of s+2
+// preceded, for the first sweep of a run, by
+//   k_params(s) + riders: the whole bulk pass of sweep s+1
+// and the last sweep of a call by a plain k_spec_resolve(s): what a caller can observe after n sweeps is the state after
+// exactly n sweeps.  The riders count under the labels the sweep STARTS with: exactly the statistics a later sweep needs
+// iff no scan in between changes a label.  A scan that does change one stalls the pipeline (every later launch is a no-op,
+// the gated parameter step of the next sweep writes nothing), the host finishes it with the resident grid and continues in
+// the serial form; what the riders counted is dropped.  Every sweep still streams all of X and X^T once.
+static int enqueue_sweep_ahead(gg_model* m, const gg_data* d, uint32_t sweep, bool more) {
   int rc;
-  const int buf = m->cur, P = m->pcur;
-  if (!m->G_valid || m->G_uid != d->uid) {
-    m->zeroed[buf] = false;
-    if ((rc = enqueue_bulk(m, d, buf, 3, true, sweep))) return rc;
-    m->G_valid = true;
-    m->G_uid = d->uid;
+  const int a = m->cur, b = (a + 1) % 3, c = (a + 2) % 3, P = m->pcur;
+  if (!m->pre) {
+    if (!(m->ahead && m->ahead_uid == d->uid)) {
+      // prologue: nothing was counted ahead for this sweep (first sweep, new data or labels, after a stall)
+      drop_ahead(m);
+      if ((rc = enqueue_bulk(m, d, a, 3, true, sweep))) return rc;
+    }
+    if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, b))) return rc;
+    // parameter step of this sweep; the whole bulk pass of the next one rides along
+    if ((rc = enqueue_params(m, d, a, true, true, true, c, sweep, P, b, more ? 2 : 0))) return rc;
   }
-  if ((rc = enqueue_params(m, d, buf, true, true, true, false, sweep, P))) return rc;
-  if (m->use_scan) {
-    if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P))) return rc;
+  m->m_pending = true;     // resample_m of this sweep: drawn by the next parameter step (or at the next sync)
+  m->m_sweep = sweep;
+  if (more) {
+    if ((rc = launch_sweep_q(m, d, a, b, c, sweep, P))) return rc;
+    m->pre = true;
   } else {
-    if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
-    if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P, false))) return rc;
+    // last sweep of the call: the scan alone (+ the rest of the next sweep's pass when it did not ride above)
+    if ((rc = launch_spec_resolve(m, d, a, sweep, 1 - P, m->pre ? -1 : b))) return rc;
+    m->pre = false;
   }
-  if ((rc = launch_apply_L(m, d, buf, 1))) return rc;   // the scan's changes -> G (no-op behind a stall)
   m->st.resolve_rounds += 1;
-  m->m_pending = true;
-  m->m_sweep = sweep;
   m->pcur = 1 - P;
+  m->cur = b;
+  m->ahead = true;          // valid once the batch is confirmed clean (model_sync drops it after a stall)
+  m->ahead_uid = d->uid;
   return GG_OK;
 }
 
-// Pipelined form (scan models): the bulk statistics of sweep i+1 are computed on a second stream
-// WHILE sweep i's params -> speculate -> resolve chain runs, under the labels sweep i starts with.
-// They are exactly the statistics sweep i+1 needs iff sweep i's scan changes no label; a scan that
-// changes any label raises the flush flag (k_resolve, flush_on_change), every later pipeline kernel
-// becomes a no-op, and the host restarts from a fresh bulk pass.  Every sweep still streams all of
-// A, A^T, W, W^T once: the work is overlapped, not skipped.
-static int enqueue_sweep_pipe(gg_model* m, const gg_data* d, uint32_t sweep) {
-  int rc;
-  const int g = m->cur, P = m->pcur;
-  const bool cap = m->capturing;
-  if (cap) {
-    // fork point of the captured graph: brings the bulk stream into the capture
-    GG_HIP(hipEventRecord(m->ev_scan, m->stream));
-  } else if (!m->next_bulk) {
-    // prologue: statistics of THIS sweep (labels final on the scan stream)
-    if ((rc = ensure_perm(m))) return rc;
-    GG_HIP(hipEventRecord(m->ev_scan, m->stream));
-    GG_HIP(hipStreamWaitEvent(m->sb, m->ev_scan, 0));
-    GG_HIP(hipMemsetAsync(m->Gbuf[g], 0, m->Gbytes, m->sb));
-    if ((rc = enqueue_bulk(m, d, g, 3, true, sweep, m->sb, P))) return rc;
-    GG_HIP(hipEventRecord(m->ev_bulk[g], m->sb));
-  }
-  // early bulk of the next sweep, under the same labels
-  GG_HIP(hipStreamWaitEvent(m->sb, m->ev_scan, 0));      // previous scan done: labels final, G[1-g] free
-  {
-    const size_t words = m->Gbytes / 8;
-    int nb = (int)((words + 256 * 8 - 1) / (256 * 8));
-    if (nb > 2048) nb = 2048;
-    k_zero_if_live<<<nb, 256, 0, m->sb>>>(m->rs, reinterpret_cast<unsigned long long*>(m->Gbuf[1 - g]), words);
-  }
-  if ((rc = enqueue_bulk(m, d, 1 - g, 3, true, sweep + 1, m->sb, P))) return rc;
-  GG_HIP(hipEventRecord(m->ev_bulk[1 - g], m->sb));
-  // this sweep's scan chain (sweep index read from the control block: identical arguments every replay)
-  if (!cap) GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[g], 0));
-  if ((rc = enqueue_params(m, d, g, true, true, true, false, sweep, P, true))) return rc;
-  if ((rc = launch_speculate(m, d, g, 0, -1, sweep, true, true))) return rc;
-  if ((rc = launch_resolve(m, d, g, sweep, false, true, 1 - P, true, true))) return rc;
-  if (cap) {
-    // join the bulk stream back before the capture ends
-    GG_HIP(hipEventRecord(m->ev_join, m->sb));
-    GG_HIP(hipStreamWaitEvent(m->stream, m->ev_join, 0));
-    return GG_OK;
-  }
-  GG_HIP(hipEventRecord(m->ev_scan, m->stream));
-  m->st.resolve_rounds += 1;
-  m->m_pending = true;
-  m->m_sweep = sweep;
-  m->cur = 1 - g;
-  m->pcur = 1 - P;
-  m->next_bulk = true;
-  m->zeroed[0] = m->zeroed[1] = false;
-  return GG_OK;
-}
-
-// One pipelined sweep replayed from a hipGraph captured for the current buffer parity.
-static int launch_sweep_graph(gg_model* m, const gg_data* d, uint32_t sweep) {
-  int rc;
-  const int g = m->cur, P = m->pcur;
-  if (m->gexec[g][P] && m->gdata_uid[g][P] != d->uid) {
-    GG_HIP(hipGraphExecDestroy(m->gexec[g][P]));
-    m->gexec[g][P] = nullptr;
-  }
-  if (!m->gexec[g][P]) {
-    hipGraph_t graph = nullptr;
-    GG_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
-    m->capturing = true;
-    rc = enqueue_sweep_pipe(m, d, 0);
-    m->capturing = false;
-    hipError_t e = hipStreamEndCapture(m->stream, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-    if (e != hipSuccess) return gg_fail(GG_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    GG_HIP(hipGraphInstantiate(&m->gexec[g][P], graph, nullptr, nullptr, 0));
-    GG_HIP(hipGraphDestroy(graph));
-    m->gdata_uid[g][P] = d->uid;
-  }
-  GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[g], 0));   // this sweep's statistics (enqueued eagerly or by the last replay)
-  GG_HIP(hipGraphLaunch(m->gexec[g][P], m->stream));
-  GG_HIP(hipEventRecord(m->ev_scan, m->stream));             // eager marker: the replay (scan + early bulk) is done
-  GG_HIP(hipEventRecord(m->ev_bulk[1 - g], m->stream));
-  m->st.resolve_rounds += 1;
-  m->m_pending = true;
-  m->m_sweep = sweep;
-  m->cur = 1 - g;
-  m->pcur = 1 - P;
-  m->next_bulk = true;
-  return GG_OK;
-}
-
-static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep) {
+static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep, bool more) {
   const bool learn_params = (m->kind != GG_BERN_ADJ && m->kind != GG_FIXED_W);
   if (!learn_params) return GG_OK;
-  if (m->incr) return enqueue_sweep_incr(m, d, sweep);
-  if (!m->pipe) return enqueue_sweep_serial(m, d, sweep);
-  // replay from the graph when the pipeline is primed (statistics of this sweep in flight, a predecessor
-  // sweep whose m is pending) and this sweep is not one of the HIP-event timing samples
-  const bool sampled = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0;
-  if (m->use_graph && m->next_bulk && m->m_pending && !sampled && m->beta == 1.0) return launch_sweep_graph(m, d, sweep);
-  return enqueue_sweep_pipe(m, d, sweep);
-}
-
-// Leave pipelined mode before anything else touches the statistics buffers or the scan stream's state.
-static int drain_pipe(gg_model* m) {
-  if (m->pipe && m->next_bulk) {
-    GG_HIP(hipStreamSynchronize(m->sb));
-    m->next_bulk = false;
-    m->zeroed[0] = m->zeroed[1] = false;
-  }
-  return GG_OK;
+  if (m->can_ahead && !m->use_scan && m->scan_pref < 0) return enqueue_sweep_ahead(m, d, sweep, more);
+  return enqueue_sweep_serial(m, d, sweep);
 }
 
 static void begin_call(gg_model* m) {
@@ -1260,10 +1314,9 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
   if (!ctl_fresh) GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   for (;;) {
     bool abort0 = false;
-    if (m->pipe) GG_HIP(hipStreamSynchronize(m->sb));
     if (ctl_fresh) ctl_fresh = false;
     else if ((rc = read_ctl(m))) return rc;
-    if (m->h_rs[3] == 2 && !m->incr) {
+    if (m->h_rs[3] == 2) {
       // A k_scan exchange timed out (the resident grid could not assemble - a device shared with other processes, say)
       // and left the scan as a stalled one at a consistent position: carry on with the launch-per-change form, for good.
       if ((rc = write_ctl_word(m, 3, 0))) return rc;
@@ -1277,10 +1330,11 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       write_ctl_word(m, 3, 0);
       m->pending = 0;
       m->todo = 0;
-      m->next_bulk = false;
-      m->zeroed[0] = m->zeroed[1] = false;
-      m->G_valid = false;
+      m->ahead = false;
+      m->pre = false;
+      m->zeroed[0] = m->zeroed[1] = m->zeroed[2] = false;
       set_pend_data(m, nullptr);
+      if (st3 & 8) return gg_fail(GG_ERR_HIP, "k_sweep_q: the scan's verdict did not arrive (device hung?); set GG_AHEAD=0");
       if (st3 & 2) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out (the resident grid did not assemble); set GG_SCAN=0");
       if (st3 & 4) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out inside the statistics flush; set GG_SCAN=0");
       return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
@@ -1308,7 +1362,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       m->cur0 = m->cur; m->pcur0 = m->pcur;
       if (scan && (rc = write_ctl_word(m, 5, 0))) return rc;
       for (int i = 0; i < take; ++i)
-        if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i))) return rc;
+        if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i, i + 1 < take))) return rc;
       m->pending = take;
       m->todo -= take;
       GG_HIP(hipEventRecord(m->ev_call1, m->stream));
@@ -1316,8 +1370,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
     }
     // A scan stalled: the sweeps enqueued behind it ran as no-ops and must be enqueued again.  A chain that keeps
     // changing labels stalls every sweep, so stop running ahead (depth 1) until batches come back clean.
-    if (!m->pipe && m->scan_pref >= 0) m->depth = 1;   // (the pipelined form keeps its own look-ahead discipline; the adaptive
-                                                       // form switches to the resident scan below, which cannot stall)
+    if (m->scan_pref >= 0) m->depth = 1;   // (the adaptive form switches to the resident scan below, which cannot stall)
     if (m->scan_pref < 0) {   // the chain is changing labels: k_scan from the next sweep on
       // (a stall soon after the last switch back: the chain changes labels now and then - hold the resident form longer)
       // Break-even: a quiet sweep costs ~4 us more in the resident form, a stall ~400 us in the other one (slow path,
@@ -1336,16 +1389,15 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
     const int completed = mid ? done + 1 : done;       // after the slow path below
     if (mid) {
       const int s_idx = done;                          // index of the stalled sweep within the batch
-      const int buf_s = (m->cur0 + s_idx) & 1, P_s = (m->pcur0 + s_idx) & 1;
+      const int buf_s = (m->cur0 + s_idx) % 3, P_s = (m->pcur0 + s_idx) & 1;
       if (abort0) {
         // nothing of this scan is decided yet (statistics, parameters and tables of the sweep are in place): run it in
         // the speculative form; what that leaves unfinished is finished below like any other stalled scan
         if ((rc = write_ctl_word(m, 4, 0))) return rc;
         if ((rc = launch_speculate(m, d, buf_s, 0, -1, m->sweep + (uint32_t)s_idx, true))) return rc;
-        if ((rc = launch_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s, false))) return rc;
+        if ((rc = launch_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
       }
-      if ((rc = finish_scan(m, d, m->incr ? m->cur0 : buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
-      if (m->incr && (rc = launch_apply_L(m, d, m->cur0, 2))) return rc;   // what the rounds applied lazily -> all of G
+      if ((rc = finish_scan(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
     } else {
       if ((rc = write_ctl_word(m, 4, 0))) return rc;
     }
@@ -1356,21 +1408,22 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       if (sw != ~0u && sw >= m->sweep + (uint32_t)completed) sw = ~0u;
     m->sweep += (uint32_t)completed;
     m->st.sweeps += (uint64_t)completed;
-    m->cur = m->incr ? m->cur0 : ((m->cur0 + completed) & 1);
+    m->cur = (m->cur0 + completed) % 3;
     m->pcur = (m->pcur0 + completed) & 1;
-    m->next_bulk = false;
-    if (m->pipe) m->zeroed[0] = m->zeroed[1] = false;
-    else if (m->incr) { m->zeroed[0] = m->zeroed[1] = false; }
-    else { m->zeroed[1 - m->cur] = false; m->zeroed[m->cur] = true; }   // serial form: k_params of the last completed sweep zeroed it
+    // Whatever the sweeps behind the stall were to count or zero did not happen, and what the riders of the stalled sweep
+    // counted ahead belongs to labels that have changed since: every buffer is zeroed again before its next use.
+    m->ahead = false;
+    m->pre = false;
+    m->zeroed[0] = m->zeroed[1] = m->zeroed[2] = false;
     m->pending = 0;
-    // words 5 (completed scans of the batch) and 6 (sweep index) in one stream-ordered copy from pinned staging
-    m->h_rs[24] = 0; m->h_rs[25] = (int32_t)m->sweep;
-    GG_HIP(hipMemcpyAsync(m->rs + 5, m->h_rs + 24, 2 * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    // word 5 (completed scans of the batch) restarts: a stream-ordered copy from pinned staging
+    m->h_rs[24] = 0;
+    GG_HIP(hipMemcpyAsync(m->rs + 5, m->h_rs + 24, sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
     m->cur0 = m->cur; m->pcur0 = m->pcur;
     m->todo += remaining;
     const int take = m->todo < m->depth ? m->todo : m->depth;
     for (int i = 0; i < take; ++i)
-      if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i))) return rc;
+      if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i, i + 1 < take))) return rc;
     m->pending = take;
     m->todo -= take;
     if (take == 0) break;
@@ -1398,6 +1451,12 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
                       (h[5] + h[7]) * 0.01);
   }
   GG_HIP(hipEventSynchronize(m->ev_call1));
+  if (m->swq_dbg) {
+    long long h[8];
+    GG_HIP(hipMemcpy(h, m->swq_dbg, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[1]) fprintf(stderr, "[swq dbg] %s last fused launch: scan done %.2f us, parameters done %.2f us, first rider starts %.2f us, riders done %.2f us (after the first workgroup started)\n",
+                      m->is_adj ? "adj" : "w", (h[1] - h[0]) * 0.01, (h[2] - h[0]) * 0.01, (h[4] - h[0]) * 0.01, (h[3] - h[0]) * 0.01);
+  }
   set_pend_data(m, nullptr);   // nothing of this model is in flight on the network any more
   if ((rc = collect_timing(m))) return rc;
   return GG_OK;
@@ -1439,8 +1498,6 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   if (rc) return rc;
   if (n_sweeps <= 0) return GG_OK;
   if ((m->pending || m->todo) && (m->pend_data != d || m->beta != beta) && (rc = model_sync(m))) return rc;
-  // pipelined form: statistics computed ahead belong to the data (and labels) of the previous call
-  if (m->pipe && m->pend_data != d && (rc = drain_pipe(m))) return rc;
   if (m->pending == 0 && m->todo == 0) {
     if (m->parts_done) { m->sweep += 1; m->parts_done = 0; }   // step-wise parts were drawn under this index already
     begin_call(m);
@@ -1450,7 +1507,9 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   m->beta = beta;
   for (int s = 0; s < n_sweeps; ++s) {
     if (m->todo > 0 || m->pending >= m->depth) { m->todo += 1; continue; }   // not further ahead than `depth`
-    if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)m->pending))) return rc;
+    // (`more`: another sweep of this call follows directly - the quiet form then runs the sweep as one fused launch)
+    const bool more = s + 1 < n_sweeps && m->pending + 1 < m->depth;
+    if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)m->pending, more))) return rc;
     m->pending += 1;
   }
   return GG_OK;
@@ -1477,7 +1536,7 @@ int gg_sync_many(gg_model** ms, int32_t n) {
   for (int i = 0; i < n; ++i) {
     gg_model* m = ms[i];
     if (!m) return gg_fail(GG_ERR_INVALID, "null model");
-    if (m->eig || m->ld || m->pipe || (m->pending == 0 && m->todo == 0)) continue;
+    if (m->eig || m->ld || (m->pending == 0 && m->todo == 0)) continue;
     GG_HIP(hipSetDevice(m->cfg.device));
     GG_HIP(hipEventRecord(m->ev_call1, m->stream));
     GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 24 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
@@ -1485,7 +1544,7 @@ int gg_sync_many(gg_model** ms, int32_t n) {
   }
   for (int i = 0; i < n; ++i) {
     gg_model* m = ms[i];
-    if (!fresh[(size_t)i]) { if (m->pipe) slow = true; continue; }
+    if (!fresh[(size_t)i]) continue;
     GG_HIP(hipSetDevice(m->cfg.device));
     GG_HIP(hipStreamSynchronize(m->stream));
     if (m->h_rs[4] || m->h_rs[3] || m->todo > 0) slow = true;
@@ -1568,11 +1627,9 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   if (m->ld) { gg_latent_set_beta(m->ld, beta); return gg_latent_resample(m->ld, d, parts, 0); }
   int rc = model_sync(m);
   if (rc) return rc;
-  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   m->beta = beta;
   if (parts != GG_PART_M) rc = check_data(m, d);  // resample_m needs the labels only (adjacency.py:697-702)
   if (rc) return rc;
-  if ((rc = drain_pipe(m))) return rc;
   // Philox counters are addressed by (seed, site, sweep, index): a part asked for again under the same sweep index
   // would redraw the very same variates (a deterministic map, not a Markov kernel), so it starts a new sweep index.
   parts &= (GG_PART_PARAMS | GG_PART_C | GG_PART_M);
@@ -1584,13 +1641,16 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   const bool do_m = (parts & GG_PART_M) && m->sbm;
   const int buf = m->cur;
   if (do_params || do_c) {
-    if ((rc = enqueue_bulk(m, d, buf, do_c ? 3 : 1, false))) return rc;
-    if ((rc = enqueue_params(m, d, buf, do_params, do_params, do_c, false, m->sweep))) return rc;
+    // statistics under the current labels: counted ahead by the last sweep's riders, or one bulk pass now
+    const bool have = m->ahead && m->ahead_uid == d->uid;
+    if (!have) { drop_ahead(m); if ((rc = enqueue_bulk(m, d, buf, do_c ? 3 : 1, false))) return rc; }
+    if ((rc = enqueue_params(m, d, buf, do_params, do_params, do_c, -1, m->sweep))) return rc;
+    if (do_c) { m->ahead = false; m->zeroed[buf] = false; }   // the scan below may change labels: not the next sweep's statistics
   }
   if (do_c) {
     if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false))) return rc;
     const int pw = 1 - m->pcur;
-    if ((rc = launch_resolve(m, d, buf, m->sweep, false, true, pw, false))) return rc;
+    if ((rc = launch_resolve(m, d, buf, m->sweep, false, true, pw))) return rc;
     m->st.resolve_rounds += 1;
     if ((rc = finish_scan(m, d, buf, m->sweep, false, true, pw))) return rc;
     m->pcur = pw;   // the completed scan left the sort of the final labels there
@@ -1621,15 +1681,13 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: block models only");
   int rc = model_sync(m);
   if (rc) return rc;
-  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   if ((rc = check_data(m, d))) return rc;
   if (n < 0 || n >= m->N) return gg_fail(GG_ERR_INVALID, "node %d out of range", n);
-  if ((rc = drain_pipe(m))) return rc;
   m->beta = 1.0;
   begin_call(m);
   const int buf = m->cur;
-  if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;
-  if ((rc = enqueue_params(m, d, buf, false, false, true, false, m->sweep))) return rc;
+  if (!(m->ahead && m->ahead_uid == d->uid)) { drop_ahead(m); if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc; }
+  if ((rc = enqueue_params(m, d, buf, false, false, true, -1, m->sweep))) return rc;
   if ((rc = launch_speculate(m, d, buf, 0, n, m->sweep, false))) return rc;
   GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   if ((rc = read_ctl(m))) return rc;
@@ -1722,18 +1780,18 @@ static int loglik_from_tables(gg_model* m, const gg_data* d, const long long* ta
 static int ll_enqueue(gg_model* m, const gg_data* d) {
   int rc = model_sync(m);
   if (rc) return rc;
-  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   if ((rc = check_data(m, d))) return rc;
   begin_call(m);
   const int buf = m->cur;
-  if (m->pipe && m->next_bulk && m->pend_data == d) {
-    // the statistics of the current labels are already (being) computed for the next sweep: reuse them
-    GG_HIP(hipStreamWaitEvent(m->stream, m->ev_bulk[buf], 0));
-  } else {
-    if ((rc = drain_pipe(m))) return rc;
+  // The statistics of the current labels may have been counted already, for the next sweep, by the riders of the last
+  // one (ahead form): the demo loop `resample; log_probability` (examples/demo_model_comparison.py:69-72) then pays
+  // no second pass over the data - the tables come from numbers that are resident anyway.  Otherwise: one bulk pass
+  // (out-direction only) whose buffer is not reused.
+  if (!(m->ahead && m->ahead_uid == d->uid)) {
+    drop_ahead(m);
     if ((rc = enqueue_bulk(m, d, buf, 1, false))) return rc;
   }
-  if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
+  if ((rc = enqueue_params(m, d, buf, true, false, false, -1, m->sweep))) return rc;
   const size_t KK = (size_t)m->K * m->K;
   // tables and block counts through pinned staging (a copy into pageable memory costs tens of microseconds)
   GG_HIP(hipMemcpyAsync(m->h_tab, m->tab, KK * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
@@ -1788,9 +1846,8 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
   if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_bench_bulk: block models only");
   int rc = model_sync(m);
   if (rc) return rc;
-  m->G_valid = false;   // (incremental mode: this call rebuilds or overwrites the carried statistics)
   if ((rc = check_data(m, d))) return rc;
-  if ((rc = drain_pipe(m))) return rc;
+  drop_ahead(m);
   const int t0 = m->timing;
   m->timing = 0;
   const int buf = m->cur;
@@ -1835,7 +1892,7 @@ int gg_shard_tables(gg_model* m, const gg_data* d, int64_t* tables, int64_t* dia
   m->beta = 1.0;
   const int buf = m->cur;
   if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;
-  if ((rc = enqueue_params(m, d, buf, true, false, false, false, m->sweep))) return rc;
+  if ((rc = enqueue_params(m, d, buf, true, false, false, -1, m->sweep))) return rc;
   GG_HIP(hipMemcpyAsync(tables, m->tab, (size_t)m->K * m->K * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));
   diag[0] = d->d1;
@@ -1852,7 +1909,7 @@ int gg_shard_params(gg_model* m, const gg_data* d, const int64_t* tables, const 
   dg.d1 = diag[0];
   for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = diag[1 + i];
   m->shard_from_tab = true;
-  rc = enqueue_params(m, &dg, m->cur, false, true, true, false, m->sweep);
+  rc = enqueue_params(m, &dg, m->cur, false, true, true, -1, m->sweep);
   m->shard_from_tab = false;
   if (rc) return rc;
   m->spos = 0;
@@ -1869,7 +1926,7 @@ int gg_shard_next(gg_model* m, const gg_data* d, int32_t out[4]) {
   if (hi > m->Nl) hi = m->Nl;
   out[0] = 0x7fffffff; out[1] = 0; out[2] = 0; out[3] = wend;
   if (hi > lo && m->K > 1) {
-    if ((rc = launch_speculate(m, d, m->cur, lo, -1, m->sweep, false, false, 0, hi - lo))) return rc;
+    if ((rc = launch_speculate(m, d, m->cur, lo, -1, m->sweep, false, 0, hi - lo))) return rc;
     k_first_changer<<<1, 1024, 0, m->stream>>>(m->c, m->cand, m->n0, lo, hi, m->rs + 12);
     GG_HIP(hipGetLastError());
     GG_HIP(hipMemcpyAsync(m->h_rs, m->rs + 12, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
@@ -1903,7 +1960,6 @@ int gg_shard_finish(gg_model* m) {
   m->sweep += 1;
   m->st.sweeps += 1;
   m->zeroed[m->cur] = false;
-  GG_HIP(hipMemcpy(m->rs + 6, &m->sweep, 4, hipMemcpyHostToDevice));
   return GG_OK;
 }
 

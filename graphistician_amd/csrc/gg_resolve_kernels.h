@@ -58,6 +58,7 @@ struct gg_resolve_args {
   uint32_t site, sweep;
   long long* dbg;   // optional phase timestamps of k_round (GG_ROUND_DBG), [workgroup][8]
   int keep_L;       // incremental statistics: a completed scan leaves its change list in place for the flush into G
+  unsigned* verdict;   // fused quiet-chain launch: where the resolving workgroup publishes (tag << 1 | changed)
 };
 
 
@@ -356,9 +357,17 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
 //     under the right labels and kept its own): it is accepted - label, block counts, change list - and the scan is left
 //     STALLED behind it, for the resident grid to finish (finish_scan: k_apply_L + k_scan in resume mode).
 // A quiet scan costs one launch (~10 us) instead of two (9 + 8.5 us).
-template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_spec_resolve(gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap) {
-  if (g.rs[4]) return;   // behind a stalled scan of this pipeline: no-op (uniform)
+#ifndef GG_RIDE_UJ
+#define GG_RIDE_UJ 2
+#endif
+#ifndef GG_RIDE_WAVES
+#define GG_RIDE_WAVES 4   // waves per SIMD the riding variants are compiled for (<= 128 VGPRs): the riders need the occupancy
+#endif
+// The speculative scan of one workgroup of `nfront` (block indices 0 .. nfront-1 of the launch): see k_spec_resolve.
+// vtag != 0: the resolving workgroup also publishes the verdict word (gg_wait_verdict).
+template <int NT, bool ADJ, int UJ_, int SPLIT>
+__device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, int stage_tables, int32_t* __restrict__ ap,
+                                                     const unsigned nfront, const unsigned vtag) {
   const gg_node_ctx& x = g.x;
   const int tid = threadIdx.x, N = x.N, K = x.K;
   __shared__ unsigned long long s_fmin;
@@ -366,14 +375,18 @@ __global__ __launch_bounds__(256) void k_spec_resolve(gg_resolve_args g, int sta
   if (tid == 0) s_fmin = GG_NO_CHANGE;
   int n;
   bool live;
-  const int lab = gg_spec_eval<NT, ADJ>(x, 0, g.seed, g.site, g.sweep, -1, nullptr, stage_tables, &n, &live);   // (syncs inside)
+  // the node's current label: fetched now, compared after the evaluation (one dependent round trip less at the end)
+  const int n_mine = (int)blockIdx.x * (256 / x.Kp) + tid / x.Kp;
+  const int cn_pre = x.c[x.n0 + (n_mine < N ? n_mine : N - 1)];
+  // (riding variants: shallow table batches - the registers buy the riders' occupancy; same fma order, same bits)
+  const int lab = gg_spec_eval<NT, ADJ, UJ_, SPLIT>(x, 0, g.seed, g.site, g.sweep, -1, nullptr, stage_tables, &n, &live);   // (syncs inside)
   if (live && tid % x.Kp == 0) {
     ap[n] = 0;   // no entry of this scan's change list is applied to the node yet
-    const int cn = x.c[x.n0 + n];
+    const int cn = cn_pre;
     if (lab != cn) atomicMin(&s_fmin, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
   }
   if (g.tail_sort)
-    for (int n2 = blockIdx.x * 256 + tid; n2 < N; n2 += gridDim.x * 256) g.perm[n2] = g.perm_prev[n2];
+    for (int n2 = blockIdx.x * 256 + tid; n2 < N; n2 += nfront * 256) g.perm[n2] = g.perm_prev[n2];
   __syncthreads();
   if (tid == 0) {
     const unsigned long long mine = s_fmin;
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(256) void k_spec_resolve(gg_resolve_args g, int sta
       unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]), mine);
       asm volatile("" ::"v"(old) : "memory");   // the ticket is not drawn before the min has been performed
     }
-    s_last = (atomicAdd(&g.rs[10], 1) == (int)gridDim.x - 1) ? 1 : 0;
+    s_last = (atomicAdd(&g.rs[10], 1) == (int)nfront - 1) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
@@ -398,6 +411,7 @@ __global__ __launch_bounds__(256) void k_spec_resolve(gg_resolve_args g, int sta
       g.rs[7] = 1;
       __hip_atomic_store(&g.rs[10], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(0, 0, 0, 1, 0);
+      if (vtag) __hip_atomic_store(g.verdict, vtag << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else if (tid == 0) {
     const int f = (int)(best >> 12), ca = (int)((best >> 6) & 63u), cb = (int)(best & 63u);
@@ -412,7 +426,56 @@ __global__ __launch_bounds__(256) void k_spec_resolve(gg_resolve_args g, int sta
     g.rs[4] = 1;
     __hip_atomic_store(&g.rs[10], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(f + 1, 1, 0, 0, 0);
+    if (vtag) __hip_atomic_store(g.verdict, (vtag << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// RIDE: riders of the next sweep's bulk pass behind the front workgroups (gg_block_kernels.h).  SPLIT: compiled for the
+// K > 32 conditional with unstaged tables (1) or for the other two forms (0).
+template <int NT, bool ADJ, int RIDE = 0, int SPLIT = 0>
+__global__ __launch_bounds__(256, ((RIDE && !SPLIT) ? GG_RIDE_WAVES : 1)) void k_spec_resolve(
+    gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap, gg_ride_args ride = gg_ride_args()) {
+  if (g.rs[4]) return;   // behind a stalled scan of this pipeline: no-op (uniform)
+  if (RIDE && (int)blockIdx.x >= ride.front) {
+    gg_ride<ADJ, (ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : 4))), RIDE == 2>(ride);
+    return;
+  }
+  const unsigned nfront = RIDE ? (unsigned)ride.front : gridDim.x;
+  gg_spec_resolve_body<NT, ADJ, (RIDE ? GG_RIDE_UJ : 0), SPLIT>(g, stage_tables, ap, nfront, 0u);
+}
+
+// The quiet chain's sweep in ONE launch.  Block ranges:
+//   [0, nspec)                 the speculative scan of sweep s              (k_spec_resolve's workgroups)
+//   [nspec, nspec + nparams)   the parameter step of sweep s+1              (k_params' workgroups; they gather and reduce their
+//                              pair tables while the scan is evaluated, then wait for its verdict before they write a word)
+//   [nspec + nparams, ...)     riders: the bulk pass that counts the statistics of sweep s+2
+// Valid because a scan that changes no label leaves every input of the steps riding with it as it was; a scan that does
+// change one raises the stall flag as ever, the parameter workgroups of sweep s+1 drop what they computed, and the host
+// resumes in the serial form.  The scan workgroups come first in the grid, so they are resident before any workgroup that
+// waits for them.
+template <int NT, bool ADJ, int NTL, int SPLIT>
+__global__ __launch_bounds__(256, (SPLIT ? 1 : GG_RIDE_WAVES)) void k_sweep_q(gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap,
+                                                                                 gg_params_args pg, gg_ride_args ride, int nspec, unsigned vtag) {
+  if (g.rs[4]) return;
+  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : 4));
+  const int bid = (int)blockIdx.x;
+  const long long t0 = ride.dbg ? wall_clock64() : 0;
+  if (ride.dbg && threadIdx.x == 0) atomicMin(reinterpret_cast<unsigned long long*>(&ride.dbg[0]), (unsigned long long)t0);
+  int role;
+  if (bid >= ride.front) {
+    role = 3;
+    if (ride.dbg && threadIdx.x == 0) atomicMin(reinterpret_cast<unsigned long long*>(&ride.dbg[4]), (unsigned long long)t0);
+    gg_ride<ADJ, B, NTL == 1>(ride);
+  } else if (bid >= nspec) {
+    role = 2;
+    __builtin_amdgcn_s_setprio(2);   // the latency chain goes first at every issue slot it can use
+    gg_params_body<ADJ, B>(pg, bid - nspec, (unsigned)(ride.front - nspec), vtag);
+  } else {
+    role = 1;
+    __builtin_amdgcn_s_setprio(2);
+    gg_spec_resolve_body<NT, ADJ, GG_RIDE_UJ, SPLIT>(g, stage_tables, ap, (unsigned)nspec, vtag);
+  }
+  if (ride.dbg && threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&ride.dbg[role]), (unsigned long long)wall_clock64());
 }
 
 // Apply the change list to the resident statistics of every node (chip-wide):

@@ -1,6 +1,6 @@
 """Randomised parity stress: small Gaussian-SBM networks of random shape (N, K, B, density, self-connection conventions),
 a few sweeps each in uneven chunks, engine against the oracle, labels and parameters bit for bit.  Run it under the
-scan-form switches as well (GG_SCAN=0 / 1, GG_SCAN_SPIN=2, GG_INCREMENTAL=1).
+scan-form switches as well (GG_SCAN=0 / 1, GG_SCAN_SPIN=2, GG_AHEAD=0).
 
     python tests/fuzz_parity.py [cases] [seed]        (FUZZ_VERBOSE=1 prints every configuration,
                                                        FUZZ_EXTENDED=1 adds tempering and shared-covariance weights)

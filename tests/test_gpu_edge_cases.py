@@ -159,42 +159,79 @@ def test_python_data_cache_and_state_roundtrip(abi):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K", [(150, 5), (420, 40)])
-def test_incremental_statistics_mode_is_the_same_chain(abi, N, K, monkeypatch):
-    """GG_INCREMENTAL=1: per-node statistics carried from sweep to sweep (changes flushed in) instead of recounted.
-    Same labels and parameters bit for bit, through burn-in, across calls that invalidate the carried statistics
-    (log_likelihood, node_lp) and after the labels are replaced from outside."""
-    monkeypatch.setenv("GG_INCREMENTAL", "1")
-    A, W, _ = planted_sbm(N, K, seed=21)
+@pytest.mark.parametrize("ahead,split", [("0", None), (None, None), (None, "0"), (None, "1"), (None, "0.27")])
+def test_ahead_form_is_the_same_chain(abi, monkeypatch, ahead, split):
+    """The ahead form (default while a chain is quiet): the bulk pass of sweep s+1 rides in the k_params and k_spec_resolve
+    launches of sweep s and is dropped when the scan changes a label.  Same labels and parameters bit for bit as the
+    oracle - and as the serial form (GG_AHEAD=0) - for any split of the riders between the two launches, through burn-in
+    (resident scan), the quiet phase, calls that use or invalidate the statistics counted ahead (log_likelihood, node_lp,
+    step-wise parts), labels replaced from outside, and another network on the same models."""
+    if ahead is not None:
+        monkeypatch.setenv("GG_AHEAD", ahead)
+    if split is not None:
+        monkeypatch.setenv("GG_RIDE_SPLIT", split)
+    N, K = 260, 4
+    A, W, _ = planted_sbm(N, K, seed=77)
+    A2, W2, _ = planted_sbm(N, K, seed=78)
     q, shift = O.quantise(A, W)
-    sa, sw = AdjState(N, K, seed=3), WState(N, K, 1, seed=4)
-    d = abi.DeviceData(A, W)
+    q2, shift2 = O.quantise(A2, W2)
+    sa, sw = AdjState(N, K, seed=15), WState(N, K, 1, seed=16)
+    d, d2 = abi.DeviceData(A, W), abi.DeviceData(A2, W2)
     adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=51, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
     adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
     adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
     w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=52, special_case_self_conns=1)
     w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
     w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
-    ps = sa.p_self
-    sweep = 0
-    for phase in range(3):
-        n = 3 if phase < 2 else 2
-        adj.resample_async(d, n); w.resample_async(d, n)
+    st = dict(ps=sa.p_self, sweep=0)
+
+    def run(n, dd, AA, qq, sh):
+        adj.resample_async(dd, n); w.resample_async(dd, n)
         abi.sync_many([adj, w])
         for _ in range(n):
-            ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 51, sweep)
-            O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 52, sweep)
-            sweep += 1
-        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), phase
-        assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p)
-        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), phase
+            st["ps"] = O.sbm_adj_sweep(AA, sa.c, sa.m, sa.p, st["ps"], sa.pi, 1.0, 1.0, 1, 51, st["sweep"])
+            O.sbm_w_sweep(AA, qq, sh, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 52, st["sweep"])
+            st["sweep"] += 1
+        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), st["sweep"]
+        assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p) and np.array_equal(adj.get(abi.ST_M, (K,)), sa.m)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), st["sweep"]
         assert np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu) and np.array_equal(w.get(abi.ST_SIGMA, (K, K, 1, 1)), sw.sigma)
-        if phase == 0:       # calls that rebuild the statistics buffers
-            adj.log_likelihood(d); w.log_likelihood(d); adj.node_lp(d, 1, K)
-        if phase == 1:       # labels replaced from outside
-            rng = np.random.RandomState(9)
-            sa.c[:] = rng.choice(K, size=N); sw.c[:] = rng.choice(K, size=N)
-            adj.set(abi.ST_C, sa.c, np.int32); w.set(abi.ST_C, sw.c, np.int32)
+        assert np.array_equal(w.get(abi.ST_M, (K,)), sw.m)
+
+    def ll_check(dd, AA, qq, sh):
+        ll = sum(abi.log_likelihood_many([adj, w], dd))
+        ref = O.sbm_adj_loglik(AA, sa.c, sa.p, st["ps"]) + O.sbm_w_loglik(AA, qq, sh, sw.c, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, 1)
+        assert abs(ll - ref) <= 1e-9 * abs(ref)
+
+    run(6, d, A, q, shift)            # burn-in: resident scan
+    run(40, d, A, q, shift)           # settles; the adaptive form goes back to the speculative launches (ahead form)
+    assert adj.stats()["label_changes"] > 0
+    ll_check(d, A, q, shift)          # log-likelihood from the statistics counted ahead
+    run(3, d, A, q, shift)
+    assert np.array_equal(adj.node_lp(d, 7, K), O.sbm_adj_node_lp(A, sa.c, sa.m, sa.p, 1, 7))
+    run(1, d, A, q, shift); run(2, d, A, q, shift)
+    # step-wise parts between full sweeps (they share the statistics counted ahead, then invalidate them)
+    adj.resample_part(d, abi.PART_PARAMS)
+    st["ps"] = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, st["ps"], sa.pi, 1.0, 1.0, 1, 51, st["sweep"], O.PART_PARAMS)
+    adj.resample_part(d, abi.PART_C)
+    O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, st["ps"], sa.pi, 1.0, 1.0, 1, 51, st["sweep"], O.PART_C)
+    adj.resample_part(d, abi.PART_M)
+    O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, st["ps"], sa.pi, 1.0, 1.0, 1, 51, st["sweep"], O.PART_M)
+    assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p)
+    w.resample(d, 1)
+    O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 52, st["sweep"])
+    st["sweep"] += 1
+    run(5, d, A, q, shift)
+    # another network on the same models, and back
+    run(4, d2, A2, q2, shift2)
+    ll_check(d2, A2, q2, shift2)
+    run(7, d, A, q, shift)
+    # labels replaced from outside
+    rng = np.random.RandomState(9)
+    sa.c[:] = rng.choice(K, size=N); sw.c[:] = rng.choice(K, size=N)
+    adj.set(abi.ST_C, sa.c, np.int32); w.set(abi.ST_C, sw.c, np.int32)
+    run(30, d, A, q, shift)
+    ll_check(d, A, q, shift)
 
 
 @pytest.mark.gpu
@@ -231,9 +268,6 @@ def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin)
     """A k_scan exchange that times out (GG_SCAN_SPIN: a handful of polls instead of 4 million - what a device shared
     with other processes would do to the resident grid) leaves the scan as a consistent stalled one; the engine carries
     on with restart rounds for good and the chain stays the oracle's bit for bit."""
-    if os.environ.get("GG_INCREMENTAL") == "1":
-        pytest.skip("with carried statistics a timed-out resident scan is a hard error (the written-back statistics of a "
-                    "half-finished round cannot be trusted)")
     monkeypatch.setenv("GG_SCAN", "1")
     monkeypatch.setenv("GG_SCAN_SPIN", str(spin))
     N, K = 400, 16
@@ -255,9 +289,8 @@ def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin)
         O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 82, s)
     assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p)
     assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu)
-    # (with a few more polls the 25 workgroups sometimes do meet in time, and the pipelined form never runs the resident
-    # scan: then nothing is printed)
-    if spin == 1 and os.environ.get("GG_PIPELINE") != "1":
+    # (with a few more polls the 25 workgroups sometimes do meet in time: then nothing is printed)
+    if spin == 1:
         assert "timed out" in capfd.readouterr().err
 
 
@@ -383,8 +416,6 @@ def test_weights_with_large_tables_fit_in_lds(abi, monkeypatch, K, B, form):
 def test_timeout_right_after_the_last_node_changed(abi, monkeypatch):
     """Found by tests/fuzz_parity.py: N = K = 17 moves the last node often; a resident scan that gives up on the exchange
     confirming that change used to leave the scan stalled at pos == N, where the restart rounds have nothing to do."""
-    if os.environ.get("GG_INCREMENTAL") == "1":
-        pytest.skip("a timed-out resident scan is a hard error with carried statistics")
     from tests.fuzz_parity import one_case
     monkeypatch.setenv("GG_SCAN_SPIN", "2")
     for seed in (702605259, 702605260, 702605261):
