@@ -24,6 +24,10 @@ PART_PARAMS, PART_C, PART_M, PART_OMEGA, PART_F, PART_MU0, PART_LMBDA, PART_ALL 
 ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NUMERIC = -1, -2, -3, -4, -5
 
 
+HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64)
+HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64)
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, text):
         super().__init__("graphgibbs error %d: %s" % (code, text))
@@ -48,8 +52,8 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_update", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_shard_sizes", "gg_shard_tables",
-           "gg_shard_params", "gg_shard_next", "gg_shard_apply", "gg_shard_finish", "gg_shard_log_likelihood",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
+           "gg_comm_create_host", "gg_comm_destroy", "gg_comm_info", "gg_shard_sweep", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws"]
 
 
@@ -103,13 +107,13 @@ def lib():
         L.gg_data_create_shard.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
         L.gg_data_create_sbm_shard.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp, C.c_double,
                                                C.c_double, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
-        L.gg_shard_sizes.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-        L.gg_shard_tables.argtypes = [vp, vp, vp, vp]
-        L.gg_shard_params.argtypes = [vp, vp, vp, vp]
-        L.gg_shard_next.argtypes = [vp, vp, vp]
-        L.gg_shard_apply.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
-        L.gg_shard_finish.argtypes = [vp]
-        L.gg_shard_log_likelihood.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double)]
+        L.gg_comm_unique_id.argtypes = [vp]
+        L.gg_comm_create_rccl.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, C.c_int32]
+        L.gg_comm_create_host.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, HOST_ALLREDUCE, HOST_ALLGATHER, vp, C.c_int32]
+        L.gg_comm_destroy.argtypes = [vp]
+        L.gg_comm_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.gg_shard_sweep.argtypes = [vp, vp, vp, C.c_int32]
+        L.gg_shard_log_likelihood.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
         L.gg_selftest_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, C.c_int64]
         L.gg_selftest_draws.argtypes = [C.c_int32, C.c_int32, C.c_uint64, vp, C.c_int32, vp, C.c_int64, C.c_int32]
         _lib = L
@@ -282,39 +286,13 @@ class Model(object):
         check(lib().gg_node_lp(self._h, data.handle, n, _ptr(lp)))
         return lp
 
-    # ---- sharded single chain (step API) ----
-    def shard_sizes(self):
-        a, b = C.c_int32(0), C.c_int32(0)
-        check(lib().gg_shard_sizes(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+    # ---- one chain sharded over several GPUs (graphistician_amd/sharded.py) ----
+    def shard_sweep(self, data, comm, n=1):
+        check(lib().gg_shard_sweep(self._h, data.handle, comm.handle, int(n)))
 
-    def shard_tables(self, data):
-        nt, nd = self.shard_sizes()
-        t, d = np.zeros(nt, dtype=np.int64), np.zeros(nd, dtype=np.int64)
-        check(lib().gg_shard_tables(self._h, data.handle, _ptr(t), _ptr(d)))
-        return t, d
-
-    def shard_params(self, data, tables, diag):
-        t = np.ascontiguousarray(tables, dtype=np.int64)
-        d = np.ascontiguousarray(diag, dtype=np.int64)
-        check(lib().gg_shard_params(self._h, data.handle, _ptr(t), _ptr(d)))
-
-    def shard_next(self, data):
-        out = np.zeros(4, dtype=np.int32)
-        check(lib().gg_shard_next(self._h, data.handle, _ptr(out)))
-        return out
-
-    def shard_apply(self, data, node, a, b):
-        check(lib().gg_shard_apply(self._h, data.handle, int(node), int(a), int(b)))
-
-    def shard_finish(self):
-        check(lib().gg_shard_finish(self._h))
-
-    def shard_log_likelihood(self, data, tables, diag):
-        t = np.ascontiguousarray(tables, dtype=np.int64)
-        d = np.ascontiguousarray(diag, dtype=np.int64)
+    def shard_log_likelihood(self, data, comm):
         out = C.c_double(0)
-        check(lib().gg_shard_log_likelihood(self._h, data.handle, _ptr(t), _ptr(d), C.byref(out)))
+        check(lib().gg_shard_log_likelihood(self._h, data.handle, comm.handle, C.byref(out)))
         return out.value
 
     def stats(self):
@@ -342,6 +320,72 @@ class Model(object):
     def close(self):
         if self._h:
             lib().gg_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm(object):
+    """Communicator of a sharded chain (include/graphgibbs.h): RCCL, or host callbacks for the protocol tests."""
+
+    def __init__(self, handle, keep=()):
+        self._h = handle
+        self._keep = keep          # ctypes callbacks must outlive the communicator
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().gg_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, rank, world, unique_id, device=0):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib().gg_comm_create_rccl(C.byref(h), rank, world, buf, device))
+        return cls(h)
+
+    @classmethod
+    def host(cls, rank, world, allreduce_sum, allgather, device=0):
+        """allreduce_sum(int64 ndarray) -> ndarray (sum over ranks); allgather(int32 ndarray) -> (world, n) ndarray."""
+        def ar(user, buf, n):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                a[:] = allreduce_sum(a.copy())
+                return 0
+            except Exception:      # never raise through the C frame
+                return 1
+
+        def ag(user, send, recv, n):
+            try:
+                s = np.ctypeslib.as_array(send, shape=(n,)).copy()
+                r = np.ctypeslib.as_array(recv, shape=(world * n,))
+                r[:] = np.asarray(allgather(s), dtype=np.int32).reshape(-1)
+                return 0
+            except Exception:
+                return 1
+
+        car, cag = HOST_ALLREDUCE(ar), HOST_ALLGATHER(ag)
+        h = C.c_void_p()
+        check(lib().gg_comm_create_host(C.byref(h), rank, world, car, cag, None, device))
+        return cls(h, keep=(car, cag))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        r, w, k, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
+        check(lib().gg_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k), C.byref(n)))
+        return dict(rank=r.value, world=w.value, rccl=bool(k.value), collectives=n.value)
+
+    def close(self):
+        if self._h:
+            lib().gg_comm_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

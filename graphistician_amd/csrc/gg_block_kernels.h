@@ -316,6 +316,7 @@ struct gg_ride_args {
   int w0, w1;                // this launch carries items [w0, w1)
   int front;                 // block index of the first rider
   int nriders;               // rider workgroups in the launch (persistent: item w, w + nriders, ...)
+  int delay;                 // riders sleep this many x 127 x 64 clocks before their first load (GG_RIDER_DELAY; tuning)
   long long* dbg;            // GG_SWQ_DBG: [0] first workgroup start, [1] last scan end, [2] last parameter end, [3] last rider end,
                              //             [4] first rider start, [5] verdict seen by the parameter workgroups (max)
 };
@@ -325,6 +326,7 @@ struct gg_ride_args {
 // workgroups sees: enough in flight to saturate HBM, not four times that (measured: DESIGN.md section 5).
 template <bool ADJ, int B, bool NTL>
 __device__ __forceinline__ void gg_ride(const gg_ride_args& r) {
+  for (int i = 0; i < r.delay; ++i) __builtin_amdgcn_s_sleep(127);
   for (int w = r.w0 + ((int)blockIdx.x - r.front); w < r.w1; w += r.nriders) {
     const int strip = w % r.strips, sl = (w / r.strips) % r.nslots, dir = w / (r.strips * r.nslots);
     if (ADJ)
@@ -775,6 +777,11 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g, gg_ride_args r
   gg_params_body<ADJ, B>(g, (int)blockIdx.x, nfront, 0u);
 }
 
+#define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index)
+#define GG_RS_NTOT 23        //                total number of nodes
+#define GG_SHARD_WINDOW 4096
+#define GG_SHARD_NONE 0x7fffffff
+
 // ------------------------------------------------------------------ per-node conditional
 struct gg_node_ctx {
   double beta;     // AIS inverse temperature (1 = plain Gibbs)
@@ -1102,7 +1109,7 @@ template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
                                                    uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
                                                    double* __restrict__ lp_out, const int32_t* __restrict__ ctl,
-                                                   int stage_tables, int sweep_from_ctl, int round_mode, int32_t* __restrict__ ap) {
+                                                   int stage_tables, int shard_mode, int round_mode, int32_t* __restrict__ ap) {
   if (round_mode) {            // device-driven restart round: start where the scan stands, unless it is done
     if (ctl[7]) return;
     n_begin = ctl[0];
@@ -1112,7 +1119,18 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
   } else if (ctl && ctl[4]) {
     return;
   }
-  if (sweep_from_ctl) sweep = (uint32_t)ctl[6];
+  if (shard_mode) {
+    // device-driven sharded scan: the window [spos, spos + GG_SHARD_WINDOW) of GLOBAL node indices, of which this rank
+    // evaluates its own nodes; the position lives in the control block (gg_shard_sweep)
+    const int spos = ctl[GG_RS_SPOS], ntot = ctl[GG_RS_NTOT];
+    if (spos >= ntot) return;
+    const int wend = spos + GG_SHARD_WINDOW < ntot ? spos + GG_SHARD_WINDOW : ntot;
+    int lo = spos - x.n0, hi = wend - x.n0;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > x.N ? x.N : hi;
+    if (hi <= lo || lo + (int)blockIdx.x * (256 / x.Kp) >= hi) return;
+    n_begin = lo;
+  }
   int n;
   bool live;
   const int lab = gg_spec_eval<NT, ADJ>(x, n_begin, seed, site, sweep, lp_node, lp_out, stage_tables, &n, &live);
@@ -1165,30 +1183,49 @@ __global__ __launch_bounds__(256) void k_shared_cov(gg_params_args g) {
   }
 }
 
-// Sharded scan helpers -------------------------------------------------------------------------
-// First local node in [lo, hi) whose speculated label differs from its current one.
-__global__ __launch_bounds__(1024) void k_first_changer(const int32_t* __restrict__ c, const int32_t* __restrict__ cand,
-                                                        int n0, int lo, int hi, int32_t* __restrict__ out) {
+// Sharded scan helpers (gg_shard_sweep) ---------------------------------------------------------
+// First OWNED node of the current window whose speculated label differs from its current one -> trip = {node, old, new}
+// (global index; GG_SHARD_NONE if there is none or the scan is over).  One workgroup.
+__global__ __launch_bounds__(1024) void k_shard_first(const int32_t* __restrict__ c, const int32_t* __restrict__ cand, int n0, int Nl,
+                                                      int32_t* __restrict__ rs, int32_t* __restrict__ trip) {
   __shared__ int s_first;
-  if (threadIdx.x == 0) s_first = 0x7fffffff;
+  if (threadIdx.x == 0) { s_first = GG_SHARD_NONE; rs[1] = 0; }   // (the last round's one-entry change list is spent)
   __syncthreads();
-  for (int nl = lo + threadIdx.x; nl < hi; nl += blockDim.x)
+  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT];
+  int lo = 0, hi = 0;
+  if (spos < ntot) {
+    const int wend = spos + GG_SHARD_WINDOW < ntot ? spos + GG_SHARD_WINDOW : ntot;
+    lo = spos - n0; hi = wend - n0;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > Nl ? Nl : hi;
+  }
+  for (int nl = lo + (int)threadIdx.x; nl < hi; nl += blockDim.x)
     if (cand[nl] != c[n0 + nl]) { atomicMin(&s_first, nl); break; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int f = s_first;
-    if (f == 0x7fffffff) { out[0] = 0x7fffffff; out[1] = 0; out[2] = 0; }
-    else { out[0] = n0 + f; out[1] = c[n0 + f]; out[2] = cand[f]; }
+    if (f == GG_SHARD_NONE) { trip[0] = GG_SHARD_NONE; trip[1] = 0; trip[2] = 0; }
+    else { trip[0] = n0 + f; trip[1] = c[n0 + f]; trip[2] = cand[f]; }
   }
 }
 
-// Every rank applies the winning change to its copy of the labels and records it as the pending list L.
-__global__ void k_apply_change(int32_t* c, int32_t* cnt, int32_t* L, int32_t* rs, int n, int a, int b) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    c[n] = b;
+// Every rank picks the earliest change among the gathered candidates and applies it to its copy of the labels (the
+// statistics of its own nodes follow in k_apply_L), or moves the window on.  One thread.
+__global__ void k_shard_pick(int32_t* c, int32_t* cnt, int32_t* L, int32_t* rs, const int32_t* __restrict__ all, int world) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT];
+  if (spos >= ntot) return;
+  int best = GG_SHARD_NONE, a = 0, b = 0;
+  for (int r = 0; r < world; ++r)
+    if (all[3 * r] < best) { best = all[3 * r]; a = all[3 * r + 1]; b = all[3 * r + 2]; }
+  if (best == GG_SHARD_NONE) {
+    rs[GG_RS_SPOS] = spos + GG_SHARD_WINDOW < ntot ? spos + GG_SHARD_WINDOW : ntot;
+  } else {
+    c[best] = b;
     cnt[a] -= 1; cnt[b] += 1;
-    L[0] = n; L[1] = a; L[2] = b;
+    L[0] = best; L[1] = a; L[2] = b;
     rs[1] = 1;
     rs[2] += 1;
+    rs[GG_RS_SPOS] = best + 1;
   }
 }

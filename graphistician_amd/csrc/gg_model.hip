@@ -10,6 +10,7 @@
 
 #include "gg_common.h"
 #include <thread>
+#include <rccl/rccl.h>
 #include "gg_block_kernels.h"
 #include "gg_resolve_kernels.h"
 #include "gg_scan_kernels.h"
@@ -41,7 +42,11 @@ struct gg_model {
   int N, K, Kp, B, NT, NSI, Np, NTAB;   // N = all nodes (labels, rows); Np = padded number of OWNED nodes
   int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded)
   bool sharded;
-  int spos;                             // sharded scan position
+  long long* sh_buf;                    // sharded chain: device staging of the diagonal statistics (all-reduce)
+  int32_t *sh_trip, *sh_all;            // this rank's first changer {node, old, new}; the gathered ones [world][3]
+  long long sh_diag[1 + GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];   // global diagonal statistics of network sh_diag_uid
+  unsigned long long sh_diag_uid;
+  int sh_world;
   gg_eigen* eig;
   gg_latent* ld;                // GG_LATENT_DIST, GG_LATENT_DIST_W: everything lives in gg_latent.hip
   // device state
@@ -380,7 +385,7 @@ int gg_model_destroy(gg_model* m) {
   if (m->pend_data) { hipStreamSynchronize(m->stream); set_pend_data(m, nullptr); }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
-                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict};
+                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -688,6 +693,11 @@ static gg_ride_args make_ride(const gg_model* m, const gg_data* d, int nbuf, int
     if (cap < 0) { const char* e = getenv("GG_RIDERS"); cap = e && atoi(e) > 0 ? atoi(e) : 2048; }
     r.nriders = (r.w1 - r.w0) < cap ? (r.w1 - r.w0) : cap;
   }
+  {
+    static int dly = -1;
+    if (dly < 0) { const char* e = getenv("GG_RIDER_DELAY"); dly = e ? atoi(e) : 0; }
+    r.delay = part == 2 ? dly : 0;
+  }
   *nriders = r.nriders;
   *ntl = bs.ntl ? 1 : 0;
   if (bytes) *bytes = 2.0 * m->N * (double)m->N * (m->is_adj ? 1.0 : 4.0 * m->B) * (double)(r.w1 - r.w0) / (double)(W > 0 ? W : 1);
@@ -784,7 +794,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
 }
 
 static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined,
-                            int round_window = 0, int explicit_count = 0) {
+                            int round_window = 0, int explicit_count = 0, bool shard_mode = false) {
   gg_node_ctx x = node_ctx(m, d, buf);
   const int K = m->K, per = 256 / m->Kp;
   const int count = round_window > 0 ? round_window : (explicit_count > 0 ? explicit_count : (m->Nl - n_begin));
@@ -792,7 +802,7 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
   if (nb < 1) nb = 1;
   uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
   double* lpo = lp_node >= 0 ? m->lp_out : nullptr;
-  const int32_t* ctl = (pipelined || round_window > 0) ? m->rs : nullptr;
+  const int32_t* ctl = (pipelined || round_window > 0 || shard_mode) ? m->rs : nullptr;
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
@@ -805,7 +815,7 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
     k_speculate<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl,    \
-                                                        stage, 0, round_window > 0 ? 1 : 0, m->ap);                       \
+                                                        stage, shard_mode ? 1 : 0, round_window > 0 ? 1 : 0, m->ap);      \
   } while (0)
   if (m->is_adj) SPEC(2, true);
   else if (m->B == 1) SPEC(3, false);
@@ -981,7 +991,7 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   return GG_OK;
 }
 
-static int launch_apply_L(gg_model* m, const gg_data* d, int buf, int mode = 0) {
+static int launch_apply_L(gg_model* m, const gg_data* d, int buf, int mode = 0, bool reset = true) {
   gg_node_ctx x = node_ctx(m, d, buf);
   int nb = (m->Nl + 255) / 256;
 #define APL(NTV, ADJV)                                                                                             \
@@ -993,8 +1003,10 @@ static int launch_apply_L(gg_model* m, const gg_data* d, int buf, int mode = 0) 
   else APL(15, false);
 #undef APL
   GG_HIP(hipGetLastError());
-  k_reset_L<<<1, 64, 0, m->stream>>>(m->rs, mode);
-  GG_HIP(hipGetLastError());
+  if (reset) {
+    k_reset_L<<<1, 64, 0, m->stream>>>(m->rs, mode);
+    GG_HIP(hipGetLastError());
+  }
   return GG_OK;
 }
 
@@ -1869,112 +1881,231 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
   return GG_OK;
 }
 
-// ---- sharded single chain: step API (include/graphgibbs.h) ------------------------------------
-static int shard_check(gg_model* m, const gg_data* d) {
-  if (!m) return gg_fail(GG_ERR_INVALID, "null model");
+// ---- sharded single chain (include/graphgibbs.h) ----------------------------------
+// Communicator: RCCL (device buffers, collectives enqueued on the engine stream: xGMI inside a node) or a pair of host
+// callbacks (the protocol test harness: gloo through ctypes; buffers are staged through the host).
+struct gg_comm {
+  int rank, world, device;
+  ncclComm_t nccl;
+  gg_host_allreduce_fn ar;
+  gg_host_allgather_fn ag;
+  void* user;
+  std::vector<long long> h64;
+  std::vector<int32_t> h32s, h32r;
+  unsigned long long collectives;   // collectives issued through this communicator
+};
+
+static int comm_allreduce_i64(gg_comm* c, long long* dbuf, size_t n, hipStream_t st) {
+  c->collectives += 1;
+  if (c->world == 1) return GG_OK;
+  if (c->nccl) {
+    const ncclResult_t r = ncclAllReduce(dbuf, dbuf, n, ncclInt64, ncclSum, c->nccl, st);
+    if (r != ncclSuccess) return gg_fail(GG_ERR_HIP, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    return GG_OK;
+  }
+  c->h64.resize(n);
+  GG_HIP(hipMemcpyAsync(c->h64.data(), dbuf, n * 8, hipMemcpyDeviceToHost, st));
+  GG_HIP(hipStreamSynchronize(st));
+  if (c->ar(c->user, reinterpret_cast<int64_t*>(c->h64.data()), (int64_t)n)) return gg_fail(GG_ERR_HIP, "host all-reduce callback failed");
+  GG_HIP(hipMemcpyAsync(dbuf, c->h64.data(), n * 8, hipMemcpyHostToDevice, st));
+  GG_HIP(hipStreamSynchronize(st));
+  return GG_OK;
+}
+
+static int comm_allgather_i32(gg_comm* c, const int32_t* dsend, int32_t* drecv, size_t n, hipStream_t st) {
+  c->collectives += 1;
+  if (c->world == 1) {
+    GG_HIP(hipMemcpyAsync(drecv, dsend, n * 4, hipMemcpyDeviceToDevice, st));
+    return GG_OK;
+  }
+  if (c->nccl) {
+    const ncclResult_t r = ncclAllGather(dsend, drecv, n, ncclInt32, c->nccl, st);
+    if (r != ncclSuccess) return gg_fail(GG_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+    return GG_OK;
+  }
+  c->h32s.resize(n); c->h32r.resize(n * c->world);
+  GG_HIP(hipMemcpyAsync(c->h32s.data(), dsend, n * 4, hipMemcpyDeviceToHost, st));
+  GG_HIP(hipStreamSynchronize(st));
+  if (c->ag(c->user, c->h32s.data(), c->h32r.data(), (int64_t)n)) return gg_fail(GG_ERR_HIP, "host all-gather callback failed");
+  GG_HIP(hipMemcpyAsync(drecv, c->h32r.data(), n * 4 * c->world, hipMemcpyHostToDevice, st));
+  GG_HIP(hipStreamSynchronize(st));
+  return GG_OK;
+}
+
+int gg_comm_unique_id(uint8_t* out128) {
+  if (!out128) return gg_fail(GG_ERR_INVALID, "gg_comm_unique_id: null argument");
+  ncclUniqueId id;
+  const ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return gg_fail(GG_ERR_HIP, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, 128);
+  return GG_OK;
+}
+
+int gg_comm_create_rccl(gg_comm** out, int32_t rank, int32_t world, const uint8_t* id128, int32_t device) {
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return gg_fail(GG_ERR_INVALID, "gg_comm_create_rccl: bad arguments");
+  int rc = gg_ensure_device(device);
+  if (rc) return rc;
+  gg_comm* c = new gg_comm();
+  c->rank = rank; c->world = world; c->device = device; c->nccl = nullptr; c->ar = nullptr; c->ag = nullptr; c->user = nullptr;
+  c->collectives = 0;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  const ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
+  if (r != ncclSuccess) { delete c; return gg_fail(GG_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r)); }
+  *out = c;
+  return GG_OK;
+}
+
+int gg_comm_create_host(gg_comm** out, int32_t rank, int32_t world, gg_host_allreduce_fn ar, gg_host_allgather_fn ag, void* user,
+                        int32_t device) {
+  if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && (!ar || !ag)))
+    return gg_fail(GG_ERR_INVALID, "gg_comm_create_host: bad arguments");
+  int rc = gg_ensure_device(device);
+  if (rc) return rc;
+  gg_comm* c = new gg_comm();
+  c->rank = rank; c->world = world; c->device = device; c->nccl = nullptr; c->ar = ar; c->ag = ag; c->user = user;
+  c->collectives = 0;
+  *out = c;
+  return GG_OK;
+}
+
+int gg_comm_destroy(gg_comm* c) {
+  if (!c) return GG_OK;
+  if (c->nccl) { hipSetDevice(c->device); ncclCommDestroy(c->nccl); }
+  delete c;
+  return GG_OK;
+}
+
+int gg_comm_info(const gg_comm* c, int32_t* rank, int32_t* world, int32_t* is_rccl, uint64_t* collectives) {
+  if (!c) return gg_fail(GG_ERR_INVALID, "null communicator");
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (is_rccl) *is_rccl = c->nccl ? 1 : 0;
+  if (collectives) *collectives = c->collectives;
+  return GG_OK;
+}
+
+static int shard_check(gg_model* m, const gg_data* d, const gg_comm* c) {
+  if (!m || !c) return gg_fail(GG_ERR_INVALID, "null model or communicator");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "sharding: block models only");
   if (m->kind != GG_SBM_ADJ && m->kind != GG_SBM_GAUSS_W) return gg_fail(GG_ERR_UNSUPPORTED, "sharding: SBM kinds only");
+  if (c->device != m->cfg.device) return gg_fail(GG_ERR_INVALID, "communicator on device %d, model on device %d", c->device, m->cfg.device);
   return d ? check_data(m, d) : GG_OK;
 }
 
-int gg_shard_sizes(gg_model* m, int32_t* ntab_total, int32_t* ndiag) {
-  if (!m || m->eig || m->ld) return gg_fail(GG_ERR_INVALID, "gg_shard_sizes: block model expected");
-  if (ntab_total) *ntab_total = m->K * m->K * m->NTAB;
-  if (ndiag) *ndiag = 1 + gg_nsi(GG_MAXB);
+// Global diagonal statistics (label independent): all-reduced once per network, then cached in the model.
+static int shard_global_diag(gg_model* m, const gg_data* d, gg_comm* c) {
+  if (m->sh_diag_uid == d->uid) return GG_OK;
+  const int nd = 1 + gg_nsi(GG_MAXB);
+  long long h[1 + GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];
+  h[0] = d->d1;
+  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) h[1 + i] = d->dS[i];
+  GG_HIP(hipMemcpyAsync(m->sh_buf, h, nd * 8, hipMemcpyHostToDevice, m->stream));
+  int rc = comm_allreduce_i64(c, m->sh_buf, nd, m->stream);
+  if (rc) return rc;
+  GG_HIP(hipMemcpyAsync(m->sh_diag, m->sh_buf, nd * 8, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipStreamSynchronize(m->stream));
+  m->sh_diag_uid = d->uid;
   return GG_OK;
 }
 
-int gg_shard_tables(gg_model* m, const gg_data* d, int64_t* tables, int64_t* diag) {
-  int rc = shard_check(m, d);
-  if (rc) return rc;
-  if (!tables || !diag) return gg_fail(GG_ERR_INVALID, "gg_shard_tables: null output");
-  m->beta = 1.0;
+// K x K tables of the whole network under the current labels: local bulk pass + pair tables, all-reduced in place (device).
+static int shard_global_tables(gg_model* m, const gg_data* d, gg_comm* c, int dirs) {
+  int rc;
   const int buf = m->cur;
-  if ((rc = enqueue_bulk(m, d, buf, 3, false))) return rc;
+  if ((rc = enqueue_bulk(m, d, buf, dirs, false))) return rc;
   if ((rc = enqueue_params(m, d, buf, true, false, false, -1, m->sweep))) return rc;
-  GG_HIP(hipMemcpyAsync(tables, m->tab, (size_t)m->K * m->K * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipStreamSynchronize(m->stream));
-  diag[0] = d->d1;
-  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) diag[1 + i] = d->dS[i];
-  return GG_OK;
+  return comm_allreduce_i64(c, m->tab, (size_t)m->K * m->K * m->NTAB, m->stream);
 }
 
-int gg_shard_params(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag) {
-  int rc = shard_check(m, d);
+// n half-sweeps (adjacency.py:615-618 / weights.py:394-397) of a chain whose nodes are sharded over the communicator's
+// ranks.  Per half-sweep: one all-reduce of the integer tables; the scan in rounds of
+//   speculate (own nodes of the window) -> first changer -> ALL-GATHER of (node, old, new) -> pick + apply,
+// all enqueued on the engine stream in batches, the host reading the scan position once per batch.  Every rank issues the
+// same collectives (the position it reads is the same everywhere), and rounds beyond the scan's end are no-ops.
+int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
+  int rc = shard_check(m, d, c);
   if (rc) return rc;
-  GG_HIP(hipMemcpyAsync(m->tab, tables, (size_t)m->K * m->K * m->NTAB * 8, hipMemcpyHostToDevice, m->stream));
-  // global diagonal statistics go into the kernel arguments through a temporary copy of the data header
-  gg_data dg = *d;
-  dg.d1 = diag[0];
-  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = diag[1 + i];
-  m->shard_from_tab = true;
-  rc = enqueue_params(m, &dg, m->cur, false, true, true, -1, m->sweep);
-  m->shard_from_tab = false;
-  if (rc) return rc;
-  m->spos = 0;
-  return GG_OK;
-}
-
-int gg_shard_next(gg_model* m, const gg_data* d, int32_t out[4]) {
-  int rc = shard_check(m, d);
-  if (rc) return rc;
-  const int W = 4096;
-  const int wend = (m->spos + W < m->N) ? m->spos + W : m->N;
-  int lo = m->spos - m->n0, hi = wend - m->n0;
-  if (lo < 0) lo = 0;
-  if (hi > m->Nl) hi = m->Nl;
-  out[0] = 0x7fffffff; out[1] = 0; out[2] = 0; out[3] = wend;
-  if (hi > lo && m->K > 1) {
-    if ((rc = launch_speculate(m, d, m->cur, lo, -1, m->sweep, false, 0, hi - lo))) return rc;
-    k_first_changer<<<1, 1024, 0, m->stream>>>(m->c, m->cand, m->n0, lo, hi, m->rs + 12);
-    GG_HIP(hipGetLastError());
-    GG_HIP(hipMemcpyAsync(m->h_rs, m->rs + 12, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-    GG_HIP(hipStreamSynchronize(m->stream));
-    out[0] = m->h_rs[0]; out[1] = m->h_rs[1]; out[2] = m->h_rs[2];
+  if (!m->sharded && c->world > 1) return gg_fail(GG_ERR_INVALID, "gg_shard_sweep: the model was not created with a node shard");
+  if (!m->sh_buf) {
+    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, 4)) || (rc = dmalloc(&m->sh_all, (size_t)3 * c->world + 4))) return rc;
+    m->sh_world = c->world;
   }
-  return GG_OK;
-}
-
-int gg_shard_apply(gg_model* m, const gg_data* d, int32_t node, int32_t a, int32_t b) {
-  int rc = shard_check(m, d);
-  if (rc) return rc;
-  if (node < 0) { m->spos = a; return GG_OK; }
-  if (node >= m->N || a < 0 || a >= m->K || b < 0 || b >= m->K) return gg_fail(GG_ERR_INVALID, "gg_shard_apply: bad change");
-  k_apply_change<<<1, 64, 0, m->stream>>>(m->c, m->cnt, m->L, m->rs, node, a, b);
-  GG_HIP(hipGetLastError());
-  if ((rc = launch_apply_L(m, d, m->cur))) return rc;     // statistics of the owned nodes (edges to / from `node`)
-  m->spos = node + 1;
-  m->perm_valid = false;
-  m->st.label_changes += 1;
-  return GG_OK;
-}
-
-int gg_shard_finish(gg_model* m) {
-  int rc = shard_check(m, nullptr);
-  if (rc) return rc;
-  k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
-                                                      m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
-  GG_HIP(hipGetLastError());
+  if (m->sh_world != c->world) return gg_fail(GG_ERR_INVALID, "gg_shard_sweep: the communicator's size changed");
+  drop_ahead(m);
+  m->beta = 1.0;
+  if ((rc = shard_global_diag(m, d, c))) return rc;
+  gg_data dg = *d;     // kernel arguments take the GLOBAL diagonal statistics
+  dg.d1 = m->sh_diag[0];
+  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = m->sh_diag[1 + i];
+  const int buf = m->cur;
+  for (int s = 0; s < n; ++s) {
+    if ((rc = shard_global_tables(m, d, c, 3))) return rc;
+    m->shard_from_tab = true;
+    rc = enqueue_params(m, &dg, buf, false, true, true, -1, m->sweep);
+    m->shard_from_tab = false;
+    if (rc) return rc;
+    if (m->K > 1) {
+      m->h_rs[24] = 0; m->h_rs[25] = m->N;
+      GG_HIP(hipMemcpyAsync(m->rs + GG_RS_SPOS, m->h_rs + 24, 2 * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+      const int per = 256 / m->Kp;
+      int batch = 8;
+      for (;;) {
+        for (int r = 0; r < batch; ++r) {
+          if (m->Nl > 0) {
+            const int count = m->Nl < GG_SHARD_WINDOW ? m->Nl : GG_SHARD_WINDOW;
+            (void)per;
+            if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false, 0, count, true))) return rc;
+          }
+          k_shard_first<<<1, 1024, 0, m->stream>>>(m->c, m->cand, m->n0, m->Nl, m->rs, m->sh_trip);
+          GG_HIP(hipGetLastError());
+          if ((rc = comm_allgather_i32(c, m->sh_trip, m->sh_all, 3, m->stream))) return rc;
+          k_shard_pick<<<1, 64, 0, m->stream>>>(m->c, m->cnt, m->L, m->rs, m->sh_all, c->world);
+          GG_HIP(hipGetLastError());
+          if (m->Nl > 0 && (rc = launch_apply_L(m, d, buf, 0, false))) return rc;   // statistics of the owned nodes
+        }
+        GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 24 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+        GG_HIP(hipStreamSynchronize(m->stream));
+        if (m->h_rs[3]) { write_ctl_word(m, 3, 0); return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite"); }
+        if (m->h_rs[GG_RS_SPOS] >= m->N) break;
+        if (batch < 128) batch *= 2;
+      }
+      m->st.label_changes = (uint64_t)m->h_rs[2];
+      m->perm_valid = false;
+    }
+    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+                                                        m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
+    GG_HIP(hipGetLastError());
+    m->sweep += 1;
+    m->st.sweeps += 1;
+    m->zeroed[buf] = false;
+  }
   GG_HIP(hipStreamSynchronize(m->stream));
-  m->sweep += 1;
-  m->st.sweeps += 1;
-  m->zeroed[m->cur] = false;
   return GG_OK;
 }
 
-int gg_shard_log_likelihood(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag, double* out) {
-  int rc = shard_check(m, d);
+// log-likelihood of the sharded chain (abstractions.py:111-115, weights.py:316-331) from the all-reduced tables.
+int gg_shard_log_likelihood(gg_model* m, const gg_data* d, gg_comm* c, double* out) {
+  int rc = shard_check(m, d, c);
   if (rc) return rc;
-  if (!tables || !diag || !out) return gg_fail(GG_ERR_INVALID, "gg_shard_log_likelihood: null argument");
-  std::vector<int32_t> cnt(m->K);
-  if ((rc = ensure_perm(m))) return rc;
-  GG_HIP(hipMemcpyAsync(cnt.data(), m->cnt, m->K * 4, hipMemcpyDeviceToHost, m->stream));
+  if (!out) return gg_fail(GG_ERR_INVALID, "gg_shard_log_likelihood: null output");
+  if (!m->sh_buf) {
+    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, 4)) || (rc = dmalloc(&m->sh_all, (size_t)3 * c->world + 4))) return rc;
+    m->sh_world = c->world;
+  }
+  drop_ahead(m);
+  if ((rc = shard_global_diag(m, d, c))) return rc;
+  if ((rc = shard_global_tables(m, d, c, 1))) return rc;
+  const size_t KK = (size_t)m->K * m->K;
+  GG_HIP(hipMemcpyAsync(m->h_tab, m->tab, KK * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
+  GG_HIP(hipMemcpyAsync(m->h_tab + KK * m->NTAB, m->cnt, m->K * 4, hipMemcpyDeviceToHost, m->stream));
   GG_HIP(hipStreamSynchronize(m->stream));
   gg_data dg = *d;
-  dg.d1 = diag[0];
-  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = diag[1 + i];
-  return loglik_from_tables(m, &dg, (const long long*)tables, cnt.data(), out);
+  dg.d1 = m->sh_diag[0];
+  for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = m->sh_diag[1 + i];
+  return loglik_from_tables(m, &dg, m->h_tab, reinterpret_cast<const int32_t*>(m->h_tab + KK * m->NTAB), out);
 }
 
 int gg_last_stats(gg_model* m, gg_stats* out) {

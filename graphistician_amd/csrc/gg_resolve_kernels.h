@@ -371,7 +371,7 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
   const gg_node_ctx& x = g.x;
   const int tid = threadIdx.x, N = x.N, K = x.K;
   __shared__ unsigned long long s_fmin;
-  __shared__ int s_last;
+  __shared__ int s_last, s_any;
   if (tid == 0) s_fmin = GG_NO_CHANGE;
   int n;
   bool live;
@@ -394,11 +394,16 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
       unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]), mine);
       asm volatile("" ::"v"(old) : "memory");   // the ticket is not drawn before the min has been performed
     }
-    s_last = (atomicAdd(&g.rs[10], 1) == (int)nfront - 1) ? 1 : 0;
+    // one 64-bit ticket: low word = workgroups done, high word = workgroups that reported a changer - the last one then
+    // knows whether the minimum has to be fetched at all (a quiet scan saves that dependent round trip)
+    const unsigned long long tk = atomicAdd(reinterpret_cast<unsigned long long*>(&g.rs[10]),
+                                            1ull + (mine != GG_NO_CHANGE ? (1ull << 32) : 0ull));
+    s_last = ((unsigned)(tk & 0xffffffffull) == nfront - 1u) ? 1 : 0;
+    s_any = ((tk >> 32) != 0ull || mine != GG_NO_CHANGE) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
-  if (tid == 0) s_fmin = atomicExch(reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]), GG_NO_CHANGE);
+  if (tid == 0) s_fmin = s_any ? atomicExch(reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]), GG_NO_CHANGE) : GG_NO_CHANGE;
   __syncthreads();
   const unsigned long long best = s_fmin;
   if (best == GG_NO_CHANGE) {
@@ -409,7 +414,7 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
       g.rs[1] = 0;
       g.rs[5] += 1;
       g.rs[7] = 1;
-      __hip_atomic_store(&g.rs[10], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(&g.rs[10]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(0, 0, 0, 1, 0);
       if (vtag) __hip_atomic_store(g.verdict, vtag << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -424,7 +429,7 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
     g.rs[2] += 1;
     g.rs[9] += 1;
     g.rs[4] = 1;
-    __hip_atomic_store(&g.rs[10], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&g.rs[10]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(f + 1, 1, 0, 0, 0);
     if (vtag) __hip_atomic_store(g.verdict, (vtag << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

@@ -2,9 +2,10 @@
 
 Each rank owns a contiguous range of nodes and stores the matching column shards of the data and
 of its transpose (`DeviceData.shard`), so the block histograms of its own nodes are complete
-locally.  What travels, per half-sweep:
+locally.  What travels, per half-sweep (all inside `gg_shard_sweep`, on the
+engine stream, device buffers):
 
-  * one all-reduce (SUM, int64) of the K x K sufficient-statistic tables and the diagonal statistics
+  * one all-reduce (SUM, int64) of the K x K sufficient-statistic tables
     -> every rank draws the same parameters from the same Philox stream (adjacency.py:620-648,
     weights.py:399-413);
   * the sequential scan (adjacency.py:650-695, weights.py:415-488): ranks speculate their own nodes
@@ -16,75 +17,63 @@ All traffic is integer, so the result does not depend on the number of ranks: la
 parameters are bit-identical to `SBMAdjacencyDistribution.resample` on one GPU (tests/test_sharded.py).
 This replaces the approximate "shard-synchronous" schedule sketched in SURVEY.md section 8e.
 
-`comm` needs `allreduce_sum(int64 ndarray) -> ndarray` and `allgather(int32 ndarray) -> (world, n) ndarray`.
+The collectives are RCCL calls made by `libgraphgibbs.so` itself (`rccl_comm`: one process per GPU; the
+128-byte unique id travels once through the launcher's store).  `host_comm` routes them through host
+callbacks instead - gloo in the CPU-side protocol tests, where several ranks share one GPU.
+torch.distributed is only the launcher / rendezvous here, never on the data path.
 """
 import numpy as np
 
 from . import _abi
 
-NONE = 0x7fffffff
+
+def shard_range(N, rank, world):
+    """Contiguous node ranges that cover [0, N), every rank non-empty (sizes differ by at most one)."""
+    if N < world:
+        raise ValueError("cannot shard %d nodes over %d ranks: every rank needs at least one node" % (N, world))
+    base, extra = divmod(N, world)
+    n0 = rank * base + min(rank, extra)
+    return n0, n0 + base + (1 if rank < extra else 0)
 
 
-class LocalComm(object):
-    """Single rank."""
-    rank, world = 0, 1
-
-    def allreduce_sum(self, a):
-        return a
-
-    def allgather(self, a):
-        return np.asarray(a)[None, :]
+def local_comm(device=0):
+    """Single rank (no collective ever leaves the device)."""
+    return _abi.Comm.rccl(0, 1, _abi.Comm.unique_id(), device=device)
 
 
-class TorchComm(object):
-    """torch.distributed (backend "nccl" = RCCL over xGMI on GPU tensors, or "gloo" on host tensors)."""
-
-    def __init__(self):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-
-    def allreduce_sum(self, a):
-        t = self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
-
-    def allgather(self, a):
-        t = self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
-        out = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
-        return self.torch.stack(out).cpu().numpy()
+def rccl_comm(dist, device):
+    """RCCL communicator over the ranks of an initialised torch.distributed group (used as rendezvous only: rank 0's
+    unique id is broadcast as a Python object)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [_abi.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return _abi.Comm.rccl(rank, world, box[0], device=device)
 
 
-def shard_range(N, rank, world, align=64):
-    """Contiguous, 64-aligned node ranges that cover [0, N)."""
-    per = -(-N // world)
-    per = -(-per // align) * align
-    n0 = min(rank * per, N)
-    return n0, min(n0 + per, N)
+def host_comm(dist, device=0):
+    """The same protocol with the collectives done by torch.distributed on host tensors (gloo): the test harness for
+    more ranks than there are GPUs."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def allreduce_sum(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def allgather(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.stack(out).numpy()
+
+    return _abi.Comm.host(rank, world, allreduce_sum, allgather, device=device)
 
 
-def half_sweep(model, data, comm):
-    """One resample(...) of a sharded SBM component (adjacency.py:615-618 / weights.py:394-397)."""
-    t, dg = model.shard_tables(data)
-    both = comm.allreduce_sum(np.concatenate([t, dg]))
-    model.shard_params(data, both[:t.size], both[t.size:])
-    while True:
-        out = model.shard_next(data)                       # (node, old, new, window end)
-        allg = comm.allgather(out[:3])
-        w = int(np.argmin(allg[:, 0]))
-        if allg[w, 0] == NONE:
-            model.shard_apply(data, -1, int(out[3]), 0)    # quiet window: move on
-            if out[3] >= data.N:
-                break
-        else:
-            model.shard_apply(data, int(allg[w, 0]), int(allg[w, 1]), int(allg[w, 2]))
-    model.shard_finish()
+def half_sweep(model, data, comm, n=1):
+    """n x resample(...) of a sharded SBM component (adjacency.py:615-618 / weights.py:394-397)."""
+    model.shard_sweep(data, comm, n)
 
 
 def log_likelihood(model, data, comm):
-    t, dg = model.shard_tables(data)
-    both = comm.allreduce_sum(np.concatenate([t, dg]))
-    return model.shard_log_likelihood(data, both[:t.size], both[t.size:])
+    return model.shard_log_likelihood(data, comm)

@@ -222,24 +222,31 @@ int gg_bench_stream(int32_t device, int64_t bytes, int32_t reps, int32_t mode, d
  * gg_last_stats reports bulk_ms / bulk_launches / bulk_bytes for the sampled launches; 0 = off. */
 int gg_set_timing(gg_model* m, int32_t on);
 
-/* ---- sharded single chain, step API (block models, beta = 1).  One half-sweep is
- *   gg_shard_tables   -> [all-reduce SUM of tables and diag over ranks]
- *   gg_shard_params   (draw parameters from the global tables; the scan position is reset)
- *   loop: gg_shard_next -> [all-gather of (node, old, new); the smallest node wins] -> gg_shard_apply
- *   gg_shard_finish   (resample_m)
- * Every rank holds all labels; statistics of its own nodes are complete locally; all traffic is integer
- * (exact, order independent), so the chain equals the single-GPU chain bit for bit for any number of ranks.
- * tables: int64 [K*K*ntab]; diag: int64 [ndiag] (gg_shard_sizes). */
-int gg_shard_sizes(gg_model* m, int32_t* ntab_total, int32_t* ndiag);
-int gg_shard_tables(gg_model* m, const gg_data* d, int64_t* tables, int64_t* diag);
-int gg_shard_params(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag);
-/* out = {first local node in the current window whose draw differs from its label (INT32_MAX if none), old, new, window end} */
-int gg_shard_next(gg_model* m, const gg_data* d, int32_t out[4]);
-/* node >= 0: every rank applies the winning change; node < 0: nothing changed, move on to position `a` (the window end) */
-int gg_shard_apply(gg_model* m, const gg_data* d, int32_t node, int32_t a, int32_t b);
-int gg_shard_finish(gg_model* m);
-/* log-likelihood from all-reduced tables / diag (abstractions.py:111-115, weights.py:316-331) */
-int gg_shard_log_likelihood(gg_model* m, const gg_data* d, const int64_t* tables, const int64_t* diag, double* out);
+/* ---- one chain sharded over the GPUs of a node (block models GG_SBM_ADJ / GG_SBM_GAUSS_W, beta = 1) ---------------------
+ * SURVEY.md section 8(e), DESIGN.md section 8.  Rank r owns nodes [shard_begin, shard_end) (gg_config) and holds the matching
+ * column shard of the network (gg_data_create_shard / gg_data_create_sbm_shard); every rank holds all labels.  All traffic
+ * is integer (exact, order independent), so the chain equals the single-GPU chain bit for bit for any number of ranks.
+ * Collectives go through a communicator:
+ *   gg_comm_create_rccl   RCCL on device buffers, enqueued on the engine stream (xGMI inside a node); the 128-byte unique id
+ *                         comes from gg_comm_unique_id on one rank and reaches the others through whatever launched them;
+ *   gg_comm_create_host   a pair of host callbacks (in-place SUM of int64; all-gather of int32) - the protocol's test
+ *                         harness (gloo through ctypes), buffers staged through the host.
+ * gg_shard_sweep runs n half-sweeps: per half-sweep one all-reduce of the K x K integer tables, then the sequential scan
+ * (adjacency.py:650-695, weights.py:415-488) in rounds - every rank speculates its own nodes of the current window, an
+ * all-gather of (first changed node, old, new) picks the earliest change, every rank applies it - enqueued in batches on
+ * the engine stream; the host reads the scan position once per batch, never once per change. */
+typedef struct gg_comm gg_comm;
+typedef int (*gg_host_allreduce_fn)(void* user, int64_t* buf, int64_t n);                          /* in place, SUM over ranks */
+typedef int (*gg_host_allgather_fn)(void* user, const int32_t* send, int32_t* recv, int64_t n);    /* recv[world][n] */
+int gg_comm_unique_id(uint8_t* out128);
+int gg_comm_create_rccl(gg_comm** out, int32_t rank, int32_t world, const uint8_t* id128, int32_t device);
+int gg_comm_create_host(gg_comm** out, int32_t rank, int32_t world, gg_host_allreduce_fn ar, gg_host_allgather_fn ag, void* user,
+                        int32_t device);
+int gg_comm_destroy(gg_comm* c);
+int gg_comm_info(const gg_comm* c, int32_t* rank, int32_t* world, int32_t* is_rccl, uint64_t* collectives);
+int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n_half_sweeps);
+/* log-likelihood from the all-reduced tables (abstractions.py:111-115, weights.py:316-331) */
+int gg_shard_log_likelihood(gg_model* m, const gg_data* d, gg_comm* c, double* out);
 
 /* Device self-test of the shared arithmetic spec: evaluates exp/log/sqrt/div
  * on the device for n inputs (parity tests compare with the host build). */

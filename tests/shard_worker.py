@@ -16,12 +16,16 @@ def main():
     from graphistician_amd import sharded as S
     from oracle import oracle as O
     from tests.helpers import planted_sbm, AdjState, WState
-    comm = S.TorchComm()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    # one rank: the RCCL communicator (the library's own ncclAllReduce / ncclAllGather calls run, over one rank);
+    # several ranks sharing the test box's single GPU: the same protocol over host callbacks (gloo)
+    use_rccl = os.environ.get("GG_SHARD_COMM", "rccl" if world == 1 else "host") == "rccl"
+    comm = S.rccl_comm(dist, 0) if use_rccl else S.host_comm(dist, 0)
     N, K, nsweeps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     B = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     special = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     A, W, _ = planted_sbm(N, K, B=B, seed=77)
-    n0, n1 = S.shard_range(N, comm.rank, comm.world)
+    n0, n1 = S.shard_range(N, rank, world)
     data = abi.DeviceData.shard(A, W, n0, n1, device=0)
     a, w = AdjState(N, K, seed=5), WState(N, K, B, seed=6)
     adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=901, tau1=1.0, tau0=1.0, allow_self_connections=1,
@@ -34,11 +38,14 @@ def main():
                        (abi.ST_MU_SELF, w.mu_self, np.float64), (abi.ST_SIGMA_SELF, w.sigma_self, np.float64),
                        (abi.ST_NIW, w.niw, np.float64), (abi.ST_NIW_SELF, w.niw_self, np.float64)):
         wm.set(sid, v, dt)
-    for s in range(nsweeps):
+    for s in range(nsweeps - 1):
         S.half_sweep(adj, data, comm)
         S.half_sweep(wm, data, comm)
+    if nsweeps > 1:                      # (two half-sweeps in one call as well)
+        S.half_sweep(adj, data, comm, 1)
+        S.half_sweep(wm, data, comm, 1)
     ll = S.log_likelihood(adj, data, comm) + S.log_likelihood(wm, data, comm)
-    if comm.rank == 0:
+    if rank == 0:
         q, shift = O.quantise(A, W)
         ps = a.p_self
         for s in range(nsweeps):
@@ -53,8 +60,11 @@ def main():
         ref = (O.sbm_adj_loglik(A, a.c, a.p, ps, True, bool(special)) +
                O.sbm_w_loglik(A, q, shift, w.c, w.mu, w.sigma, w.mu_self, w.sigma_self, bool(special)))
         assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
-        print("SHARD-OK world=%d N=%d K=%d B=%d special=%d sweeps=%d changes=%d" % (comm.world, N, K, B, special, nsweeps,
-              adj.stats()["label_changes"] + wm.stats()["label_changes"]))
+        info = comm.info()
+        assert info["world"] == world and info["rccl"] == use_rccl and info["collectives"] > 2 * nsweeps
+        print("SHARD-OK world=%d N=%d K=%d B=%d special=%d sweeps=%d changes=%d comm=%s collectives=%d" % (
+            world, N, K, B, special, nsweeps, adj.stats()["label_changes"] + wm.stats()["label_changes"],
+            "rccl" if info["rccl"] else "host", info["collectives"]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,5 +1,7 @@
-"""Exact sharded chain: 1, 2 and 3 ranks — processes sharing the one GPU of the test
-box, collectives over gloo — must all reproduce the oracle's single sequential chain bit for bit."""
+"""Exact sharded chain: 1, 2 and 3 ranks must all reproduce the oracle's single sequential chain bit
+for bit.  One rank runs the library's RCCL communicator (ncclAllReduce / ncclAllGather on the engine stream); two and three
+ranks are processes sharing the one GPU of the test box, so the same device-driven protocol runs over the host-callback
+communicator (gloo) — RCCL refuses two ranks on one device."""
 import os
 import subprocess
 import sys
@@ -41,3 +43,14 @@ def test_sharded_bench_is_rank_count_invariant():
         assert r["n_gpus"] == world and r["scaling"] == "strong"
         digests.append((r["config"]["labels_digest"], r["config"]["label_changes_in_timed_region"]))
     assert digests[0] == digests[1], digests
+
+
+def test_shard_ranges_cover_and_are_never_empty():
+    from graphistician_amd.sharded import shard_range
+    for N, world in ((100, 3), (64, 8), (65536, 8), (7, 7), (129, 2), (1000, 6)):
+        edges = [shard_range(N, r, world) for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == N
+        assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+        assert all(n1 > n0 for n0, n1 in edges)
+    with pytest.raises(ValueError):
+        shard_range(3, 0, 4)
