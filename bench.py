@@ -685,7 +685,10 @@ def main():
                     "value": nll / ell, "unit": "evaluations/s", "ms": ell / nll * 1e3, "algorithmic_bytes": ll_bytes,
                     "effective_GBs": ll_bytes * nll / ell / 1e9,
                     "note": "log p(A | .) + log p(W | A, .) of the whole network (networks.py:28-31), both halves at once "
-                            "(gg_log_likelihood_many): a bulk pass over A and over W plus the K x K closed form; not part of `value`"}
+                            "(gg_log_likelihood_many).  After a sweep of a quiet chain the statistics of the current labels are resident "
+                            "already (the riders of the last sweep counted them for the next one), so the evaluation is the K x K "
+                            "tables + the closed form on the device and one 16-byte copy back - no second pass over the data; "
+                            "effective_GBs prices it as if it had streamed A and W once.  Not part of `value`"}
             except Exception as exc:
                 out["log_likelihood_sweep"] = {"error": str(exc)}
         _progress("stream probe")

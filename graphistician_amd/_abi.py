@@ -52,7 +52,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_update", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_predictive_ll", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
            "gg_comm_create_host", "gg_comm_destroy", "gg_comm_info", "gg_shard_sweep", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws"]
 
@@ -101,6 +101,7 @@ def lib():
         L.gg_log_likelihood_many.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int32, C.POINTER(C.c_double)]
         L.gg_log_likelihood.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gg_node_lp.argtypes = [vp, vp, C.c_int32, vp]
+        L.gg_predictive_ll.argtypes = [vp, vp, vp, vp, vp, vp]
         L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gg_set_timing.argtypes = [vp, C.c_int32]
         L.gg_bench_bulk.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -280,6 +281,17 @@ class Model(object):
         out = C.c_double(0)
         check(lib().gg_log_likelihood(self._h, data.handle, C.byref(out)))
         return out.value
+
+    def predictive_ll(self, a_row, a_col, w_row=None, w_col=None, K=1):
+        """ll[k] of a held-out node's row and column for each block k it may belong to (gg_predictive_ll)."""
+        ar = np.ascontiguousarray(np.asarray(a_row) != 0, dtype=np.uint8)
+        ac = np.ascontiguousarray(np.asarray(a_col) != 0, dtype=np.uint8)
+        wr = None if w_row is None else np.ascontiguousarray(w_row, dtype=np.float64)
+        wc = None if w_col is None else np.ascontiguousarray(w_col, dtype=np.float64)
+        out = np.zeros(K)
+        check(lib().gg_predictive_ll(self._h, _ptr(ar), _ptr(ac), _ptr(wr) if wr is not None else None,
+                                     _ptr(wc) if wc is not None else None, _ptr(out)))
+        return out
 
     def node_lp(self, data, n, K):
         lp = np.zeros(K)

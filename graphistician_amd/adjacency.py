@@ -7,6 +7,7 @@ reference uses.  Constructor signatures, attribute names and assertion
 behaviour follow the reference (file:line cited per member).
 """
 import numpy as np
+from scipy.special import logsumexp
 from scipy.stats import beta as _beta, dirichlet as _dirichlet
 
 from . import _abi
@@ -211,6 +212,12 @@ class BetaBernoulliAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, E
         if self.self_connection:
             p_row[-1] = p_col[-1] = self.p_self
         return p_row, p_col
+
+    def approx_predictive_ll(self, Arow, Acol, M=100):
+        """abstractions.py:157-182 on the engine: the predictive parameters of this model are not random, so the M-draw average
+        is the one log-likelihood of the held-out row and column (gg_predictive_ll)."""
+        assert Arow.shape == Acol.shape == (self.N + 1,)
+        return float(self._engine().predictive_ll(Arow, Acol, K=1)[0])
 
 
 class LatentDistanceAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacked):
@@ -439,6 +446,16 @@ class SBMAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacke
         if not self.allow_self_connections:
             np.fill_diagonal(P, 0.0)
         return P[-1, :], P[:, -1]
+
+    def approx_predictive_ll(self, Arow, Acol, M=100):
+        """abstractions.py:157-182 on the engine.  A predictive draw (adjacency.py:562-573) is the held-out node's block
+        c2 ~ Cat(m); the engine returns the log-likelihood of its row and column for every block (gg_predictive_ll: labels
+        and parameters stay on the device), the M draws average over them."""
+        assert Arow.shape == Acol.shape == (self.N + 1,)
+        m = self.m
+        ll_k = self._engine().predictive_ll(Arow, Acol, K=self.C)
+        c2 = np.random.choice(self.C, p=m, size=M)
+        return float(-np.log(M) + logsumexp(ll_k[c2]))
 
     def invariant_sbm_order(self):
         # adjacency.py:575-591

@@ -1229,3 +1229,176 @@ __global__ void k_shard_pick(int32_t* c, int32_t* cnt, int32_t* L, int32_t* rs, 
     rs[GG_RS_SPOS] = best + 1;
   }
 }
+
+// ------------------------------------------------------------------ log-likelihood from the K x K tables, on the device
+// abstractions.py:111-115 (adjacency: sum_ab n1 log p + n0 log(1 - clip(p)) + diagonal) and weights.py:316-331 (weights:
+// sum_ab [n g + h.s1 + Q.s2] + the self Gaussian on the diagonal edges), evaluated by one workgroup from the pair tables
+// k_params has just reduced: the caller gets ONE double back instead of fetching tables and parameters (the demo loop
+// `resample; log_probability`, examples/demo_model_comparison.py:69-72, pays this per iteration).  Pair terms are summed by a
+// fixed-shape tree, so the value does not depend on scheduling.
+struct gg_ll_args {
+  int is_adj, K, B, NSI, NTAB, special, shift;
+  const long long* tab;
+  const int32_t* cnt;
+  const double *p, *p_self, *mu, *sigma, *mu_self, *sigma_self;
+  long long d1, d0;
+  long long dS[GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];
+  int diag_zero;        // adjacency.py:525-526 with the special case: the diagonal has probability 0
+  double* out;          // out[0] = log-likelihood, out[1] = 1.0 if a covariance was not positive definite
+};
+
+__device__ __forceinline__ double gg_ll_bern(double P, long long n1, long long n0) {
+  const double Pc = P < 1e-64 ? 1e-64 : (P > 1 - 1e-64 ? 1 - 1e-64 : P);   // safe_P, abstractions.py:92-94
+  double v = 0.0;
+  if (n1) v += (double)n1 * log(P);
+  if (n0) v += (double)n0 * log(1.0 - Pc);
+  return v;
+}
+
+__device__ __forceinline__ double gg_ll_gauss(const double* mu, const double* sig, int B, int NSI, double n, const long long* hl,
+                                              double sc1, double sc2, bool* bad) {
+  if (n == 0) return 0.0;
+  double e[GG_MAXNT];
+  if (gg_gauss_table(mu, sig, B, e)) { *bad = true; return 0.0; }
+  double v = n * e[0];
+  for (int s = 0; s < NSI; ++s) v += e[1 + s] * (gg_hilo_to_double(hl[2 * s], hl[2 * s + 1]) * (s < B ? sc1 : sc2));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_loglik(gg_ll_args g) {
+  __shared__ double s_part[256];
+  __shared__ int s_bad;
+  const int K = g.K, KK = K * K, tid = threadIdx.x;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const double sc1 = gg_pow2i(-g.shift), sc2 = gg_pow2i(-2 * g.shift);
+  double acc = 0.0;
+  bool bad = false;
+  for (int ab = tid; ab < KK; ab += 256) {       // (fixed assignment of pairs to lanes)
+    const int a = ab / K, b = ab % K;
+    if (g.is_adj) {
+      const long long n1 = g.tab[ab];
+      const long long pairs = (long long)g.cnt[a] * g.cnt[b] - ((a == b && g.special) ? g.cnt[a] : 0);
+      acc += gg_ll_bern(g.p[ab], n1, pairs - n1);
+    } else {
+      const long long* e = g.tab + (size_t)ab * g.NTAB;
+      acc += gg_ll_gauss(g.mu + (size_t)ab * g.B, g.sigma + (size_t)ab * g.B * g.B, g.B, g.NSI, (double)e[0], e + 1, sc1, sc2, &bad);
+    }
+  }
+  if (bad) atomicOr(&s_bad, 1);
+  s_part[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (tid < s) s_part[tid] += s_part[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double ll = s_part[0];
+    if (g.is_adj) {
+      if (g.diag_zero) ll += gg_ll_bern(0.0, g.d1, g.d0);
+      else if (g.special) ll += gg_ll_bern(*g.p_self, g.d1, g.d0);
+    } else if (g.special) {
+      long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+      for (int s = 0; s < g.NSI; ++s) { hl[2 * s] = g.dS[s] >> 32; hl[2 * s + 1] = g.dS[s] & 0xffffffffll; }
+      bool b2 = false;
+      ll += gg_ll_gauss(g.mu_self, g.sigma_self, g.B, g.NSI, (double)g.d1, hl, sc1, sc2, &b2);
+      if (b2) s_bad = 1;
+    }
+    g.out[0] = ll;
+    g.out[1] = s_bad ? 1.0 : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------ predictive log-likelihood of a held-out node
+// abstractions.py:157-182 (adjacency) / :313-357 (Gaussian weights): the log-likelihood of an (N+1)-th node's row and
+// column under predictive parameters.  For the block models those parameters depend on a draw only through the new node's
+// block c2 ~ Cat(m) (adjacency.py:562-573, weights.py:375-389; K = 1 kinds: not at all), so the M-draw Monte-Carlo average
+// needs ll[k] for each block k once: workgroup k sums the 2N edge terms under "the new node is in block k" - labels and
+// parameters never leave the device - and the caller averages exp(ll[c2_m]) over its M draws.
+//   adjacency: ll[k] = sum_n a_row[n] log P[k,c_n] + (1 - a_row[n]) log(1 - P[k,c_n]) + (same with P[c_n,k] on the column)
+//              + the self entry: P[k,k] (0 when self connections are not allowed; the K = 1 kinds use p_self)
+//   weights:   ll[k] = sum_{n: a_row[n]} log N(w_row[n]; mu[k,c_n], Sigma[k,c_n]) + sum_{n: a_col[n]} log N(w_col[n]; mu[c_n,k], ..)
+//              + the self entry under the self Gaussian (special case) or pair (k,k)
+// P is clipped to [1e-64, 1 - 1e-64] as the reference does (abstractions.py:171-174).
+struct gg_pred_args {
+  int is_adj, K, B, N, special, allow_self, use_self_param;
+  const int32_t* c;
+  const double *p, *p_self, *mu, *sigma, *mu_self, *sigma_self;
+  const uint8_t *a_row, *a_col;     // [N + 1]
+  const double *w_row, *w_col;      // [N + 1][B]
+  double* out;                      // [K]; out[K] = 1.0 if a covariance was not positive definite
+};
+
+__global__ __launch_bounds__(256) void k_pred_ll(gg_pred_args g) {
+  extern __shared__ double s_tabs[];      // adjacency: [4][K] log terms; weights: [2][K][NT] Gaussian coefficient tables
+  __shared__ double s_part[256];
+  __shared__ int s_bad;
+  const int K = g.K, B = g.B, N = g.N, k = blockIdx.x, tid = threadIdx.x;
+  const int NT = 1 + B + B * (B + 1) / 2;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  auto clipP = [](double P) { return P < 1e-64 ? 1e-64 : (P > 1 - 1e-64 ? 1 - 1e-64 : P); };
+  if (g.is_adj) {
+    for (int j = tid; j < K; j += 256) {
+      const double pr = clipP(g.p[(size_t)k * K + j]), pc = clipP(g.p[(size_t)j * K + k]);
+      s_tabs[j] = log(pr); s_tabs[K + j] = log(1.0 - pr); s_tabs[2 * K + j] = log(pc); s_tabs[3 * K + j] = log(1.0 - pc);
+    }
+  } else {
+    for (int j = tid; j < 2 * K; j += 256) {
+      const int jj = j % K, dir = j / K;
+      const size_t ab = dir == 0 ? (size_t)k * K + jj : (size_t)jj * K + k;
+      if (gg_gauss_table(g.mu + ab * B, g.sigma + ab * B * B, B, s_tabs + (size_t)j * NT)) atomicOr(&s_bad, 1);
+    }
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    const int j = g.c[n];
+    if (g.is_adj) {
+      acc += g.a_row[n] ? s_tabs[j] : s_tabs[K + j];
+      acc += g.a_col[n] ? s_tabs[2 * K + j] : s_tabs[3 * K + j];
+    } else {
+      for (int dir = 0; dir < 2; ++dir) {
+        if (!(dir == 0 ? g.a_row[n] : g.a_col[n])) continue;
+        const double* w = (dir == 0 ? g.w_row : g.w_col) + (size_t)n * B;
+        const double* e = s_tabs + ((size_t)dir * K + j) * NT;
+        double v = e[0];
+        int t = 1 + B;
+        for (int r = 0; r < B; ++r) v += e[1 + r] * w[r];
+        for (int r = 0; r < B; ++r)
+          for (int q = r; q < B; ++q) v += e[t++] * w[r] * w[q];
+        acc += v;
+      }
+    }
+  }
+  s_part[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (tid < s) s_part[tid] += s_part[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double ll = s_part[0];
+    // the new node's self entry (index N of the row; the column's copy is not counted twice: abstractions.py:162,170)
+    if (g.is_adj) {
+      double ps = g.use_self_param ? *g.p_self : g.p[(size_t)k * K + k];
+      if (!g.allow_self) ps = 0.0;
+      ps = clipP(ps);
+      ll += g.a_row[N] ? log(ps) : log(1.0 - ps);
+    } else if (g.a_row[N]) {
+      double e[GG_MAXNT];
+      const double* mu = g.use_self_param ? g.mu_self : g.mu + ((size_t)k * K + k) * B;
+      const double* sg = g.use_self_param ? g.sigma_self : g.sigma + ((size_t)k * K + k) * B * B;
+      if (gg_gauss_table(mu, sg, B, e)) s_bad = 1;
+      const double* w = g.w_row + (size_t)N * B;
+      double v = e[0];
+      int t = 1 + B;
+      for (int r = 0; r < B; ++r) v += e[1 + r] * w[r];
+      for (int r = 0; r < B; ++r)
+        for (int q = r; q < B; ++q) v += e[t++] * w[r] * w[q];
+      ll += v;
+    }
+    g.out[k] = ll;
+    if (s_bad) g.out[K] = 1.0;
+  }
+}

@@ -72,6 +72,8 @@ struct gg_model {
   long long* tab;
   int32_t *rs, *L;   // rs = control block (gg_resolve_kernels.h)
   double* lp_out;
+  double* ll_out;              // k_loglik's result {log-likelihood, not-positive-definite flag}
+  bool ll_host_form;
   bool m_pending;              // resample_m of sweep m_sweep not drawn yet (done by the next k_params or at sync)
   uint32_t m_sweep;
   double beta;                 // inverse temperature of the sweeps being enqueued / pending
@@ -267,7 +269,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
       (rc = dmalloc(&m->labb[1], K + 1)) || (rc = dmalloc(&m->m, K)) ||
       (rc = dmalloc(&m->logm, K)) || (rc = dmalloc(&m->pi, K)) || (rc = dmalloc(&m->T, KK * NT)) ||
       (rc = dmalloc(&m->Tout, (size_t)K * NT * m->Kp)) || (rc = dmalloc(&m->Tin, (size_t)K * NT * m->Kp)) ||
-      (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 32)) || (rc = dmalloc(&m->lp_out, K)))
+      (rc = dmalloc(&m->tab, KK * m->NTAB)) || (rc = dmalloc(&m->rs, 32)) || (rc = dmalloc(&m->lp_out, K)) || (rc = dmalloc(&m->ll_out, 2)))
     return rc;
   {
     // the 64-bit word the workgroups report their first changer to starts (and is always left) at "none"
@@ -385,7 +387,7 @@ int gg_model_destroy(gg_model* m) {
   if (m->pend_data) { hipStreamSynchronize(m->stream); set_pend_data(m, nullptr); }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
-                  m->rs, m->L, m->lp_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all};
+                  m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -1793,8 +1795,9 @@ static int ll_enqueue(gg_model* m, const gg_data* d) {
   int rc = model_sync(m);
   if (rc) return rc;
   if ((rc = check_data(m, d))) return rc;
-  begin_call(m);
   const int buf = m->cur;
+  // (no event bracket around this call: two records and an elapsed-time query cost as much as the kernels they would time)
+  m->ev_used = 0; m->ev_sweep.clear(); m->ev_bytes.clear();
   // The statistics of the current labels may have been counted already, for the next sweep, by the riders of the last
   // one (ahead form): the demo loop `resample; log_probability` (examples/demo_model_comparison.py:69-72) then pays
   // no second pass over the data - the tables come from numbers that are resident anyway.  Otherwise: one bulk pass
@@ -1805,18 +1808,39 @@ static int ll_enqueue(gg_model* m, const gg_data* d) {
   }
   if ((rc = enqueue_params(m, d, buf, true, false, false, -1, m->sweep))) return rc;
   const size_t KK = (size_t)m->K * m->K;
-  // tables and block counts through pinned staging (a copy into pageable memory costs tens of microseconds)
-  GG_HIP(hipMemcpyAsync(m->h_tab, m->tab, KK * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipMemcpyAsync(m->h_tab + KK * m->NTAB, m->cnt, m->K * 4, hipMemcpyDeviceToHost, m->stream));
-  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  const bool host_form = m->is_adj && !m->cfg.allow_self_connections && m->kind == GG_SBM_ADJ && !m->cfg.special_case_self_conns;
+  if (host_form) {
+    // (the one combination whose diagonal needs per-node terms, adjacency.py:525-526 without the special case: host closed form)
+    GG_HIP(hipMemcpyAsync(m->h_tab, m->tab, KK * m->NTAB * 8, hipMemcpyDeviceToHost, m->stream));
+    GG_HIP(hipMemcpyAsync(m->h_tab + KK * m->NTAB, m->cnt, m->K * 4, hipMemcpyDeviceToHost, m->stream));
+  } else {
+    gg_ll_args g;
+    memset(&g, 0, sizeof(g));
+    g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.B = m->B; g.NSI = m->NSI; g.NTAB = m->NTAB;
+    g.special = m->cfg.special_case_self_conns ? 1 : 0;
+    g.shift = m->is_adj ? 0 : d->shift;
+    g.tab = m->tab; g.cnt = m->cnt;
+    g.p = m->p; g.p_self = m->p_self; g.mu = m->mu; g.sigma = m->sigma; g.mu_self = m->mu_self; g.sigma_self = m->sigma_self;
+    g.d1 = d->d1; g.d0 = (long long)m->N - d->d1;
+    for (int i = 0; i < gg_nsi(GG_MAXB); ++i) g.dS[i] = d->dS[i];
+    g.diag_zero = (m->is_adj && !m->cfg.allow_self_connections && m->kind == GG_SBM_ADJ) ? 1 : 0;
+    g.out = m->ll_out;
+    k_loglik<<<1, 256, 0, m->stream>>>(g);
+    GG_HIP(hipGetLastError());
+    GG_HIP(hipMemcpyAsync(m->h_tab, m->ll_out, 2 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  }
+  m->ll_host_form = host_form;
   return GG_OK;
 }
 
-// ... and, once they have arrived, the closed form on the host.
+// ... and, once it has arrived, the value (or, for the one host-form combination, the closed form from the tables).
 static int ll_finish(gg_model* m, const gg_data* d, double* out) {
   GG_HIP(hipStreamSynchronize(m->stream));
-  int rc = collect_timing(m);
-  if (rc) return rc;
+  if (!m->ll_host_form) {
+    const double* r = reinterpret_cast<const double*>(m->h_tab);
+    *out = r[1] != 0.0 ? NAN : r[0];     // (a covariance that is not positive definite: NaN, as the host form returns)
+    return GG_OK;
+  }
   const size_t KK = (size_t)m->K * m->K;
   return loglik_from_tables(m, d, m->h_tab, reinterpret_cast<const int32_t*>(m->h_tab + KK * m->NTAB), out);
 }
@@ -2106,6 +2130,56 @@ int gg_shard_log_likelihood(gg_model* m, const gg_data* d, gg_comm* c, double* o
   dg.d1 = m->sh_diag[0];
   for (int i = 0; i < gg_nsi(GG_MAXB); ++i) dg.dS[i] = m->sh_diag[1 + i];
   return loglik_from_tables(m, &dg, m->h_tab, reinterpret_cast<const int32_t*>(m->h_tab + KK * m->NTAB), out);
+}
+
+// Predictive log-likelihood of a held-out (N+1)-th node, per block of the new node (k_pred_ll).
+int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, const double* w_row, const double* w_col, double* ll_k) {
+  if (!m || !a_row || !a_col || !ll_k) return gg_fail(GG_ERR_INVALID, "gg_predictive_ll: null argument");
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_predictive_ll: block models only (the other kinds draw latent features per sample: host code)");
+  if (m->sharded) return gg_fail(GG_ERR_UNSUPPORTED, "gg_predictive_ll: not for node shards");
+  if (!m->is_adj && (!w_row || !w_col)) return gg_fail(GG_ERR_INVALID, "gg_predictive_ll: weight kinds need the weight row and column");
+  int rc = model_sync(m);
+  if (rc) return rc;
+  const int N = m->N, K = m->K, B = m->B;
+  const size_t na = (size_t)N + 1, nw = ((size_t)N + 1) * B;
+  unsigned char* dbuf = nullptr;
+  const size_t bytes = 2 * na + (m->is_adj ? 0 : 2 * nw * 8) + 16;
+  GG_HIP(hipMalloc((void**)&dbuf, bytes + (size_t)(K + 1) * 8 + 64));
+  // layout: [w_row | w_col] (doubles first: alignment) | a_row | a_col | out[K + 1]
+  double* d_w = reinterpret_cast<double*>(dbuf);
+  unsigned char* d_a = dbuf + (m->is_adj ? 0 : 2 * nw * 8);
+  double* d_out = reinterpret_cast<double*>(dbuf + ((bytes + 7) & ~(size_t)7));
+  if (!m->is_adj) {
+    if (gg_first_nonfinite(w_row, nw) >= 0 || gg_first_nonfinite(w_col, nw) >= 0) { hipFree(dbuf); return gg_fail(GG_ERR_INVALID, "gg_predictive_ll: non-finite weight"); }
+    GG_HIP(hipMemcpyAsync(d_w, w_row, nw * 8, hipMemcpyHostToDevice, m->stream));
+    GG_HIP(hipMemcpyAsync(d_w + nw, w_col, nw * 8, hipMemcpyHostToDevice, m->stream));
+  }
+  GG_HIP(hipMemcpyAsync(d_a, a_row, na, hipMemcpyHostToDevice, m->stream));
+  GG_HIP(hipMemcpyAsync(d_a + na, a_col, na, hipMemcpyHostToDevice, m->stream));
+  GG_HIP(hipMemsetAsync(d_out, 0, (size_t)(K + 1) * 8, m->stream));
+  gg_pred_args g;
+  memset(&g, 0, sizeof(g));
+  g.is_adj = m->is_adj ? 1 : 0; g.K = K; g.B = B; g.N = N;
+  g.special = m->cfg.special_case_self_conns ? 1 : 0;
+  g.allow_self = (m->kind == GG_SBM_ADJ && !m->cfg.allow_self_connections) ? 0 : 1;
+  // the new node's self entry: the SBM adjacency model uses p[c2, c2] (adjacency.py:562-573), the K = 1 adjacency kinds their
+  // p_self; the weight kinds their self Gaussian when self connections are special-cased (weights.py:144-152, 375-389)
+  g.use_self_param = m->is_adj ? (m->kind != GG_SBM_ADJ && g.special) : g.special;
+  g.c = m->c; g.p = m->p; g.p_self = m->p_self; g.mu = m->mu; g.sigma = m->sigma; g.mu_self = m->mu_self; g.sigma_self = m->sigma_self;
+  g.a_row = d_a; g.a_col = d_a + na; g.w_row = d_w; g.w_col = d_w + nw;
+  g.out = d_out;
+  const size_t lds = m->is_adj ? (size_t)4 * K * 8 : (size_t)2 * K * m->NT * 8;
+  k_pred_ll<<<K, 256, lds, m->stream>>>(g);
+  hipError_t e = hipGetLastError();
+  std::vector<double> h((size_t)K + 1);
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, m->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  hipFree(dbuf);
+  if (e != hipSuccess) return gg_fail(GG_ERR_HIP, "gg_predictive_ll failed: %s", hipGetErrorString(e));
+  if (h[(size_t)K] != 0.0) return gg_fail(GG_ERR_NUMERIC, "gg_predictive_ll: a block covariance is not positive definite");
+  for (int k = 0; k < K; ++k) ll_k[k] = h[(size_t)k];
+  return GG_OK;
 }
 
 int gg_last_stats(gg_model* m, gg_stats* out) {

@@ -8,6 +8,7 @@ that expose the attributes the reference reads (`mu`, `sigma`, `sigma_chol`,
 `mu_0`, `sigma_0`, `nu_0`, `kappa_0`).
 """
 import numpy as np
+from scipy.special import logsumexp
 from scipy.stats import dirichlet as _dirichlet, invwishart as _invwishart, multivariate_normal as _mvn
 
 from . import _abi
@@ -270,6 +271,12 @@ class NIWGaussianWeightDistribution(_WeightsBase):
         Lrow[-1, :, :] = Lcol[-1, :, :] = self._self_gaussian.sigma_chol
         return Murow, Mucol, Lrow, Lcol
 
+    def approx_predictive_ll(self, Arow, Acol, Wrow, Wcol, M=100):
+        """abstractions.py:313-357 on the engine: one Gaussian for every edge of the held-out node, the self Gaussian for its
+        self connection (weights.py:144-152) - nothing to average over."""
+        assert Arow.shape == Acol.shape == (self.N + 1,)
+        return float(self._engine().predictive_ll(Arow, Acol, Wrow, Wcol, K=1)[0])
+
     def resample(self, data, beta=1.0):
         """weights.py:154-162.  beta < 1: tempered posterior (build-defined for weights: the Gaussian likelihood
         to the power beta scales the sufficient statistics, the way graph_models.py:366-367 scales counts)."""
@@ -429,6 +436,16 @@ class SBMGaussianWeightDistribution(_WeightsBase):
             Murow[-1] = Mucol[-1] = self._self_gaussian.mu
             Lrow[-1] = Lcol[-1] = self._self_gaussian.sigma_chol
         return Murow, Mucol, Lrow, Lcol
+
+    def approx_predictive_ll(self, Arow, Acol, Wrow, Wcol, M=100):
+        """abstractions.py:313-357 on the engine: a predictive draw (weights.py:375-389) is the held-out node's block
+        c2 ~ Cat(m); the engine evaluates the Gaussian log-densities of its row and column for every block
+        (gg_predictive_ll), the M draws average over them."""
+        assert Arow.shape == Acol.shape == (self.N + 1,)
+        m = self.m
+        ll_k = self._engine().predictive_ll(Arow, Acol, Wrow, Wcol, K=self.C)
+        c2 = np.random.choice(self.C, p=m, size=M)
+        return float(-np.log(M) + logsumexp(ll_k[c2]))
 
     # -- Gibbs (weights.py:394-498): on the device ---------------------------------
     def _run(self, data, parts, beta=1.0):

@@ -207,6 +207,12 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out);
  * run concurrently. */
 int gg_log_likelihood_many(gg_model** models, const gg_data* const* data, int32_t n, double* out);
 
+/* approx_predictive_ll (abstractions.py:157-182, 313-357; networks.py:60-67), the held-out evaluation of
+ * examples/demo_model_comparison.py:61-74: log-likelihood of an (N+1)-th node's row and column, a_row / a_col uint8 [N+1]
+ * (entry N = the self connection), w_row / w_col double [N+1][B] (weight kinds; NULL otherwise), for each block k the new
+ * node may belong to -> ll_k[K] (K = 1 kinds: one value).  The caller draws c2 ~ Cat(m) M times and averages exp(ll_k[c2]). */
+int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, const double* w_row, const double* w_col, double* ll_k);
+
 /* Conditional log-probabilities lp[K] of node n under the current state
  * (the vector handed to sample_discrete_from_log at adjacency.py:695 /
  * weights.py:488) — for parity tests. */

@@ -495,3 +495,44 @@ def test_every_adjacency_and_weight_class_combination_runs(abi):
     log_likelihood / log_prior / log_probability finite, predictive parameters (tests/combo_smoke.py)."""
     from tests.combo_smoke import main
     assert main() == 0
+
+
+@pytest.mark.gpu
+def test_predictive_ll_on_the_device_matches_the_reference_formula(abi):
+    """approx_predictive_ll (abstractions.py:157-182, 313-357) evaluated by gg_predictive_ll: with m concentrated on one block
+    every predictive draw puts the held-out node there, so the generic host code (the reference's double loop over draws and
+    nodes, graphistician_amd/abstractions.py) and the engine must return the same number, for every block, for both
+    self-connection conventions, for the K = 1 kinds, and the M-draw average must be the log-mean-exp over sampled blocks."""
+    from scipy.special import logsumexp
+    from graphistician_amd.abstractions import AdjacencyDistribution, GaussianWeightDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution, BetaBernoulliAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution, NIWGaussianWeightDistribution
+    np.random.seed(5)
+    N, C, B = 37, 4, 2
+    Arow, Acol = np.random.rand(N + 1) < 0.4, np.random.rand(N + 1) < 0.6
+    Acol[-1] = Arow[-1] = True
+    Wrow, Wcol = np.random.randn(N + 1, B), np.random.randn(N + 1, B)
+    Wcol[-1] = Wrow[-1]
+    for special, allow in ((True, True), (False, True), (False, False)):
+        a = SBMAdjacencyDistribution(N, C=C, special_case_self_conns=special, allow_self_connections=allow)
+        w = SBMGaussianWeightDistribution(N, B=B, C=C, special_case_self_conns=special)
+        for k in range(C):
+            a.m = np.eye(C)[k]; w.m = np.eye(C)[k]
+            ref_a = AdjacencyDistribution.approx_predictive_ll(a, Arow, Acol, M=3)
+            assert abs(a.approx_predictive_ll(Arow, Acol, M=3) - ref_a) <= 1e-10 * abs(ref_a), (special, allow, k)
+            ref_w = GaussianWeightDistribution.approx_predictive_ll(w, Arow, Acol, Wrow, Wcol, M=3)
+            assert abs(w.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=3) - ref_w) <= 1e-10 * abs(ref_w), (special, k)
+        # a proper m: the estimate is the log-mean-exp of the per-block values over the sampled blocks
+        a.m = np.array([0.1, 0.2, 0.3, 0.4])
+        ll_k = a._engine().predictive_ll(Arow, Acol, K=C)
+        np.random.seed(11)
+        got = a.approx_predictive_ll(Arow, Acol, M=50)
+        np.random.seed(11)
+        c2 = np.random.choice(C, p=a.m, size=50)
+        assert abs(got - (-np.log(50) + logsumexp(ll_k[c2]))) < 1e-12
+    bb = BetaBernoulliAdjacencyDistribution(N)
+    ref = AdjacencyDistribution.approx_predictive_ll(bb, Arow, Acol, M=2)
+    assert abs(bb.approx_predictive_ll(Arow, Acol) - ref) <= 1e-10 * abs(ref)
+    niw = NIWGaussianWeightDistribution(N, B=B)
+    ref = GaussianWeightDistribution.approx_predictive_ll(niw, Arow, Acol, Wrow, Wcol, M=2)
+    assert abs(niw.approx_predictive_ll(Arow, Acol, Wrow, Wcol) - ref) <= 1e-10 * abs(ref)
