@@ -174,6 +174,17 @@ __device__ __forceinline__ uint4 gg_stream_load(const uint4* p) {
 // Weights: 4 int32 per lane per row = 4 / B elements; per element edge count,
 // sum q_r, sum q_r q_s in 64-bit integers.
 // One (column strip, label slot, direction) work item of the weight pass; a workgroup of 256 threads.
+// Row element of the weight pass as an int4 (component 3 unused for B = 3, whose elements are 12 bytes: three dwords).
+struct __attribute__((packed, aligned(4))) gg_i3 { int x, y, z; };
+template <int B, bool NTL>
+__device__ __forceinline__ int4 gg_load_welem(const int32_t* __restrict__ p) {
+  if (B == 3) {
+    const gg_i3 v = *reinterpret_cast<const gg_i3*>(p);
+    return make_int4(v.x, v.y, v.z, 0);
+  }
+  return gg_stream_load<NTL>(reinterpret_cast<const int4*>(p));
+}
+
 template <int B, int U, bool NTL>
 __device__ __forceinline__ void gg_bulk_w_body(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
                                                int Np, const int32_t* __restrict__ perm,
@@ -249,7 +260,7 @@ __device__ __forceinline__ void gg_bulk_w_body(const int32_t* __restrict__ XT, c
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int iu = perm[row0 + r + 4 * u];
-        v[u] = gg_stream_load<NTL>(reinterpret_cast<const int4*>(X + ((size_t)iu * Np + col0) * B));
+        v[u] = gg_load_welem<B, NTL>(X + ((size_t)iu * Np + col0) * B);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) accumulate(v[u]);
@@ -258,7 +269,7 @@ __device__ __forceinline__ void gg_bulk_w_body(const int32_t* __restrict__ XT, c
     }
     for (; r < nrows; r += 4) {
       int i0 = perm[row0 + r];
-      int4 v0 = gg_stream_load<NTL>(reinterpret_cast<const int4*>(X + ((size_t)i0 * Np + col0) * B));
+      int4 v0 = gg_load_welem<B, NTL>(X + ((size_t)i0 * Np + col0) * B);
       accumulate(v0);
       since += 1;
       if (since > 120) { flush(); since = 0; }

@@ -235,9 +235,9 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->K = m->sbm ? cfg->K : 1;
   if (m->K < 1 || m->K > 64) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "number of blocks C=%d not in 1..64", m->K); }
   m->B = m->is_adj ? 1 : cfg->B;
-  if (!m->is_adj && !(m->B == 1 || m->B == 2 || m->B == 4)) {
+  if (!m->is_adj && !(m->B >= 1 && m->B <= GG_MAXB)) {
     delete m;
-    return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d: the HIP engine supports B in {1,2,4}", cfg->B);
+    return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d: the HIP engine supports B in 1..%d", cfg->B, GG_MAXB);
   }
   if ((cfg->kind == GG_SBM_ADJ || cfg->kind == GG_BB_ADJ) &&
       !(cfg->tau1 > 0.0 && cfg->tau0 > 0.0 && cfg->tau1 - cfg->tau1 == 0.0 && cfg->tau0 - cfg->tau0 == 0.0)) {
@@ -656,6 +656,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
     switch (m->B) {
       case 1: BULKW(1, 4); break;
       case 2: BULKW(2, 4); break;
+      case 3: BULKW(3, 4); break;
       case 4: BULKW(4, 4); break;
     }
 #undef BULKW
@@ -777,6 +778,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
     if (m->is_adj) PRM(true, 1);
     else if (m->B == 1) PRM(false, 1);
     else if (m->B == 2) PRM(false, 2);
+    else if (m->B == 3) PRM(false, 3);
     else PRM(false, 4);
 #undef PRM
     if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
@@ -784,11 +786,13 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   } else if (m->is_adj) k_params<true, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 1) k_params<false, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 2) k_params<false, 2><<<nwg, 256, 0, m->stream>>>(g);
+  else if (m->B == 3) k_params<false, 3><<<nwg, 256, 0, m->stream>>>(g);
   else k_params<false, 4><<<nwg, 256, 0, m->stream>>>(g);
   GG_HIP(hipGetLastError());
   if (g.shared && draw) {   // weights.py:545-552: the shared covariance and, with it, the coefficient tables
     if (m->B == 1) k_shared_cov<1><<<1, 256, 0, m->stream>>>(g);
     else if (m->B == 2) k_shared_cov<2><<<1, 256, 0, m->stream>>>(g);
+    else if (m->B == 3) k_shared_cov<3><<<1, 256, 0, m->stream>>>(g);
     else k_shared_cov<4><<<1, 256, 0, m->stream>>>(g);
     GG_HIP(hipGetLastError());
   }
@@ -822,6 +826,7 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
   if (m->is_adj) SPEC(2, true);
   else if (m->B == 1) SPEC(3, false);
   else if (m->B == 2) SPEC(6, false);
+  else if (m->B == 3) SPEC(10, false);
   else SPEC(15, false);
 #undef SPEC
   GG_HIP(hipGetLastError());
@@ -892,6 +897,7 @@ static int launch_sweep_q(gg_model* m, const gg_data* d, int a, int b, int c, ui
   if (m->is_adj) SWQ(2, true);
   else if (m->B == 1) SWQ(3, false);
   else if (m->B == 2) SWQ(6, false);
+  else if (m->B == 3) SWQ(10, false);
   else SWQ(15, false);
 #undef SWQ
 #undef SWQ1
@@ -944,6 +950,7 @@ static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t 
   if (m->is_adj) SPR(2, true);
   else if (m->B == 1) SPR(3, false);
   else if (m->B == 2) SPR(6, false);
+  else if (m->B == 3) SPR(10, false);
   else SPR(15, false);
 #undef SPR
 #undef SPR1
@@ -987,6 +994,7 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   if (m->is_adj) RES(2, true);
   else if (m->B == 1) RES(3, false);
   else if (m->B == 2) RES(6, false);
+  else if (m->B == 3) RES(10, false);
   else RES(15, false);
 #undef RES
   GG_HIP(hipGetLastError());
@@ -1002,6 +1010,7 @@ static int launch_apply_L(gg_model* m, const gg_data* d, int buf, int mode = 0, 
   if (m->is_adj) APL(2, true);
   else if (m->B == 1) APL(3, false);
   else if (m->B == 2) APL(6, false);
+  else if (m->B == 3) APL(10, false);
   else APL(15, false);
 #undef APL
   GG_HIP(hipGetLastError());
@@ -1050,6 +1059,7 @@ static int launch_round(gg_model* m, const gg_data* d, int buf, uint32_t sweep, 
   if (m->is_adj) RND(2, true);
   else if (m->B == 1) RND(3, false);
   else if (m->B == 2) RND(6, false);
+  else if (m->B == 3) RND(10, false);
   else RND(15, false);
 #undef RND
   GG_HIP(hipGetLastError());
@@ -1108,6 +1118,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   if (m->is_adj) SCN(2, true);
   else if (m->B == 1) SCN(3, false);
   else if (m->B == 2) SCN(6, false);
+  else if (m->B == 3) SCN(10, false);
   else SCN(15, false);
 #undef SCN
   GG_HIP(hipGetLastError());

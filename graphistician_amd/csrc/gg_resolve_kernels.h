@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, ((RIDE && !SPLIT) ? GG_RIDE_WAVES : 1)) void k
     gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap, gg_ride_args ride = gg_ride_args()) {
   if (g.rs[4]) return;   // behind a stalled scan of this pipeline: no-op (uniform)
   if (RIDE && (int)blockIdx.x >= ride.front) {
-    gg_ride<ADJ, (ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : 4))), RIDE == 2>(ride);
+    gg_ride<ADJ, (ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)))), RIDE == 2>(ride);
     return;
   }
   const unsigned nfront = RIDE ? (unsigned)ride.front : gridDim.x;
@@ -462,7 +462,7 @@ template <int NT, bool ADJ, int NTL, int SPLIT>
 __global__ __launch_bounds__(256, (SPLIT ? 1 : GG_RIDE_WAVES)) void k_sweep_q(gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap,
                                                                                  gg_params_args pg, gg_ride_args ride, int nspec, unsigned vtag) {
   if (g.rs[4]) return;
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : 4));
+  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
   const int bid = (int)blockIdx.x;
   const long long t0 = ride.dbg ? wall_clock64() : 0;
   if (ride.dbg && threadIdx.x == 0) atomicMin(reinterpret_cast<unsigned long long*>(&ride.dbg[0]), (unsigned long long)t0);

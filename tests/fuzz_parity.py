@@ -67,7 +67,7 @@ def run(cases, seed0, verbose=False, extended=False):
     for case in range(cases):
         N = int(rng.choice([5, 17, 33, 64, 65, 100, 129, 200, 257, 300]))
         K = min(int(rng.choice([2, 3, 4, 7, 16, 17, 33, 40, 64])), N)
-        B = int(rng.choice([1, 1, 1, 2, 4]))
+        B = int(rng.choice([1, 1, 1, 2, 3, 4]))
         special = int(rng.rand() < 0.7)
         seed = int(rng.randint(1, 1 << 30))
         chunks = (1, int(rng.randint(1, 4)), int(rng.randint(1, 12)))

@@ -111,7 +111,7 @@ def test_weights_b4_chain(abi):
         assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), st.c)
     assert np.array_equal(w.get(abi.ST_SIGMA, (K, K, B, B)), st.sigma)
     with pytest.raises(abi.EngineError):
-        abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=3, seed=1)       # B = 3 is not supported by the HIP kernels
+        abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=5, seed=1)       # B <= 4 (GG_MAXB)
 
 
 def test_model_reuse_across_data_and_async_batches(abi):
@@ -406,7 +406,7 @@ def test_weights_with_large_tables_fit_in_lds(abi, monkeypatch, K, B, form):
     assert np.array_equal(w.get(abi.ST_MU, (K, K, B)), st.mu) and np.array_equal(w.get(abi.ST_SIGMA, (K, K, B, B)), st.sigma)
     # a refused call must not poison the ones after it (sticky HIP error): the handle is still usable
     with pytest.raises(abi.EngineError):
-        abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=3, seed=1)
+        abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=5, seed=1)
     w.resample(d, 1)
     O.sbm_w_sweep(A, q, shift, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, st.niw, st.niw_self, 1, 9, 3)
     assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), st.c)

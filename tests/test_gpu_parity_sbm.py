@@ -65,7 +65,7 @@ def test_device_draws_bitexact(abi):
     assert np.array_equal(abi.selftest_draws(2, 9, [3.0, 40.5], 20000), O.beta_vec(9, 3.0, 40.5, 20000))
     alpha = np.array([0.5, 1.0, 7.0, 100.0, 3.0])
     assert np.array_equal(abi.selftest_draws(3, 11, alpha, 5000, stride=5), O.dirichlet_vec(11, alpha, 5000))
-    for B in [1, 2, 4]:
+    for B in [1, 2, 3, 4]:
         rng = np.random.RandomState(B)
         X = rng.randn(50, B) + 1.0
         niw = O.pack_niw(rng.randn(B), np.eye(B) * 1.5, B + 2, 0.7)
@@ -150,7 +150,7 @@ def test_w_node_lp_bitexact(abi, N, K, B, special):
 
 
 @pytest.mark.parametrize("N,K,B,special", [(60, 3, 1, 1), (150, 6, 2, 0), (260, 16, 1, 1), (300, 48, 1, 1), (260, 40, 2, 0),
-                                           (330, 24, 2, 1)])
+                                           (330, 24, 2, 1), (170, 5, 3, 1), (301, 20, 3, 0), (140, 40, 3, 1)])
 def test_w_chain_bitexact(abi, N, K, B, special):
     A, W, _ = planted_sbm(N, K, B=B, seed=5 * N)
     q, shift = O.quantise(A, W)
