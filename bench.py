@@ -264,7 +264,7 @@ def extra_big(abi, device, N=65536, K=64, burnin=12, warmup=2, steps=20):
     per_ms = r["bulk"]["w_ms"] / max(r["bulk"]["w_n"], 1)
     alg = r["bulk"]["w_bytes"] / max(r["bulk"]["w_n"], 1)
     ach = r["bulk"]["w_bytes"] / (r["bulk"]["w_ms"] * 1e-3) / 1e9 if r["bulk"]["w_ms"] > 0 else 0.0
-    sweep_bytes = 2.0 * N * N * 5.0
+    sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
     out = {"workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1 (BASELINE.json configs[3] on one GPU)" % (N, K),
            "value": steps / r["elapsed"], "unit": "sweeps/s", "ms_per_step": r["elapsed"] / steps * 1e3, "steps": steps,
            "burn_in_sweeps": burnin, "label_changes_per_sweep": r["changes"] / float(steps),
@@ -298,7 +298,7 @@ def extra_ais(abi, device, N=8192, R=3, B=100, steps_per_B=2):
                         "(BASELINE.json configs[4]; its 8 chains are independent, one per GPU)" % (R, N, B, steps_per_B),
             "value": nsweeps / el, "unit": "sweeps/s (including the per-temperature log-likelihood)", "seconds_per_chain": el,
             "tempered_sweeps": nsweeps, "log_likelihood_evaluations": B - 1, "log_Z_one_chain": float(logZ),
-            "sweep_algorithmic_bytes": 2.0 * N * N, "log_likelihood_algorithmic_bytes": 1.0 * N * N}
+            "sweep_algorithmic_bytes": 2.0 * N * N / 8.0, "log_likelihood_algorithmic_bytes": 1.0 * N * N / 8.0}
 
 
 def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
@@ -488,12 +488,12 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     digest = int(np.bitwise_xor.reduce(adj.get(abi.ST_C, (N,), np.int32) * np.arange(1, N + 1, dtype=np.int32)))
     cinfo = comm.info()
     if rank == 0:
-        sweep_bytes = 2.0 * N * N * (1.0 + 4.0)
+        sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
         print(json.dumps({
             "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": args.steps / el,
             "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int64 statistics / f64 conditionals (u8 adjacency, 24-bit fixed-point weights in int32)",
+            "dtype": "int64 statistics / f64 conditionals (bit-packed adjacency, 24-bit fixed-point weights in int32)",
             "data": "synthetic",
             "config": {"workload": "ONE Gaussian SBM chain, N=%d, K=%d, B=1, node-sharded over %d rank(s)" % (N, K, world),
                        "parallelism": "exact node sharding: all-reduce of K x K integer tables + all-gather of label changes "
@@ -618,7 +618,7 @@ def main():
         per_launch_ms = bulk["w_ms"] / max(bulk["w_n"], 1)
         alg_bytes = bulk["w_bytes"] / max(bulk["w_n"], 1)
         achieved = bulk["w_bytes"] / (bulk["w_ms"] * 1e-3) / 1e9 if bulk["w_ms"] > 0 else 0.0
-        sweep_bytes = 2.0 * N * N * (1.0 + 4.0)
+        sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
         sa_ms, sa_b = adj.bench_bulk(data, 20)
         sw_ms, sw_b = w.bench_bulk(data, 20)
         out = {
@@ -632,7 +632,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int64 statistics / f64 conditionals (u8 adjacency, 24-bit fixed-point weights in int32)",
+            "dtype": "int64 statistics / f64 conditionals (bit-packed adjacency, 24-bit fixed-point weights in int32)",
             "data": "synthetic",
             "config": {
                 "workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1, dense adjacency (%s)" % (
@@ -680,7 +680,7 @@ def main():
                 for _ in range(nll):
                     abi.log_likelihood_many([adj, w], data)
                 ell = time.perf_counter() - t0l
-                ll_bytes = float(N) * N * (1 + 4)
+                ll_bytes = float(N) * N * (0.125 + 4)
                 out["log_likelihood_sweep"] = {
                     "value": nll / ell, "unit": "evaluations/s", "ms": ell / nll * 1e3, "algorithmic_bytes": ll_bytes,
                     "effective_GBs": ll_bytes * nll / ell / 1e9,

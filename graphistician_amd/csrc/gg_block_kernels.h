@@ -85,49 +85,57 @@ __device__ __forceinline__ bool gg_find_slot(const int32_t* __restrict__ lab_sta
 
 // Adjacency: 16 uint8 per lane per row, SWAR byte counters (<= 255 rows per wave).
 // blockIdx.z selects the direction: 0 = out-statistics (reads X^T), 1 = in-statistics (reads X).
+// Single entry of a bit-packed adjacency matrix: `at` is the linear index row * Np + col of the byte layout (Np is a
+// multiple of 64, so rows are whole words).
+__device__ __forceinline__ bool gg_abit(const uint32_t* __restrict__ X, size_t at) { return (X[at >> 5] >> (at & 31)) & 1u; }
+
 // One (column strip, label slot, direction) work item of the adjacency pass; a workgroup of 256 threads.
+// The matrices are bit-packed (gg_data::Ab, AbT): a strip is 1024 columns = 32 words per row, so half a wave reads one row
+// (128 contiguous bytes) and the other half the next; every lane keeps BIT-SLICED counters for its 32 columns - plane b
+// holds bit b of each column's count, a row's word is added with a ripple of and / xor - and expands them to integers at
+// the end.  8 planes: at most 255 rows per lane (RW <= 1020 rows per slot, 8 rows in flight per workgroup).
 template <bool NTL>
-__device__ __forceinline__ void gg_bulk_adj_body(const uint8_t* __restrict__ XT, const uint8_t* __restrict__ X1,
+__device__ __forceinline__ void gg_bulk_adj_body(const uint32_t* __restrict__ XT, const uint32_t* __restrict__ X1,
                                                  int Np, const int32_t* __restrict__ perm,
                                                  const int32_t* __restrict__ lab_start, int K, int RW,
                                                  int32_t* __restrict__ G0, int32_t* __restrict__ G1, int dir, int strip,
                                                  int slot) {
   __shared__ unsigned int s_bins[1024];
-  const uint8_t* __restrict__ X = dir == 0 ? XT : X1;
+  const uint32_t* __restrict__ X = dir == 0 ? XT : X1;
   int32_t* __restrict__ G = dir == 0 ? G0 : G1;
   int k, row0, nrows;
   if (!gg_find_slot(lab_start, K, RW, slot, &k, &row0, &nrows)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col0 = strip * 1024 + lane * 16;
+  const int Wb = Np >> 5;                       // words per row
+  const int wcol = strip * 32 + (lane & 31);    // this lane's word within the row
+  const int rsub = wave * 2 + (lane >> 5);      // which of the 8 rows in flight is this lane's
   for (int i = tid; i < 1024; i += 256) s_bins[i] = 0;
   __syncthreads();
-  unsigned int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  if (col0 < Np) {
-    int r = wave;
-    for (; r + 12 < nrows; r += 16) {  // 4 rows in flight per wave
-      int i0 = perm[row0 + r], i1 = perm[row0 + r + 4], i2 = perm[row0 + r + 8], i3 = perm[row0 + r + 12];
-      uint4 v0 = gg_stream_load<NTL>(reinterpret_cast<const uint4*>(X + (size_t)i0 * Np + col0));
-      uint4 v1 = gg_stream_load<NTL>(reinterpret_cast<const uint4*>(X + (size_t)i1 * Np + col0));
-      uint4 v2 = gg_stream_load<NTL>(reinterpret_cast<const uint4*>(X + (size_t)i2 * Np + col0));
-      uint4 v3 = gg_stream_load<NTL>(reinterpret_cast<const uint4*>(X + (size_t)i3 * Np + col0));
-      a0 += v0.x + v1.x + v2.x + v3.x;
-      a1 += v0.y + v1.y + v2.y + v3.y;
-      a2 += v0.z + v1.z + v2.z + v3.z;
-      a3 += v0.w + v1.w + v2.w + v3.w;
-    }
-    for (; r < nrows; r += 4) {
-      int i0 = perm[row0 + r];
-      uint4 v0 = gg_stream_load<NTL>(reinterpret_cast<const uint4*>(X + (size_t)i0 * Np + col0));
-      a0 += v0.x; a1 += v0.y; a2 += v0.z; a3 += v0.w;
-    }
-    unsigned int acc[4] = {a0, a1, a2, a3};
+  unsigned pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto add = [&](unsigned w) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int b = 0; b < 8; ++b) {
+      const unsigned t = pl[b] & w;
+      pl[b] ^= w;
+      w = t;
+    }
+  };
+  if (wcol < Wb) {
+    int r = rsub;
+    for (; r + 24 < nrows; r += 32) {      // 4 rows in flight per lane
+      const int i0 = perm[row0 + r], i1 = perm[row0 + r + 8], i2 = perm[row0 + r + 16], i3 = perm[row0 + r + 24];
+      const unsigned w0 = X[(size_t)i0 * Wb + wcol], w1 = X[(size_t)i1 * Wb + wcol], w2 = X[(size_t)i2 * Wb + wcol],
+                     w3 = X[(size_t)i3 * Wb + wcol];
+      add(w0); add(w1); add(w2); add(w3);
+    }
+    for (; r < nrows; r += 8) add(X[(size_t)perm[row0 + r] * Wb + wcol]);
+#pragma unroll 4
+    for (int c = 0; c < 32; ++c) {
+      unsigned v = 0;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        unsigned int v = (acc[w] >> (8 * b)) & 255u;
-        if (v) atomicAdd(&s_bins[lane * 16 + w * 4 + b], v);
-      }
+      for (int b = 0; b < 8; ++b) v |= ((pl[b] >> c) & 1u) << b;
+      if (v) atomicAdd(&s_bins[(lane & 31) * 32 + c], v);
+    }
   }
   __syncthreads();
   for (int i = tid; i < 1024; i += 256) {
@@ -138,7 +146,7 @@ __device__ __forceinline__ void gg_bulk_adj_body(const uint8_t* __restrict__ XT,
 }
 
 template <bool NTL>
-__global__ __launch_bounds__(256) void k_bulk_adj(const uint8_t* __restrict__ XT, const uint8_t* __restrict__ X1,
+__global__ __launch_bounds__(256) void k_bulk_adj(const uint32_t* __restrict__ XT, const uint32_t* __restrict__ X1,
                                                   int Np, const int32_t* __restrict__ perm,
                                                   const int32_t* __restrict__ lab_start, int K, int RW,
                                                   int32_t* __restrict__ G0, int32_t* __restrict__ G1, int dir0,
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, 
 // X^T while those few hundred workgroups wait on dependent loads.  Every sweep still streams all of the data once; a scan
 // that does change a label stalls the pipeline as before, and the riders' statistics are discarded.
 struct gg_ride_args {
-  const void* XT;            // adjacency: uint8 A^T / A; weights: int32 Wq^T / Wq
+  const void* XT;            // adjacency: bit-packed A^T / A (uint32 words); weights: int32 Wq^T / Wq
   const void* X1;
   int Np, K, RW;
   const int32_t* perm;       // label sort the sweep starts with
@@ -341,7 +349,7 @@ __device__ __forceinline__ void gg_ride(const gg_ride_args& r) {
   for (int w = r.w0 + ((int)blockIdx.x - r.front); w < r.w1; w += r.nriders) {
     const int strip = w % r.strips, sl = (w / r.strips) % r.nslots, dir = w / (r.strips * r.nslots);
     if (ADJ)
-      gg_bulk_adj_body<NTL>(reinterpret_cast<const uint8_t*>(r.XT), reinterpret_cast<const uint8_t*>(r.X1), r.Np, r.perm, r.lab_start,
+      gg_bulk_adj_body<NTL>(reinterpret_cast<const uint32_t*>(r.XT), reinterpret_cast<const uint32_t*>(r.X1), r.Np, r.perm, r.lab_start,
                             r.K, r.RW, r.Gc0, r.Gc1, dir, strip, sl);
     else
       gg_bulk_w_body<B, 4, NTL>(reinterpret_cast<const int32_t*>(r.XT), reinterpret_cast<const int32_t*>(r.X1), r.Np, r.perm,

@@ -77,6 +77,7 @@ static inline int gg_nsi(int B) { return B + B * (B + 1) / 2; }
 
 // Device-resident network.  Layout:
 //   A, AT   : uint8  [N][Np]      off-diagonal adjacency and its transpose (diag = 0, pad = 0)
+//   Ab, AbT : uint32 [N][Np/32]   the same, bit-packed (block adjacency models: 1/8 of the bytes per pass)
 //   Wq, WqT : int32  [N][Np][B]   fixed-point weights, GG_NO_EDGE in component 0 where A == 0 / diag / pad
 //   dA, dWq : the diagonal, kept apart because the reference special-cases self connections
 struct gg_data {
@@ -87,6 +88,10 @@ struct gg_data {
   int shift;
   long long n_edges;
   uint8_t *A, *AT, *dA;
+  // the same off-diagonal adjacency and its transpose, one BIT per entry ([N][Np / 32] words, bit j of row i = A[i][j]):
+  // what the block adjacency models read (their bulk pass counts by positional popcount, their scans test single bits);
+  // the byte matrices stay for the kernels that want whole rows as bytes (eigenmodel, latent-distance) and for download
+  uint32_t *Ab, *AbT;
   int32_t *Wq, *WqT, *dWq;
   // label-independent diagonal statistics (exact)
   long long d1;                              // number of self edges

@@ -155,6 +155,8 @@ static int alloc_data(gg_data* d) {
   GG_HIP(hipMalloc(&d->A, nA));
   GG_HIP(hipMalloc(&d->AT, nA));
   GG_HIP(hipMalloc(&d->dA, (size_t)d->N));
+  GG_HIP(hipMalloc((void**)&d->Ab, nA / 8));
+  GG_HIP(hipMalloc((void**)&d->AbT, nA / 8));
   GG_HIP(hipMemsetAsync(d->A, 0, nA, d->stream));
   GG_HIP(hipMemsetAsync(d->AT, 0, nA, d->stream));
   if (d->has_w) {
@@ -165,6 +167,31 @@ static int alloc_data(gg_data* d) {
     k_fill_i32<<<2048, 256, 0, d->stream>>>(d->Wq, nW, d->B, GG_NO_EDGE);
     k_fill_i32<<<2048, 256, 0, d->stream>>>(d->WqT, nW, d->B, GG_NO_EDGE);
   }
+  return GG_OK;
+}
+
+// 32 adjacency bytes -> one word of the bit matrix (bit j of the word = byte j != 0).
+__global__ void k_pack_bits(const uint8_t* __restrict__ A, uint32_t* __restrict__ Ab, size_t nwords) {
+  size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; w < nwords; w += stride) {
+    const uint4* src = reinterpret_cast<const uint4*>(A + w * 32);
+    const uint4 lo = src[0], hi = src[1];
+    const unsigned v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned bits = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bits |= (((v[q] >> (8 * b)) & 255u) ? 1u : 0u) << (4 * q + b);
+    Ab[w] = bits;
+  }
+}
+
+static int pack_bits(gg_data* d) {
+  const size_t nwords = (size_t)d->N * d->Np / 32;
+  k_pack_bits<<<2048, 256, 0, d->stream>>>(d->A, d->Ab, nwords);
+  k_pack_bits<<<2048, 256, 0, d->stream>>>(d->AT, d->AbT, nwords);
+  GG_HIP(hipGetLastError());
   return GG_OK;
 }
 
@@ -180,7 +207,7 @@ static int make_transposes(gg_data* d) {
     }
   }
   GG_HIP(hipGetLastError());
-  return GG_OK;
+  return pack_bits(d);
 }
 
 static void diag_stats_host(gg_data* d, const uint8_t* dA, const int32_t* dWq) {
@@ -371,6 +398,7 @@ static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c
                                                      p_self, dmu, dsd, mu_self, sqrt(sigma_self), seed,
                                                      ldexp(1.0, d->shift), 1 << qb);
     GG_HIP(hipGetLastError());
+    if ((rc = pack_bits(d))) return rc;
   }
   std::vector<uint8_t> hdA(Nl);
   std::vector<int32_t> hdW(Nl);
@@ -424,6 +452,7 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
   GG_HIP(hipMemcpyAsync(d->A, hA.data(), nA, hipMemcpyHostToDevice, d->stream));
   GG_HIP(hipMemcpyAsync(d->AT, hAT.data(), nA, hipMemcpyHostToDevice, d->stream));
   GG_HIP(hipMemcpyAsync(d->dA, hdA.data(), Nl, hipMemcpyHostToDevice, d->stream));
+  { int rcp = pack_bits(d); if (rcp) { gg_data_destroy(d); return rcp; } }
   std::vector<int32_t> hW, hWT, hdW;
   if (W) {
     double wmax = 0.0;   // global scale: identical on every rank
@@ -496,6 +525,8 @@ static void data_free(gg_data* d) {
   hipSetDevice(d->device);
   if (d->A) hipFree(d->A);
   if (d->AT) hipFree(d->AT);
+  if (d->Ab) hipFree(d->Ab);
+  if (d->AbT) hipFree(d->AbT);
   if (d->dA) hipFree(d->dA);
   if (d->Wq) hipFree(d->Wq);
   if (d->WqT) hipFree(d->WqT);

@@ -617,7 +617,7 @@ static bulk_shape bulk_shape_of(const gg_model* m, int ndirs) {
   b.RW = bulk_rw(m, b.strips, ndirs);
   b.nslots = (m->N + b.RW - 1) / b.RW + m->K;
   // non-temporal loads once a pass streams more than the Infinity Cache holds (see gg_stream_load)
-  b.ntl = (double)ndirs * m->N * (double)m->Np * (m->is_adj ? 1.0 : 4.0 * m->B) > gg_nt_threshold();
+  b.ntl = (double)ndirs * m->N * (double)m->Np * (m->is_adj ? 0.125 : 4.0 * m->B) > gg_nt_threshold();
   return b;
 }
 
@@ -640,10 +640,10 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   const int RW = bs.RW;
   if (m->is_adj) {
     if (bs.ntl)
-      k_bulk_adj<true><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
+      k_bulk_adj<true><<<grd, 256, 0, st>>>(d->AbT, d->Ab, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
     else
-      k_bulk_adj<false><<<grd, 256, 0, st>>>(d->AT, d->A, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
-    if (timed) m->ev_bytes.push_back((double)ndirs * N * (double)N);
+      k_bulk_adj<false><<<grd, 256, 0, st>>>(d->AbT, d->Ab, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
+    if (timed) m->ev_bytes.push_back((double)ndirs * N * (double)N / 8.0);
   } else {
     const bool ntl = bs.ntl;
 #define BULKW(BV, UV)                                                                                                 \
@@ -678,8 +678,8 @@ static gg_ride_args make_ride(const gg_model* m, const gg_data* d, int nbuf, int
   gg_ride_args r;
   memset(&r, 0, sizeof(r));
   const bulk_shape bs = bulk_shape_of(m, 2);
-  r.XT = m->is_adj ? (const void*)d->AT : (const void*)d->WqT;
-  r.X1 = m->is_adj ? (const void*)d->A : (const void*)d->Wq;
+  r.XT = m->is_adj ? (const void*)d->AbT : (const void*)d->WqT;
+  r.X1 = m->is_adj ? (const void*)d->Ab : (const void*)d->Wq;
   r.Np = m->Np; r.K = m->K; r.RW = bs.RW;
   r.perm = m->permb[P]; r.lab_start = m->labb[P];
   r.Gc0 = gcnt(m, nbuf, 0); r.Gc1 = gcnt(m, nbuf, 1); r.Gs0 = gs(m, nbuf, 0); r.Gs1 = gs(m, nbuf, 1);
@@ -703,7 +703,7 @@ static gg_ride_args make_ride(const gg_model* m, const gg_data* d, int nbuf, int
   }
   *nriders = r.nriders;
   *ntl = bs.ntl ? 1 : 0;
-  if (bytes) *bytes = 2.0 * m->N * (double)m->N * (m->is_adj ? 1.0 : 4.0 * m->B) * (double)(r.w1 - r.w0) / (double)(W > 0 ? W : 1);
+  if (bytes) *bytes = 2.0 * m->N * (double)m->N * (m->is_adj ? 0.125 : 4.0 * m->B) * (double)(r.w1 - r.w0) / (double)(W > 0 ? W : 1);
   return r;
 }
 
@@ -844,7 +844,7 @@ static gg_resolve_args fill_spec_args(gg_model* m, const gg_data* d, int buf, ui
   g.flush_on_change = 0; g.sweep_from_ctl = 0; g.round_mode = 0; g.window = 0; g.stage_tables = 0;
   g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
   g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
-  g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
+  g.XA = d->Ab; g.XAT = d->AbT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = nullptr;
   g.keep_L = 0;
@@ -977,7 +977,7 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
   g.stage_tables = m->resolve_stage ? 1 : 0;
   g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
   g.Lmax = m->Lmax; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
-  g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
+  g.XA = d->Ab; g.XAT = d->AbT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = nullptr;
   g.keep_L = 0;
@@ -1006,7 +1006,7 @@ static int launch_apply_L(gg_model* m, const gg_data* d, int buf, int mode = 0, 
   int nb = (m->Nl + 255) / 256;
 #define APL(NTV, ADJV)                                                                                             \
   k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, m->ap, gcnt(m, buf, 0), gcnt(m, buf, 1),          \
-                                                  gs(m, buf, 0), gs(m, buf, 1), d->A, d->AT, d->Wq, d->WqT, mode)
+                                                  gs(m, buf, 0), gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT, mode)
   if (m->is_adj) APL(2, true);
   else if (m->B == 1) APL(3, false);
   else if (m->B == 2) APL(6, false);
@@ -1035,7 +1035,7 @@ static int launch_round(gg_model* m, const gg_data* d, int buf, uint32_t sweep, 
   g.stage_tables = 0;
   g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
   g.Lmax = m->Lcap; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 0;
-  g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
+  g.XA = d->Ab; g.XAT = d->AbT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = m->dbg;
   g.keep_L = 0;
@@ -1092,7 +1092,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   g.flush_on_change = 0; g.sweep_from_ctl = 0; g.round_mode = 0; g.window = 0;
   g.site_m = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
   g.Lmax = m->Lcap; g.max_idle = m->max_idle; g.CH = m->CH; g.fresh = 1;
-  g.XA = d->A; g.XAT = d->AT; g.XW = d->Wq; g.XWT = d->WqT;
+  g.XA = d->Ab; g.XAT = d->AbT; g.XW = d->Wq; g.XWT = d->WqT;
   g.seed = m->cfg.seed; g.site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C; g.sweep = sweep;
   g.dbg = m->dbg;
   g.keep_L = 0;
@@ -1909,7 +1909,7 @@ int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_la
   float ms = 0;
   GG_HIP(hipEventElapsedTime(&ms, m->ev_call0, m->ev_call1));
   *ms_per_launch = ms / (reps > 0 ? reps : 1);
-  if (bytes_per_launch) *bytes_per_launch = 2.0 * m->N * (double)m->N * (m->is_adj ? 1.0 : 4.0 * m->B);
+  if (bytes_per_launch) *bytes_per_launch = 2.0 * m->N * (double)m->N * (m->is_adj ? 0.125 : 4.0 * m->B);
   m->zeroed[buf] = false;
   m->timing = t0;
   m->st.bulk_bytes = 0; m->st.bulk_launches = 0;

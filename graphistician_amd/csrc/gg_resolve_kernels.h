@@ -50,8 +50,8 @@ struct gg_resolve_args {
   int max_idle;
   int CH;
   int fresh;     // 1: L is empty on entry
-  const uint8_t* XA;   // adjacency rows / transposed rows
-  const uint8_t* XAT;
+  const uint32_t* XA;   // adjacency / its transpose, bit-packed (gg_abit)
+  const uint32_t* XAT;
   const int32_t* XW;   // weights
   const int32_t* XWT;
   uint64_t seed;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
     }
     for (int idx = tid; idx < nch * nch; idx += nth) {
       int i2 = idx % nch, i1 = idx / nch;
-      if (ADJ) s_blka[i1 * CH + i2] = g.XA[(size_t)(pos0 + i1) * Np + pos0 + i2];
+      if (ADJ) s_blka[i1 * CH + i2] = gg_abit(g.XA, (size_t)(pos0 + i1) * Np + pos0 + i2) ? 1 : 0;
       else
         for (int r = 0; r < B; ++r)
           s_blkw[(i1 * CH + i2) * B + r] = g.XW[((size_t)(pos0 + i1) * Np + pos0 + i2) * B + r];
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
       long long* gso = ADJ ? nullptr : &s_gs[((size_t)(0 * CH + i) * K) * NSI];
       long long* gsi = ADJ ? nullptr : &s_gs[((size_t)(1 * CH + i) * K) * NSI];
       if (ADJ) {
-        gg_apply_edge<NT, ADJ>(gco, gso, a, b, K, nullptr, g.XAT[at] != 0);  // edge (pos0+i) -> n2
-        gg_apply_edge<NT, ADJ>(gci, gsi, a, b, K, nullptr, g.XA[at] != 0);   // edge n2 -> (pos0+i)
+        gg_apply_edge<NT, ADJ>(gco, gso, a, b, K, nullptr, gg_abit(g.XAT, at));  // edge (pos0+i) -> n2
+        gg_apply_edge<NT, ADJ>(gci, gsi, a, b, K, nullptr, gg_abit(g.XA, at));   // edge n2 -> (pos0+i)
       } else {
         const int32_t* qo = g.XWT + at * B;
         const int32_t* qi = g.XW + at * B;
@@ -490,8 +490,8 @@ __global__ __launch_bounds__(256, (SPLIT ? 1 : GG_RIDE_WAVES)) void k_sweep_q(gg
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* __restrict__ L,
                                                  const int32_t* __restrict__ rs, int32_t* __restrict__ ap, int32_t* Gc0,
-                                                 int32_t* Gc1, long long* Gs0, long long* Gs1, const uint8_t* XA,
-                                                 const uint8_t* XAT, const int32_t* XW, const int32_t* XWT, int mode) {
+                                                 int32_t* Gc1, long long* Gs0, long long* Gs1, const uint32_t* XA,
+                                                 const uint32_t* XAT, const int32_t* XW, const int32_t* XWT, int mode) {
   // mode 0: flush between restart rounds (nothing to do once the scan is done); mode 1: end-of-scan flush of
   // the incremental-statistics pipeline (nothing to do behind a stalled scan: the slow path flushes); 2: always
   constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
     const int n2 = L[e * 3], a = L[e * 3 + 1], b = L[e * 3 + 2];
     const size_t at = (size_t)n2 * Np + n;
     if (ADJ) {
-      int xo = XAT[at] != 0, xi = XA[at] != 0;
+      int xo = gg_abit(XAT, at) ? 1 : 0, xi = gg_abit(XA, at) ? 1 : 0;
       if (xo) { Gc0[(size_t)a * Np + n] -= 1; Gc0[(size_t)b * Np + n] += 1; }
       if (xi) { Gc1[(size_t)a * Np + n] -= 1; Gc1[(size_t)b * Np + n] += 1; }
     } else {
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
       if (ADJ) {
         uint8_t xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = dd[u] == 0 ? g.XAT[at[u]] : g.XA[at[u]];
+        for (int u = 0; u < U; ++u) xv[u] = gg_abit(dd[u] == 0 ? g.XAT : g.XA, at[u]) ? 1 : 0;
 #pragma unroll
         for (int u = 0; u < U; ++u)
           if (ok[u] && xv[u] != 0) {

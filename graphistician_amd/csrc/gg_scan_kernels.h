@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         if (ADJ) {
           uint8_t xv[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) xv[u] = dd[u] == 0 ? g.XAT[at[u]] : g.XA[at[u]];
+          for (int u = 0; u < U; ++u) xv[u] = gg_abit(dd[u] == 0 ? g.XAT : g.XA, at[u]) ? 1 : 0;
 #pragma unroll
           for (int u = 0; u < U; ++u)
             if (ok[u] && xv[u] != 0) move_edge(dd[u], ii[u], ia[u], ib[u], nullptr);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         if (n0 + i < N && n0 + i != f) {
           const size_t at = (size_t)f * Np + n0 + i;
           if (ADJ) {
-            if ((d == 0 ? g.XAT[at] : g.XA[at]) != 0) move_edge(d, i, ca, cb, nullptr);
+            if (gg_abit(d == 0 ? g.XAT : g.XA, at)) move_edge(d, i, ca, cb, nullptr);
           } else {
             const int32_t* q = (d == 0 ? g.XWT : g.XW) + at * B;
             int32_t qq[B];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
             const size_t at = (size_t)n2 * Np + n;
             for (int d = 0; d < 2; ++d) {
               if (ADJ) {
-                if ((d == 0 ? g.XAT[at] : g.XA[at]) != 0) { a.Gc0[d * dstride + (size_t)ba * Np + n] -= 1; a.Gc0[d * dstride + (size_t)bb * Np + n] += 1; }
+                if (gg_abit(d == 0 ? g.XAT : g.XA, at)) { a.Gc0[d * dstride + (size_t)ba * Np + n] -= 1; a.Gc0[d * dstride + (size_t)bb * Np + n] += 1; }
               } else {
                 const int32_t* q = (d == 0 ? g.XWT : g.XW) + at * B;
                 if (q[0] == GG_NO_EDGE) continue;
