@@ -343,6 +343,9 @@ struct gg_ride_args {
 // Riders are persistent: `nriders` workgroups walk the work items with that stride.  Their number bounds the bytes the pass
 // keeps in flight (workgroups x 4 waves x 4 KB), and with it the loaded latency every dependent load of the front
 // workgroups sees: enough in flight to saturate HBM, not four times that (measured: DESIGN.md section 5).
+#ifndef GG_RIDE_U
+#define GG_RIDE_U 8   // rows a rider wave keeps in flight (measured at N=4096: 8 rows x 256-row items 31.8 us per sweep of the weight model alone, 4 x 192: 35.0)
+#endif
 template <bool ADJ, int B, bool NTL>
 __device__ __forceinline__ void gg_ride(const gg_ride_args& r) {
   for (int i = 0; i < r.delay; ++i) __builtin_amdgcn_s_sleep(127);
@@ -352,7 +355,7 @@ __device__ __forceinline__ void gg_ride(const gg_ride_args& r) {
       gg_bulk_adj_body<NTL>(reinterpret_cast<const uint32_t*>(r.XT), reinterpret_cast<const uint32_t*>(r.X1), r.Np, r.perm, r.lab_start,
                             r.K, r.RW, r.Gc0, r.Gc1, dir, strip, sl);
     else
-      gg_bulk_w_body<B, 4, NTL>(reinterpret_cast<const int32_t*>(r.XT), reinterpret_cast<const int32_t*>(r.X1), r.Np, r.perm,
+      gg_bulk_w_body<B, GG_RIDE_U, NTL>(reinterpret_cast<const int32_t*>(r.XT), reinterpret_cast<const int32_t*>(r.X1), r.Np, r.perm,
                                 r.lab_start, r.K, r.RW, r.Gc0, r.Gc1, r.Gs0, r.Gs1, dir, strip, sl);
     __syncthreads();   // the body's LDS bins are reused by the next item
   }

@@ -580,11 +580,10 @@ static int bulk_rw(const gg_model* m, int strips, int ndirs) {
     if (o > 0) return o > 1020 ? 1020 : (o + 3) / 4 * 4;
   }
   (void)strips; (void)ndirs;
-  // Rows per workgroup, measured on MI355X inside the whole sweep (both halves' passes share the chip): at N=4096 the
-  // weight pass is fastest at 160-192 rows (5.45 TB/s alone against 5.2 at 128), and the adjacency pass, which has slack,
-  // disturbs it least at 192-256 rows (fewer, longer workgroups: its own rate falls from 4.0 to 3.1 TB/s, the sweep gains
-  // 4 %); N=16384 prefers 512-768 for both.  Larger N keeps the same number of row slots per label.
-  long long rw = (long long)m->N * 3 / 64;
+  // Rows per workgroup, measured on MI355X inside the whole sweep (round 2, riders of the ahead form, the weight model alone:
+  // 128 rows 33.7 us per sweep, 192: 35.0, 256: 31.8 with 8 rows in flight per wave, 384: 34.5, 512: 38.0; the plain kernel
+  // of the serial form is within 2 % over 160-256).  Larger N keeps the same number of row slots per label.
+  long long rw = (long long)m->N / 16;
   rw = (rw + 3) / 4 * 4;
   if (rw < 16) rw = 16;
   if (rw > 1020) rw = 1020;
