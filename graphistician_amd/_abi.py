@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "_build", "libgraphgibbs.so")
 # enums of include/graphgibbs.h
 SBM_ADJ, BB_ADJ, BERN_ADJ, SBM_GAUSS_W, NIW_W, FIXED_W, LOGISTIC_EIG, PROBIT_EIG, LATENT_DIST, SBM_GAUSS_SHCOV_W = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 LATENT_DIST_W = 11
+SBM_JOINT = 12
 (ST_C, ST_M, ST_PI, ST_P, ST_P_SELF, ST_MU, ST_SIGMA, ST_MU_SELF, ST_SIGMA_SELF, ST_NIW, ST_NIW_SELF, ST_SWEEP, ST_F,
  ST_LMBDA, ST_MU0, ST_MU_LMBDA) = range(1, 17)
 ST_OMEGA_S = 17

@@ -15,6 +15,18 @@
 #include "gg_common.h"
 #include "spec/gg_shcov.h"
 
+// ------------------------------------------------------------------ statistics per (node, block) as a template constant
+// Every scan kernel is instantiated on NT, the number of spec-order doubles per (direction, block) of a node's conditional
+// (gg_lp.h): 2 = adjacency {ones, zeros}; 3 / 6 / 10 / 15 = Gaussian weights of dimension B = 1..4 {n, s1_r, s2_rs};
+// 4 / 7 / 11 / 16 = the JOINT model (one label vector for adjacency and weights, stochastic_block_model.py:252-302):
+// the Gaussian statistics followed by the number of potential partners in the block, whose coefficient is log(1 - p)
+// (gg_joint_table).  Integer statistics kept per node: NSI = B + B (B + 1) / 2 in both weight forms, none for the adjacency.
+__host__ __device__ constexpr bool gg_tJ(int NT) { return NT == 4 || NT == 7 || NT == 11 || NT == 16; }
+__host__ __device__ constexpr int gg_tB(int NT) {
+  return (NT == 2 || NT == 3 || NT == 4) ? 1 : ((NT == 6 || NT == 7) ? 2 : ((NT == 10 || NT == 11) ? 3 : 4));
+}
+__host__ __device__ constexpr int gg_tNSI(int NT) { return NT == 2 ? 1 : NT - 1 - (gg_tJ(NT) ? 1 : 0); }
+
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ long long gg_shfl_down_ll(long long v, int delta) {
   int lo = __shfl_down((int)(v & 0xffffffffll), delta);
@@ -541,12 +553,13 @@ __device__ __forceinline__ bool gg_wait_verdict(int32_t* ctl, unsigned* verdict,
 
 // The parameter step of one workgroup (`bid` of `nfront`).  gate_tag != 0: nothing is written before the verdict of the
 // scan that runs in the same launch has arrived, and nothing at all if that scan changed a label.
-template <bool ADJ, int B>
+template <bool ADJ, int B, bool JOINT = false>
 __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid, const unsigned nfront, const unsigned gate_tag) {
   const int K = g.K;
   constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
   constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;
-  constexpr int NT = ADJ ? 2 : (1 + B + B * (B + 1) / 2);
+  constexpr int NTG = 1 + B + B * (B + 1) / 2;            // Gaussian coefficients
+  constexpr int NT = ADJ ? 2 : NTG + (JOINT ? 1 : 0);     // + the joint model's partner coefficient
   auto housekeeping = [&]() {
     if (g.do_prep && bid == 0 && threadIdx.x == 0) {   // a new scan follows: reset its per-scan words
       g.ctl[7] = 0;
@@ -718,9 +731,24 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
           bad = true;
           for (int i = 0; i < NT; ++i) e[i] = gg_nan();
         }
+        double pj = 0.0;
+        if (JOINT) {
+          // stochastic_block_model.py:232-250 resample_p: edges / non-edges of the block pair, the diagonal included
+          if (g.do_draw) {
+            const long long n1 = s_tab[0];
+            const long long pairs = (long long)g.cnt[a] * (long long)g.cnt[b];
+            gg_stream sp;
+            gg_stream_init(&sp, g.seed, GG_SITE_ADJ_P, g.sweep, (uint32_t)t);
+            pj = gg_beta(&sp, g.ah.tau1 + g.beta * (double)n1, g.ah.tau0 + g.beta * (double)(pairs - n1));
+          } else {
+            pj = g.p[t];
+          }
+          if (g.do_prep && !bad) gg_joint_table(e, NTG, pj);
+        }
         if (gate_tag && !early_gate) commit = gg_poll_verdict(g.ctl, g.verdict, gate_tag, 0);
         if (commit) {
           if (bad) atomicOr(&g.ctl[3], 1);
+          if (JOINT && g.do_draw) g.p[t] = pj;
           if (g.do_draw && !g.shared) {
             for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
             for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
@@ -788,7 +816,7 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
   }
 }
 
-template <bool ADJ, int B, int RIDE = 0>   // RIDE: 0 none, 1 riders with plain loads, 2 riders with non-temporal loads
+template <bool ADJ, int B, int RIDE = 0, bool JOINT = false>   // RIDE: 0 none, 1 riders with plain loads, 2 riders with non-temporal loads
 __global__ __launch_bounds__(256) void k_params(gg_params_args g, gg_ride_args ride = gg_ride_args()) {
   if (g.ctl[4]) return;
   if (RIDE && (int)blockIdx.x >= ride.front) {
@@ -796,7 +824,7 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g, gg_ride_args r
     return;
   }
   const unsigned nfront = RIDE ? (unsigned)ride.front : gridDim.x;   // the workgroups that do k_params' own work
-  gg_params_body<ADJ, B>(g, (int)blockIdx.x, nfront, 0u);
+  gg_params_body<ADJ, B, JOINT>(g, (int)blockIdx.x, nfront, 0u);
 }
 
 #define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index)
@@ -862,7 +890,7 @@ __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n,
 #pragma unroll
   for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_i[t], lp);
   if (!x.special) {
-    constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+    constexpr int B = gg_tB(NT);
     const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
     double self[NT];
     if (ADJ) {
@@ -879,6 +907,7 @@ __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n,
         for (int r = 0; r < B; ++r)
           for (int s = r; s < B; ++s) self[t++] = (double)((long long)q[r] * (long long)q[s]) * sc2;
       }
+      if (gg_tJ(NT)) self[NT - 1] = 1.0;   // the node is its own one potential partner (stochastic_block_model.py:291-296)
     }
     double acc = 0.0;
 #pragma unroll
@@ -1020,8 +1049,8 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
 template <int NT, bool ADJ>
 __device__ __forceinline__ void gg_stats_to_double(int cnt_o, int cnt_i, const long long* so_i, const long long* si_i,
                                                    int cx, double sc1, double sc2, double* so, double* si) {
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
-  constexpr int NSI = NT - 1;
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
   if (ADJ) {
     so[0] = (double)cnt_o; so[1] = (double)(cx - cnt_o);
     si[0] = (double)cnt_i; si[1] = (double)(cx - cnt_i);
@@ -1034,6 +1063,7 @@ __device__ __forceinline__ void gg_stats_to_double(int cnt_o, int cnt_i, const l
       so[1 + s] = (double)so_i[s] * sc;
       si[1 + s] = (double)si_i[s] * sc;
     }
+    if (gg_tJ(NT)) { so[NT - 1] = (double)cx; si[NT - 1] = (double)cx; }   // joint model: potential partners in the block
   }
 }
 
@@ -1041,10 +1071,10 @@ template <int NT, bool ADJ>
 __device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n, int k) {
   const int cn = x.c[x.n0 + n];
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
-  constexpr int NSI = NT - 1;
+  constexpr int NSI = gg_tNSI(NT);
   auto ld = [&](int j, double* so, double* si) {
     const size_t gi = (size_t)j * x.Np + n;
-    int cx = ADJ ? (x.cnt[j] - (cn == j ? 1 : 0)) : 0;
+    int cx = (ADJ || gg_tJ(NT)) ? (x.cnt[j] - (cn == j ? 1 : 0)) : 0;
     long long a[NSI > 0 ? NSI : 1], b[NSI > 0 ? NSI : 1];
     if (!ADJ) {
 #pragma unroll
@@ -1068,7 +1098,7 @@ template <int NT, bool ADJ, int UJ_ = 0, int SPLIT = -1>
 __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, uint64_t seed, uint32_t site, uint32_t sweep,
                                             int lp_node, double* __restrict__ lp_out, int stage_tables, int* n_out,
                                             bool* live_out) {
-  constexpr int NSI = ADJ ? 0 : NT - 1;
+  constexpr int NSI = ADJ ? 0 : gg_tNSI(NT);
   extern __shared__ __align__(16) unsigned char s_spec[];
   const int K = x.K, Kp = x.Kp;
   const int per = 256 / Kp;
@@ -1091,10 +1121,11 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
       dst[0] = (double)gc;
       dst[ts] = (double)(cx - gc);
     } else {
-      constexpr int B = (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+      constexpr int B = gg_tB(NT);
       dst[0] = (double)gc;
 #pragma unroll
       for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
+      if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0));
     }
   }
   const int ntab = K * NT * Kp;
@@ -1265,6 +1296,7 @@ struct gg_ll_args {
   const double *p, *p_self, *mu, *sigma, *mu_self, *sigma_self;
   long long d1, d0;
   long long dS[GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];
+  int joint;            // GG_SBM_JOINT: Bernoulli terms of every block pair (diagonal included) on top of the Gaussian ones
   int diag_zero;        // adjacency.py:525-526 with the special case: the diagonal has probability 0
   double* out;          // out[0] = log-likelihood, out[1] = 1.0 if a covariance was not positive definite
 };
@@ -1305,6 +1337,7 @@ __global__ __launch_bounds__(256) void k_loglik(gg_ll_args g) {
     } else {
       const long long* e = g.tab + (size_t)ab * g.NTAB;
       acc += gg_ll_gauss(g.mu + (size_t)ab * g.B, g.sigma + (size_t)ab * g.B * g.B, g.B, g.NSI, (double)e[0], e + 1, sc1, sc2, &bad);
+      if (g.joint) acc += gg_ll_bern(g.p[ab], e[0], (long long)g.cnt[a] * g.cnt[b] - e[0]);
     }
   }
   if (bad) atomicOr(&s_bad, 1);

@@ -39,6 +39,7 @@ struct gg_model {
   gg_config cfg;
   int kind;
   bool is_adj, is_block, sbm;
+  bool joint;                           // GG_SBM_JOINT: a weight model that also carries p and the adjacency terms of the conditional
   int N, K, Kp, B, NT, NSI, Np, NTAB;   // N = all nodes (labels, rows); Np = padded number of OWNED nodes
   int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded)
   bool sharded;
@@ -133,7 +134,7 @@ static void set_pend_data(gg_model* m, const gg_data* d) {
 
 static int model_kind_ok(int kind) {
   return kind == GG_SBM_ADJ || kind == GG_BB_ADJ || kind == GG_BERN_ADJ || kind == GG_SBM_GAUSS_W || kind == GG_NIW_W ||
-         kind == GG_FIXED_W || kind == GG_SBM_GAUSS_SHCOV_W;
+         kind == GG_FIXED_W || kind == GG_SBM_GAUSS_SHCOV_W || kind == GG_SBM_JOINT;
 }
 
 template <typename T>
@@ -229,7 +230,8 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->cfg = *cfg;
   m->kind = cfg->kind;
   m->is_adj = (cfg->kind == GG_SBM_ADJ || cfg->kind == GG_BB_ADJ || cfg->kind == GG_BERN_ADJ);
-  m->sbm = (cfg->kind == GG_SBM_ADJ || cfg->kind == GG_SBM_GAUSS_W || cfg->kind == GG_SBM_GAUSS_SHCOV_W);
+  m->sbm = (cfg->kind == GG_SBM_ADJ || cfg->kind == GG_SBM_GAUSS_W || cfg->kind == GG_SBM_GAUSS_SHCOV_W || cfg->kind == GG_SBM_JOINT);
+  m->joint = cfg->kind == GG_SBM_JOINT;
   m->is_block = true;
   m->N = cfg->N;
   m->K = m->sbm ? cfg->K : 1;
@@ -239,13 +241,17 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d: the HIP engine supports B in 1..%d", cfg->B, GG_MAXB);
   }
-  if ((cfg->kind == GG_SBM_ADJ || cfg->kind == GG_BB_ADJ) &&
+  if (m->joint && m->B > 2) {
+    delete m;
+    return gg_fail(GG_ERR_UNSUPPORTED, "GG_SBM_JOINT: weight dimension B=%d (the joint model's scan kernels are built for B <= 2)", cfg->B);
+  }
+  if ((cfg->kind == GG_SBM_ADJ || cfg->kind == GG_BB_ADJ || cfg->kind == GG_SBM_JOINT) &&
       !(cfg->tau1 > 0.0 && cfg->tau0 > 0.0 && cfg->tau1 - cfg->tau1 == 0.0 && cfg->tau0 - cfg->tau0 == 0.0)) {
     delete m;
     return gg_fail(GG_ERR_INVALID, "Beta prior (tau1, tau0) = (%g, %g) must be positive and finite", cfg->tau1, cfg->tau0);
   }
   m->Kp = gg_next_pow2(m->K < 2 ? 2 : m->K);
-  m->NT = m->is_adj ? 2 : gg_nt_gauss(m->B);
+  m->NT = m->is_adj ? 2 : gg_nt_gauss(m->B) + (m->joint ? 1 : 0);
   m->NSI = m->is_adj ? 0 : gg_nsi(m->B);
   m->NTAB = m->is_adj ? 1 : 1 + 2 * m->NSI;
   m->n0 = 0; m->Nl = m->N; m->sharded = false;
@@ -257,6 +263,8 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->Np = gg_round_up(m->Nl, 64);
   // NIW / non-SBM weight kinds always keep a separate self Gaussian (weights.py:91-94)
   if (m->kind == GG_NIW_W || m->kind == GG_FIXED_W) m->cfg.special_case_self_conns = 1;
+  if (m->joint) m->cfg.special_case_self_conns = 0;   // stochastic_block_model.py:291-296: the diagonal belongs to pair (c_n, c_n)
+  if (m->joint && m->sharded) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "GG_SBM_JOINT: not for node shards"); }
   if (m->kind == GG_SBM_GAUSS_SHCOV_W && !m->cfg.special_case_self_conns && m->sharded) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "SBMGaussianWeightSharedCov without special_case_self_conns: the node-sharded chain does not carry the diagonal's share of the pair tables");
@@ -281,9 +289,10 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     if ((rc = dmalloc(&m->Gbuf[b], m->Gbytes))) return rc;
     m->zeroed[b] = true;
   }
-  if (m->is_adj) {
+  if (m->is_adj || m->joint) {
     if ((rc = dmalloc(&m->p, KK)) || (rc = dmalloc(&m->p_self, 1))) return rc;
-  } else {
+  }
+  if (!m->is_adj) {
     if ((rc = dmalloc(&m->mu, KK * B)) || (rc = dmalloc(&m->sigma, KK * B * B)) || (rc = dmalloc(&m->mu_self, B)) ||
         (rc = dmalloc(&m->sigma_self, (size_t)B * B)) || (rc = dmalloc(&m->csc, KK * (B * B + 1))))
       return rc;
@@ -331,7 +340,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     // The ahead form (enqueue_sweep_ahead): while the chain is quiet, the next sweep's bulk pass rides in this sweep's
     // k_params and k_spec_resolve launches.  GG_AHEAD=0 keeps every sweep in the serial form (bulk -> params -> scan).
     const char* ea = getenv("GG_AHEAD");
-    m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0);
+    m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0) && !m->joint;   // (the joint kind runs the serial form)
     const char* ers = getenv("GG_RIDE_SPLIT");
     m->ride_split = ers ? atof(ers) : -1.0;   // (default chosen below, once the scan forms of this shape are known)
     if (can_scan) {
@@ -359,11 +368,12 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   std::vector<double> ones(K, 1.0), um(K, 1.0 / K), half(KK, 0.5);
   GG_HIP(hipMemcpy(m->pi, ones.data(), K * 8, hipMemcpyHostToDevice));
   GG_HIP(hipMemcpy(m->m, um.data(), K * 8, hipMemcpyHostToDevice));
-  if (m->is_adj) {
+  if (m->is_adj || m->joint) {
     GG_HIP(hipMemcpy(m->p, half.data(), KK * 8, hipMemcpyHostToDevice));
     double h = 0.5;
     GG_HIP(hipMemcpy(m->p_self, &h, 8, hipMemcpyHostToDevice));
-  } else {
+  }
+  if (!m->is_adj) {
     memset(&m->niw, 0, sizeof(gg_niw));
     for (int i = 0; i < B; ++i) m->niw.sigma_0[i * B + i] = 1.0;
     m->niw.nu_0 = B + 2; m->niw.kappa_0 = 1.0;
@@ -406,7 +416,7 @@ static int state_ptr(gg_model* m, int id, void** p, size_t* nbytes) {
     case GG_ST_C: *p = m->c; *nbytes = (size_t)m->N * 4; break;
     case GG_ST_M: *p = m->m; *nbytes = K * 8; break;
     case GG_ST_PI: *p = m->pi; *nbytes = K * 8; break;
-    case GG_ST_P: if (m->is_adj) { *p = m->p; *nbytes = KK * 8; } break;
+    case GG_ST_P: if (m->is_adj || m->joint) { *p = m->p; *nbytes = KK * 8; } break;
     case GG_ST_P_SELF: if (m->is_adj) { *p = m->p_self; *nbytes = 8; } break;
     case GG_ST_MU: if (!m->is_adj) { *p = m->mu; *nbytes = KK * B * 8; } break;
     case GG_ST_SIGMA: if (!m->is_adj) { *p = m->sigma; *nbytes = KK * B * B * 8; } break;
@@ -783,6 +793,8 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
     if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
     m->zeroed[ride_next] = false;
   } else if (m->is_adj) k_params<true, 1><<<nwg, 256, 0, m->stream>>>(g);
+  else if (m->joint && m->B == 1) k_params<false, 1, 0, true><<<nwg, 256, 0, m->stream>>>(g);
+  else if (m->joint) k_params<false, 2, 0, true><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 1) k_params<false, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 2) k_params<false, 2><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->B == 3) k_params<false, 3><<<nwg, 256, 0, m->stream>>>(g);
@@ -823,6 +835,8 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
                                                         stage, shard_mode ? 1 : 0, round_window > 0 ? 1 : 0, m->ap);      \
   } while (0)
   if (m->is_adj) SPEC(2, true);
+  else if (m->joint && m->B == 1) SPEC(4, false);
+  else if (m->joint) SPEC(7, false);
   else if (m->B == 1) SPEC(3, false);
   else if (m->B == 2) SPEC(6, false);
   else if (m->B == 3) SPEC(10, false);
@@ -947,6 +961,8 @@ static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t 
     }                                                                                                                      \
   } while (0)
   if (m->is_adj) SPR(2, true);
+  else if (m->joint && m->B == 1) SPR(4, false);
+  else if (m->joint) SPR(7, false);
   else if (m->B == 1) SPR(3, false);
   else if (m->B == 2) SPR(6, false);
   else if (m->B == 3) SPR(10, false);
@@ -991,6 +1007,8 @@ static int launch_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep
     k_resolve<NTV, ADJV><<<1, 1024, lds, m->stream>>>(g);                                                        \
   } while (0)
   if (m->is_adj) RES(2, true);
+  else if (m->joint && m->B == 1) RES(4, false);
+  else if (m->joint) RES(7, false);
   else if (m->B == 1) RES(3, false);
   else if (m->B == 2) RES(6, false);
   else if (m->B == 3) RES(10, false);
@@ -1007,6 +1025,8 @@ static int launch_apply_L(gg_model* m, const gg_data* d, int buf, int mode = 0, 
   k_apply_L<NTV, ADJV><<<nb, 256, 0, m->stream>>>(x, m->L, m->rs, m->ap, gcnt(m, buf, 0), gcnt(m, buf, 1),          \
                                                   gs(m, buf, 0), gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT, mode)
   if (m->is_adj) APL(2, true);
+  else if (m->joint && m->B == 1) APL(4, false);
+  else if (m->joint) APL(7, false);
   else if (m->B == 1) APL(3, false);
   else if (m->B == 2) APL(6, false);
   else if (m->B == 3) APL(10, false);
@@ -1056,6 +1076,8 @@ static int launch_round(gg_model* m, const gg_data* d, int buf, uint32_t sweep, 
                                                     gs(m, buf, 1), stage, round_id);                              \
   } while (0)
   if (m->is_adj) RND(2, true);
+  else if (m->joint && m->B == 1) RND(4, false);
+  else if (m->joint) RND(7, false);
   else if (m->B == 1) RND(3, false);
   else if (m->B == 2) RND(6, false);
   else if (m->B == 3) RND(10, false);
@@ -1115,6 +1137,8 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     k_scan<NTV, ADJV><<<a.G, 256, lds, m->stream>>>(a);                                                            \
   } while (0)
   if (m->is_adj) SCN(2, true);
+  else if (m->joint && m->B == 1) SCN(4, false);
+  else if (m->joint) SCN(7, false);
   else if (m->B == 1) SCN(3, false);
   else if (m->B == 2) SCN(6, false);
   else if (m->B == 3) SCN(10, false);
@@ -1834,6 +1858,7 @@ static int ll_enqueue(gg_model* m, const gg_data* d) {
     g.d1 = d->d1; g.d0 = (long long)m->N - d->d1;
     for (int i = 0; i < gg_nsi(GG_MAXB); ++i) g.dS[i] = d->dS[i];
     g.diag_zero = (m->is_adj && !m->cfg.allow_self_connections && m->kind == GG_SBM_ADJ) ? 1 : 0;
+    g.joint = m->joint ? 1 : 0;
     g.out = m->ll_out;
     k_loglik<<<1, 256, 0, m->stream>>>(g);
     GG_HIP(hipGetLastError());
@@ -2148,6 +2173,7 @@ int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, co
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_predictive_ll: block models only (the other kinds draw latent features per sample: host code)");
   if (m->sharded) return gg_fail(GG_ERR_UNSUPPORTED, "gg_predictive_ll: not for node shards");
+  if (m->joint) return gg_fail(GG_ERR_UNSUPPORTED, "gg_predictive_ll: not for the joint model (the reference defines no predictive parameters for it)");
   if (!m->is_adj && (!w_row || !w_col)) return gg_fail(GG_ERR_INVALID, "gg_predictive_ll: weight kinds need the weight row and column");
   int rc = model_sync(m);
   if (rc) return rc;

@@ -84,8 +84,8 @@ template <int NT, bool ADJ>
 __device__ __forceinline__ void gg_apply_edge(int* gc, long long* gs, int a, int b, int K, const int32_t* q,
                                               bool is_edge) {
   // move one edge's statistics from block a to block b of one node/direction
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
-  constexpr int NSI = NT - 1;
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
   if (!is_edge) return;
   atomicSub(&gc[a], 1);
   atomicAdd(&gc[b], 1);
@@ -141,8 +141,8 @@ __device__ __forceinline__ void gg_scan_tail(const gg_resolve_args& g, const int
 
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
-  constexpr int NSI = NT - 1;
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
   const gg_node_ctx& x = g.x;
   const int N = x.N, K = x.K, Kp = x.Kp, Np = x.Np, CH = g.CH;
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(1024) void k_resolve(gg_resolve_args g) {
       const int n = pos0 + ii;
       const int cn = s_c[ii];
       auto ld = [&](int j, double* so, double* si) {
-        int cx = ADJ ? (s_cnt[j] - (cn == j ? 1 : 0)) : 0;
+        int cx = (ADJ || gg_tJ(NT)) ? (s_cnt[j] - (cn == j ? 1 : 0)) : 0;
         const long long* a = ADJ ? nullptr : &s_gs[((size_t)(0 * CH + ii) * K + j) * NSI];
         const long long* b = ADJ ? nullptr : &s_gs[((size_t)(1 * CH + ii) * K + j) * NSI];
         gg_stats_to_double<NT, ADJ>(s_gc[(0 * CH + ii) * K + j], s_gc[(1 * CH + ii) * K + j], a, b, cx, sc1, sc2, so, si);
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, ((RIDE && !SPLIT) ? GG_RIDE_WAVES : 1)) void k
     gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap, gg_ride_args ride = gg_ride_args()) {
   if (g.rs[4]) return;   // behind a stalled scan of this pipeline: no-op (uniform)
   if (RIDE && (int)blockIdx.x >= ride.front) {
-    gg_ride<ADJ, (ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)))), RIDE == 2>(ride);
+    gg_ride<ADJ, (gg_tB(NT)), RIDE == 2>(ride);
     return;
   }
   const unsigned nfront = RIDE ? (unsigned)ride.front : gridDim.x;
@@ -462,7 +462,7 @@ template <int NT, bool ADJ, int NTL, int SPLIT>
 __global__ __launch_bounds__(256, (SPLIT ? 1 : GG_RIDE_WAVES)) void k_sweep_q(gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap,
                                                                                  gg_params_args pg, gg_ride_args ride, int nspec, unsigned vtag) {
   if (g.rs[4]) return;
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
+  constexpr int B = gg_tB(NT);
   const int bid = (int)blockIdx.x;
   const long long t0 = ride.dbg ? wall_clock64() : 0;
   if (ride.dbg && threadIdx.x == 0) atomicMin(reinterpret_cast<unsigned long long*>(&ride.dbg[0]), (unsigned long long)t0);
@@ -494,8 +494,8 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
                                                  const uint32_t* XAT, const int32_t* XW, const int32_t* XWT, int mode) {
   // mode 0: flush between restart rounds (nothing to do once the scan is done); mode 1: end-of-scan flush of
   // the incremental-statistics pipeline (nothing to do behind a stalled scan: the slow path flushes); 2: always
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
-  constexpr int NSI = NT - 1;
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= x.N) return;
   if (mode == 0 ? rs[7] != 0 : (mode == 1 ? rs[4] != 0 : false)) return;
@@ -554,8 +554,8 @@ __global__ void k_reset_L(int32_t* rs, int mode) {
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __restrict__ ap, int32_t* Gc0, int32_t* Gc1,
                                                long long* Gs0, long long* Gs1, int stage_tables, int round_id) {
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
-  constexpr int NSI = NT - 1;
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
   constexpr int U = 4;   // corrections in flight per thread
 #define GG_TS(slot) do { if (g.dbg && threadIdx.x == 0) g.dbg[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
   const long long ts0 = g.dbg ? wall_clock64() : 0;
@@ -741,6 +741,7 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
           if (dirty) Gs0[gi * NSI + s] = v;
           dst[(1 + s) * ts] = (double)v * (s < B ? sc1 : sc2);
         }
+        if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0));
       }
     }
     if (tid < per && n0 + tid < wend) ap[n0 + tid] = nL;

@@ -90,8 +90,8 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
 
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
-  constexpr int B = ADJ ? 1 : (NT == 3 ? 1 : (NT == 6 ? 2 : (NT == 10 ? 3 : 4)));
-  constexpr int NSI = NT - 1;
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
   constexpr int U = 4;
   const gg_resolve_args& g = a.r;
   const gg_node_ctx& x = g.x;
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
             dst[0] = (double)gc;
 #pragma unroll
             for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)s_gs[(size_t)idx * NSI + s] * (s < B ? sc1 : sc2);
+            if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(s_cnt[j] - (s_c[i] == j ? 1 : 0));
           }
         }
       }

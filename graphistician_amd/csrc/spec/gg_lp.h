@@ -26,7 +26,7 @@
 #include "gg_draws.h"
 
 #define GG_LOG_2PI 1.8378770664093453
-#define GG_MAXNT (1 + GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)
+#define GG_MAXNT (2 + GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)   /* + 1: the joint model's partner statistic */
 
 GG_HD int gg_nt_gauss(int B) { return 1 + B + B * (B + 1) / 2; }
 
@@ -74,6 +74,17 @@ GG_HD int gg_gauss_table(const double* mu, const double* sigma, int B, double* o
   for (int r = 0; r < B; ++r)
     for (int s = r; s < B; ++s) out[t++] = (r == s) ? -0.5 * P[r * B + r] : -P[r * B + s];
   return 0;
+}
+
+// Joint SBM (one label vector for adjacency and weights, stochastic_block_model.py:252-302): per ordered pair of nodes
+// the conditional adds Bernoulli(p).log_probability(A) = A log p + (1 - A) log(1 - p) to A * log N(W) (:280-296).  Summed
+// over a node's potential partners in block j: (g + log p - log(1 - p)) * #edges + h.s1 + Q.s2 + log(1 - p) * #partners,
+// i.e. the Gaussian table entry with its first coefficient shifted, followed by one more coefficient for the statistic
+// "potential partners in the block" (block size, minus one for the node's own block).  e: NTg Gaussian entries in, NTg + 1 out.
+GG_HD void gg_joint_table(double* e, int NTg, double p) {
+  const double l1 = gg_log(p), l0 = gg_log(1.0 - p);
+  e[0] = (e[0] + l1) - l0;
+  e[NTg] = l0;
 }
 
 // Categorical draw from unnormalised log-probabilities with one uniform:

@@ -45,6 +45,10 @@ enum gg_status {
  *  GG_SBM_GAUSS_SHCOV_W  weights.py:501-610  SBMGaussianWeightSharedCov (one covariance for all block pairs; GG_ST_NIW packs
  *                   the mean prior mu_0, the inverse-Wishart scale lmbda_0 and nu_0; GG_ST_SIGMA holds the shared
  *                   covariance in every pair)
+ *  GG_SBM_JOINT     stochastic_block_model.py:202-309, 589-678  GaussianStochasticBlockModel (legacy): ONE label vector drives
+ *                   adjacency and weights - resample = weight models of every block pair (:220-226) -> resample_p (:232-250)
+ *                   -> resample_c with Bernoulli + Gaussian terms (:252-302) -> resample_m (:304-309).  State: GG_ST_C, M, PI,
+ *                   P, MU, SIGMA, NIW; no special-cased self connections (the diagonal belongs to pair (c_n, c_n)); B <= 2.
  *  GG_LATENT_DIST   adjacency.py:191-437  LatentDistanceAdjacencyDistribution (HMC; D = dim, sigma_F = sigma;
  *                   parts: GG_PART_F = L, GG_PART_MU0 = mu_0, GG_PART_LMBDA = mu_self)
  *  GG_LATENT_DIST_W weights.py:613-903    LatentDistanceGaussianWeightDistribution (B = 1; D = dim; state: GG_ST_F = L,
@@ -63,7 +67,8 @@ enum gg_kind {
   GG_PROBIT_EIG = 8,
   GG_LATENT_DIST = 9,
   GG_SBM_GAUSS_SHCOV_W = 10,
-  GG_LATENT_DIST_W = 11
+  GG_LATENT_DIST_W = 11,
+  GG_SBM_JOINT = 12
 };
 
 typedef struct gg_config {

@@ -178,6 +178,36 @@ def sbm_w_loglik(A, q, shift, c, mu, sigma, mu_self, sigma_self, special=True):
                                   _f64(sigma_self), int(special))
 
 
+# ---------------------------------------------------------------- joint SBM (stochastic_block_model.py:202-309)
+def sbm_joint_sweep(A, q, shift, c, m, p, mu, sigma, pi, niw, tau1, tau0, seed, sweep, parts=PART_ALL, beta=1.0):
+    """In-place sweep of (c, m, p, mu, sigma) of the joint model (one label vector for adjacency and weights)."""
+    N, K, B = A.shape[0], m.shape[0], q.shape[2]
+    A8, pA = _u8(A != 0)
+    rc = lib().orc_sbm_joint_sweep(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(p), _f64(mu), _f64(sigma),
+                                   _f64(np.ascontiguousarray(pi, dtype=np.float64)), _f64(niw), C.c_double(tau1), C.c_double(tau0),
+                                   C.c_uint64(seed), C.c_uint32(sweep), int(parts), C.c_double(beta))
+    if rc:
+        raise RuntimeError("oracle sbm_joint_sweep failed rc=%d" % rc)
+
+
+def sbm_joint_node_lp(A, q, shift, c, m, p, mu, sigma, n1, literal=False):
+    N, K, B = A.shape[0], m.shape[0], q.shape[2]
+    A8, pA = _u8(A != 0)
+    lp = np.zeros(K)
+    f = lib().orc_sbm_joint_node_lp_literal if literal else lib().orc_sbm_joint_node_lp
+    rc = f(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(p), _f64(mu), _f64(sigma), int(n1), _f64(lp))
+    if rc:
+        raise RuntimeError("oracle sbm_joint_node_lp failed rc=%d" % rc)
+    return lp
+
+
+def sbm_joint_loglik(A, q, shift, c, p, mu, sigma):
+    N, B, K = A.shape[0], q.shape[2], p.shape[0]
+    A8, pA = _u8(A != 0)
+    lib().orc_sbm_joint_loglik.restype = C.c_double
+    return lib().orc_sbm_joint_loglik(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(p), _f64(mu), _f64(sigma))
+
+
 def niw_w_sweep(A, q, shift, mu, sigma, mu_self, sigma_self, niw, niw_self, seed, sweep, beta=1.0):
     N, B = A.shape[0], q.shape[2]
     A8, pA = _u8(A != 0)

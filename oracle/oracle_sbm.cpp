@@ -688,4 +688,146 @@ void orc_niw_vec(uint64_t seed, const double* niw, int B, double n_obs, const do
 }
 int orc_gauss_table(const double* mu, const double* sigma, int B, double* out) { return gg_gauss_table(mu, sigma, B, out); }
 
+
+// ---------------------------------------------------------------------------
+// Joint SBM: ONE label vector for adjacency and weights (legacy GaussianStochasticBlockModel,
+// stochastic_block_model.py:202-309, 589-678).
+//   resample (:206-230): weight model of every block pair from the edges of the pair (A * c1_and_c2: the diagonal
+//     belongs to pair (c_n, c_n), nothing is special-cased) -> resample_p (:232-250: edges / non-edges of the pair,
+//     diagonal included) -> resample_c (:252-302) -> resample_m (:304-309).
+//   resample_c: lp[cn1] = log m[cn1] + sum_{n2 != n1} [ Bern(p[cn1,cn2]).lp(A[n1,n2]) + Bern(p[cn2,cn1]).lp(A[n2,n1])
+//                         + A[n1,n2] log N(W[n1,n2]; cn1,cn2) + A[n2,n1] log N(W[n2,n1]; cn2,cn1) ]
+//                         + Bern(p[cn1,cn1]).lp(A[n1,n1]) + A[n1,n1] log N(W[n1,n1]; cn1,cn1).
+// Count form: the Gaussian statistics of SBMGaussianWeightDistribution plus, per block, the number of potential
+// partners (block size, minus one in the node's own block), with the coefficients of gg_joint_table.
+// ---------------------------------------------------------------------------
+static void joint_tables(int K, int B, const double* m, const double* p, const double* mu, const double* sigma,
+                         double* logm, double* T, int* bad) {
+  const int NTg = gg_nt_gauss(B), NT = NTg + 1;
+  for (int k = 0; k < K; ++k) logm[k] = gg_log(m[k]);
+  for (int ab = 0; ab < K * K; ++ab) {
+    double* e = T + (size_t)ab * NT;
+    if (gg_gauss_table(mu + (size_t)ab * B, sigma + (size_t)ab * B * B, B, e)) { *bad = 1; return; }
+    gg_joint_table(e, NTg, p[ab]);
+  }
+}
+
+static void joint_node_lp(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, const int32_t* c,
+                          const double* logm, const double* T, int n1, double* lp, double beta) {
+  const int NTg = gg_nt_gauss(B), NT = NTg + 1;
+  std::vector<WStat> so(K), si(K);
+  std::vector<int> cnt(K, 0);
+  for (int k = 0; k < K; ++k) { wstat_zero(&so[k]); wstat_zero(&si[k]); }
+  for (int n2 = 0; n2 < N; ++n2) {
+    cnt[c[n2]] += 1;
+    if (n2 == n1) continue;
+    if (A[(size_t)n1 * N + n2]) wstat_add(&so[c[n2]], q + ((size_t)n1 * N + n2) * B, B);
+    if (A[(size_t)n2 * N + n1]) wstat_add(&si[c[n2]], q + ((size_t)n2 * N + n1) * B, B);
+  }
+  std::vector<double> dso((size_t)K * NT), dsi((size_t)K * NT);
+  for (int k = 0; k < K; ++k) {
+    pack_stat(&so[k], B, shift, dso.data() + (size_t)k * NT);
+    pack_stat(&si[k], B, shift, dsi.data() + (size_t)k * NT);
+    const double partners = (double)(cnt[k] - (c[n1] == k ? 1 : 0));
+    dso[(size_t)k * NT + NTg] = partners;
+    dsi[(size_t)k * NT + NTg] = partners;
+  }
+  double self[GG_MAXNT];
+  WStat ss;
+  wstat_zero(&ss);
+  if (A[(size_t)n1 * N + n1]) wstat_add(&ss, q + ((size_t)n1 * N + n1) * B, B);
+  pack_stat(&ss, B, shift, self);
+  self[NTg] = 1.0;
+  for (int k = 0; k < K; ++k) lp[k] = gg_block_lp(k, K, NT, logm, T, dso.data(), dsi.data(), self, beta);
+}
+
+// parts: ORC_PART_PARAMS = weight models + p, ORC_PART_C, ORC_PART_M.
+int orc_sbm_joint_sweep(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, int32_t* c, double* m,
+                        double* p, double* mu, double* sigma, const double* pi, const double* niw, double tau1, double tau0,
+                        uint64_t seed, uint32_t sweep, int parts, double beta) {
+  if (B > GG_MAXB) return -1;
+  gg_niw h;
+  unpack_niw(niw, B, &h);
+  if (parts & ORC_PART_PARAMS) {
+    double mus[GG_MAXB], sigs[GG_MAXB * GG_MAXB], ps = 0.0;
+    sbm_w_resample_mu_sig(N, K, B, A, q, shift, c, mu, sigma, mus, sigs, &h, &h, 0, seed, sweep, beta);
+    sbm_adj_resample_p(N, K, A, c, p, &ps, tau1, tau0, 0, seed, sweep, beta);
+  }
+  if ((parts & ORC_PART_C) && K > 1) {
+    const int NT = gg_nt_gauss(B) + 1;
+    std::vector<double> logm(K), T((size_t)K * K * NT), lp(K), scratch(2 * gg_next_pow2(K));
+    int bad = 0;
+    joint_tables(K, B, m, p, mu, sigma, logm.data(), T.data(), &bad);
+    if (bad) return -2;
+    for (int n1 = 0; n1 < N; ++n1) {
+      joint_node_lp(N, K, B, A, q, shift, c, logm.data(), T.data(), n1, lp.data(), beta);
+      const double u = gg_uniform_at(seed, GG_SITE_W_C, sweep, (uint32_t)n1);
+      c[n1] = gg_categorical(lp.data(), K, u, scratch.data());
+    }
+  }
+  if (parts & ORC_PART_M) resample_m(N, K, c, pi, m, seed, GG_SITE_W_M, sweep);
+  return 0;
+}
+
+int orc_sbm_joint_node_lp(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, const int32_t* c,
+                          const double* m, const double* p, const double* mu, const double* sigma, int n1, double* lp) {
+  const int NT = gg_nt_gauss(B) + 1;
+  std::vector<double> logm(K), T((size_t)K * K * NT);
+  int bad = 0;
+  joint_tables(K, B, m, p, mu, sigma, logm.data(), T.data(), &bad);
+  if (bad) return -2;
+  joint_node_lp(N, K, B, A, q, shift, c, logm.data(), T.data(), n1, lp, 1.0);
+  return 0;
+}
+
+// The literal loop nest of stochastic_block_model.py:266-299 (cn1 outer, n2 inner, libm log per term, per-edge Gaussian
+// log-densities of the de-quantised weights) - slow, obviously faithful.
+int orc_sbm_joint_node_lp_literal(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, const int32_t* c,
+                                  const double* m, const double* p, const double* mu, const double* sigma, int n1, double* lp) {
+  double x[GG_MAXB];
+  auto bern = [](double pp, int a) { return a ? log(pp) : log(1.0 - pp); };
+  auto wll = [&](int i, int j, int ci, int cj) {
+    for (int b = 0; b < B; ++b) x[b] = ldexp((double)q[((size_t)i * N + j) * B + b], -shift);
+    return mvn_logpdf(x, mu + (size_t)(ci * K + cj) * B, sigma + (size_t)(ci * K + cj) * B * B, B);
+  };
+  for (int cn1 = 0; cn1 < K; ++cn1) {
+    double ll = log(m[cn1]);
+    for (int n2 = 0; n2 < N; ++n2) {
+      const int cn2 = c[n2];
+      if (n2 != n1) {
+        const int a12 = A[(size_t)n1 * N + n2] ? 1 : 0, a21 = A[(size_t)n2 * N + n1] ? 1 : 0;
+        ll += bern(p[cn1 * K + cn2], a12);
+        ll += bern(p[cn2 * K + cn1], a21);
+        if (a12) ll += wll(n1, n2, cn1, cn2);
+        if (a21) ll += wll(n2, n1, cn2, cn1);
+      } else {
+        const int a11 = A[(size_t)n1 * N + n1] ? 1 : 0;
+        ll += bern(p[cn1 * K + cn1], a11);
+        if (a11) ll += wll(n1, n1, cn1, cn1);
+      }
+    }
+    lp[cn1] = ll;
+  }
+  return 0;
+}
+
+// log p(A, W | c, p, mu, Sigma): every ordered pair, diagonal included (the sum the conditional above is a slice of).
+double orc_sbm_joint_loglik(int N, int K, int B, const uint8_t* A, const int32_t* q, int shift, const int32_t* c,
+                            const double* p, const double* mu, const double* sigma) {
+  double ll = 0.0, x[GG_MAXB];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      const int ab = c[i] * K + c[j];
+      const double P = p[ab], Pc = P < 1e-64 ? 1e-64 : (P > 1 - 1e-64 ? 1 - 1e-64 : P);
+      if (A[(size_t)i * N + j]) {
+        ll += log(P);
+        for (int b = 0; b < B; ++b) x[b] = ldexp((double)q[((size_t)i * N + j) * B + b], -shift);
+        ll += mvn_logpdf(x, mu + (size_t)ab * B, sigma + (size_t)ab * B * B, B);
+      } else {
+        ll += log(1.0 - Pc);
+      }
+    }
+  return ll;
+}
+
 }  // extern "C"

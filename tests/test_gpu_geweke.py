@@ -247,3 +247,23 @@ def test_device_categorical_frequencies(abi):
         keep = pr > 0
         chi2 = ((cnt[keep] - n * pr[keep]) ** 2 / (n * pr[keep])).sum()
         assert stats.chi2.sf(chi2, keep.sum() - 1) > 1e-4, (lp, cnt, n * pr)
+
+
+# ------------------------------------------------------------------ Geweke: joint SBM (stochastic_block_model.py:206-309)
+def test_geweke_joint_sbm_on_the_engine(abi):
+    """GaussianStochasticBlockModel (one label vector for adjacency and weights): alternate (A, W) ~ p(A, W | theta) and the
+    engine's joint sweep; p, m, mu and Sigma must keep their priors."""
+    from graphistician_amd.stochastic_block_model import GaussianStochasticBlockModel
+    np.random.seed(21)
+    N, C, iters = 6, 2, 6000
+    m = GaussianStochasticBlockModel(N, 1, C=C, pi=3.0, tau0=1.2, tau1=0.9, seed=77,
+                                     weight_hypers=dict(mu_0=np.zeros(1), Sigma_0=np.eye(1), nu_0=4.0, kappa_0=0.5))
+    p01, m0, mu10, s00 = [], [], [], []
+    for it in range(iters):
+        m.resample(m.rvs())
+        p01.append(m.p[0, 1]); m0.append(m.m[0]); mu10.append(m.weight_models[1][0].mu[0]); s00.append(m.weight_models[0][0].sigma[0, 0])
+    (ds, as_), (dm, am) = _niw_marginals_1d(0.0, 1.0, 4.0, 0.5)
+    check_law(p01, "beta", (0.9, 1.2), mean=0.9 / 2.1)
+    check_law(m0, "beta", (3.0, 3.0), mean=0.5)
+    check_law(mu10, dm, am, mean=0.0)
+    check_law(s00, ds, as_)

@@ -205,3 +205,46 @@ def test_bb_and_niw_config1(abi):
     ll = w.log_likelihood(d)
     ll_o = O.sbm_w_loglik(A, q, shift, np.zeros(50, np.int32), mu, sig, mus, sigs, 1)
     assert abs(ll - ll_o) <= 1e-9 * abs(ll_o)
+
+
+# ------------------------------------------------------------------ joint SBM (stochastic_block_model.py:202-309)
+@pytest.mark.parametrize("N,K,B", [(60, 3, 1), (200, 8, 1), (260, 16, 2), (300, 40, 1), (150, 33, 2)])
+def test_joint_sbm_chain_bitexact(abi, N, K, B):
+    """GG_SBM_JOINT: one label vector for adjacency and weights.  Conditionals, labels, p, (mu, Sigma), m bit-exact against
+    the oracle's restatement over several sweeps from a random start; step-wise parts; log-likelihood vs the per-pair sum."""
+    A, W, _ = planted_sbm(N, K, B=B, seed=7 * N)
+    np.fill_diagonal(A, (np.arange(N) % 2).astype(np.uint8))
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=K + 9)
+    rng = np.random.RandomState(N)
+    p = np.ascontiguousarray(rng.beta(1.0, 1.0, size=(K, K)))
+    d = abi.DeviceData(A, W)
+    m = abi.Model(kind=abi.SBM_JOINT, N=N, K=K, B=B, seed=606, tau1=1.3, tau0=0.9)
+    m.set(abi.ST_C, st.c, np.int32); m.set(abi.ST_M, st.m); m.set(abi.ST_PI, st.pi); m.set(abi.ST_P, p)
+    m.set(abi.ST_MU, st.mu); m.set(abi.ST_SIGMA, st.sigma); m.set(abi.ST_NIW, st.niw)
+    for n1 in (0, N // 2, N - 1):
+        assert np.array_equal(m.node_lp(d, n1, K), O.sbm_joint_node_lp(A, q, shift, st.c, st.m, p, st.mu, st.sigma, n1)), n1
+    nsw = 5
+    m.resample(d, nsw)
+    for s in range(nsw):
+        O.sbm_joint_sweep(A, q, shift, st.c, st.m, p, st.mu, st.sigma, st.pi, st.niw, 1.3, 0.9, 606, s)
+    assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c)
+    assert np.array_equal(m.get(abi.ST_P, (K, K)), p)
+    assert np.array_equal(m.get(abi.ST_MU, (K, K, B)), st.mu) and np.array_equal(m.get(abi.ST_SIGMA, (K, K, B, B)), st.sigma)
+    assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+    assert m.stats()["label_changes"] > 0
+    ll = m.log_likelihood(d)
+    ref = O.sbm_joint_loglik(A, q, shift, st.c, p, st.mu, st.sigma)
+    assert abs(ll - ref) <= 1e-9 * abs(ref)
+    # step-wise parts of the next sweep
+    m.resample_part(d, abi.PART_PARAMS)
+    O.sbm_joint_sweep(A, q, shift, st.c, st.m, p, st.mu, st.sigma, st.pi, st.niw, 1.3, 0.9, 606, nsw, parts=O.PART_PARAMS)
+    assert np.array_equal(m.get(abi.ST_P, (K, K)), p) and np.array_equal(m.get(abi.ST_MU, (K, K, B)), st.mu)
+    m.resample_part(d, abi.PART_C)
+    O.sbm_joint_sweep(A, q, shift, st.c, st.m, p, st.mu, st.sigma, st.pi, st.niw, 1.3, 0.9, 606, nsw, parts=O.PART_C)
+    assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c)
+    m.resample_part(d, abi.PART_M)
+    O.sbm_joint_sweep(A, q, shift, st.c, st.m, p, st.mu, st.sigma, st.pi, st.niw, 1.3, 0.9, 606, nsw, parts=O.PART_M)
+    assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+    with pytest.raises(abi.EngineError):
+        abi.Model(kind=abi.SBM_JOINT, N=N, K=K, B=3, seed=1)

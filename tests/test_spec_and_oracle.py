@@ -374,3 +374,43 @@ def test_shared_cov_oracle_without_the_self_connection_special_case():
     off = (A == 1) & ~np.eye(N, dtype=bool)
     assert np.mean(sigs) < 3.0          # had the diagonal (6 +- 0.1 against means near 0-2) been included it would be far larger
     assert abs(len(sigs) - 500) == 0 and off.sum() > 1000
+
+
+# ---------------------------------------------------------------- joint SBM (stochastic_block_model.py:252-302)
+@pytest.mark.parametrize("B", [1, 2])
+def test_joint_sbm_two_forms_agree(B):
+    """Count form of the joint conditional (Gaussian statistics + potential partners, gg_joint_table) vs the literal loop
+    nest of stochastic_block_model.py:266-299 (per pair: Bernoulli log-probabilities with libm log, per-edge Gaussian
+    log-densities)."""
+    N, K = 40, 4
+    A, W, _ = planted_sbm(N, K, B=B, seed=8)
+    np.fill_diagonal(A, (np.arange(N) % 3 == 0).astype(np.uint8))      # some self connections
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=2)
+    rng = np.random.RandomState(3)
+    p = np.ascontiguousarray(rng.beta(1.5, 1.5, size=(K, K)))
+    for n1 in (0, 3, 17, N - 1):
+        a = O.sbm_joint_node_lp(A, q, shift, st.c, st.m, p, st.mu, st.sigma, n1)
+        b = O.sbm_joint_node_lp(A, q, shift, st.c, st.m, p, st.mu, st.sigma, n1, literal=True)
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-9), (n1, a - b)
+
+
+def test_joint_sbm_sweep_is_the_two_halves_with_one_label_vector():
+    """Parameters of the joint sweep are those of the two separate models without the self-connection special case given the
+    same labels (the same conjugate draws from the same pair statistics); the scan then differs (one conditional)."""
+    N, K, B = 50, 3, 1
+    A, W, _ = planted_sbm(N, K, B=B, seed=4)
+    q, shift = O.quantise(A, W)
+    st = WState(N, K, B, seed=5)
+    p = np.full((K, K), 0.5)
+    c0 = st.c.copy()
+    mu_j, sig_j, m_j = st.mu.copy(), st.sigma.copy(), st.m.copy()
+    O.sbm_joint_sweep(A, q, shift, st.c, m_j, p, mu_j, sig_j, st.pi, st.niw, 1.0, 1.0, 31, 0, parts=O.PART_PARAMS)
+    assert np.array_equal(st.c, c0)
+    mu_w, sig_w = st.mu.copy(), st.sigma.copy()
+    O.sbm_w_sweep(A, q, shift, c0.copy(), st.m.copy(), mu_w, sig_w, st.mu_self.copy(), st.sigma_self.copy(), st.pi, st.niw,
+                  st.niw_self, 0, 31, 0, parts=O.PART_PARAMS)
+    assert np.array_equal(mu_j, mu_w) and np.array_equal(sig_j, sig_w)
+    p_a = np.full((K, K), 0.5)
+    O.sbm_adj_sweep(A, c0.copy(), st.m.copy(), p_a, 0.5, np.ones(K), 1.0, 1.0, 0, 31, 0, parts=O.PART_PARAMS)
+    assert np.array_equal(p, p_a)
