@@ -181,6 +181,30 @@ def cpu_literal_extrapolated(N, K, seed=3):
                        "by operation count: %.0f s adjacency half + %.0f s weight half per sweep" % (Na, Nb, K0, N, K, t_adj, t_w))
 
 
+def pmc_traffic(N, alg_bytes, ahead):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries (FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction: tools/scripts/profile_r02.sh, tools/pmc_traffic.py).
+    Counters cannot be collected inside this process; the figure is the measurement of this very launch shape when one is on file
+    (N = 4096: the fused sweep launch), otherwise the algorithmic bytes times the ratio measured past the Infinity Cache (N = 32768)."""
+    try:
+        here = os.path.join(ROOT, "profiles")
+        if N == 4096 and ahead:
+            e = json.load(open(os.path.join(here, "r02_pmc_traffic_n4096.json")))["k_sweep_q<3"]
+            return {"traffic": e["traffic_bytes"],
+                    "note": "measured at N=4096 on k_sweep_q<3,false,0,0> (profiles/r02_pmc_traffic_n4096.json): %.1f MB read (FETCH_SIZE x 2) + "
+                            "%.1f MB written per launch against %.1f MB algorithmic (ratio %.3f: the riders' pass plus the scan's and the "
+                            "parameter step's own reads, the zeroing of one statistics buffer and the integer atomics); at this size the 138 MB "
+                            "working set stays in the 256 MiB Infinity Cache, whose hits the memory-side counters include"
+                            % (e["hbm_read_bytes_corrected"] / 1e6, e["hbm_write_bytes"] / 1e6, e["algorithmic_bytes_per_launch"] / 1e6,
+                               e["traffic_over_algorithmic"])}
+        e = json.load(open(os.path.join(here, "r02_pmc_traffic_n32768.json")))["k_bulk_w"]
+        return {"traffic": alg_bytes * e["traffic_over_algorithmic"],
+                "note": "algorithmic bytes x %.3f, the traffic / algorithmic ratio of k_bulk_w<1,4,true> measured past the Infinity Cache at "
+                        "N=32768 (8.74 GB per launch against 8.59 GB; profiles/r02_pmc_traffic_n32768.json)" % e["traffic_over_algorithmic"]}
+    except Exception as exc:
+        return {"traffic": None, "note": "no PMC summary on file (%s)" % exc}
+
+
 def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every, barrier=lambda: None, stepwise=False):
     """One Gaussian-SBM chain (adjacency + weight models) on `data`: set-up burn-in, `warmup` untimed sweeps, `steps`
     timed sweeps.  One step = one FactorizedNetworkDistribution.resample((A,W)): the two halves are independent models
@@ -619,6 +643,7 @@ def main():
         alg_bytes = bulk["w_bytes"] / max(bulk["w_n"], 1)
         achieved = bulk["w_bytes"] / (bulk["w_ms"] * 1e-3) / 1e9 if bulk["w_ms"] > 0 else 0.0
         sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
+        pmc = pmc_traffic(N, alg_bytes, r["ahead"])
         sa_ms, sa_b = adj.bench_bulk(data, 20)
         sw_ms, sw_b = w.bench_bulk(data, 20)
         out = {
@@ -652,11 +677,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "traffic_note": "null here: PMC counters need their own rocprofv3 pass; at N=4096 the 160 MB working set also sits in the 256 MiB Infinity Cache, where the "
-                                "memory-side counters under-report.  Measured at N=32768 with rocprofv3 --pmc FETCH_SIZE / "
-                                "WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 correction): 8.74 GB per launch vs "
-                                "8.59 GB algorithmic (ratio 1.018), profiles/r01_pmc_bulk_traffic_nt.json",
+                "traffic": pmc.get("traffic"),
+                "traffic_note": pmc.get("note"),
                 "launch_ms": per_launch_ms,
                 "launch_bytes": alg_bytes,
                 "sampled_launches": int(bulk["w_n"]),
