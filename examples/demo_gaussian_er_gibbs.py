@@ -35,4 +35,4 @@ def demo(seed=1234, N=50, B=2, N_samples=100):
 
 
 if __name__ == "__main__":
-    demo()
+    demo(*[int(x) for x in sys.argv[1:]])
