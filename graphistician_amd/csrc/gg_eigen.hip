@@ -302,6 +302,10 @@ __global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, i
   eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, ex_hi, blockIdx.x, blockIdx.y, probit, ka);
 }
 
+// Order this wave's LDS operations: wait for the outstanding ones and keep the compiler from moving memory accesses across.
+// (__threadfence_block() also waits for every global store in flight - hundreds of clocks on the scan's critical path.)
+__device__ __forceinline__ void gg_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <int DM, bool FULL>
 __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t0, const double* __restrict__ S,
                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      __threadfence_block();
+      gg_lds_wait();   // LDS traffic of one wave is performed in order: the data is written before the word that announces it
       const long long c1 = dbg ? clock64() : 0;
       // statistics of this node with the previous node's change folded in (same order as the updaters':
       // earlier changes first, the previous node's last), one entry per lane
@@ -495,6 +499,7 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
       if (lvec) s_scr[NEG + lane] = gg_fma(cfp, dFl, s_st[NEG + lane]);
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
+      const long long cA = dbg ? clock64() : 0;
       if (lane == 0) {
         // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
         double L[DM][DM], hh[DM], x[DM];
@@ -518,13 +523,17 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           zz[i] = (FULL || i < D) ? s_Z[nl * DM + i] : 0.0;
           fo[i] = (FULL || i < D) ? s_Fo[nl * DM + i] : 0.0;
         }
+        if (dbg) { asm volatile("" ::"v"(L[0][0]), "v"(hh[0]), "v"(zz[0]), "v"(fo[0])); atomicAdd((unsigned long long*)&dbg[8], (unsigned long long)(clock64() - cA)); }
+        const long long cB = dbg ? clock64() : 0;
         double dmin = 1.0;           // smallest pivot: a non-positive one voids the node (checked once, off the path)
-        // Cholesky (left-looking, same order as gg_chol_d)
+        // Cholesky, RIGHT-looking: column j is scaled as soon as its pivot is known and its rank-one update is applied to
+        // the trailing columns at once, so that the only serial chain left is pivot -> reciprocal square root -> scale ->
+        // next pivot (one fma behind the scale); every other fma is independent work the scheduler can fill the chain's
+        // bubbles with.  Per element the updates arrive in the same order (k ascending) as in the left-looking form
+        // (gg_chol_d): the factor is the same to the bit.
 #pragma unroll
         for (int j = 0; j < DM; ++j) {
-          double dsum = L[j][j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) dsum = gg_fma(-L[j][k], L[j][k], dsum);
+          const double dsum = L[j][j];
           dmin = __builtin_fmin(dmin, dsum);
           // one reciprocal square root per column instead of D divisions (float-tolerance path)
           double inv = __builtin_amdgcn_rsq(dsum);               // hardware estimate, then two Newton steps
@@ -532,36 +541,40 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
           inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
           L[j][j] = inv;           // the diagonal keeps 1 / L_jj: the solves only ever divide by it
 #pragma unroll
-          for (int i = j + 1; i < DM; ++i) {
-            double v = L[i][j];
+          for (int i = j + 1; i < DM; ++i) L[i][j] = L[i][j] * inv;
 #pragma unroll
-            for (int k = 0; k < j; ++k) v = gg_fma(-L[i][k], L[j][k], v);
-            L[i][j] = v * inv;
-          }
+          for (int i = j + 1; i < DM; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) L[i][k] = gg_fma(-L[i][j], L[k][j], L[i][k]);
         }
-        // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision)
+        if (dbg) { asm volatile("" ::"v"(L[DM - 1][DM - 1])); atomicAdd((unsigned long long*)&dbg[9], (unsigned long long)(clock64() - cB)); }
+        const long long cC = dbg ? clock64() : 0;
+        // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision), both substitutions in their eager form: a finished
+        // component is folded into every later right-hand side at once (forward: the same order per component as before)
         double y[DM];
 #pragma unroll
         for (int i = 0; i < DM; ++i) {
-          double v = hh[i];
+          y[i] = gg_fma(hh[i], L[i][i], zz[i]);
+          const double u = y[i] - zz[i];
 #pragma unroll
-          for (int k = 0; k < i; ++k) v = gg_fma(-L[i][k], y[k] - zz[k], v);
-          y[i] = gg_fma(v, L[i][i], zz[i]);
+          for (int r = i + 1; r < DM; ++r) hh[r] = gg_fma(-L[r][i], u, hh[r]);
         }
 #pragma unroll
         for (int i = DM - 1; i >= 0; --i) {
-          double v = y[i];
+          x[i] = y[i] * L[i][i];
 #pragma unroll
-          for (int k = i + 1; k < DM; ++k) v = gg_fma(-L[k][i], x[k], v);
-          x[i] = v * L[i][i];
+          for (int r = 0; r < i; ++r) y[r] = gg_fma(-L[i][r], x[i], y[r]);
         }
+        if (dbg) { asm volatile("" ::"v"(x[0])); atomicAdd((unsigned long long*)&dbg[10], (unsigned long long)(clock64() - cC)); }
         const bool ok = dmin > 0.0 && x[0] == x[0];   // x[0] closes the back substitution: NaN anywhere reaches it
         if (!ok) atomicOr(status, 1);
 #pragma unroll
         for (int a1 = 0; a1 < DM; ++a1) {
           if (!ok) x[a1] = fo[a1];
           if (FULL || a1 < D) {
-            F[(size_t)n * D + a1] = x[a1];
+            // (the new feature stays in LDS, over the old one it replaces: the tile is written to global memory once, after
+            // the scan - a global store here would sit in front of every later wait of this wave)
+            s_Fo[nl * DM + a1] = x[a1];
             s_scr[a1] = x[a1] * lam[a1];            // fn
             s_scr[DM + a1] = fo[a1] * lam[a1];      // fo
           }
@@ -588,11 +601,14 @@ __global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t
         for (int w = 1; w <= 7; ++w) { const int v = (int)((pq >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
         ready = (nl + 1 < 2) || (mn >= nl);
       }
-      __threadfence_block();
+      gg_lds_wait();   // LDS traffic of one wave is performed in order: the data is written before the word that announces it
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) s_prog[0] = nl + 1;   // change nl is published
-      if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_solve += c3 - c1; }
+      if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_solve += c3 - c1; if (lane == 0) atomicAdd((unsigned long long*)&dbg[11], (unsigned long long)(cA - c1)); }
     }
+    // the tile's new features -> global memory (nothing in this launch reads them: the riders leave this tile out)
+    gg_lds_wait();
+    for (int e = lane; e < T * D; e += 64) F[(size_t)(t0 + e / D) * D + e % D] = s_Fo[(e / D) * DM + e % D];
     if (dbg && lane == 0) { atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)c_wait); atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)c_solve); atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T); }
   } else {
     // updaters: every lane owns up to RU fixed (node, entry) pairs and keeps their running values in registers;
@@ -841,7 +857,7 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   if ((rc = emalloc(&e->F, N * D)) || (rc = emalloc(&e->lmbda, D)) || (rc = emalloc(&e->mu0, 1)) ||
       (rc = emalloc(&e->mu_lmbda, D)) || (rc = emalloc(&e->S, N * e->Np)) || (rc = emalloc(&e->dO, N)) ||
       (rc = emalloc(&e->Z, N * D)) || (rc = emalloc(&e->part, (size_t)2 * EIG_T * e->NCH * e->NE)) ||
-      (rc = emalloc(&e->gpart, N * e->NG)) || (rc = emalloc(&e->status, 1)) || (rc = emalloc(&e->dbgbuf, 8)))
+      (rc = emalloc(&e->gpart, N * e->NG)) || (rc = emalloc(&e->status, 1)) || (rc = emalloc(&e->dbgbuf, 16)))
     return rc;
   const size_t nt = (N + 31) / 32;
   if ((rc = emalloc(&e->llpart, nt * nt))) return rc;
@@ -956,7 +972,7 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     static int dbgon = -1;
     if (dbgon < 0) { const char* ev = getenv("GG_EIG_DBG"); dbgon = ev ? atoi(ev) : 0; }
     long long* dbg = dbgon ? e->dbgbuf : nullptr;
-    if (dbg) GG_HIP(hipMemsetAsync(dbg, 0, 8 * sizeof(long long), st));
+    if (dbg) GG_HIP(hipMemsetAsync(dbg, 0, 16 * sizeof(long long), st));
     const int DMv = e->DM, NEGMv = DMv * (DMv + 1) / 2;
     const size_t chain_lds = (((size_t)EIG_T * (EIG_T + 1) + (size_t)EIG_T * NEGMv + 3 * (size_t)EIG_T * DMv +
                                (size_t)EIG_T * (NEGMv + DMv) + (NEGMv + DMv)) * sizeof(double) + (size_t)EIG_T * EIG_T + 64 + 15) & ~(size_t)15;
@@ -1017,8 +1033,9 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   GG_HIP(hipEventElapsedTime(&ms, e->e0, e->e1));
   e->st.total_ms = ms;
   if (getenv("GG_EIG_DBG") && (parts & GG_PART_F)) {
-    long long h[8];
+    long long h[16];
     (void)hipMemcpy(h, e->dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
+    if (h[3]) fprintf(stderr, "[eig chain]   solver lane per node: fold %.0f, load %.0f, cholesky %.0f, solves %.0f clocks\n", (double)h[11] / h[3], (double)h[8] / h[3], (double)h[9] / h[3], (double)h[10] / h[3]);
     if (h[3]) fprintf(stderr, "[eig chain] per node: wait %.0f fold %.0f solve %.0f shader clocks (%lld nodes); prologue %.0f clocks per tile (block %.0f, +loads %.0f, +cross %.0f)\n", (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / ((h[3] + EIG_T - 1) / EIG_T), (double)h[5] / 64, (double)h[6] / 64, (double)h[7] / 64);
   }
   if (stv) {

@@ -251,26 +251,42 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       }
     }
     if (g.dbg) t_load += wall_clock64() - t_begin - t_load - t_eval - t_xchg - t_apply;
+    // the node's uniform is a function of (seed, site, sweep, node): drawn once per band, not once per round (ten Philox
+    // rounds are a tenth of a round's evaluation)
+    const double u_band = gg_uniform_at(g.seed, g.site, g.sweep,
+                                        (uint32_t)(x.n0 + ((has && n0 + tid / Kp < N) ? n0 + tid / Kp : N - 1)));
     // ---- iterate until the band holds no further change
+    // Spec-order doubles of the statistics: all of them when the band starts; after an accepted change (f: ca -> cb) only
+    // the entries of blocks ca and cb can differ - edges to / from f moved between them and their sizes changed - so only
+    // those 4 * per entries are converted again.
+    auto convert = [&](int idx) {
+      const int i = idx % per, j = (idx / per) % K;
+      const int gc = s_gc[idx];
+      int ts;
+      double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
+      if (ADJ) {
+        const int cx = s_cnt[j] - (s_c[i] == j ? 1 : 0);
+        dst[0] = (double)gc;
+        dst[ts] = (double)(cx - gc);
+      } else {
+        dst[0] = (double)gc;
+#pragma unroll
+        for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)s_gs[(size_t)idx * NSI + s] * (s < B ? sc1 : sc2);
+        if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(s_cnt[j] - (s_c[i] == j ? 1 : 0));
+      }
+    };
+    int redo_a = -1, redo_b = -1;     // blocks whose entries the last accepted change touched (-1: convert everything)
     for (;;) {
       const long long c0 = g.dbg ? wall_clock64() : 0;
       __syncthreads();
       if (tid == 0) *s_min = GG_NO_CHANGE;
       if (has) {
-        for (int idx = tid; idx < 2 * K * per; idx += 256) {
-          const int i = idx % per, j = (idx / per) % K;
-          const int gc = s_gc[idx];
-          int ts;
-          double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
-          if (ADJ) {
-            const int cx = s_cnt[j] - (s_c[i] == j ? 1 : 0);
-            dst[0] = (double)gc;
-            dst[ts] = (double)(cx - gc);
-          } else {
-            dst[0] = (double)gc;
-#pragma unroll
-            for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)s_gs[(size_t)idx * NSI + s] * (s < B ? sc1 : sc2);
-            if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(s_cnt[j] - (s_c[i] == j ? 1 : 0));
+        if (redo_a < 0) {
+          for (int idx = tid; idx < 2 * K * per; idx += 256) convert(idx);
+        } else {
+          for (int e = tid; e < 4 * per; e += 256) {
+            const int i = e % per, js = (e / per) & 1, d = e / (2 * per);
+            convert((d * K + (js ? redo_b : redo_a)) * per + i);
           }
         }
       }
@@ -290,8 +306,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         if (stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab);
         else if (Kp == 64) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T, nn);
         else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
-        const double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + nn));
-        const int lab = gg_group_categorical(lp, k, K, Kp, u);
+        const int lab = gg_group_categorical(lp, k, K, Kp, u_band);
         if (live && k == 0) {
           const int cn = s_c[i];
           if (lab != cn) atomicMin(s_min, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
@@ -340,6 +355,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       }
       nL += 1; nchg += 1;
       pos = f + 1;
+      redo_a = ca; redo_b = cb;
       if (g.dbg) { __syncthreads(); t_apply += wall_clock64() - c2; }
       if (nL >= a.Lcap) {
         // the list is full: bring the statistics of every node that is not in LDS right now up to date in G
