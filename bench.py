@@ -237,7 +237,9 @@ def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every,
                           w_ms=sw["bulk_ms"], w_n=sw["bulk_launches"], w_bytes=sw["bulk_bytes"]),
                 changes=sa["label_changes"] + sw["label_changes"] - chg0,
                 changes_adj=sa["label_changes"], changes_w=sw["label_changes"],
-                ahead=bool(sw["bulk_launches"] > steps // max(every, 1) + 2))   # two timed launches per sampled sweep: the ahead form
+                # the quiet chain ran in the ahead form (fused launches carrying the next sweeps' pass) unless it was switched off
+                ahead=bool(os.environ.get("GG_AHEAD", "1") != "0" and os.environ.get("GG_SCAN") is None and
+                           sa["label_changes"] + sw["label_changes"] - chg0 == 0))
 
 
 def extra_mixing_chains(abi, data, N, K, device, burnin, steps=100):
@@ -671,8 +673,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_params<false,1,1> + k_spec_resolve<3,false,1> (riders = the weight pass k_bulk_w<1> of the next sweep)"
-                          if r["ahead"] else "k_bulk_w<1>",
+                "kernel": "k_sweep_q<3,false,0,0> (scan of sweep s | gated parameter step of sweep s+1 | riders = the weight pass "
+                          "k_bulk_w<1> for sweep s+2)" if r["ahead"] else "k_bulk_w<1>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
