@@ -107,6 +107,9 @@ struct gg_model {
   int scan_pref;                // GG_SCAN: 1 always, 0 never, unset (-1): adaptive - k_scan while the chain keeps changing labels
   long long chg_seen;           // label changes (control word 2) at the last decision
   long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
+  int scan_pref_saved;          // the preference a k_scan timeout suspended (0: none suspended)
+  uint64_t scan_retry_at;       // st.sweeps count from which the suspended preference is tried again
+  uint64_t scan_backoff;        // sweeps to wait after the next timeout (doubles with every timeout, at most 2^20)
   int scan_spin;                // polls before a k_scan exchange gives up (GG_SCAN_SPIN overrides the default for tests)
   long long scan_hold;          // clean sweeps required before leaving k_scan mode (doubles when the chain stalls again soon after)
   long long since_revert;       // sweeps completed in speculate + resolve mode since the last switch back
@@ -336,6 +339,8 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
     m->use_scan = m->scan_pref == 1;
     m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
+    m->scan_pref_saved = 0; m->scan_retry_at = 0;
+    { const char* er = getenv("GG_SCAN_RETRY"); m->scan_backoff = (er && atoll(er) > 0) ? (uint64_t)atoll(er) : 1024; }
     { const char* esp = getenv("GG_SCAN_SPIN"); m->scan_spin = esp && atoi(esp) > 0 ? atoi(esp) : GG_BAR_SPIN_LIMIT; }
     // The ahead form (enqueue_sweep_ahead): while the chain is quiet, the next sweep's bulk pass rides in this sweep's
     // k_params and k_spec_resolve launches.  GG_AHEAD=0 keeps every sweep in the serial form (bulk -> params -> scan).
@@ -1148,6 +1153,24 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   return GG_OK;
 }
 
+// A k_scan exchange timed out: the model continues with restart rounds, and tries the resident grid again after
+// scan_backoff further sweeps (1024, doubling with every timeout) - one transient (a device shared with another
+// process for a moment) must not cost the 2.6x per-change penalty for the rest of the model's life.
+static void scan_suspend(gg_model* m) {
+  if (m->scan_pref == 0) return;
+  m->scan_pref_saved = m->scan_pref;
+  m->scan_pref = 0; m->use_scan = false;
+  m->scan_retry_at = m->st.sweeps + m->scan_backoff;
+  if (m->scan_backoff < (1ull << 20)) m->scan_backoff *= 2;
+}
+static void scan_maybe_resume(gg_model* m) {
+  if (m->scan_pref_saved == 0 || m->scan_pref != 0 || m->st.sweeps < m->scan_retry_at) return;
+  m->scan_pref = m->scan_pref_saved;
+  m->scan_pref_saved = 0;
+  m->use_scan = m->scan_pref == 1;
+  m->clean_run = 0; m->since_revert = 1 << 30;
+}
+
 // Finish a scan the pipeline left unfinished.  Restart rounds are device-driven: each round is ONE launch
 // (k_round: bring the next window's statistics up to date with the change list, re-speculate it, resolve it)
 // that reads the scan position from the control block and turns into a no-op once the scan is done, so a
@@ -1170,8 +1193,8 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     if (m->h_rs[3] == 2) {
       // the resident grid timed out and left a consistent stalled scan: restart rounds from here on (see model_sync)
       if ((rc = write_ctl_word(m, 3, 0))) return rc;
-      fprintf(stderr, "graphgibbs: the resident-grid scan timed out; this model continues with restart rounds (GG_SCAN=0)\n");
-      m->scan_pref = 0; m->use_scan = false;
+      fprintf(stderr, "graphgibbs: the resident-grid scan timed out; this model continues with restart rounds for %llu sweeps\n", (unsigned long long)m->scan_backoff);
+      scan_suspend(m);
     } else {
       if (m->h_rs[3]) return GG_OK;          // (status: reported by the caller's next control-block check)
       if (m->h_rs[4]) { if ((rc = write_ctl_word(m, 4, 0))) return rc; }
@@ -1368,8 +1391,8 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       // A k_scan exchange timed out (the resident grid could not assemble - a device shared with other processes, say)
       // and left the scan as a stalled one at a consistent position: carry on with the launch-per-change form, for good.
       if ((rc = write_ctl_word(m, 3, 0))) return rc;
-      if (m->scan_pref != 0) fprintf(stderr, "graphgibbs: the resident-grid scan timed out at node %d (%d changes in its list); this model continues with restart rounds (GG_SCAN=0)\n", m->h_rs[0], m->h_rs[1]);
-      m->scan_pref = 0; m->use_scan = false;
+      if (m->scan_pref != 0) fprintf(stderr, "graphgibbs: the resident-grid scan timed out at node %d (%d changes in its list); this model continues with restart rounds for %llu sweeps\n", m->h_rs[0], m->h_rs[1], (unsigned long long)m->scan_backoff);
+      scan_suspend(m);
       m->h_rs[3] = 0;
       abort0 = m->h_rs[4] && m->h_rs[0] == 0;   // it gave up before its first decision: still a stalled scan, at node 0
     }
@@ -1400,6 +1423,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       m->sweep += (uint32_t)m->pending;
       m->st.sweeps += (uint64_t)m->pending;
       m->pending = 0;
+      scan_maybe_resume(m);
       if (m->todo == 0) break;
       // a clean batch: look further ahead again
       if (m->depth < (1 << 20)) m->depth *= 2;
@@ -1859,10 +1883,10 @@ static int ll_enqueue(gg_model* m, const gg_data* d) {
     for (int i = 0; i < gg_nsi(GG_MAXB); ++i) g.dS[i] = d->dS[i];
     g.diag_zero = (m->is_adj && !m->cfg.allow_self_connections && m->kind == GG_SBM_ADJ) ? 1 : 0;
     g.joint = m->joint ? 1 : 0;
-    g.out = m->ll_out;
+    // (the two result words go straight into the pinned, device-mapped staging: no copy to enqueue behind the kernel)
+    g.out = reinterpret_cast<double*>(m->h_tab);
     k_loglik<<<1, 256, 0, m->stream>>>(g);
     GG_HIP(hipGetLastError());
-    GG_HIP(hipMemcpyAsync(m->h_tab, m->ll_out, 2 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
   }
   m->ll_host_form = host_form;
   return GG_OK;

@@ -263,13 +263,16 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spin", [1, 3, 9])
-def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin):
+@pytest.mark.parametrize("spin,retry,nsw", [(1, 0, 5), (3, 0, 5), (9, 0, 5), (1, 2, 14)])
+def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin, retry, nsw):
     """A k_scan exchange that times out (GG_SCAN_SPIN: a handful of polls instead of 4 million - what a device shared
     with other processes would do to the resident grid) leaves the scan as a consistent stalled one; the engine carries
-    on with restart rounds for good and the chain stays the oracle's bit for bit."""
+    on with restart rounds and the chain stays the oracle's bit for bit.  The resident grid is tried again after a
+    back-off (1024 sweeps, doubling; GG_SCAN_RETRY=2 here so that 14 sweeps see several suspensions and retries)."""
     monkeypatch.setenv("GG_SCAN", "1")
     monkeypatch.setenv("GG_SCAN_SPIN", str(spin))
+    if retry:
+        monkeypatch.setenv("GG_SCAN_RETRY", str(retry))
     N, K = 400, 16
     A, W, _ = planted_sbm(N, K, seed=19)
     q, shift = O.quantise(A, W)
@@ -282,7 +285,6 @@ def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin)
     w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
     w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
     ps = sa.p_self
-    nsw = 5
     abi.resample_many([adj, w], d, nsw)
     for s in range(nsw):
         ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 81, s)
@@ -291,7 +293,10 @@ def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin)
     assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu)
     # (with a few more polls the 25 workgroups sometimes do meet in time: then nothing is printed)
     if spin == 1:
-        assert "timed out" in capfd.readouterr().err
+        err = capfd.readouterr().err
+        assert "timed out" in err
+        if retry:      # suspended, resumed, suspended again: more than one message per model
+            assert err.count("timed out") > 2
 
 
 @pytest.mark.gpu
