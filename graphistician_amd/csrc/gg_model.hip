@@ -189,6 +189,9 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
   const int K = m->K, per = 256 / m->Kp;
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
                (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)lcap * 3 * sizeof(int);
+  // the last exchange slot by slot, its surprises, per-node block sizes, scratch, one hypothesis per node of a band
+  lds += 256 * sizeof(unsigned long long) + 256 * 3 * sizeof(int) + (size_t)per * K * sizeof(int) + 16 * sizeof(int) + 16 +
+         (size_t)GG_SCAN_MAXWG * per * sizeof(short);
   if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
@@ -1124,6 +1127,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   g.keep_L = 0;
   a.ap = m->ap; a.Gc0 = gcnt(m, buf, 0); a.Gs0 = gs(m, buf, 0); a.bar = m->bar;
   a.Lcap = m->Lcap < 1024 ? m->Lcap : 1024;   // every workgroup keeps its own copy of the list in LDS (12 KB)
+  { const char* el = getenv("GG_SCAN_LCAP"); if (el && atoi(el) >= 2 && atoi(el) < a.Lcap) a.Lcap = atoi(el); }   // (tests: flush the list often)
   const int per = 256 / m->Kp;
   const int ngroups = (m->Nl + per - 1) / per;
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;

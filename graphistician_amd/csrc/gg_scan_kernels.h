@@ -7,12 +7,24 @@
 //   * per iteration every workgroup re-evaluates the nodes of its group that lie at or behind the scan position
 //     (statistics and, when they fit, coefficient tables stay in LDS), reports its first changer with a
 //     device-scope atomicMin, and meets the others at a grid barrier (one counter, bounded spin);
-//   * the minimum is the next exact change of the scan: every workgroup applies it to its own group's
-//     statistics (one byte / one int32 per node and direction from row f of X and X^T), the scan position
-//     moves behind it, and the loop continues; a band without a change is final and the grid moves on.
-// Cost: one barrier round (a few us) per accepted change instead of a kernel launch (and, before, a host round
-// trip), and no stall of the optimistic sweep pipeline.  Same statistics, same conditional, same draw as the
-// sequential loop: bit-exact (tests/test_gpu_parity_sbm.py run through this kernel).
+//   * the minimum is the next exact change of the scan; the candidates of the OTHER workgroups are kept as
+//     hypotheses (below), every workgroup applies all of them to its own group's statistics (one bit / one
+//     int32 per node and direction from row f of X and X^T), the scan position moves behind the minimum,
+//     and the loop continues; a band without a surprise is final and the grid moves on.
+// Hypotheses.  A round's exchange shows every workgroup ALL first changers, not only the earliest.  The later
+// ones were computed without the earlier ones, so they are not the chain yet - but a change elsewhere rarely
+// flips a decision (that is what the speculative form rests on), so they are taken as a hypothesis H: node n
+// sees the statistics of accepted changes + every h in H with position < n, is evaluated under them, and what a
+// workgroup reports is its first SURPRISE - the first live node whose decision differs from what H says about
+// it (a new changer, a hypothesised change that does not happen, or one that goes elsewhere).  The earliest
+// surprise p* was evaluated under hypotheses that all lie before it and are thereby confirmed (induction
+// over positions: the first is exact, so is the next, ...): everything of H before p* and the decision at p*
+// are the chain, exactly; the other surprises amend H.  A round without a surprise confirms all of H.
+// Rounds per band: 1 + the largest number of changers in one workgroup's group (+ the rare flips) instead of
+// 1 + the number of changes.  Never more rounds than before (H empty = the old protocol).
+// Cost: one barrier round (a few us) per round instead of a kernel launch (and, before, a host round
+// trip) per accepted change, and no stall of the optimistic sweep pipeline.  Same statistics, same conditional, same
+// draw as the sequential loop: bit-exact (tests/test_gpu_parity_sbm.py run through this kernel).
 //
 // Grid barrier: all G workgroups must be resident.  G <= 256 workgroups of 256 threads with <= 64 KB LDS is far
 // below what the chip holds (even with the other model's kernels in flight), and every spin is bounded: on a
@@ -50,7 +62,7 @@ struct gg_scan_args {
 // (statistics flushed into G) must be visible to the other workgroups after it.
 __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int G, unsigned tag, unsigned long long mine,
                                                  bool fenced, unsigned long long* s_min, int32_t* rs, unsigned long long* best,
-                                                 int spin_limit) {
+                                                 int spin_limit, unsigned long long* s_all = nullptr) {
   const int tid = threadIdx.x;
   // two slot arrays, alternating by round: a workgroup can be one round ahead of the slowest one (never two), and
   // must not overwrite the value the slow ones are still polling for
@@ -75,6 +87,7 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
     }
     if (__syncthreads_and(seen ? 1 : 0)) {
       if (v != GG_SLOT_NONE) atomicMin(s_min, v);
+      if (s_all) s_all[tid] = v;     // slot order = position order within a band (workgroup t owns group band G + t)
       okall = true;
       break;
     }
@@ -116,7 +129,13 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);
   off = (off + 7) & ~(size_t)7;
   unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_raw + off); off += 2 * sizeof(unsigned long long);
-  int* s_L = reinterpret_cast<int*>(s_raw + off);   // [Lcap][3]: this workgroup's own copy of the change list
+  int* s_L = reinterpret_cast<int*>(s_raw + off); off += (size_t)a.Lcap * 3 * sizeof(int);   // [Lcap][3]: this workgroup's own copy of the change list
+  off = (off + 7) & ~(size_t)7;
+  unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(s_raw + off); off += 256 * sizeof(unsigned long long);   // the last exchange, slot by slot
+  int* s_S = reinterpret_cast<int*>(s_raw + off); off += 256 * 3 * sizeof(int);      // its surprises, compacted: (node, from, to)
+  int* s_cntn = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * K * sizeof(int);   // block sizes as node i of the group sees them
+  int* s_misc = reinterpret_cast<int*>(s_raw + off); off += 16 * sizeof(int);
+  short* s_H = reinterpret_cast<short*>(s_raw + off);   // [G per] hypothesis per node of the band: -1 none, else (old << 8 | new)
 
   const size_t dstride = (size_t)K * Np;
   // The first band's statistics: 2 K per <= 512 entries, at most two per thread.  Their loads are issued before the
@@ -182,6 +201,52 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     }
   };
 
+  // the moves (f: from -> to) of a list applied to the statistics of my group's nodes (first node n0); behind_only: only to
+  // the nodes behind f - a node sees the changes at positions before its own - together with the block sizes they see
+  auto apply_moves = [&](const int* list, int count, int n0, bool behind_only) {
+    const int nitems = count * per * 2;
+    for (int base = tid; base < nitems; base += 256 * U) {
+      int ia[U], ib[U], ii[U], dd[U];
+      size_t at[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * 256;
+        const int d = idx & 1, i = (idx >> 1) % per, e = (idx >> 1) / per;
+        const int ee = idx < nitems ? e : 0;
+        const int n2 = list[ee * 3];
+        ok[u] = idx < nitems && n0 + i < N && (!behind_only || n0 + i > n2);
+        ia[u] = list[ee * 3 + 1]; ib[u] = list[ee * 3 + 2];
+        ii[u] = i; dd[u] = d;
+        at[u] = ok[u] ? (size_t)n2 * Np + n0 + i : 0;
+      }
+      if (ADJ) {
+        uint8_t xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = gg_abit(dd[u] == 0 ? g.XAT : g.XA, at[u]) ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u] && xv[u] != 0) move_edge(dd[u], ii[u], ia[u], ib[u], nullptr);
+      } else {
+        int32_t q[U][B];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t* src = (dd[u] == 0 ? g.XWT : g.XW) + at[u] * B;
+#pragma unroll
+          for (int r = 0; r < B; ++r) q[u][r] = src[r];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u] && q[u][0] != GG_NO_EDGE) move_edge(dd[u], ii[u], ia[u], ib[u], q[u]);
+      }
+      if (behind_only) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u] && dd[u] == 0) { atomicSub(&s_cntn[ii[u] * K + ia[u]], 1); atomicAdd(&s_cntn[ii[u] * K + ib[u]], 1); }
+      }
+    }
+  };
+
   for (int band = band_first; band * G < ngroups && alive; ++band) {
     const int grp = band * G + b;
     const bool has = grp < ngroups;
@@ -213,69 +278,40 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       }
       if (tid < per) s_c[tid] = (n0 + tid < N) ? g.c[n0 + tid] : 0;
       __syncthreads();
-      const int nitems = nL * per * 2;
-      for (int base = tid; base < nitems; base += 256 * U) {
-        int ia[U], ib[U], ii[U], dd[U];
-        size_t at[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int idx = base + u * 256;
-          const int d = idx & 1, i = (idx >> 1) % per, e = (idx >> 1) / per;
-          ok[u] = idx < nitems && n0 + i < N;
-          const int ee = ok[u] ? e : 0;
-          const int n2 = s_L[ee * 3];
-          ia[u] = s_L[ee * 3 + 1]; ib[u] = s_L[ee * 3 + 2];
-          ii[u] = i; dd[u] = d;
-          at[u] = ok[u] ? (size_t)n2 * Np + n0 + i : 0;
-        }
-        if (ADJ) {
-          uint8_t xv[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) xv[u] = gg_abit(dd[u] == 0 ? g.XAT : g.XA, at[u]) ? 1 : 0;
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (ok[u] && xv[u] != 0) move_edge(dd[u], ii[u], ia[u], ib[u], nullptr);
-        } else {
-          int32_t q[U][B];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int32_t* src = (dd[u] == 0 ? g.XWT : g.XW) + at[u] * B;
-#pragma unroll
-            for (int r = 0; r < B; ++r) q[u][r] = src[r];
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (ok[u] && q[u][0] != GG_NO_EDGE) move_edge(dd[u], ii[u], ia[u], ib[u], q[u]);
-        }
-      }
+      apply_moves(s_L, nL, n0, false);
     }
     if (g.dbg) t_load += wall_clock64() - t_begin - t_load - t_eval - t_xchg - t_apply;
+    // the band starts without hypotheses; every node of the group sees the block sizes of the accepted labels
+    const int band0 = band * G * per;
+    const int band1 = (band0 + G * per < N) ? band0 + G * per : N;
+    for (int idx = tid; idx < G * per; idx += 256) s_H[idx] = (short)-1;
+    for (int idx = tid; idx < per * K; idx += 256) s_cntn[idx] = s_cnt[idx % K];
     // the node's uniform is a function of (seed, site, sweep, node): drawn once per band, not once per round (ten Philox
     // rounds are a tenth of a round's evaluation)
     const double u_band = gg_uniform_at(g.seed, g.site, g.sweep,
                                         (uint32_t)(x.n0 + ((has && n0 + tid / Kp < N) ? n0 + tid / Kp : N - 1)));
-    // ---- iterate until the band holds no further change
-    // Spec-order doubles of the statistics: all of them when the band starts; after an accepted change (f: ca -> cb) only
-    // the entries of blocks ca and cb can differ - edges to / from f moved between them and their sizes changed - so only
-    // those 4 * per entries are converted again.
+    // ---- iterate until the band holds no further surprise
+    // Spec-order doubles of the statistics: all of them when the band starts and after a round with several surprises;
+    // after a single one (f: ca -> cb) only the entries of blocks ca and cb can differ - edges to / from f moved between
+    // them and their sizes changed - so only those 4 * per entries are converted again.
     auto convert = [&](int idx) {
       const int i = idx % per, j = (idx / per) % K;
       const int gc = s_gc[idx];
       int ts;
       double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
       if (ADJ) {
-        const int cx = s_cnt[j] - (s_c[i] == j ? 1 : 0);
+        const int cx = s_cntn[i * K + j] - (s_c[i] == j ? 1 : 0);
         dst[0] = (double)gc;
         dst[ts] = (double)(cx - gc);
       } else {
         dst[0] = (double)gc;
 #pragma unroll
         for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)s_gs[(size_t)idx * NSI + s] * (s < B ? sc1 : sc2);
-        if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(s_cnt[j] - (s_c[i] == j ? 1 : 0));
+        if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(s_cntn[i * K + j] - (s_c[i] == j ? 1 : 0));
       }
     };
-    int redo_a = -1, redo_b = -1;     // blocks whose entries the last accepted change touched (-1: convert everything)
+    int redo_a = -1, redo_b = -1;     // blocks whose entries the last round touched (-1: convert everything)
+    const int wv = tid >> 6, ln = tid & 63;
     for (;;) {
       const long long c0 = g.dbg ? wall_clock64() : 0;
       __syncthreads();
@@ -308,61 +344,100 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
         const int lab = gg_group_categorical(lp, k, K, Kp, u_band);
         if (live && k == 0) {
+          // what the hypotheses say about this node: it moves to h's new label, or it stays
           const int cn = s_c[i];
-          if (lab != cn) atomicMin(s_min, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
+          const int h = s_H[n - band0];
+          const int expct = h >= 0 ? (h & 0xff) : cn;
+          if (lab != expct) atomicMin(s_min, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
         }
       }
       __syncthreads();
       const long long c1 = g.dbg ? wall_clock64() : 0;
       unsigned long long best;
       {
-        const unsigned long long mine = *s_min;   // this workgroup's first changer (48-bit payload) or none
-        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, false, s_min, g.rs, &best, a.spin_limit)) {
+        const unsigned long long mine = *s_min;   // this workgroup's first surprise (48-bit payload) or none
+        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, false, s_min, g.rs, &best, a.spin_limit, s_slot)) {
           alive = false;
           break;
         }
       }
       ++it; ++wi;
-      if (best == GG_SLOT_NONE) best = GG_NO_CHANGE;
       const long long c2 = g.dbg ? wall_clock64() : 0;
       t_eval += c1 - c0; t_xchg += c2 - c1;
-      if (best == GG_NO_CHANGE) break;   // the band is final
-      const int f = (int)(best >> 12), ca = (int)((best >> 6) & 63u), cb = (int)(best & 63u);
-      if (tid == 0) {
-        s_cnt[ca] -= 1; s_cnt[cb] += 1;
-        if (has && f >= n0 && f < n0 + per) s_c[f - n0] = cb;
-        if (nL < a.Lcap) { s_L[nL * 3] = f; s_L[nL * 3 + 1] = ca; s_L[nL * 3 + 2] = cb; }
-        if (b == 0) {   // for what runs after this kernel (labels; the list, when the statistics are carried over)
-          g.c[f] = cb;
-          if (nL < a.Lcap) { g.L[nL * 3] = f; g.L[nL * 3 + 1] = ca; g.L[nL * 3 + 2] = cb; }
+      const bool quiet = best == GG_SLOT_NONE;   // no surprise anywhere: every remaining hypothesis is the chain
+      // ---- the surprises, in position order (= slot order), amend the hypotheses
+      int nS = 0;
+      if (!quiet) {
+        const unsigned long long v = s_slot[tid];
+        const bool hs = v != GG_SLOT_NONE;
+        const unsigned long long bal = __ballot(hs);
+        if (ln == 0) s_misc[wv] = __popcll(bal);
+        __syncthreads();
+        int offS = __popcll(bal & ((1ull << ln) - 1ull));
+        for (int w = 0; w < wv; ++w) offS += s_misc[w];
+        nS = s_misc[0] + s_misc[1] + s_misc[2] + s_misc[3];
+        if (hs) {
+          const int f = (int)(v >> 12), old = (int)((v >> 6) & 63u), nw = (int)(v & 63u);
+          const int h = s_H[f - band0];
+          // statistics behind f hold f in block `from` (the hypothesised label, or the old one): it goes to `nw`
+          s_S[offS * 3] = f; s_S[offS * 3 + 1] = h >= 0 ? (h & 0xff) : old; s_S[offS * 3 + 2] = nw;
+          s_H[f - band0] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
         }
+        __syncthreads();
       }
-      // statistics of my group's nodes: the edges to / from f move from block ca to block cb
-      if (has && tid < per * 2) {
-        const int d = tid & 1, i = tid >> 1;
-        if (n0 + i < N && n0 + i != f) {
-          const size_t at = (size_t)f * Np + n0 + i;
-          if (ADJ) {
-            if (gg_abit(d == 0 ? g.XAT : g.XA, at)) move_edge(d, i, ca, cb, nullptr);
-          } else {
-            const int32_t* q = (d == 0 ? g.XWT : g.XW) + at * B;
-            int32_t qq[B];
-#pragma unroll
-            for (int r = 0; r < B; ++r) qq[r] = q[r];
-            if (qq[0] != GG_NO_EDGE) move_edge(d, i, ca, cb, qq);
+      // ---- accept: the hypotheses at positions [pos, hi) - up to and including the earliest surprise - are the chain
+      const int hi = quiet ? band1 : (int)(best >> 12) + 1;
+      bool cut = false;       // the list filled up before the end of the range
+      {
+        const int len = hi - pos;
+        const int chunk = (len + 255) / 256;
+        const int lo_t = pos + tid * chunk;
+        int cnt_t = 0;
+        for (int q = 0; q < chunk; ++q) { const int n = lo_t + q; if (n < hi && s_H[n - band0] >= 0) ++cnt_t; }
+        int incl = cnt_t;
+        for (int dlt = 1; dlt < 64; dlt <<= 1) { const int o = __shfl_up(incl, dlt); if (ln >= dlt) incl += o; }
+        if (ln == 63) s_misc[4 + wv] = incl;
+        __syncthreads();
+        int e = incl - cnt_t;
+        for (int w = 0; w < wv; ++w) e += s_misc[4 + w];
+        const int total = s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
+        const int room = a.Lcap - nL;
+        const int take = total < room ? total : room;
+        for (int q = 0; q < chunk; ++q) {
+          const int n = lo_t + q;
+          if (n >= hi) break;
+          const int h = s_H[n - band0];
+          if (h < 0) continue;
+          if (e < take) {
+            const int old = h >> 8, nw = h & 0xff;
+            int* dstL = s_L + (size_t)(nL + e) * 3;
+            dstL[0] = n; dstL[1] = old; dstL[2] = nw;
+            atomicSub(&s_cnt[old], 1); atomicAdd(&s_cnt[nw], 1);
+            if (b == 0) {   // for what runs after this kernel (labels; the list, for a scan that is handed to restart rounds)
+              g.c[n] = nw;
+              int32_t* dstG = g.L + (size_t)(nL + e) * 3;
+              dstG[0] = n; dstG[1] = old; dstG[2] = nw;
+            }
+            if (e == take - 1) s_misc[8] = n;
           }
+          ++e;
         }
+        __syncthreads();
+        cut = take < total;
+        if (take > 0) pos = cut ? s_misc[8] + 1 : hi;
+        else if (!cut) pos = hi;
+        nL += take; nchg += take;
       }
-      nL += 1; nchg += 1;
-      pos = f + 1;
-      redo_a = ca; redo_b = cb;
+      // ---- statistics of my group's nodes behind each surprise: the edges to / from f move between blocks
+      if (has && nS > 0) apply_moves(s_S, nS, n0, true);
+      if (nS == 1) { redo_a = s_S[1]; redo_b = s_S[2]; } else redo_a = redo_b = -1;
       if (g.dbg) { __syncthreads(); t_apply += wall_clock64() - c2; }
       if (nL >= a.Lcap) {
         // the list is full: bring the statistics of every node that is not in LDS right now up to date in G
-        // (earlier bands: written back with ap entries applied; later bands: as the bulk pass left them), then
+        // (earlier bands: as the bulk pass left them + ap entries; later bands: as the bulk pass left them), then
         // start a fresh list.  Grid-wide, followed by a barrier.
         {
-          // (earlier bands' write-backs and ap entries were plain stores of other workgroups: fenced meeting first)
+          // (earlier bands' ap entries were plain stores of other workgroups: fenced meeting first)
           unsigned long long dummy;
           if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), GG_SLOT_NONE, true, s_min, g.rs, &dummy, a.spin_limit)) { alive = false; break; }
           ++it;
@@ -403,6 +478,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
         nL = 0;
         flushed = true;
       }
+      if (quiet && !cut) break;   // the band is final
     }
     if (!alive) break;
     // the band is final: write the group's statistics back (exact under the labels so far) for the incremental path

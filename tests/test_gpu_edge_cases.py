@@ -235,11 +235,16 @@ def test_ahead_form_is_the_same_chain(abi, monkeypatch, ahead, split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K", [(300, 7), (1100, 64)])
-def test_resident_grid_scan_is_the_same_chain(abi, N, K, monkeypatch):
-    """GG_SCAN=1: the scan as one resident-grid launch (k_scan: grid-wide exchange per accepted change).  Same chain bit
-    for bit, burn-in included; N=1100, K=64 needs two bands of node groups (lazy change list at band load)."""
+@pytest.mark.parametrize("N,K,lcap", [(300, 7, 0), (1100, 64, 0), (300, 7, 3), (1100, 64, 5), (700, 16, 2)])
+def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, monkeypatch):
+    """GG_SCAN=1: the scan as one resident-grid launch (k_scan: one grid-wide exchange per round, every round accepting the
+    hypothesised changes up to the earliest surprise).  Same chain bit for bit, burn-in included (random start: hundreds
+    of changes per scan, several changers per workgroup); N=1100, K=64 needs two bands of node groups (lazy change list
+    at band load); GG_SCAN_LCAP: a change list of 2-5 entries, so that acceptances are cut short and the chip-wide
+    flush of the list runs many times per scan."""
     monkeypatch.setenv("GG_SCAN", "1")
+    if lcap:
+        monkeypatch.setenv("GG_SCAN_LCAP", str(lcap))
     A, W, _ = planted_sbm(N, K, seed=31)
     q, shift = O.quantise(A, W)
     sa, sw = AdjState(N, K, seed=5), WState(N, K, 1, seed=6)
