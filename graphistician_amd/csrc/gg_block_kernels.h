@@ -568,7 +568,7 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
     }
     // k_scan's exchange slots (2 x 256, one per 128-byte line): tag 0 = never written
     if (g.do_prep && g.bar)
-      for (unsigned sl = bid * blockDim.x + threadIdx.x; sl < 512u; sl += nfront * blockDim.x) g.bar[(size_t)sl * GG_SLOT_PAD] = 0ull;
+      for (unsigned sl = bid * blockDim.x + threadIdx.x; sl < 512u * 4u; sl += nfront * blockDim.x) g.bar[(size_t)(sl >> 2) * GG_SLOT_PAD + (sl & 3u)] = 0ull;   // (k_scan uses words 0..3 of a slot line)
     if (g.zero_ptr) {
       size_t i = (size_t)bid * blockDim.x + threadIdx.x;
       size_t stride = (size_t)nfront * blockDim.x;
@@ -921,7 +921,8 @@ __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n,
 // node's out / in statistics towards block j as doubles in spec order.
 template <int NT, bool ADJ, int UJ_ = 0, class Loader>
 __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld,
-                                                  const double* __restrict__ Tout, const double* __restrict__ Tin) {
+                                                  const double* __restrict__ Tout, const double* __restrict__ Tin,
+                                                  const double* logm_k = nullptr) {
   if (k >= x.K) return -gg_inf();
   const int K = x.K, Kp = x.Kp;
   double acc_o[NT], acc_i[NT];
@@ -961,7 +962,54 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
       acc_i[t] = gg_fma(Tin[((size_t)j * NT + t) * Kp + k], si[t], acc_i[t]);
     }
   }
-  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i);
+  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, logm_k);
+}
+
+// The same with ONE copy of the table T[a][b][t] (rows padded to RS doubles, RS odd: lane k's reads of row k fall into
+// different LDS banks) instead of the two lane-major layouts: out-coefficient (j, t) of lane k = T[k][j][t], in-coefficient
+// = T[j][k][t].  Half the LDS of the two layouts: what lets K = 32..64 keep the table next to the statistics (k_scan).
+template <int NT, bool ADJ, class Loader>
+__device__ __forceinline__ double gg_node_lp_core_t1(const gg_node_ctx& x, int n, int k, Loader ld,
+                                                     const double* __restrict__ T1, int RS, const double* logm_k = nullptr) {
+  if (k >= x.K) return -gg_inf();
+  const int K = x.K;
+  double acc_o[NT], acc_i[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc_o[t] = 0.0; acc_i[t] = 0.0; }
+  const double* To = T1 + (size_t)k * RS;
+  const double* Ti = T1 + (size_t)k * NT;
+  constexpr int UJ = NT <= 3 ? 4 : 2;
+  int j = 0;
+  for (; j + UJ <= K; j += UJ) {
+    double to[UJ][NT], ti[UJ][NT];
+#pragma unroll
+    for (int u = 0; u < UJ; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        to[u][t] = To[(j + u) * NT + t];
+        ti[u][t] = Ti[(size_t)(j + u) * RS + t];
+      }
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) {
+      double so[NT], si[NT];
+      ld(j + u, so, si);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc_o[t] = gg_fma(to[u][t], so[t], acc_o[t]);
+        acc_i[t] = gg_fma(ti[u][t], si[t], acc_i[t]);
+      }
+    }
+  }
+  for (; j < K; ++j) {
+    double so[NT], si[NT];
+    ld(j, so, si);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc_o[t] = gg_fma(To[j * NT + t], so[t], acc_o[t]);
+      acc_i[t] = gg_fma(Ti[(size_t)j * RS + t], si[t], acc_i[t]);
+    }
+  }
+  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, logm_k);
 }
 
 // Where the spec-order doubles of (direction d, block j, node i of the workgroup) live in LDS: element t is at
@@ -979,7 +1027,8 @@ __device__ __forceinline__ size_t gg_st_slot(bool split, int dj /* d * K + j */,
 // order of gg_block_lp.  Same chains, same order, same bits.  s_st: [dir][j][NT][4] (gg_st_slot with split = true),
 // s_acc: [4][2 NT][64].
 template <int NT, bool ADJ>
-__device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const double* s_st, double* s_acc, int n) {
+__device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const double* s_st, double* s_acc, int n,
+                                               const double* T1 = nullptr, int RS = 0) {
   constexpr int NCH = 2 * NT;
   constexpr int CPW = (NCH + 3) / 4;                                         // chains per wave
   constexpr int UJ = CPW == 1 ? 64 : (CPW == 2 ? 32 : (CPW <= 4 ? 16 : 8));   // table entries in flight per chain
@@ -999,11 +1048,22 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
         const int ch = w + 4 * c;
         if (ch < NCH) {
           const int d = ch / NT, t = ch % NT;
-          const double* Tb = (d == 0 ? x.Tout : x.Tin) + (size_t)t * 64 + k;
+          if (T1) {
+            // one padded copy of T[a][b][t] in LDS (gg_node_lp_core_t1): out = T[k][j][t], in = T[j][k][t]
+            const double* Tb = T1 + (d == 0 ? (size_t)k * RS : (size_t)k * NT) + t;
+            const int js = d == 0 ? NT : RS;
 #pragma unroll
-          for (int u = 0; u < UJ; ++u) {
-            const int jj = (j + u < K) ? j + u : K - 1;
-            tv[c][u] = Tb[(size_t)jj * NT * 64];
+            for (int u = 0; u < UJ; ++u) {
+              const int jj = (j + u < K) ? j + u : K - 1;
+              tv[c][u] = Tb[(size_t)jj * js];
+            }
+          } else {
+            const double* Tb = (d == 0 ? x.Tout : x.Tin) + (size_t)t * 64 + k;
+#pragma unroll
+            for (int u = 0; u < UJ; ++u) {
+              const int jj = (j + u < K) ? j + u : K - 1;
+              tv[c][u] = Tb[(size_t)jj * NT * 64];
+            }
           }
         }
       }

@@ -189,13 +189,19 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
   const int K = m->K, per = 256 / m->Kp;
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
                (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)lcap * 3 * sizeof(int);
-  // the last exchange slot by slot, its surprises, per-node block sizes, scratch, one hypothesis per node of a band
-  lds += 256 * sizeof(unsigned long long) + 256 * 3 * sizeof(int) + (size_t)per * K * sizeof(int) + 16 * sizeof(int) + 16 +
+  // deviations, the round's surprises, per-node block sizes, scratch, one hypothesis per node of a band
+  lds += 136 * sizeof(unsigned long long) + 256 * 3 * sizeof(int) + (size_t)per * K * sizeof(int) + 16 * sizeof(int) + 16 +
          (size_t)GG_SCAN_MAXWG * per * sizeof(short);
   if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
-  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
-  if (stage) lds += table_bytes(m);
-  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);
+  // coefficient table: both lane-major layouts when that stays below 64 KB (1); else one padded copy of T[a][b][t], as
+  // far as the LDS goes (2: K = 32..64 at B = 1); else from global memory (0).  Kp = 64 without layout 1 evaluates with
+  // gg_lp_split4, which needs its meeting place.
+  const size_t split_acc = m->Kp == 64 ? (size_t)4 * 2 * m->NT * 64 * sizeof(double) : 0;
+  const size_t one_copy = (size_t)K * ((K * m->NT) | 1) * sizeof(double);
+  int stage = 0;
+  if (lds + table_bytes(m) <= 64 * 1024) { stage = 1; lds += table_bytes(m); }
+  else if (lds + split_acc + one_copy <= GG_LDS_LIMIT) { stage = 2; lds += split_acc + one_copy; }
+  else lds += split_acc;
   if (stage_out) *stage_out = stage;
   return lds;
 }
@@ -1132,7 +1138,13 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   const int ngroups = (m->Nl + per - 1) / per;
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
   int stage;
-  const size_t lds = lds_scan(m, a.Lcap, &stage);
+  size_t lds = lds_scan(m, a.Lcap, &stage);
+  if (stage == 0 && a.Lcap > 256) {
+    // a shorter change list (flushed into G more often) when that is what lets the coefficient table into LDS
+    int stage_s;
+    const size_t lds_s = lds_scan(m, 256, &stage_s);
+    if (stage_s != 0) { a.Lcap = 256; lds = lds_s; stage = stage_s; }
+  }
   if (lds > GG_LDS_LIMIT)
     return gg_fail(GG_ERR_UNSUPPORTED, "the resident-grid scan needs %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
   g.stage_tables = stage;

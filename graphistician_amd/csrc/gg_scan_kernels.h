@@ -62,7 +62,7 @@ struct gg_scan_args {
 // (statistics flushed into G) must be visible to the other workgroups after it.
 __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int G, unsigned tag, unsigned long long mine,
                                                  bool fenced, unsigned long long* s_min, int32_t* rs, unsigned long long* best,
-                                                 int spin_limit, unsigned long long* s_all = nullptr) {
+                                                 int spin_limit) {
   const int tid = threadIdx.x;
   // two slot arrays, alternating by round: a workgroup can be one round ahead of the slowest one (never two), and
   // must not overwrite the value the slow ones are still polling for
@@ -87,7 +87,6 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
     }
     if (__syncthreads_and(seen ? 1 : 0)) {
       if (v != GG_SLOT_NONE) atomicMin(s_min, v);
-      if (s_all) s_all[tid] = v;     // slot order = position order within a band (workgroup t owns group band G + t)
       okall = true;
       break;
     }
@@ -95,6 +94,50 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
   }
   if (!okall && tid == 0) atomicOr(&rs[3], 2);
   if (fenced) __threadfence();
+  __syncthreads();
+  *best = *s_min;
+  __syncthreads();
+  return okall;
+}
+
+// The round's exchange carries up to GG_SCAN_NW surprises per workgroup: words 0..NW-1 of its slot line, each tagged on its
+// own (no ordering between them is needed), in position order - word 0 is the workgroup's earliest.  Lane t ends up with
+// the words of slot t in v[]; *best is the minimum over all word 0s.  Slot order = position order within a band
+// (workgroup t owns group band G + t).
+#define GG_SCAN_NW 4
+__device__ __forceinline__ bool gg_grid_exchange_multi(unsigned long long* slots, int G, unsigned tag, const unsigned long long* s_mine,
+                                                       unsigned long long* s_min, int32_t* rs, unsigned long long* best,
+                                                       int spin_limit, unsigned long long (&v)[GG_SCAN_NW]) {
+  const int tid = threadIdx.x;
+  slots += (size_t)(tag & 1u) * GG_SCAN_MAXWG * GG_SLOT_PAD;
+  __syncthreads();
+  if (tid == 0) *s_min = GG_SLOT_NONE;
+  if (tid < GG_SCAN_NW)
+    __hip_atomic_store(&slots[(size_t)blockIdx.x * GG_SLOT_PAD + tid], ((unsigned long long)(tag & 0xffffu) << 48) | (s_mine[tid] & GG_SLOT_NONE),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  bool okall = false;
+  unsigned seen = tid >= G ? (1u << GG_SCAN_NW) - 1u : 0u;
+#pragma unroll
+  for (int w = 0; w < GG_SCAN_NW; ++w) v[w] = GG_SLOT_NONE;
+  for (int spin = 0; spin < spin_limit; ++spin) {
+    if (seen != (1u << GG_SCAN_NW) - 1u) {
+      unsigned long long wd[GG_SCAN_NW];
+#pragma unroll
+      for (int w = 0; w < GG_SCAN_NW; ++w)
+        wd[w] = __hip_atomic_load(&slots[(size_t)tid * GG_SLOT_PAD + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int w = 0; w < GG_SCAN_NW; ++w)
+        if (!(seen & (1u << w)) && (unsigned)(wd[w] >> 48) == (tag & 0xffffu)) { seen |= 1u << w; v[w] = wd[w] & GG_SLOT_NONE; }
+    }
+    if (__syncthreads_and(seen == (1u << GG_SCAN_NW) - 1u ? 1 : 0)) {
+      if (v[0] != GG_SLOT_NONE) atomicMin(s_min, v[0]);
+      okall = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(GG_SCAN_POLL_SLEEP);
+  }
+  if (!okall && tid == 0) atomicOr(&rs[3], 2);
   __syncthreads();
   *best = *s_min;
   __syncthreads();
@@ -120,10 +163,16 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   long long* s_gs = reinterpret_cast<long long*>(s_raw);
   size_t off = ADJ ? 0 : (size_t)2 * K * per * NSI * sizeof(long long);
   double* s_st = reinterpret_cast<double*>(s_raw + off); off += (size_t)2 * K * per * NT * sizeof(double);
+  // stage_tables: 1 the two lane-major layouts of the coefficient table in LDS, 2 one padded copy of T[a][b][t] (half the
+  // bytes: K = 32..64), 0 none (table entries from global memory)
   double* s_T = reinterpret_cast<double*>(s_raw + off);
   const int ntab = K * NT * Kp;
-  if (stage_tables) off += (size_t)2 * ntab * sizeof(double);
-  else if (Kp == 64) off += (size_t)4 * 2 * NT * 64 * sizeof(double);
+  const int RS = (K * NT) | 1;
+  if (stage_tables == 1) off += (size_t)2 * ntab * sizeof(double);
+  else if (stage_tables == 2) off += (size_t)K * RS * sizeof(double);
+  double* s_acc = reinterpret_cast<double*>(s_raw + off);     // gg_lp_split4: where the chains of the four waves meet
+  const bool split = stage_tables != 1 && Kp == 64;
+  if (split) off += (size_t)4 * 2 * NT * 64 * sizeof(double);
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
   int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);
@@ -131,7 +180,8 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_raw + off); off += 2 * sizeof(unsigned long long);
   int* s_L = reinterpret_cast<int*>(s_raw + off); off += (size_t)a.Lcap * 3 * sizeof(int);   // [Lcap][3]: this workgroup's own copy of the change list
   off = (off + 7) & ~(size_t)7;
-  unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(s_raw + off); off += 256 * sizeof(unsigned long long);   // the last exchange, slot by slot
+  unsigned long long* s_dev = reinterpret_cast<unsigned long long*>(s_raw + off); off += 128 * sizeof(unsigned long long);   // deviation of node i of the group (or none)
+  unsigned long long* s_mine = reinterpret_cast<unsigned long long*>(s_raw + off); off += 8 * sizeof(unsigned long long);    // the first GG_SCAN_NW of them
   int* s_S = reinterpret_cast<int*>(s_raw + off); off += 256 * 3 * sizeof(int);      // its surprises, compacted: (node, from, to)
   int* s_cntn = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * K * sizeof(int);   // block sizes as node i of the group sees them
   int* s_misc = reinterpret_cast<int*>(s_raw + off); off += 16 * sizeof(int);
@@ -161,8 +211,10 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
     }
   }
   for (int k = tid; k < K; k += 256) s_cnt[k] = g.cnt[k];
-  if (stage_tables) {
+  if (stage_tables == 1) {
     for (int idx = tid; idx < ntab; idx += 256) { s_T[idx] = x.Tout[idx]; s_T[ntab + idx] = x.Tin[idx]; }
+  } else if (stage_tables == 2) {
+    for (int idx = tid; idx < K * K * NT; idx += 256) s_T[(size_t)(idx / (K * NT)) * RS + idx % (K * NT)] = x.T[idx];
   }
   // nothing of this scan's list is in G yet.  Every node's entry is zeroed by the workgroup that OWNS the node's group -
   // the one that writes it again at the end of the band - so that no address has two unordered writers (the common
@@ -170,6 +222,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   for (int grp = b; grp < ngroups; grp += G)
     if (tid < per && grp * per + tid < N) a.ap[grp * per + tid] = 0;
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  const double logm_k = x.logm[(tid % Kp) < K ? tid % Kp : 0];   // (the same in every round: not behind each round's chains)
 
   int pos = a.resume ? g.rs[0] : 0, nL = 0, nchg = 0;   // (resume: uniform, written by an earlier launch)
   const long long t_init0 = g.dbg ? wall_clock64() : 0;
@@ -298,7 +351,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       const int i = idx % per, j = (idx / per) % K;
       const int gc = s_gc[idx];
       int ts;
-      double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
+      double* dst = s_st + gg_st_slot(split, idx / per, i, per, NT, &ts);
       if (ADJ) {
         const int cx = s_cntn[i * K + j] - (s_c[i] == j ? 1 : 0);
         dst[0] = (double)gc;
@@ -339,27 +392,43 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
           for (int t = 0; t < NT; ++t) { so[t] = pa[t]; si[t] = pb[t]; }
         };
         double lp;
-        if (stage_tables) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab);
-        else if (Kp == 64) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T, nn);
-        else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
+        if (stage_tables == 1) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab, &logm_k);
+        else if (split) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_acc, nn, stage_tables == 2 ? s_T : nullptr, RS);
+        else if (stage_tables == 2) lp = gg_node_lp_core_t1<NT, ADJ>(x, nn, k, ld, s_T, RS, &logm_k);
+        else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin, &logm_k);
         const int lab = gg_group_categorical(lp, k, K, Kp, u_band);
-        if (live && k == 0) {
+        if (k == 0) {
           // what the hypotheses say about this node: it moves to h's new label, or it stays
-          const int cn = s_c[i];
-          const int h = s_H[n - band0];
-          const int expct = h >= 0 ? (h & 0xff) : cn;
-          if (lab != expct) atomicMin(s_min, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
+          unsigned long long dv = GG_SLOT_NONE;
+          if (live) {
+            const int cn = s_c[i];
+            const int h = s_H[n - band0];
+            const int expct = h >= 0 ? (h & 0xff) : cn;
+            if (lab != expct) dv = ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab;
+          }
+          s_dev[i] = dv;
         }
       }
       __syncthreads();
+      if (tid < 64) {
+        // this workgroup's first GG_SCAN_NW surprises, in position order (the later ones were evaluated without the earlier
+        // ones of this round: hypotheses like everybody else's)
+        if (tid < GG_SCAN_NW) s_mine[tid] = GG_SLOT_NONE;
+        int have = 0;
+        for (int base = 0; base < per; base += 64) {
+          const unsigned long long dv = base + tid < per ? s_dev[base + tid] : GG_SLOT_NONE;
+          const unsigned long long bal = __ballot(dv != GG_SLOT_NONE);
+          const int rk = have + __popcll(bal & ((1ull << tid) - 1ull));
+          if (dv != GG_SLOT_NONE && rk < GG_SCAN_NW) s_mine[rk] = dv;
+          have += __popcll(bal);
+        }
+      }
       const long long c1 = g.dbg ? wall_clock64() : 0;
       unsigned long long best;
-      {
-        const unsigned long long mine = *s_min;   // this workgroup's first surprise (48-bit payload) or none
-        if (!gg_grid_exchange(a.bar, G, (unsigned)(it + 1), mine == GG_NO_CHANGE ? GG_SLOT_NONE : mine, false, s_min, g.rs, &best, a.spin_limit, s_slot)) {
-          alive = false;
-          break;
-        }
+      unsigned long long sv[GG_SCAN_NW];
+      if (!gg_grid_exchange_multi(a.bar, G, (unsigned)(it + 1), s_mine, s_min, g.rs, &best, a.spin_limit, sv)) {
+        alive = false;
+        break;
       }
       ++it; ++wi;
       const long long c2 = g.dbg ? wall_clock64() : 0;
@@ -368,20 +437,27 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
       // ---- the surprises, in position order (= slot order), amend the hypotheses
       int nS = 0;
       if (!quiet) {
-        const unsigned long long v = s_slot[tid];
-        const bool hs = v != GG_SLOT_NONE;
-        const unsigned long long bal = __ballot(hs);
-        if (ln == 0) s_misc[wv] = __popcll(bal);
+        int cnt_s = 0;
+#pragma unroll
+        for (int w = 0; w < GG_SCAN_NW; ++w) cnt_s += sv[w] != GG_SLOT_NONE ? 1 : 0;
+        int incl = cnt_s;
+        for (int dlt = 1; dlt < 64; dlt <<= 1) { const int o = __shfl_up(incl, dlt); if (ln >= dlt) incl += o; }
+        if (ln == 63) s_misc[wv] = incl;
         __syncthreads();
-        int offS = __popcll(bal & ((1ull << ln) - 1ull));
+        int offS = incl - cnt_s;
         for (int w = 0; w < wv; ++w) offS += s_misc[w];
         nS = s_misc[0] + s_misc[1] + s_misc[2] + s_misc[3];
-        if (hs) {
+        if (nS > 256) nS = 256;     // (what does not fit is reported again next round: it is not in H)
+#pragma unroll
+        for (int w = 0; w < GG_SCAN_NW; ++w) {
+          const unsigned long long v = sv[w];
+          if (v == GG_SLOT_NONE || offS >= 256) continue;
           const int f = (int)(v >> 12), old = (int)((v >> 6) & 63u), nw = (int)(v & 63u);
           const int h = s_H[f - band0];
           // statistics behind f hold f in block `from` (the hypothesised label, or the old one): it goes to `nw`
           s_S[offS * 3] = f; s_S[offS * 3 + 1] = h >= 0 ? (h & 0xff) : old; s_S[offS * 3 + 2] = nw;
           s_H[f - band0] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
+          ++offS;
         }
         __syncthreads();
       }

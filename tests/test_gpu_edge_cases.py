@@ -235,7 +235,7 @@ def test_ahead_form_is_the_same_chain(abi, monkeypatch, ahead, split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K,lcap", [(300, 7, 0), (1100, 64, 0), (300, 7, 3), (1100, 64, 5), (700, 16, 2)])
+@pytest.mark.parametrize("N,K,lcap", [(300, 7, 0), (1100, 64, 0), (900, 32, 0), (700, 40, 0), (300, 7, 3), (1100, 64, 5), (700, 16, 2)])
 def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, monkeypatch):
     """GG_SCAN=1: the scan as one resident-grid launch (k_scan: one grid-wide exchange per round, every round accepting the
     hypothesised changes up to the earliest surprise).  Same chain bit for bit, burn-in included (random start: hundreds
