@@ -107,6 +107,7 @@ struct gg_model {
   int scan_pref;                // GG_SCAN: 1 always, 0 never, unset (-1): adaptive - k_scan while the chain keeps changing labels
   long long chg_seen;           // label changes (control word 2) at the last decision
   long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
+  int ahead_cap;                // speculative form: sweeps enqueued ahead of the last confirmed one (64, doubling per clean batch up to 512)
   int scan_pref_saved;          // the preference a k_scan timeout suspended (0: none suspended)
   uint64_t scan_retry_at;       // st.sweeps count from which the suspended preference is tried again
   uint64_t scan_backoff;        // sweeps to wait after the next timeout (doubles with every timeout, at most 2^20)
@@ -193,14 +194,15 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
   lds += 136 * sizeof(unsigned long long) + 256 * 3 * sizeof(int) + (size_t)per * K * sizeof(int) + 16 * sizeof(int) + 16 +
          (size_t)GG_SCAN_MAXWG * per * sizeof(short);
   if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
-  // coefficient table: both lane-major layouts when that stays below 64 KB (1); else one padded copy of T[a][b][t], as
-  // far as the LDS goes (2: K = 32..64 at B = 1); else from global memory (0).  Kp = 64 without layout 1 evaluates with
+  // coefficient table: both lane-major layouts when that stays below 64 KB (1); else one padded copy of T[a][b][t] when
+  // that stays below 72 KB (2: K up to 32 at B = 1); else from global memory (0).  (At K = 64 the one copy fits the 150 KB
+  // but gains 10 % of a round's evaluation and leaves no room for anything else on the CU: not taken.)  Kp = 64 without layout 1 evaluates with
   // gg_lp_split4, which needs its meeting place.
   const size_t split_acc = m->Kp == 64 ? (size_t)4 * 2 * m->NT * 64 * sizeof(double) : 0;
   const size_t one_copy = (size_t)K * ((K * m->NT) | 1) * sizeof(double);
   int stage = 0;
   if (lds + table_bytes(m) <= 64 * 1024) { stage = 1; lds += table_bytes(m); }
-  else if (lds + split_acc + one_copy <= GG_LDS_LIMIT) { stage = 2; lds += split_acc + one_copy; }
+  else if (lds + split_acc + one_copy <= 72 * 1024) { stage = 2; lds += split_acc + one_copy; }   // (two workgroups per CU)
   else lds += split_acc;
   if (stage_out) *stage_out = stage;
   return lds;
@@ -348,7 +350,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
     m->use_scan = m->scan_pref == 1;
     m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
-    m->scan_pref_saved = 0; m->scan_retry_at = 0;
+    m->scan_pref_saved = 0; m->scan_retry_at = 0; m->ahead_cap = 64;
     { const char* er = getenv("GG_SCAN_RETRY"); m->scan_backoff = (er && atoll(er) > 0) ? (uint64_t)atoll(er) : 1024; }
     { const char* esp = getenv("GG_SCAN_SPIN"); m->scan_spin = esp && atoi(esp) > 0 ? atoi(esp) : GG_BAR_SPIN_LIMIT; }
     // The ahead form (enqueue_sweep_ahead): while the chain is quiet, the next sweep's bulk pass rides in this sweep's
@@ -1139,24 +1141,19 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
   int stage;
   size_t lds = lds_scan(m, a.Lcap, &stage);
-  if (stage == 0 && a.Lcap > 256) {
-    // a shorter change list (flushed into G more often) when that is what lets the coefficient table into LDS
-    int stage_s;
-    const size_t lds_s = lds_scan(m, 256, &stage_s);
-    if (stage_s != 0) { a.Lcap = 256; lds = lds_s; stage = stage_s; }
-  }
   if (lds > GG_LDS_LIMIT)
     return gg_fail(GG_ERR_UNSUPPORTED, "the resident-grid scan needs %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
   g.stage_tables = stage;
-#define SCN(NTV, ADJV)                                                                                            \
+#define SCN1(NTV, ADJV, SPV)                                                                                       \
   do {                                                                                                            \
     static bool attr_set = false;                                                                                 \
     if (!attr_set && lds > 48 * 1024) {                                                                           \
-      GG_HIP(hipFuncSetAttribute((const void*)k_scan<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+      GG_HIP(hipFuncSetAttribute((const void*)k_scan<NTV, ADJV, SPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
       attr_set = true;                                                                                            \
     }                                                                                                             \
-    k_scan<NTV, ADJV><<<a.G, 256, lds, m->stream>>>(a);                                                            \
+    k_scan<NTV, ADJV, SPV><<<a.G, 256, lds, m->stream>>>(a);                                                       \
   } while (0)
+#define SCN(NTV, ADJV) do { if (stage != 1 && m->Kp == 64) SCN1(NTV, ADJV, true); else SCN1(NTV, ADJV, false); } while (0)
   if (m->is_adj) SCN(2, true);
   else if (m->joint && m->B == 1) SCN(4, false);
   else if (m->joint) SCN(7, false);
@@ -1164,6 +1161,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   else if (m->B == 2) SCN(6, false);
   else if (m->B == 3) SCN(10, false);
   else SCN(15, false);
+#undef SCN1
 #undef SCN
   GG_HIP(hipGetLastError());
   return GG_OK;
@@ -1444,13 +1442,19 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       // a clean batch: look further ahead again
       if (m->depth < (1 << 20)) m->depth *= 2;
       // (adaptive form, speculate + resolve: a stall turns everything enqueued behind it into no-op launches, ~15 us per
-      // sweep - do not run further ahead than a stall costs anyway; the resident scan cannot stall)
+      // sweep - do not run much further ahead than a stall costs anyway: 64 sweeps, doubling with every clean batch up to
+      // 512 (a chain that has been quiet that long rarely stalls); the resident scan cannot stall)
       int take = m->todo < m->depth ? m->todo : m->depth;
-      if (m->scan_pref < 0 && !m->use_scan && take > 64) take = 64;
+      if (m->scan_pref < 0 && !m->use_scan) {
+        if (m->ahead_cap < 512) m->ahead_cap *= 2;
+        if (take > m->ahead_cap) take = m->ahead_cap;
+      }
       m->cur0 = m->cur; m->pcur0 = m->pcur;
       if (scan && (rc = write_ctl_word(m, 5, 0))) return rc;
+      // (`more` also for the last sweep of the batch when the call has further sweeps to enqueue: the quiet form's pipeline
+      // - parameters of the next sweep, statistics of the one after - is not drained at a batch boundary)
       for (int i = 0; i < take; ++i)
-        if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i, i + 1 < take))) return rc;
+        if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)i, i + 1 < take || m->todo > take))) return rc;
       m->pending = take;
       m->todo -= take;
       GG_HIP(hipEventRecord(m->ev_call1, m->stream));
@@ -1459,6 +1463,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
     // A scan stalled: the sweeps enqueued behind it ran as no-ops and must be enqueued again.  A chain that keeps
     // changing labels stalls every sweep, so stop running ahead (depth 1) until batches come back clean.
     if (m->scan_pref >= 0) m->depth = 1;   // (the adaptive form switches to the resident scan below, which cannot stall)
+    m->ahead_cap = 64;
     if (m->scan_pref < 0) {   // the chain is changing labels: k_scan from the next sweep on
       // (a stall soon after the last switch back: the chain changes labels now and then - hold the resident form longer)
       // Break-even: a quiet sweep costs ~4 us more in the resident form, a stall ~400 us in the other one (slow path,
@@ -1559,7 +1564,8 @@ int gg_set_timing(gg_model* m, int32_t on) {
 }
 
 // Enqueue n sweeps and return without waiting; gg_sync (or any state read) completes them.
-int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
+// more_after: the caller enqueues further sweeps of this model before it synchronises (gg_resample_many's interleaving)
+static int resample_async_impl(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta, bool more_after) {
   if (!m) return gg_fail(GG_ERR_INVALID, "null model");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
@@ -1594,13 +1600,19 @@ int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double be
   set_pend_data(m, d);
   m->beta = beta;
   for (int s = 0; s < n_sweeps; ++s) {
-    if (m->todo > 0 || m->pending >= m->depth) { m->todo += 1; continue; }   // not further ahead than `depth`
-    // (`more`: another sweep of this call follows directly - the quiet form then runs the sweep as one fused launch)
-    const bool more = s + 1 < n_sweeps && m->pending + 1 < m->depth;
+    const bool spec_form = m->scan_pref < 0 && !m->use_scan;
+    if (m->todo > 0 || m->pending >= m->depth || (spec_form && m->pending >= m->ahead_cap)) { m->todo += 1; continue; }   // not further ahead than `depth`
+    // (`more`: another sweep of this call follows - the quiet form then runs the sweep as one fused launch; also when the
+    // next one is only enqueued at the sync, so that the pipeline is not drained at the batch boundary)
+    const bool more = s + 1 < n_sweeps || more_after;
     if ((rc = enqueue_sweep(m, d, m->sweep + (uint32_t)m->pending, more))) return rc;
     m->pending += 1;
   }
   return GG_OK;
+}
+
+int gg_resample_async(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta) {
+  return resample_async_impl(m, d, n_sweeps, beta, false);
 }
 
 int gg_sync(gg_model* m) {
@@ -1676,7 +1688,7 @@ int gg_resample_many(gg_model** ms, const gg_data* const* ds, int32_t n, int32_t
     // between the models, so that none of them waits for another's whole batch; completion is shared (gg_sync_many)
     for (int s = 0; s < n_sweeps; ++s)
       for (int i = 0; i < n; ++i) {
-        const int rc = gg_resample_async(ms[i], ds[i], 1, beta);
+        const int rc = resample_async_impl(ms[i], ds[i], 1, beta, s + 1 < n_sweeps);
         if (rc) return rc;
       }
     return gg_sync_many(ms, n);

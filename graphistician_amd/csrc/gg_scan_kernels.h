@@ -144,8 +144,10 @@ __device__ __forceinline__ bool gg_grid_exchange_multi(unsigned long long* slots
   return okall;
 }
 
-template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
+// SPLIT: the Kp = 64 evaluation without both table layouts in LDS (gg_lp_split4) - its own instantiation, so that the other
+// shapes do not carry its registers; two workgroups per CU in either case (both models' scan grids resident together).
+template <int NT, bool ADJ, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   constexpr int B = gg_tB(NT);
   constexpr int NSI = gg_tNSI(NT);
   constexpr int U = 4;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void k_scan(gg_scan_args a) {
   if (stage_tables == 1) off += (size_t)2 * ntab * sizeof(double);
   else if (stage_tables == 2) off += (size_t)K * RS * sizeof(double);
   double* s_acc = reinterpret_cast<double*>(s_raw + off);     // gg_lp_split4: where the chains of the four waves meet
-  const bool split = stage_tables != 1 && Kp == 64;
+  constexpr bool split = SPLIT;   // (the host: stage_tables != 1 && Kp == 64)
   if (split) off += (size_t)4 * 2 * NT * 64 * sizeof(double);
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
