@@ -717,9 +717,15 @@ static gg_ride_args make_ride(const gg_model* m, const gg_data* d, int nbuf, int
   r.w1 = (part == 0 || part == 2) ? (int)ws : (int)W;
   r.front = front;
   {
-    static int cap = -1;   // GG_RIDERS: most rider workgroups per launch (a cap below ~512 starves the pass, above it changes nothing: measured)
+    static int cap = -1, cap_a = -1;   // GG_RIDERS: most rider workgroups per launch (a cap below ~512 starves the pass, above it changes nothing: measured)
     if (cap < 0) { const char* e = getenv("GG_RIDERS"); cap = e && atoi(e) > 0 ? atoi(e) : 2048; }
-    r.nriders = (r.w1 - r.w0) < cap ? (r.w1 - r.w0) : cap;
+    if (cap_a < 0) { const char* e = getenv("GG_RIDERS_A"); cap_a = e && atoi(e) > 0 ? atoi(e) : 0; }
+    // (the adjacency model's pass is small and its chain has slack: with 11/16 of its items as workgroups, each walking
+    // one or two, the weight model's riders find their slots sooner - 36.6 against 37.8 us per sweep at N=4096, measured
+    // over 128..256; fewer than 5/8 and the adjacency chain becomes the slower one)
+    int cp = cap;
+    if (m->is_adj) { cp = cap_a > 0 ? cap_a : (r.w1 - r.w0) * 11 / 16; if (cp < 1) cp = 1; if (cp > cap) cp = cap; }
+    r.nriders = (r.w1 - r.w0) < cp ? (r.w1 - r.w0) : cp;
   }
   {
     static int dly = -1;
