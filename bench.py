@@ -477,11 +477,21 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     N, K = args.nodes, args.blocks
     # collectives: the library's own RCCL calls (one process per GPU); GG_BENCH_BACKEND=gloo (CPU-side tests, several ranks on
     # one GPU) routes them through host callbacks instead.  torch.distributed is the launcher / rendezvous only.
-    if world > 1:
-        import torch.distributed as tdist
-        comm = S.rccl_comm(tdist, device) if os.environ.get("GG_BENCH_BACKEND", "nccl") == "nccl" else S.host_comm(tdist, device)
-    else:
-        comm = S.local_comm(device)
+    # (RCCL greets with a version banner on stdout when its first communicator comes up: that goes to stderr here, stdout
+    # carries the one JSON line)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            import torch.distributed as tdist
+            comm = S.rccl_comm(tdist, device) if os.environ.get("GG_BENCH_BACKEND", "nccl") == "nccl" else S.host_comm(tdist, device)
+        else:
+            comm = S.local_comm(device)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     n0, n1 = S.shard_range(N, rank, world)
     truth = planted_truth(N, K, seed=1234)
     data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
@@ -504,6 +514,7 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     for _ in range(args.warmup):
         S.half_sweep(adj, data, comm); S.half_sweep(w, data, comm)
     chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
+    rnd0 = adj.stats()["resolve_rounds"] + w.stats()["resolve_rounds"]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -511,6 +522,7 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     barrier()
     el = max_over_ranks(time.perf_counter() - t0)
     chg = adj.stats()["label_changes"] + w.stats()["label_changes"] - chg0
+    rnd = adj.stats()["resolve_rounds"] + w.stats()["resolve_rounds"] - rnd0
     digest = int(np.bitwise_xor.reduce(adj.get(abi.ST_C, (N,), np.int32) * np.arange(1, N + 1, dtype=np.int32)))
     cinfo = comm.info()
     if rank == 0:
@@ -522,11 +534,13 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
             "dtype": "int64 statistics / f64 conditionals (bit-packed adjacency, 24-bit fixed-point weights in int32)",
             "data": "synthetic",
             "config": {"workload": "ONE Gaussian SBM chain, N=%d, K=%d, B=1, node-sharded over %d rank(s)" % (N, K, world),
-                       "parallelism": "exact node sharding: all-reduce of K x K integer tables + all-gather of label changes "
+                       "parallelism": "exact node sharding: all-reduce of K x K integer tables + one all-gather of surprises per scan round "
                                       "(%s, %d ranks seen by the communicator)" % ("RCCL, device buffers on the engine stream" if cinfo["rccl"]
                                                                                   else "host callbacks (gloo)", cinfo["world"]),
                        "collectives_in_run": int(cinfo["collectives"]),
                        "us_per_label_change": (el / max(chg, 1)) * 1e6 if chg else None,
+                       "scan_rounds_in_timed_region": int(rnd),
+                       "us_per_scan_round": (el / max(rnd, 1)) * 1e6 if rnd else None,
                        "label_changes_in_timed_region": int(chg), "labels_digest": digest,
                        "sweep_algorithmic_bytes": sweep_bytes, "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9},
             "roofline": {"bound": "hbm", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS * world,

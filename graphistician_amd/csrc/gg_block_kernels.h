@@ -829,6 +829,10 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g, gg_ride_args r
 
 #define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index)
 #define GG_RS_NTOT 23        //                total number of nodes
+#define GG_RS_WBASE 21       //                first node of the band the scan stands in
+#define GG_RS_NMV 20         //                moves the last round's surprises made (k_shard_fold -> k_shard_moves)
+#define GG_RS_ROUNDS 14      //                rounds of the sharded scan that did something
+#define GG_SHARD_M 32        // surprises a rank reports per round
 #define GG_SHARD_WINDOW 4096
 #define GG_SHARD_NONE 0x7fffffff
 
@@ -840,6 +844,7 @@ struct gg_node_ctx {
   int special;     // special_case_self_conns
   const int32_t* c;
   const int32_t* cnt;
+  const int32_t* cntn;   // [N][K] block sizes as node n sees them (sharded scan with hypotheses), or null: cnt for every node
   const double* logm;
   const double* T;
   const double* Tout;
@@ -1134,7 +1139,7 @@ __device__ __forceinline__ double gg_node_lp_global(const gg_node_ctx& x, int n,
   constexpr int NSI = gg_tNSI(NT);
   auto ld = [&](int j, double* so, double* si) {
     const size_t gi = (size_t)j * x.Np + n;
-    int cx = (ADJ || gg_tJ(NT)) ? (x.cnt[j] - (cn == j ? 1 : 0)) : 0;
+    int cx = (ADJ || gg_tJ(NT)) ? ((x.cntn ? x.cntn[(size_t)n * x.K + j] : x.cnt[j]) - (cn == j ? 1 : 0)) : 0;
     long long a[NSI > 0 ? NSI : 1], b[NSI > 0 ? NSI : 1];
     if (!ADJ) {
 #pragma unroll
@@ -1177,7 +1182,7 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
     int ts;
     double* dst = s_st + gg_st_slot(!stage_tables && Kp == 64, idx / per, i, per, NT, &ts);
     if (ADJ) {
-      const int cx = x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0);
+      const int cx = (x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0);
       dst[0] = (double)gc;
       dst[ts] = (double)(cx - gc);
     } else {
@@ -1185,7 +1190,7 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
       dst[0] = (double)gc;
 #pragma unroll
       for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
-      if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)(x.cnt[j] - (x.c[x.n0 + n] == j ? 1 : 0));
+      if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)((x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0));
     }
   }
   const int ntab = K * NT * Kp;
@@ -1235,9 +1240,9 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
   if (shard_mode) {
     // device-driven sharded scan: the window [spos, spos + GG_SHARD_WINDOW) of GLOBAL node indices, of which this rank
     // evaluates its own nodes; the position lives in the control block (gg_shard_sweep)
-    const int spos = ctl[GG_RS_SPOS], ntot = ctl[GG_RS_NTOT];
+    const int spos = ctl[GG_RS_SPOS], ntot = ctl[GG_RS_NTOT], wbase = ctl[GG_RS_WBASE];
     if (spos >= ntot) return;
-    const int wend = spos + GG_SHARD_WINDOW < ntot ? spos + GG_SHARD_WINDOW : ntot;
+    const int wend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;   // the band the scan stands in
     int lo = spos - x.n0, hi = wend - x.n0;
     lo = lo < 0 ? 0 : lo;
     hi = hi > x.N ? x.N : hi;
@@ -1296,51 +1301,153 @@ __global__ __launch_bounds__(256) void k_shared_cov(gg_params_args g) {
   }
 }
 
-// Sharded scan helpers (gg_shard_sweep) ---------------------------------------------------------
-// First OWNED node of the current window whose speculated label differs from its current one -> trip = {node, old, new}
-// (global index; GG_SHARD_NONE if there is none or the scan is over).  One workgroup.
-__global__ __launch_bounds__(1024) void k_shard_first(const int32_t* __restrict__ c, const int32_t* __restrict__ cand, int n0, int Nl,
-                                                      int32_t* __restrict__ rs, int32_t* __restrict__ trip) {
-  __shared__ int s_first;
-  if (threadIdx.x == 0) { s_first = GG_SHARD_NONE; rs[1] = 0; }   // (the last round's one-entry change list is spent)
-  __syncthreads();
-  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT];
+// ---- the sharded scan's round (gg_shard_sweep), with hypotheses exactly as in k_scan (gg_scan_kernels.h): every rank keeps
+// the same hypothesis H per node of the band, its own nodes' statistics hold every accepted or hypothesised change at a
+// position before theirs, and what a rank reports are the first GG_SHARD_M SURPRISES among its own nodes - decisions that
+// differ from what H says.  Ranks own contiguous node ranges, so the gathered reports are in position order; everything of
+// H before the earliest one, and that one itself, is the sequential chain.  One all-gather per ROUND, not per change.
+__global__ __launch_bounds__(1024) void k_shard_surprises(const int32_t* __restrict__ c, const int32_t* __restrict__ cand,
+                                                          const short* __restrict__ H, int n0, int Nl,
+                                                          const int32_t* __restrict__ rs, int32_t* __restrict__ trip) {
+  __shared__ int s_scan[1024];
+  const int t = (int)threadIdx.x;
+  if (t < GG_SHARD_M) { trip[3 * t] = GG_SHARD_NONE; trip[3 * t + 1] = 0; trip[3 * t + 2] = 0; }
+  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT], wbase = rs[GG_RS_WBASE];
   int lo = 0, hi = 0;
   if (spos < ntot) {
-    const int wend = spos + GG_SHARD_WINDOW < ntot ? spos + GG_SHARD_WINDOW : ntot;
+    const int wend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;
     lo = spos - n0; hi = wend - n0;
     lo = lo < 0 ? 0 : lo;
     hi = hi > Nl ? Nl : hi;
   }
-  for (int nl = lo + (int)threadIdx.x; nl < hi; nl += blockDim.x)
-    if (cand[nl] != c[n0 + nl]) { atomicMin(&s_first, nl); break; }
+  const int len = hi > lo ? hi - lo : 0;
+  const int chunk = (len + 1023) / 1024;
+  const int my_lo = lo + t * chunk, my_hi = (my_lo + chunk < hi) ? my_lo + chunk : hi;
+  auto deviates = [&](int nl) {
+    const int h = H[n0 + nl - wbase];
+    return cand[nl] != (h >= 0 ? (h & 0xff) : c[n0 + nl]);
+  };
+  int cnt = 0;
+  for (int nl = my_lo; nl < my_hi; ++nl) cnt += deviates(nl) ? 1 : 0;
+  s_scan[t] = cnt;
   __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? s_scan[t - d] : 0;
+    __syncthreads();
+    s_scan[t] += v;
+    __syncthreads();
+  }
+  int idx = s_scan[t] - cnt;
+  for (int nl = my_lo; nl < my_hi && idx < GG_SHARD_M; ++nl)
+    if (deviates(nl)) { trip[3 * idx] = n0 + nl; trip[3 * idx + 1] = c[n0 + nl]; trip[3 * idx + 2] = cand[nl]; ++idx; }
+}
+
+// Every rank folds the gathered surprises into H (writing the statistics moves they imply: node f leaves block `from` - its
+// hypothesised label, or its old one - for block `to`), accepts the hypotheses at positions up to and including the earliest
+// surprise (all of the band's when there is none) into its copy of the labels and counts, and moves the scan on.
+__global__ __launch_bounds__(256) void k_shard_fold(int32_t* c, int32_t* cnt, short* H, int32_t* rs, const int32_t* __restrict__ all,
+                                                    int world, int32_t* __restrict__ mv) {
+  __shared__ int s_hi, s_quiet, s_acc;
+  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT], wbase = rs[GG_RS_WBASE];
+  if (spos >= ntot) { if (threadIdx.x == 0) rs[GG_RS_NMV] = 0; return; }
+  const int bend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;
   if (threadIdx.x == 0) {
-    const int f = s_first;
-    if (f == GG_SHARD_NONE) { trip[0] = GG_SHARD_NONE; trip[1] = 0; trip[2] = 0; }
-    else { trip[0] = n0 + f; trip[1] = c[n0 + f]; trip[2] = cand[f]; }
+    int nmv = 0, pstar = GG_SHARD_NONE;
+    for (int e = 0; e < world * GG_SHARD_M; ++e) {
+      const int f = all[3 * e];
+      if (f == GG_SHARD_NONE) continue;
+      const int old = all[3 * e + 1], nw = all[3 * e + 2];
+      if (pstar == GG_SHARD_NONE) pstar = f;        // (position order: the first is the earliest)
+      const int h = H[f - wbase];
+      mv[3 * nmv] = f; mv[3 * nmv + 1] = h >= 0 ? (h & 0xff) : old; mv[3 * nmv + 2] = nw;
+      ++nmv;
+      H[f - wbase] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
+    }
+    rs[GG_RS_NMV] = nmv;
+    rs[GG_RS_ROUNDS] += 1;
+    s_quiet = pstar == GG_SHARD_NONE ? 1 : 0;
+    s_hi = s_quiet ? bend : pstar + 1;
+    s_acc = 0;
+  }
+  __syncthreads();
+  const int hi = s_hi;
+  int mine = 0;
+  for (int n = spos + (int)threadIdx.x; n < hi; n += (int)blockDim.x) {
+    const int h = H[n - wbase];
+    if (h < 0) continue;
+    c[n] = h & 0xff;
+    atomicSub(&cnt[h >> 8], 1);
+    atomicAdd(&cnt[h & 0xff], 1);
+    ++mine;
+  }
+  if (mine) atomicAdd(&s_acc, mine);
+  __syncthreads();
+  if (s_quiet)     // the band is final: the next one starts without hypotheses
+    for (int i = (int)threadIdx.x; i < GG_SHARD_WINDOW; i += (int)blockDim.x) H[i] = (short)-1;
+  if (threadIdx.x == 0) {
+    rs[2] += s_acc;
+    rs[GG_RS_SPOS] = hi;
+    if (s_quiet) rs[GG_RS_WBASE] = bend;
   }
 }
 
-// Every rank picks the earliest change among the gathered candidates and applies it to its copy of the labels (the
-// statistics of its own nodes follow in k_apply_L), or moves the window on.  One thread.
-__global__ void k_shard_pick(int32_t* c, int32_t* cnt, int32_t* L, int32_t* rs, const int32_t* __restrict__ all, int world) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT];
-  if (spos >= ntot) return;
-  int best = GG_SHARD_NONE, a = 0, b = 0;
-  for (int r = 0; r < world; ++r)
-    if (all[3 * r] < best) { best = all[3 * r]; a = all[3 * r + 1]; b = all[3 * r + 2]; }
-  if (best == GG_SHARD_NONE) {
-    rs[GG_RS_SPOS] = spos + GG_SHARD_WINDOW < ntot ? spos + GG_SHARD_WINDOW : ntot;
-  } else {
-    c[best] = b;
-    cnt[a] -= 1; cnt[b] += 1;
-    L[0] = best; L[1] = a; L[2] = b;
-    rs[1] = 1;
-    rs[2] += 1;
-    rs[GG_RS_SPOS] = best + 1;
+// The moves of the last round applied to the statistics (and the block sizes) of this rank's nodes BEHIND the moved node.
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_shard_moves(gg_node_ctx x, const int32_t* __restrict__ mv, const int32_t* __restrict__ rs,
+                                                     int32_t* __restrict__ cntn, int32_t* Gc0, int32_t* Gc1, long long* Gs0,
+                                                     long long* Gs1, const uint32_t* XA, const uint32_t* XAT, const int32_t* XW,
+                                                     const int32_t* XWT) {
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= x.N) return;
+  const int nmv = rs[GG_RS_NMV], Np = x.Np, K = x.K;
+  for (int e = blockIdx.y; e < nmv; e += gridDim.y) {
+    const int f = mv[3 * e], a = mv[3 * e + 1], b = mv[3 * e + 2];
+    if (x.n0 + n <= f) continue;
+    atomicSub(&cntn[(size_t)n * K + a], 1);
+    atomicAdd(&cntn[(size_t)n * K + b], 1);
+    const size_t at = (size_t)f * Np + n;
+    if (ADJ) {
+      if (gg_abit(XAT, at)) { atomicSub(&Gc0[(size_t)a * Np + n], 1); atomicAdd(&Gc0[(size_t)b * Np + n], 1); }
+      if (gg_abit(XA, at)) { atomicSub(&Gc1[(size_t)a * Np + n], 1); atomicAdd(&Gc1[(size_t)b * Np + n], 1); }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int32_t* q = (d == 0 ? XWT : XW) + at * B;
+        int32_t qq[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) qq[r] = q[r];
+        if (qq[0] == GG_NO_EDGE) continue;
+        int32_t* Gc = d == 0 ? Gc0 : Gc1;
+        long long* Gs = d == 0 ? Gs0 : Gs1;
+        atomicSub(&Gc[(size_t)a * Np + n], 1);
+        atomicAdd(&Gc[(size_t)b * Np + n], 1);
+        long long v[NSI > 0 ? NSI : 1];
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < B; ++r) v[t++] = qq[r];
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+          for (int s = r; s < B; ++s) v[t++] = (long long)qq[r] * (long long)qq[s];
+#pragma unroll
+        for (int s = 0; s < NSI; ++s) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&Gs[((size_t)a * Np + n) * NSI + s]), (unsigned long long)(-v[s]));
+          atomicAdd(reinterpret_cast<unsigned long long*>(&Gs[((size_t)b * Np + n) * NSI + s]), (unsigned long long)v[s]);
+        }
+      }
+    }
   }
+}
+
+// start of a sharded scan: no hypotheses, every own node sees the block sizes of the labels as they are
+__global__ void k_shard_init(const int32_t* __restrict__ cnt, int32_t* __restrict__ cntn, short* __restrict__ H, int Nl, int K,
+                             int32_t* __restrict__ rs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) rs[GG_RS_ROUNDS] = 0;
+  if (i < (size_t)Nl * K) cntn[i] = cnt[i % K];
+  if (i < GG_SHARD_WINDOW) H[i] = (short)-1;
 }
 
 // ------------------------------------------------------------------ log-likelihood from the K x K tables, on the device

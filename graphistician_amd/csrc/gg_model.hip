@@ -107,6 +107,9 @@ struct gg_model {
   int scan_pref;                // GG_SCAN: 1 always, 0 never, unset (-1): adaptive - k_scan while the chain keeps changing labels
   long long chg_seen;           // label changes (control word 2) at the last decision
   long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
+  int32_t* sh_cntn;             // sharded scan: [Nl][K] block sizes as own node n sees them
+  short* sh_H;                  //               [GG_SHARD_WINDOW] hypothesis per node of the band
+  int32_t* sh_mv;               //               moves of the last round's surprises, (node, from, to)
   int ahead_cap;                // speculative form: sweeps enqueued ahead of the last confirmed one (64, doubling per clean batch up to 512)
   int scan_pref_saved;          // the preference a k_scan timeout suspended (0: none suspended)
   uint64_t scan_retry_at;       // st.sweeps count from which the suspended preference is tried again
@@ -413,7 +416,8 @@ int gg_model_destroy(gg_model* m) {
   if (m->pend_data) { hipStreamSynchronize(m->stream); set_pend_data(m, nullptr); }
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
-                  m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all};
+                  m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all,
+                  m->sh_cntn, m->sh_H, m->sh_mv};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -586,7 +590,7 @@ static gg_node_ctx node_ctx(const gg_model* m, const gg_data* d, int buf) {
   x.n0 = m->n0;
   x.N = m->Nl; x.Np = m->Np; x.K = m->K; x.Kp = m->Kp; x.B = m->B; x.shift = m->is_adj ? 0 : d->shift;
   x.special = m->cfg.special_case_self_conns;
-  x.c = m->c; x.cnt = m->cnt; x.logm = m->logm; x.T = m->T; x.Tout = m->Tout; x.Tin = m->Tin;
+  x.c = m->c; x.cnt = m->cnt; x.cntn = nullptr; x.logm = m->logm; x.T = m->T; x.Tout = m->Tout; x.Tin = m->Tin;
   x.Gcnt[0] = gcnt(m, buf, 0); x.Gcnt[1] = gcnt(m, buf, 1); x.GS[0] = gs(m, buf, 0); x.GS[1] = gs(m, buf, 1);
   x.dA = d->dA; x.dWq = d->dWq;
   return x;
@@ -835,6 +839,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
 static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined,
                             int round_window = 0, int explicit_count = 0, bool shard_mode = false) {
   gg_node_ctx x = node_ctx(m, d, buf);
+  if (shard_mode) x.cntn = m->sh_cntn;   // block sizes as each own node sees them (hypotheses at earlier positions included)
   const int K = m->K, per = 256 / m->Kp;
   const int count = round_window > 0 ? round_window : (explicit_count > 0 ? explicit_count : (m->Nl - n_begin));
   int nb = (count + per - 1) / per;
@@ -2137,9 +2142,26 @@ static int shard_global_tables(gg_model* m, const gg_data* d, gg_comm* c, int di
   return comm_allreduce_i64(c, m->tab, (size_t)m->K * m->K * m->NTAB, m->stream);
 }
 
+static int launch_shard_moves(gg_model* m, const gg_data* d, int buf) {
+  gg_node_ctx x = node_ctx(m, d, buf);
+  dim3 grd((m->Nl + 255) / 256, 8);
+#define SHM(NTV, ADJV)                                                                                                 \
+  k_shard_moves<NTV, ADJV><<<grd, 256, 0, m->stream>>>(x, m->sh_mv, m->rs, m->sh_cntn, gcnt(m, buf, 0), gcnt(m, buf, 1),  \
+                                                       gs(m, buf, 0), gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT)
+  if (m->is_adj) SHM(2, true);
+  else if (m->B == 1) SHM(3, false);
+  else if (m->B == 2) SHM(6, false);
+  else if (m->B == 3) SHM(10, false);
+  else SHM(15, false);
+#undef SHM
+  GG_HIP(hipGetLastError());
+  return GG_OK;
+}
+
 // n half-sweeps (adjacency.py:615-618 / weights.py:394-397) of a chain whose nodes are sharded over the communicator's
 // ranks.  Per half-sweep: one all-reduce of the integer tables; the scan in rounds of
-//   speculate (own nodes of the window) -> first changer -> ALL-GATHER of (node, old, new) -> pick + apply,
+//   speculate (own nodes of the band, under the hypotheses) -> first surprises -> ALL-GATHER of (node, old, new) x GG_SHARD_M
+//   -> fold / accept up to the earliest surprise -> moves of the own nodes' statistics         (k_shard_* kernels),
 // all enqueued on the engine stream in batches, the host reading the scan position once per batch.  Every rank issues the
 // same collectives (the position it reads is the same everywhere), and rounds beyond the scan's end are no-ops.
 int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
@@ -2147,8 +2169,15 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
   if (rc) return rc;
   if (!m->sharded && c->world > 1) return gg_fail(GG_ERR_INVALID, "gg_shard_sweep: the model was not created with a node shard");
   if (!m->sh_buf) {
-    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, 4)) || (rc = dmalloc(&m->sh_all, (size_t)3 * c->world + 4))) return rc;
+    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, (size_t)3 * GG_SHARD_M + 4)) ||
+        (rc = dmalloc(&m->sh_all, (size_t)3 * GG_SHARD_M * c->world + 4)))
+      return rc;
     m->sh_world = c->world;
+  }
+  if (!m->sh_cntn) {
+    if ((rc = dmalloc(&m->sh_cntn, (size_t)(m->Nl > 0 ? m->Nl : 1) * m->K)) || (rc = dmalloc(&m->sh_H, (size_t)GG_SHARD_WINDOW)) ||
+        (rc = dmalloc(&m->sh_mv, (size_t)3 * GG_SHARD_M * c->world + 4)))
+      return rc;
   }
   if (m->sh_world != c->world) return gg_fail(GG_ERR_INVALID, "gg_shard_sweep: the communicator's size changed");
   drop_ahead(m);
@@ -2165,23 +2194,29 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
     m->shard_from_tab = false;
     if (rc) return rc;
     if (m->K > 1) {
-      m->h_rs[24] = 0; m->h_rs[25] = m->N;
-      GG_HIP(hipMemcpyAsync(m->rs + GG_RS_SPOS, m->h_rs + 24, 2 * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
-      const int per = 256 / m->Kp;
+      // control words 20..23: moves of the last round, band start, scan position, number of nodes
+      m->h_rs[24] = 0; m->h_rs[25] = 0; m->h_rs[26] = 0; m->h_rs[27] = m->N;
+      GG_HIP(hipMemcpyAsync(m->rs + GG_RS_NMV, m->h_rs + 24, 4 * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+      {
+        const size_t cells = (size_t)m->Nl * m->K > (size_t)GG_SHARD_WINDOW ? (size_t)m->Nl * m->K : (size_t)GG_SHARD_WINDOW;
+        k_shard_init<<<(unsigned)((cells + 255) / 256), 256, 0, m->stream>>>(m->cnt, m->sh_cntn, m->sh_H, m->Nl, m->K, m->rs);
+        GG_HIP(hipGetLastError());
+      }
       int batch = 8;
       for (;;) {
         for (int r = 0; r < batch; ++r) {
+          // one round: own nodes of the band behind the scan position evaluated under the hypotheses -> the first
+          // GG_SHARD_M surprises -> ALL-GATHER -> fold into the hypotheses, accept up to the earliest surprise -> moves
           if (m->Nl > 0) {
             const int count = m->Nl < GG_SHARD_WINDOW ? m->Nl : GG_SHARD_WINDOW;
-            (void)per;
             if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false, 0, count, true))) return rc;
           }
-          k_shard_first<<<1, 1024, 0, m->stream>>>(m->c, m->cand, m->n0, m->Nl, m->rs, m->sh_trip);
+          k_shard_surprises<<<1, 1024, 0, m->stream>>>(m->c, m->cand, m->sh_H, m->n0, m->Nl, m->rs, m->sh_trip);
           GG_HIP(hipGetLastError());
-          if ((rc = comm_allgather_i32(c, m->sh_trip, m->sh_all, 3, m->stream))) return rc;
-          k_shard_pick<<<1, 64, 0, m->stream>>>(m->c, m->cnt, m->L, m->rs, m->sh_all, c->world);
+          if ((rc = comm_allgather_i32(c, m->sh_trip, m->sh_all, 3 * GG_SHARD_M, m->stream))) return rc;
+          k_shard_fold<<<1, 256, 0, m->stream>>>(m->c, m->cnt, m->sh_H, m->rs, m->sh_all, c->world, m->sh_mv);
           GG_HIP(hipGetLastError());
-          if (m->Nl > 0 && (rc = launch_apply_L(m, d, buf, 0, false))) return rc;   // statistics of the owned nodes
+          if (m->Nl > 0 && (rc = launch_shard_moves(m, d, buf))) return rc;   // statistics of the owned nodes
         }
         GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 24 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
         GG_HIP(hipStreamSynchronize(m->stream));
@@ -2190,6 +2225,7 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
         if (batch < 128) batch *= 2;
       }
       m->st.label_changes = (uint64_t)m->h_rs[2];
+      m->st.resolve_rounds += (uint64_t)m->h_rs[GG_RS_ROUNDS];
       m->perm_valid = false;
     }
     k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
@@ -2209,7 +2245,9 @@ int gg_shard_log_likelihood(gg_model* m, const gg_data* d, gg_comm* c, double* o
   if (rc) return rc;
   if (!out) return gg_fail(GG_ERR_INVALID, "gg_shard_log_likelihood: null output");
   if (!m->sh_buf) {
-    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, 4)) || (rc = dmalloc(&m->sh_all, (size_t)3 * c->world + 4))) return rc;
+    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, (size_t)3 * GG_SHARD_M + 4)) ||
+        (rc = dmalloc(&m->sh_all, (size_t)3 * GG_SHARD_M * c->world + 4)))
+      return rc;
     m->sh_world = c->world;
   }
   drop_ahead(m);

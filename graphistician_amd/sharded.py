@@ -8,10 +8,12 @@ engine stream, device buffers):
   * one all-reduce (SUM, int64) of the K x K sufficient-statistic tables
     -> every rank draws the same parameters from the same Philox stream (adjacency.py:620-648,
     weights.py:399-413);
-  * the sequential scan (adjacency.py:650-695, weights.py:415-488): ranks speculate their own nodes
-    window by window; an all-gather of (first node whose draw differs from its label, old, new)
-    triples picks the earliest change, every rank applies it (labels are replicated, the statistics
-    of owned nodes are corrected from the local row of X / X^T) and the scan resumes after it.
+  * the sequential scan (adjacency.py:650-695, weights.py:415-488) in rounds over 4096-node bands: every
+    rank evaluates its own nodes under the changes hypothesised so far and reports the first 32 whose
+    decision differs from the hypothesis, as (node, old, new) triples; ONE all-gather per round; every
+    rank then accepts the hypotheses up to the earliest report (labels are replicated, the statistics
+    of owned nodes are corrected from the local rows of X / X^T) and amends the rest.  A round
+    without a report closes the band.
 
 All traffic is integer, so the result does not depend on the number of ranks: labels and drawn
 parameters are bit-identical to `SBMAdjacencyDistribution.resample` on one GPU (tests/test_sharded.py).

@@ -243,8 +243,9 @@ int gg_set_timing(gg_model* m, int32_t on);
  *   gg_comm_create_host   a pair of host callbacks (in-place SUM of int64; all-gather of int32) - the protocol's test
  *                         harness (gloo through ctypes), buffers staged through the host.
  * gg_shard_sweep runs n half-sweeps: per half-sweep one all-reduce of the K x K integer tables, then the sequential scan
- * (adjacency.py:650-695, weights.py:415-488) in rounds - every rank speculates its own nodes of the current window, an
- * all-gather of (first changed node, old, new) picks the earliest change, every rank applies it - enqueued in batches on
+ * (adjacency.py:650-695, weights.py:415-488) in rounds - every rank evaluates its own nodes of the current 4096-node band
+ * under the changes hypothesised so far and reports its first 32 surprises (node, old, new); one all-gather per round; every
+ * rank accepts the hypotheses up to the earliest surprise and amends the rest - enqueued in batches on
  * the engine stream; the host reads the scan position once per batch, never once per change. */
 typedef struct gg_comm gg_comm;
 typedef int (*gg_host_allreduce_fn)(void* user, int64_t* buf, int64_t n);                          /* in place, SUM over ranks */
