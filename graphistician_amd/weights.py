@@ -635,10 +635,29 @@ class LatentDistanceGaussianWeightDistribution(_WeightsBase):
         self.initialize_from_prior()
         self._self_gaussian.resample()
 
+    def _location_objective(self, Lflat, A, W):
+        """-log p(W, L | b, sigma, eta) as a function of the locations and its gradient (weights.py:701-733 hands the same
+        function to autograd; the gradient here is written out: d/dl_i = (2/sigma) sum_j (r_ij a_ij + r_ji a_ji)(l_i - l_j)
+        + l_i / eta for the NEGATIVE log probability, r = W - (-|l_i - l_j|^2 + b), a = off-diagonal edge mask)."""
+        N = self.N
+        L = Lflat.reshape(N, self.dim)
+        diff = L[:, None, :] - L[None, :, :]
+        Mu = -(diff ** 2).sum(2) + self.b
+        Aoff = np.asarray(A, dtype=np.float64) * (1.0 - np.eye(N))
+        R = (np.asarray(W, dtype=np.float64).reshape(N, N) - Mu) * Aoff
+        lmb = 1.0 / float(np.asarray(self.cov.sigma).ravel()[0])
+        f = 0.5 * lmb * (R ** 2).sum() + 0.5 * (L * L).sum() / self.eta + 0.5 * self.b ** 2
+        S = R + R.T
+        g = 2.0 * lmb * (S.sum(1)[:, None] * L - S.dot(L)) + L / self.eta
+        return f, g.ravel()
+
     def initialize_hypers(self, W):
-        # weights.py:676-678 optimises L by BFGS on the autograd gradient; a few HMC sweeps from the prior draw do
-        # that job here (the optimiser is initialisation only, not part of the sampler)
-        pass
+        # weights.py:676-678, 792-808: the initial locations by BFGS on -log p with every pair counted as an edge (host
+        # code in the reference as well: initialisation, not part of the sampler)
+        from scipy.optimize import minimize
+        A = np.ones((self.N, self.N))
+        res = minimize(self._location_objective, np.ravel(self.L), args=(A, W), jac=True, method="BFGS")
+        self.L = res.x.reshape(self.N, self.dim)
 
     def log_prior(self):
         # weights.py:680-701

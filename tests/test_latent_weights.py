@@ -167,3 +167,32 @@ def test_engine_chain_matches_oracle_and_fits():
     assert m.Mu.shape == (N, N, 1) and m.Sigma.shape == (N, N, 1, 1)
     # the data were generated with sigma = 0.09 around -D + 0.5: the residual variance must have come down towards it
     assert m.cov.sigma[0, 0] < 0.5
+
+
+@pytest.mark.gpu
+def test_initialize_hypers_optimises_the_locations():
+    """weights.py:676-678, 792-808: initialize_hypers = BFGS on -log p(W, L | b, sigma, eta) with every pair counted as an edge.
+    The written-out gradient against central differences of the objective (the reference differentiates the same function
+    with autograd), and the optimum: a complete weighted graph generated from planted locations gives their pairwise
+    distances back."""
+    from graphistician_amd.weights import LatentDistanceGaussianWeightDistribution
+    rng = np.random.RandomState(3)
+    N, dim, b = 36, 2, 0.5
+    Lt = 0.7 * rng.randn(N, dim)
+    Dt = ((Lt[:, None, :] - Lt[None, :, :]) ** 2).sum(2)
+    W = (-Dt + b + 0.05 * rng.randn(N, N))[:, :, None]
+    np.random.seed(1)
+    m = LatentDistanceGaussianWeightDistribution(N, dim=dim, b=b, sigma=np.array([[0.05]]), eta=1.0, seed=5)
+    A = np.ones((N, N))
+    x = rng.randn(N * dim) * 0.5
+    f0, g0 = m._location_objective(x, A, W)
+    for i in rng.choice(N * dim, 12, replace=False):
+        e = np.zeros(N * dim); e[i] = 1e-5
+        fd = (m._location_objective(x + e, A, W)[0] - m._location_objective(x - e, A, W)[0]) / 2e-5
+        assert abs(fd - g0[i]) <= 1e-5 * max(1.0, abs(fd)), (i, fd, g0[i])
+    f_start = m._location_objective(np.ravel(m.L), A, W)[0]
+    m.initialize_hypers(W)
+    f_end = m._location_objective(np.ravel(m.L), A, W)[0]
+    assert f_end < 0.05 * f_start
+    off = ~np.eye(N, dtype=bool)
+    assert np.corrcoef(m.D[off], Dt[off])[0, 1] > 0.98
