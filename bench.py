@@ -216,7 +216,9 @@ def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every,
     for _ in range(warmup):
         adj.resample(data, 1)
         w.resample(data, 1)
-    chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
+    st0a, st0w = adj.stats(), w.stats()
+    chg0 = st0a["label_changes"] + st0w["label_changes"]
+    rnd0 = st0a["resolve_rounds"] + st0w["resolve_rounds"]
     adj.set_timing(every)
     w.set_timing(every)
     barrier()
@@ -236,6 +238,7 @@ def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every,
                 bulk=dict(adj_ms=sa["bulk_ms"], adj_n=sa["bulk_launches"], adj_bytes=sa["bulk_bytes"],
                           w_ms=sw["bulk_ms"], w_n=sw["bulk_launches"], w_bytes=sw["bulk_bytes"]),
                 changes=sa["label_changes"] + sw["label_changes"] - chg0,
+                rounds=sa["resolve_rounds"] + sw["resolve_rounds"] - rnd0,
                 changes_adj=sa["label_changes"], changes_w=sw["label_changes"],
                 # the quiet chain ran in the ahead form (fused launches carrying the next sweeps' pass) unless it was switched off
                 ahead=bool(os.environ.get("GG_AHEAD", "1") != "0" and os.environ.get("GG_SCAN") is None and
@@ -249,7 +252,9 @@ def extra_mixing_chains(abi, data, N, K, device, burnin, steps=100):
     for seed in (2, 4):
         r = run_chain(abi, data, N, K, seed, device, burnin, 10, steps, 0)
         out.append({"chain_seed": seed, "value": steps / r["elapsed"], "unit": "sweeps/s", "ms_per_step": r["elapsed"] / steps * 1e3,
-                    "label_changes_per_sweep": r["changes"] / float(steps)})
+                    "label_changes_per_sweep": r["changes"] / float(steps),
+                    # both models' scans: 1 per quiet scan, 1 per grid-wide exchange of a resident scan (hypothesis rounds)
+                    "scan_rounds_per_sweep": r["rounds"] / float(steps)})
         del r
     return out
 

@@ -1211,8 +1211,7 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     if ((rc = read_ctl(m))) return rc;
     if (m->h_rs[4] && m->h_rs[0] != 0) {
       if ((rc = launch_apply_L(m, d, buf))) return rc;
-      if ((rc = launch_scan(m, d, buf, sweep, tail_sort, pw, true))) return rc;
-      m->st.resolve_rounds += 1;
+      if ((rc = launch_scan(m, d, buf, sweep, tail_sort, pw, true))) return rc;   // (its rounds are counted on the device)
       if ((rc = read_ctl(m))) return rc;
     }
     if (m->h_rs[3] == 2) {
@@ -1313,7 +1312,7 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
       if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
       if ((rc = launch_resolve(m, d, buf, sweep, false, true, 1 - P))) return rc;
     }
-    m->st.resolve_rounds += 1;
+    if (!m->use_scan) m->st.resolve_rounds += 1;   // (k_scan counts its exchange rounds on the device: gg_last_stats)
     m->m_pending = true;   // drawn by the next sweep's k_params (or at the next sync)
     m->m_sweep = sweep;
     m->pcur = 1 - P;
@@ -2321,6 +2320,11 @@ int gg_last_stats(gg_model* m, gg_stats* out) {
   int rc = model_sync(m);
   if (rc) return rc;
   *out = m->st;
+  if (m->sbm && !m->sharded && m->K > 1) {
+    // rounds of the resident scans (one grid-wide exchange each), counted by k_scan itself
+    if ((rc = read_ctl(m))) return rc;
+    out->resolve_rounds += (uint64_t)(uint32_t)m->h_rs[GG_RS_ROUNDS];
+  }
   return GG_OK;
 }
 

@@ -631,6 +631,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   if (tid == 0) {
     g.rs[0] = 0;
     g.rs[1] = g.keep_L ? nL : 0;
+    g.rs[GG_RS_ROUNDS] += (int)it;     // exchange rounds of this scan (gg_stats.resolve_rounds)
     g.rs[2] += nchg;
     g.rs[9] += nchg;
     g.rs[5] += 1;

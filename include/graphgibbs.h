@@ -128,7 +128,7 @@ enum gg_part {
 typedef struct gg_stats {
   uint64_t sweeps;              /* sweeps run on this handle */
   uint64_t label_changes;       /* labels changed by resample_c since creation */
-  uint64_t resolve_rounds;      /* speculate/resolve rounds (1 per half-sweep when nothing changes) */
+  uint64_t resolve_rounds;      /* rounds of the node scans: 1 per quiet scan, 1 per grid-wide exchange of a resident scan */
   double bulk_bytes;            /* algorithmic bytes streamed by the bulk statistics kernels, last call */
   double bulk_ms;               /* HIP-event time of those kernels, last call */
   uint64_t bulk_launches;       /* number of bulk kernel launches, last call */

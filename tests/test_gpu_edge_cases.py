@@ -265,6 +265,12 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, monkeypatch):
     assert np.array_equal(adj.get(abi.ST_M, (K,)), sa.m)
     assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_MU, (K, K, 1)), sw.mu)
     assert adj.stats()["label_changes"] > 0
+    for mdl in (adj, w):
+        st = mdl.stats()
+        # hypothesis rounds: one grid-wide exchange accepts every hypothesised change up to the earliest surprise, so a
+        # scan takes far fewer exchanges than it changes labels (one per change before)
+        if st["label_changes"] > 200 and not lcap:
+            assert st["resolve_rounds"] * 3 < st["label_changes"], st
 
 
 @pytest.mark.gpu
