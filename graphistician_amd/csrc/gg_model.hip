@@ -943,6 +943,16 @@ static int launch_sweep_q(gg_model* m, const gg_data* d, int a, int b, int c, ui
 #undef SWQ1
   if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
   GG_HIP(hipGetLastError());
+  if (pg.shared) {
+    // weights.py:545-552: the shared covariance of sweep + 1 and, with it, the coefficient tables - the second half of the
+    // parameter step, as behind every k_params (enqueue_params).  A no-op behind a scan that changed a label (stall flag),
+    // like the gated first half inside the launch.
+    if (m->B == 1) k_shared_cov<1><<<1, 256, 0, m->stream>>>(pg);
+    else if (m->B == 2) k_shared_cov<2><<<1, 256, 0, m->stream>>>(pg);
+    else if (m->B == 3) k_shared_cov<3><<<1, 256, 0, m->stream>>>(pg);
+    else k_shared_cov<4><<<1, 256, 0, m->stream>>>(pg);
+    GG_HIP(hipGetLastError());
+  }
   m->zeroed[c] = false;
   return GG_OK;
 }

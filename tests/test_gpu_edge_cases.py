@@ -439,12 +439,27 @@ def test_timeout_right_after_the_last_node_changed(abi, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_shared_covariance_kind_in_the_ahead_form(abi, monkeypatch):
+    """Found by the extended fuzz of the release soak: the quiet chain's fused launch ran the first half of the
+    shared-covariance parameter step (means, centred scatter) and left out the second (the covariance draw and the tables,
+    `k_shared_cov`, weights.py:545-552) - visible as soon as such a chain was quiet for two sweeps in a row.  The two cases
+    it was found with, and a larger network that settles within the call; with and without the ahead form."""
+    from tests.fuzz_parity import one_case
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("GG_AHEAD", ahead)
+        assert one_case(5, 5, 4, 1, 154869791, (1, 2, 9), 0.5, True) is None
+        assert one_case(17, 17, 4, 1, 567335410, (3, 12), 1.0, True) is None
+        assert one_case(200, 4, 2, 1, 99, (1, 3, 40), 1.0, True) is None
+        assert one_case(129, 3, 1, 0, 7, (2, 30), 0.83, True) is None
+
+
+@pytest.mark.gpu
 def test_short_parity_fuzz(abi):
     """Thirty random shapes / conventions / chunkings, engine against the oracle bit for bit (tests/fuzz_parity.py; longer
     streams under every scan-form switch are part of the release soak, profiles/README.md)."""
     from tests.fuzz_parity import run
     assert run(30, 20261003) == []
-    assert run(20, 20261004, extended=True) == []     # tempered sweeps and shared-covariance weights as well
+    assert run(40, 20261004, extended=True) == []     # tempered sweeps and shared-covariance weights as well
 
 
 @pytest.mark.gpu
