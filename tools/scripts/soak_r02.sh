@@ -17,3 +17,5 @@ for env in "GG_X=1" "GG_SCAN=1" "GG_SCAN=0" "GG_SCAN_SPIN=2" "GG_AHEAD=0" "GG_SC
   i=$((i+1))
 done
 cat $O
+echo "float-model shape sweep (tests/fuzz_float_models.py): $(timeout -k 10 900 python tests/fuzz_float_models.py 2>&1 | tail -1)" >> $O
+tail -2 $O
