@@ -56,6 +56,14 @@ def one_case(N, K, B, special, seed, chunks, beta=1.0, shared_cov=False):
         if not ok:
             return "N=%d K=%d B=%d special=%d seed=%d beta=%g shared_cov=%d after %d sweeps" % (N, K, B, special, seed, beta,
                                                                                                   shared_cov, done)
+        # log p(A | .) + log p(W | A, .) of the network (networks.py:28-31) between the chunks: after a quiet sweep the engine
+        # takes it from the statistics counted ahead (float sums in another order than the oracle's: 1e-9)
+        ll = float(np.sum(abi.log_likelihood_many([adj, w], d)))
+        ref = (O.sbm_adj_loglik(A, sa.c, sa.p, ps, True, bool(special)) +
+               O.sbm_w_loglik(A, q, shift, sw.c, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, bool(special)))
+        if not (abs(ll - ref) <= 1e-9 * abs(ref) + 1e-7 or (np.isnan(ll) and np.isnan(ref)) or (np.isinf(ref) and ll == ref)):
+            return "N=%d K=%d B=%d special=%d seed=%d beta=%g shared_cov=%d after %d sweeps: log-likelihood %r, oracle %r" % (
+                N, K, B, special, seed, beta, shared_cov, done, ll, ref)
     return None
 
 
