@@ -24,6 +24,26 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_JSON_OUT = None
+
+
+def _claim_stdout():
+    """stdout carries exactly ONE line, the JSON result: the descriptor is kept aside for it and everything else that
+    writes to fd 1 from here on (RCCL greets with a version banner when its first communicator comes up, for one) lands on
+    stderr."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def _progress(msg):
     sys.stderr.write("[bench] %s\n" % msg)
     sys.stderr.flush()
@@ -380,7 +400,7 @@ def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
         el1 = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / el1, "unit": "sweeps/s", "cores": 1, "kind": "port",
                                "sample": "1 full sweep of the same N=%d D=%d network, oracle/ C++ -O2, 1 thread" % (N, D)}
-    print(json.dumps(out))
+    _emit(json.dumps(out))
 
 
 def bench_latent(args, abi, device, rank, world, barrier, max_over_ranks):
@@ -426,7 +446,7 @@ def bench_latent(args, abi, device, rank, world, barrier, max_over_ranks):
         el1 = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / el1, "unit": "sweeps/s", "cores": 1, "kind": "port",
                                "sample": "1 resample of the same N=%d network, oracle/ C++ -O2, 1 thread" % N}
-    print(json.dumps(out))
+    _emit(json.dumps(out))
 
 
 def bench_latent_w(args, abi, device, rank, world, barrier, max_over_ranks):
@@ -472,7 +492,7 @@ def bench_latent_w(args, abi, device, rank, world, barrier, max_over_ranks):
         el1 = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / el1, "unit": "sweeps/s", "cores": 1, "kind": "port",
                                "sample": "1 resample of the same N=%d network, oracle/ C++ -O2, 1 thread" % N}
-    print(json.dumps(out))
+    _emit(json.dumps(out))
 
 
 def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
@@ -532,7 +552,7 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     cinfo = comm.info()
     if rank == 0:
         sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
-        print(json.dumps({
+        _emit(json.dumps({
             "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": args.steps / el,
             "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -575,6 +595,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the multi-process protocol (rendezvous, barrier, max-over-ranks) without the engine")
     args = ap.parse_args()
+    _claim_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -612,7 +633,7 @@ def main():
         barrier()
         el = max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
-            print(json.dumps({"metric": "dry-run", "value": world * args.steps / el, "unit": "sweeps/s", "n_gpus": world,
+            _emit(json.dumps({"metric": "dry-run", "value": world * args.steps / el, "unit": "sweeps/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                               "elapsed_s": el, "scaling": "weak"}))
         if dist is not None:
@@ -769,7 +790,7 @@ def main():
                 except Exception as exc:
                     legs[name] = {"error": str(exc)}
             out["other_configs"] = legs
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
