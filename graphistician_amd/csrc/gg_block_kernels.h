@@ -12,6 +12,7 @@
 // gives the same bits and the sequential scan of the reference can be resolved
 // speculatively (kernel k_resolve) without changing a single draw.
 #pragma once
+#include <type_traits>
 #include "gg_common.h"
 #include "spec/gg_shcov.h"
 
@@ -1036,7 +1037,10 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
                                                const double* T1 = nullptr, int RS = 0) {
   constexpr int NCH = 2 * NT;
   constexpr int CPW = (NCH + 3) / 4;                                         // chains per wave
-  constexpr int UJ = CPW == 1 ? 64 : (CPW == 2 ? 32 : (CPW <= 4 ? 16 : 8));   // table entries in flight per chain
+#ifndef GG_SPLIT_UJ2
+#define GG_SPLIT_UJ2 16
+#endif
+  constexpr int UJ = CPW == 1 ? 64 : (CPW == 2 ? GG_SPLIT_UJ2 : (CPW <= 4 ? 16 : 8));   // table entries in flight per chain
   const int w = threadIdx.x >> 6, k = threadIdx.x & 63, K = x.K;
   // values the tail needs, fetched now so that their latency hides behind the chains
   const double logm_k = x.logm[k < K ? k : 0];
@@ -1046,7 +1050,12 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[c][i] = 0.0;
   if (k < K) {
-    for (int j = 0; j < K; j += UJ) {
+    // One batch of UJ consecutive j: the table entries are fetched first (all in flight together), then the chains run.
+    // FULL batches carry no bounds checks: with a check per step every step becomes its own basic block, whose LDS read
+    // of the four nodes' statistics is waited for before its four fma - 100 clocks per step, 8 of 10 us of a K = 64
+    // evaluation (measured); without them the block is straight-line code and the reads run ahead of the arithmetic.
+    auto batch = [&](int j, auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
       double tv[CPW][UJ];
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
@@ -1059,14 +1068,14 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
             const int js = d == 0 ? NT : RS;
 #pragma unroll
             for (int u = 0; u < UJ; ++u) {
-              const int jj = (j + u < K) ? j + u : K - 1;
+              const int jj = (FULL || j + u < K) ? j + u : K - 1;
               tv[c][u] = Tb[(size_t)jj * js];
             }
           } else {
             const double* Tb = (d == 0 ? x.Tout : x.Tin) + (size_t)t * 64 + k;
 #pragma unroll
             for (int u = 0; u < UJ; ++u) {
-              const int jj = (j + u < K) ? j + u : K - 1;
+              const int jj = (FULL || j + u < K) ? j + u : K - 1;
               tv[c][u] = Tb[(size_t)jj * NT * 64];
             }
           }
@@ -1080,17 +1089,34 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
           const int d = ch / NT, t = ch % NT;
           // split layout of the statistics: [dir][j][t][node] - the four nodes of a (j, t) are one 32-byte read
           const double* sb = s_st + ((size_t)d * K * NT + t) * 4;
+          // the four nodes' statistics of UB steps are read before the first of them is used (left to itself the compiler
+          // reads each step's 32 bytes right in front of its four fma and waits for them: one LDS latency per step)
+          constexpr int UB = UJ < 4 ? UJ : 4;
 #pragma unroll
-          for (int u = 0; u < UJ; ++u) {
-            if (j + u < K) {
-              const double* sp = sb + (size_t)(j + u) * NT * 4;
+          for (int u0 = 0; u0 < UJ; u0 += UB) {
+            double spv[UB][4];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) acc[c][i] = gg_fma(tv[c][u], sp[i], acc[c][i]);
+            for (int b2 = 0; b2 < UB; ++b2) {
+              const int jj = (FULL || j + u0 + b2 < K) ? j + u0 + b2 : K - 1;
+              const double* sp = sb + (size_t)jj * NT * 4;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) spv[b2][i] = sp[i];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int b2 = 0; b2 < UB; ++b2) {
+              if (FULL || j + u0 + b2 < K) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[c][i] = gg_fma(tv[c][u0 + b2], spv[b2][i], acc[c][i]);
+              }
             }
           }
         }
       }
-    }
+    };
+    int j = 0;
+    for (; j + UJ <= K; j += UJ) batch(j, std::true_type());
+    if (j < K) batch(j, std::false_type());
   }
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {

@@ -1557,11 +1557,11 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
   }
   m->st.label_changes = (uint64_t)m->h_rs[2];
   if (m->dbg && m->use_scan) {
-    long long h[8];
+    long long h[11];
     GG_HIP(hipMemcpy(h, m->dbg, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[3]) fprintf(stderr, "[scan dbg] %s last scan: %lld rounds; per round eval %.2f exchange %.2f apply %.2f us; start-up %.2f group loads %.2f tail %.2f us; kernel %.2f us\n",
-                      m->is_adj ? "adj" : "w", h[3], h[0] * 0.01 / h[3], h[1] * 0.01 / h[3], h[2] * 0.01 / h[3], h[7] * 0.01, h[4] * 0.01, h[6] * 0.01,
-                      (h[5] + h[7]) * 0.01);
+    if (h[3]) fprintf(stderr, "[scan dbg] %s last scan: %lld rounds; per round eval %.2f (convert %.2f, conditional %.2f, draw + report %.2f) exchange %.2f apply %.2f us; start-up %.2f group loads %.2f tail %.2f us; kernel %.2f us\n",
+                      m->is_adj ? "adj" : "w", h[3], h[0] * 0.01 / h[3], h[8] * 0.01 / h[3], h[9] * 0.01 / h[3], h[10] * 0.01 / h[3],
+                      h[1] * 0.01 / h[3], h[2] * 0.01 / h[3], h[7] * 0.01, h[4] * 0.01, h[6] * 0.01, (h[5] + h[7]) * 0.01);
   }
   GG_HIP(hipEventSynchronize(m->ev_call1));
   if (m->swq_dbg) {

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   int wi = 0;                    // evaluation rounds so far: selects the rotating first-changer word
   bool alive = true, fatal = false;   // fatal: gave up inside the chip-wide flush (G half updated: not resumable)
   bool flushed = false;               // the list was flushed at least once in this scan (same in every workgroup)
-  long long t_eval = 0, t_xchg = 0, t_apply = 0, t_load = 0;
+  long long t_eval = 0, t_xchg = 0, t_apply = 0, t_load = 0, t_e1 = 0, t_e2 = 0, t_e3 = 0;
   const long long t_begin = g.dbg ? wall_clock64() : 0;
 
   // move one edge's statistics of node i (LDS) from block ba to block bb
@@ -382,6 +382,8 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
         }
       }
       __syncthreads();
+      const long long ca = g.dbg ? wall_clock64() : 0;
+      long long cb = 0;
       {
         const int i = tid / Kp, k = tid % Kp;
         const int n = n0 + i;
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
         else if (split) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_acc, nn, stage_tables == 2 ? s_T : nullptr, RS);
         else if (stage_tables == 2) lp = gg_node_lp_core_t1<NT, ADJ>(x, nn, k, ld, s_T, RS, &logm_k);
         else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin, &logm_k);
+        if (g.dbg) cb = wall_clock64();
         const int lab = gg_group_categorical(lp, k, K, Kp, u_band);
         if (k == 0) {
           // what the hypotheses say about this node: it moves to h's new label, or it stays
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
       ++it; ++wi;
       const long long c2 = g.dbg ? wall_clock64() : 0;
       t_eval += c1 - c0; t_xchg += c2 - c1;
+      t_e1 += ca - c0; t_e2 += cb - ca; t_e3 += c1 - cb;
       const bool quiet = best == GG_SLOT_NONE;   // no surprise anywhere: every remaining hypothesis is the chain
       // ---- the surprises, in position order (= slot order), amend the hypotheses
       int nS = 0;
@@ -627,6 +631,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     g.dbg[5] = wall_clock64() - t_begin;
     g.dbg[6] = wall_clock64() - t_tail0;
     g.dbg[7] = t_init0 - t_kernel0;
+    g.dbg[8] = t_e1; g.dbg[9] = t_e2; g.dbg[10] = t_e3;
   }
   if (tid == 0) {
     g.rs[0] = 0;
