@@ -195,7 +195,7 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
                (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)lcap * 3 * sizeof(int);
   // deviations, the round's surprises, per-node block sizes, scratch, one hypothesis per node of a band
   lds += 136 * sizeof(unsigned long long) + 256 * 3 * sizeof(int) + (size_t)per * K * sizeof(int) + 16 * sizeof(int) + 16 +
-         (size_t)GG_SCAN_MAXWG * per * sizeof(short);
+         (size_t)GG_SCAN_MAXWG * per * sizeof(short) + (size_t)(GG_SCAN_MAXWG * per / 32 + 2) * sizeof(unsigned);
   if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
   // coefficient table: both lane-major layouts when that stays below 64 KB (1); else one padded copy of T[a][b][t] when
   // that stays below 72 KB (2: K up to 32 at B = 1); else from global memory (0).  (At K = 64 the one copy fits the 150 KB
@@ -1557,11 +1557,12 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
   }
   m->st.label_changes = (uint64_t)m->h_rs[2];
   if (m->dbg && m->use_scan) {
-    long long h[11];
+    long long h[13];
     GG_HIP(hipMemcpy(h, m->dbg, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[3]) fprintf(stderr, "[scan dbg] %s last scan: %lld rounds; per round eval %.2f (convert %.2f, conditional %.2f, draw + report %.2f) exchange %.2f apply %.2f us; start-up %.2f group loads %.2f tail %.2f us; kernel %.2f us\n",
+    if (h[3]) fprintf(stderr, "[scan dbg] %s last scan: %lld rounds; per round eval %.2f (convert %.2f, conditional %.2f, draw + report %.2f) exchange %.2f apply %.2f (fold %.2f, accept %.2f, moves %.2f) us; start-up %.2f group loads %.2f tail %.2f us; kernel %.2f us\n",
                       m->is_adj ? "adj" : "w", h[3], h[0] * 0.01 / h[3], h[8] * 0.01 / h[3], h[9] * 0.01 / h[3], h[10] * 0.01 / h[3],
-                      h[1] * 0.01 / h[3], h[2] * 0.01 / h[3], h[7] * 0.01, h[4] * 0.01, h[6] * 0.01, (h[5] + h[7]) * 0.01);
+                      h[1] * 0.01 / h[3], h[2] * 0.01 / h[3], h[11] * 0.01 / h[3], h[12] * 0.01 / h[3], (h[2] - h[11] - h[12]) * 0.01 / h[3],
+                      h[7] * 0.01, h[4] * 0.01, h[6] * 0.01, (h[5] + h[7]) * 0.01);
   }
   GG_HIP(hipEventSynchronize(m->ev_call1));
   if (m->swq_dbg) {

@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   int* s_S = reinterpret_cast<int*>(s_raw + off); off += 256 * 3 * sizeof(int);      // its surprises, compacted: (node, from, to)
   int* s_cntn = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * K * sizeof(int);   // block sizes as node i of the group sees them
   int* s_misc = reinterpret_cast<int*>(s_raw + off); off += 16 * sizeof(int);
-  short* s_H = reinterpret_cast<short*>(s_raw + off);   // [G per] hypothesis per node of the band: -1 none, else (old << 8 | new)
+  short* s_H = reinterpret_cast<short*>(s_raw + off); off += (size_t)GG_SCAN_MAXWG * per * sizeof(short);   // [G per] hypothesis per node of the band: -1 none, else (old << 8 | new)
+  off = (off + 3) & ~(size_t)3;
+  unsigned* s_Hm = reinterpret_cast<unsigned*>(s_raw + off);   // one bit per node of the band: a hypothesis is in place
 
   const size_t dstride = (size_t)K * Np;
   // The first band's statistics: 2 K per <= 512 entries, at most two per thread.  Their loads are issued before the
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   int wi = 0;                    // evaluation rounds so far: selects the rotating first-changer word
   bool alive = true, fatal = false;   // fatal: gave up inside the chip-wide flush (G half updated: not resumable)
   bool flushed = false;               // the list was flushed at least once in this scan (same in every workgroup)
-  long long t_eval = 0, t_xchg = 0, t_apply = 0, t_load = 0, t_e1 = 0, t_e2 = 0, t_e3 = 0;
+  long long t_eval = 0, t_xchg = 0, t_apply = 0, t_load = 0, t_e1 = 0, t_e2 = 0, t_e3 = 0, t_a1 = 0, t_a2 = 0;
   const long long t_begin = g.dbg ? wall_clock64() : 0;
 
   // move one edge's statistics of node i (LDS) from block ba to block bb
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     const int band0 = band * G * per;
     const int band1 = (band0 + G * per < N) ? band0 + G * per : N;
     for (int idx = tid; idx < G * per; idx += 256) s_H[idx] = (short)-1;
+    for (int idx = tid; idx < (G * per + 31) / 32; idx += 256) s_Hm[idx] = 0u;
     for (int idx = tid; idx < per * K; idx += 256) s_cntn[idx] = s_cnt[idx % K];
     // the node's uniform is a function of (seed, site, sweep, node): drawn once per band, not once per round (ten Philox
     // rounds are a tenth of a round's evaluation)
@@ -463,19 +466,30 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           // statistics behind f hold f in block `from` (the hypothesised label, or the old one): it goes to `nw`
           s_S[offS * 3] = f; s_S[offS * 3 + 1] = h >= 0 ? (h & 0xff) : old; s_S[offS * 3 + 2] = nw;
           s_H[f - band0] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
+          if (nw == old) atomicAnd(&s_Hm[(f - band0) >> 5], ~(1u << ((f - band0) & 31)));
+          else atomicOr(&s_Hm[(f - band0) >> 5], 1u << ((f - band0) & 31));
           ++offS;
         }
         __syncthreads();
       }
+      const long long cf = g.dbg ? wall_clock64() : 0;
       // ---- accept: the hypotheses at positions [pos, hi) - up to and including the earliest surprise - are the chain
       const int hi = quiet ? band1 : (int)(best >> 12) + 1;
       bool cut = false;       // the list filled up before the end of the range
       {
-        const int len = hi - pos;
-        const int chunk = (len + 255) / 256;
-        const int lo_t = pos + tid * chunk;
+        // (mask words of 32 nodes, contiguous runs per thread so that thread order is position order; one word per thread
+        // unless K <= 4, whose bands have up to 1024 words)
+        const int p0 = pos - band0, p1 = hi - band0;          // the range, relative to the band
+        const int w_first = p0 >> 5, w_last = p1 > p0 ? ((p1 - 1) >> 5) : w_first - 1;
+        const int wpt = (w_last - w_first + 1 + 255) / 256;   // words per thread
+        auto word_mask = [&](int wd) {
+          unsigned mk = s_Hm[wd];
+          if (wd == w_first) mk &= ~0u << (p0 & 31);
+          if (wd == w_last && (p1 & 31)) mk &= ~0u >> (32 - (p1 & 31));
+          return mk;
+        };
         int cnt_t = 0;
-        for (int q = 0; q < chunk; ++q) { const int n = lo_t + q; if (n < hi && s_H[n - band0] >= 0) ++cnt_t; }
+        for (int r = 0; r < wpt; ++r) { const int wd = w_first + tid * wpt + r; if (wd <= w_last) cnt_t += __popc(word_mask(wd)); }
         int incl = cnt_t;
         for (int dlt = 1; dlt < 64; dlt <<= 1) { const int o = __shfl_up(incl, dlt); if (ln >= dlt) incl += o; }
         if (ln == 63) s_misc[4 + wv] = incl;
@@ -485,24 +499,29 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
         const int total = s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
         const int room = a.Lcap - nL;
         const int take = total < room ? total : room;
-        for (int q = 0; q < chunk; ++q) {
-          const int n = lo_t + q;
-          if (n >= hi) break;
-          const int h = s_H[n - band0];
-          if (h < 0) continue;
-          if (e < take) {
-            const int old = h >> 8, nw = h & 0xff;
-            int* dstL = s_L + (size_t)(nL + e) * 3;
-            dstL[0] = n; dstL[1] = old; dstL[2] = nw;
-            atomicSub(&s_cnt[old], 1); atomicAdd(&s_cnt[nw], 1);
-            if (b == 0) {   // for what runs after this kernel (labels; the list, for a scan that is handed to restart rounds)
-              g.c[n] = nw;
-              int32_t* dstG = g.L + (size_t)(nL + e) * 3;
-              dstG[0] = n; dstG[1] = old; dstG[2] = nw;
+        for (int r = 0; r < wpt; ++r) {
+          const int wd = w_first + tid * wpt + r;
+          if (wd > w_last) break;
+          unsigned mk = word_mask(wd);
+          while (mk) {
+            const int bit = __ffs(mk) - 1;
+            mk &= mk - 1u;
+            const int n = band0 + (wd << 5) + bit;
+            const int h = s_H[n - band0];
+            if (e < take) {
+              const int old = h >> 8, nw = h & 0xff;
+              int* dstL = s_L + (size_t)(nL + e) * 3;
+              dstL[0] = n; dstL[1] = old; dstL[2] = nw;
+              atomicSub(&s_cnt[old], 1); atomicAdd(&s_cnt[nw], 1);
+              if (b == 0) {   // for what runs after this kernel (labels; the list, for a scan that is handed to restart rounds)
+                g.c[n] = nw;
+                int32_t* dstG = g.L + (size_t)(nL + e) * 3;
+                dstG[0] = n; dstG[1] = old; dstG[2] = nw;
+              }
+              if (e == take - 1) s_misc[8] = n;
             }
-            if (e == take - 1) s_misc[8] = n;
+            ++e;
           }
-          ++e;
         }
         __syncthreads();
         cut = take < total;
@@ -510,6 +529,8 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
         else if (!cut) pos = hi;
         nL += take; nchg += take;
       }
+      const long long cg = g.dbg ? wall_clock64() : 0;
+      if (g.dbg) { t_a1 += cf - c2; t_a2 += cg - cf; }
       // ---- statistics of my group's nodes behind each surprise: the edges to / from f move between blocks
       if (has && nS > 0) apply_moves(s_S, nS, n0, true);
       if (nS == 1) { redo_a = s_S[1]; redo_b = s_S[2]; } else redo_a = redo_b = -1;
@@ -631,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     g.dbg[5] = wall_clock64() - t_begin;
     g.dbg[6] = wall_clock64() - t_tail0;
     g.dbg[7] = t_init0 - t_kernel0;
-    g.dbg[8] = t_e1; g.dbg[9] = t_e2; g.dbg[10] = t_e3;
+    g.dbg[8] = t_e1; g.dbg[9] = t_e2; g.dbg[10] = t_e3; g.dbg[11] = t_a1; g.dbg[12] = t_a2;
   }
   if (tid == 0) {
     g.rs[0] = 0;
