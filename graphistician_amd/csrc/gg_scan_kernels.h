@@ -104,7 +104,9 @@ __device__ __forceinline__ bool gg_grid_exchange(unsigned long long* slots, int 
 // own (no ordering between them is needed), in position order - word 0 is the workgroup's earliest.  Lane t ends up with
 // the words of slot t in v[]; *best is the minimum over all word 0s.  Slot order = position order within a band
 // (workgroup t owns group band G + t).
-#define GG_SCAN_NW 4
+#ifndef GG_SCAN_NW
+#define GG_SCAN_NW 2
+#endif
 __device__ __forceinline__ bool gg_grid_exchange_multi(unsigned long long* slots, int G, unsigned tag, const unsigned long long* s_mine,
                                                        unsigned long long* s_min, int32_t* rs, unsigned long long* best,
                                                        int spin_limit, unsigned long long (&v)[GG_SCAN_NW]) {
