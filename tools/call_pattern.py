@@ -27,3 +27,10 @@ def demo():
 print("resample; log_prob : %.1f us" % timed(demo))
 print("adj LL alone       : %.1f us" % timed(lambda: adj.log_likelihood(data)))
 print("w   LL alone       : %.1f us" % timed(lambda: w.log_likelihood(data)))
+abi.resample_many([adj, w], [data, data], 200)
+print("LL after a 200-sweep call : %.1f us" % timed(lambda: abi.log_likelihood_many([adj, w], [data, data])))
+adj.set_timing(12); w.set_timing(12)
+abi.resample_many([adj, w], [data, data], 200)
+sa, sw = adj.stats(), w.stats()
+adj.set_timing(0); w.set_timing(0)
+print("LL after a timed 200-sweep call + stats : %.1f us" % timed(lambda: abi.log_likelihood_many([adj, w], [data, data])))
