@@ -110,6 +110,7 @@ struct gg_model {
   int32_t* sh_cntn;             // sharded scan: [Nl][K] block sizes as own node n sees them
   short* sh_H;                  //               [GG_SHARD_WINDOW] hypothesis per node of the band
   int32_t* sh_mv;               //               moves of the last round's surprises, (node, from, to)
+  int sh_hint;                  //               rounds the last scan of this model needed (+ margin): the first batch of the next
   int ahead_cap;                // speculative form: sweeps enqueued ahead of the last confirmed one (64, doubling per clean batch up to 512)
   int scan_pref_saved;          // the preference a k_scan timeout suspended (0: none suspended)
   uint64_t scan_retry_at;       // st.sweeps count from which the suspended preference is tried again
@@ -2212,7 +2213,10 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
         k_shard_init<<<(unsigned)((cells + 255) / 256), 256, 0, m->stream>>>(m->cnt, m->sh_cntn, m->sh_H, m->Nl, m->K, m->rs);
         GG_HIP(hipGetLastError());
       }
-      int batch = 8;
+      // Rounds are enqueued in batches without host synchronisation; a round beyond the scan's end is a no-op on the device
+      // but still a collective on the wire, so the first batch is what the previous scan needed plus a margin (the same
+      // number on every rank: it comes from the replicated control block), later ones a quarter of that.
+      int batch = m->sh_hint > 0 ? m->sh_hint : 8;
       for (;;) {
         for (int r = 0; r < batch; ++r) {
           // one round: own nodes of the band behind the scan position evaluated under the hypotheses -> the first
@@ -2232,10 +2236,15 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
         GG_HIP(hipStreamSynchronize(m->stream));
         if (m->h_rs[3]) { write_ctl_word(m, 3, 0); return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite"); }
         if (m->h_rs[GG_RS_SPOS] >= m->N) break;
-        if (batch < 128) batch *= 2;
+        batch = m->sh_hint / 4 > 4 ? m->sh_hint / 4 : 4;
       }
       m->st.label_changes = (uint64_t)m->h_rs[2];
       m->st.resolve_rounds += (uint64_t)m->h_rs[GG_RS_ROUNDS];
+      {
+        const int used = m->h_rs[GG_RS_ROUNDS];
+        const int hint = used + (used / 8 > 1 ? used / 8 : 1);
+        m->sh_hint = hint < 2 ? 2 : (hint > 4096 ? 4096 : hint);
+      }
       m->perm_valid = false;
     }
     k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
