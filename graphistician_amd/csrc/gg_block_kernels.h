@@ -884,6 +884,49 @@ __device__ __forceinline__ int gg_group_categorical(double lp, int k, int K, int
   return idx > K - 1 ? K - 1 : idx;
 }
 
+// The same draw for Kp = 128 or 256 (65 <= K <= 256): the group spans two or four wavefronts, so the maximum and the scan
+// go through LDS.  The scan is the Kogge-Stone scan of gg_lp.h::gg_categorical over Kp elements, step by step
+// (y[k] = x[k] + x[k - s]): the same additions in the same order as the oracle's, hence the same bits.  Every thread of
+// the workgroup calls it (it synchronises); scr: 2 * blockDim doubles + 16 ints of LDS nobody else uses meanwhile.
+__device__ __forceinline__ int gg_group_categorical_wide(double lp, int k, int K, int Kp, double u, double* scr) {
+  const int tid = (int)threadIdx.x, BD = (int)blockDim.x;
+  const int g0 = tid - k;                       // first thread of my group
+  int* iscr = reinterpret_cast<int*>(scr + 2 * BD);
+  // maximum over the group: butterfly through LDS (any order gives the same maximum)
+  double mx = lp;
+  scr[tid] = mx;
+  __syncthreads();
+  for (int s = Kp >> 1; s >= 1; s >>= 1) {
+    const double o = scr[g0 + (k ^ s)];
+    __syncthreads();
+    mx = o > mx ? o : mx;
+    scr[tid] = mx;
+    __syncthreads();
+  }
+  double x = (k < K) ? gg_exp(lp - mx) : 0.0;
+  int cur = 0;
+  scr[tid] = x;
+  __syncthreads();
+  for (int s = 1; s < Kp; s <<= 1) {
+    double v = scr[cur * BD + tid];
+    if (k >= s) v = v + scr[cur * BD + tid - s];
+    cur ^= 1;
+    scr[cur * BD + tid] = v;
+    __syncthreads();
+  }
+  x = scr[cur * BD + tid];
+  const double tot = scr[cur * BD + g0 + K - 1];
+  const double thr = u * tot;
+  const bool flag = (k < K) && (thr > x);
+  const unsigned long long bal = __ballot(flag);
+  if ((tid & 63) == 0) iscr[tid >> 6] = __popcll(bal);
+  __syncthreads();
+  int idx = 0;
+  for (int w = 0; w < (Kp >> 6); ++w) idx += iscr[(g0 >> 6) + w];
+  __syncthreads();      // (iscr and scr are free again)
+  return idx > K - 1 ? K - 1 : idx;
+}
+
 // Combination of the finished chains of node n, label k (the tail of gg_lp.h::gg_block_lp).
 template <int NT, bool ADJ>
 __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n, int k, const double* acc_o,

@@ -111,6 +111,8 @@ struct gg_model {
   short* sh_H;                  //               [GG_SHARD_WINDOW] hypothesis per node of the band
   int32_t* sh_mv;               //               moves of the last round's surprises, (node, from, to)
   int sh_hint;                  //               rounds the last scan of this model needed (+ margin): the first batch of the next
+  bool wide;                    // 65..128 blocks: a node's lanes span two wavefronts - the resident scan's wide instantiation is the
+                                // only scan form (no speculative / restart-round fallback, no node shards, no gg_node_lp)
   int ahead_cap;                // speculative form: sweeps enqueued ahead of the last confirmed one (64, doubling per clean batch up to 512)
   int scan_pref_saved;          // the preference a k_scan timeout suspended (0: none suspended)
   uint64_t scan_retry_at;       // st.sweeps count from which the suspended preference is tried again
@@ -198,6 +200,7 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
   lds += 136 * sizeof(unsigned long long) + 256 * 3 * sizeof(int) + (size_t)per * K * sizeof(int) + 16 * sizeof(int) + 16 +
          (size_t)GG_SCAN_MAXWG * per * sizeof(short) + (size_t)(GG_SCAN_MAXWG * per / 32 + 2) * sizeof(unsigned);
   if (!m->is_adj) lds += (size_t)2 * K * per * m->NSI * sizeof(long long);
+  if (m->Kp > 64) lds += (size_t)2 * 256 * sizeof(double) + 16 * sizeof(int) + 8;   // the cross-wave categorical's scratch
   // coefficient table: both lane-major layouts when that stays below 64 KB (1); else one padded copy of T[a][b][t] when
   // that stays below 72 KB (2: K up to 32 at B = 1); else from global memory (0).  (At K = 64 the one copy fits the 150 KB
   // but gains 10 % of a round's evaluation and leaves no room for anything else on the CU: not taken.)  Kp = 64 without layout 1 evaluates with
@@ -253,7 +256,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->is_block = true;
   m->N = cfg->N;
   m->K = m->sbm ? cfg->K : 1;
-  if (m->K < 1 || m->K > 64) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "number of blocks C=%d not in 1..64", m->K); }
+  if (m->K < 1 || m->K > 128) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "number of blocks C=%d not in 1..128", m->K); }
   m->B = m->is_adj ? 1 : cfg->B;
   if (!m->is_adj && !(m->B >= 1 && m->B <= GG_MAXB)) {
     delete m;
@@ -283,6 +286,11 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if (m->kind == GG_NIW_W || m->kind == GG_FIXED_W) m->cfg.special_case_self_conns = 1;
   if (m->joint) m->cfg.special_case_self_conns = 0;   // stochastic_block_model.py:291-296: the diagonal belongs to pair (c_n, c_n)
   if (m->joint && m->sharded) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "GG_SBM_JOINT: not for node shards"); }
+  m->wide = m->K > 64;
+  if (m->wide && (m->sharded || m->joint)) {
+    delete m;
+    return gg_fail(GG_ERR_UNSUPPORTED, "C=%d: more than 64 blocks are supported for the SBM adjacency / weight kinds on one GPU (not for node shards or the joint model)", m->K);
+  }
   if (m->kind == GG_SBM_GAUSS_SHCOV_W && !m->cfg.special_case_self_conns && m->sharded) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "SBMGaussianWeightSharedCov without special_case_self_conns: the node-sharded chain does not carry the diagonal's share of the pair tables");
@@ -352,6 +360,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     const char* es = getenv("GG_SCAN");
     const bool can_scan = m->sbm && m->K > 1 && !m->sharded;
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
+    if (m->wide) m->scan_pref = 1;      // the wide instantiation of k_scan is the one scan form of 65..128 blocks
     m->use_scan = m->scan_pref == 1;
     m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
     m->scan_pref_saved = 0; m->scan_retry_at = 0; m->ahead_cap = 64;
@@ -360,7 +369,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     // The ahead form (enqueue_sweep_ahead): while the chain is quiet, the next sweep's bulk pass rides in this sweep's
     // k_params and k_spec_resolve launches.  GG_AHEAD=0 keeps every sweep in the serial form (bulk -> params -> scan).
     const char* ea = getenv("GG_AHEAD");
-    m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0) && !m->joint;   // (the joint kind runs the serial form)
+    m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0) && !m->joint && !m->wide;   // (the joint kind runs the serial form)
     const char* ers = getenv("GG_RIDE_SPLIT");
     m->ride_split = ers ? atof(ers) : -1.0;   // (default chosen below, once the scan forms of this shape are known)
     if (can_scan) {
@@ -371,6 +380,12 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
         const size_t need = lds_round(m, nullptr);
         gg_model_destroy(m);
         return gg_fail(GG_ERR_UNSUPPORTED, "K=%d with B=%d needs %zu KB of LDS per workgroup for the node scan (150 KB available)",
+                       cfg->K, cfg->B, need / 1024);
+      }
+      if (!fit_scan && m->wide) {
+        const size_t need = lds_scan(m, 1024, nullptr);
+        gg_model_destroy(m);
+        return gg_fail(GG_ERR_UNSUPPORTED, "K=%d with B=%d needs %zu KB of LDS per workgroup for the resident scan, the one scan form of more than 64 blocks (150 KB available)",
                        cfg->K, cfg->B, need / 1024);
       }
       if (!fit_scan) { m->scan_pref = 0; m->use_scan = false; m->can_ahead = false; }   // restart rounds only (their meeting place reuses dead statistics)
@@ -780,7 +795,7 @@ static gg_params_args fill_params_args(gg_model* m, const gg_data* d, int buf, b
   g.beta = m->beta;
   g.sweep_from_ctl = 0;
   g.tables_from_tab = m->shard_from_tab ? 1 : 0;
-  if (m->m_pending && prep) {
+  if (m->m_pending && prep && !m->wide) {     // (wide: k_draw_m, launched by enqueue_params - the in-kernel draw is one wave of 64)
     g.draw_m = 1; g.m_site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M; g.m_sweep = m->m_sweep;
     m->m_pending = false;
   }
@@ -797,6 +812,14 @@ static gg_params_args fill_params_args(gg_model* m, const gg_data* d, int buf, b
 static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, bool draw, bool prep, int zero_buf,
                           uint32_t sweep, int pidx = -1, int ride_next = -1, int ride_part = 0) {
   if (pidx < 0) pidx = m->pcur;
+  if (m->wide && m->m_pending && prep) {
+    // resample_m of the previous sweep (deferred to this parameter step, which takes log m from it): more than 64 blocks do
+    // not fit the one wave the parameter kernel has for it
+    k_draw_m<<<1, 128, 128 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+                                                          m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m);
+    GG_HIP(hipGetLastError());
+    m->m_pending = false;
+  }
   gg_params_args g = fill_params_args(m, d, buf, tables, draw, prep, zero_buf, sweep, pidx);
   const int nwg = m->K * m->K + 1;
   if (ride_next >= 0) {
@@ -1175,7 +1198,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     }                                                                                                             \
     k_scan<NTV, ADJV, SPV><<<a.G, 256, lds, m->stream>>>(a);                                                       \
   } while (0)
-#define SCN(NTV, ADJV) do { if (stage != 1 && m->Kp == 64) SCN1(NTV, ADJV, true); else SCN1(NTV, ADJV, false); } while (0)
+#define SCN(NTV, ADJV) do { if (m->Kp > 64) SCN1(NTV, ADJV, 2); else if (stage != 1 && m->Kp == 64) SCN1(NTV, ADJV, 1); else SCN1(NTV, ADJV, 0); } while (0)
   if (m->is_adj) SCN(2, true);
   else if (m->joint && m->B == 1) SCN(4, false);
   else if (m->joint) SCN(7, false);
@@ -1329,7 +1352,7 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
     m->pcur = 1 - P;
   } else if (m->sbm) {
     // K == 1 SBM: resample_c returns early (adjacency.py:657-658) but m is still drawn
-    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, sweep, m->m);
     GG_HIP(hipGetLastError());
   }
@@ -1425,6 +1448,13 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
     if (m->h_rs[3] == 2) {
       // A k_scan exchange timed out (the resident grid could not assemble - a device shared with other processes, say)
       // and left the scan as a stalled one at a consistent position: carry on with the launch-per-change form, for good.
+      if (m->wide) {
+        write_ctl_word(m, 3, 0);
+        m->pending = 0; m->todo = 0;
+        m->zeroed[0] = m->zeroed[1] = m->zeroed[2] = false;
+        set_pend_data(m, nullptr);
+        return gg_fail(GG_ERR_HIP, "k_scan: the resident grid timed out and C=%d has no other scan form (a device shared with other processes?)", m->K);
+      }
       if ((rc = write_ctl_word(m, 3, 0))) return rc;
       if (m->scan_pref != 0) fprintf(stderr, "graphgibbs: the resident-grid scan timed out at node %d (%d changes in its list); this model continues with restart rounds for %llu sweeps\n", m->h_rs[0], m->h_rs[1], (unsigned long long)m->scan_backoff);
       scan_suspend(m);
@@ -1545,7 +1575,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
   }
   m->pending = 0;
   if (m->m_pending) {
-    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m);
     GG_HIP(hipGetLastError());
     m->m_pending = false;
@@ -1769,7 +1799,21 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
     if ((rc = enqueue_params(m, d, buf, do_params, do_params, do_c, -1, m->sweep))) return rc;
     if (do_c) { m->ahead = false; m->zeroed[buf] = false; }   // the scan below may change labels: not the next sweep's statistics
   }
-  if (do_c) {
+  if (do_c && m->wide) {
+    // more than 64 blocks: the resident scan is the one scan form
+    const int pw = 1 - m->pcur;
+    if ((rc = launch_scan(m, d, buf, m->sweep, true, pw))) return rc;
+    if ((rc = read_ctl(m))) return rc;
+    if (m->h_rs[3]) {
+      const int st3 = m->h_rs[3];
+      write_ctl_word(m, 3, 0);
+      if (st3 & 1) return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
+      return gg_fail(GG_ERR_HIP, "k_scan: the resident grid timed out and C=%d has no other scan form", m->K);
+    }
+    m->pcur = pw;
+    if ((rc = write_ctl_word(m, 5, 0))) return rc;
+    m->st.label_changes = (uint64_t)m->h_rs[2];
+  } else if (do_c) {
     if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false))) return rc;
     const int pw = 1 - m->pcur;
     if ((rc = launch_resolve(m, d, buf, m->sweep, false, true, pw))) return rc;
@@ -1781,7 +1825,7 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   }
   if (do_m) {
     if ((rc = ensure_perm(m))) return rc;
-    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
     GG_HIP(hipGetLastError());
   }
@@ -1801,6 +1845,7 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (!m || !lp) return gg_fail(GG_ERR_INVALID, "gg_node_lp: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: block models only");
+  if (m->wide) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: not for more than 64 blocks (the per-node evaluation kernel gives a node one wavefront)");
   int rc = model_sync(m);
   if (rc) return rc;
   if ((rc = check_data(m, d))) return rc;
@@ -2247,7 +2292,7 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
       }
       m->perm_valid = false;
     }
-    k_draw_m<<<1, 64, 64 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
     GG_HIP(hipGetLastError());
     m->sweep += 1;

@@ -146,10 +146,15 @@ __device__ __forceinline__ bool gg_grid_exchange_multi(unsigned long long* slots
   return okall;
 }
 
-// SPLIT: the Kp = 64 evaluation without both table layouts in LDS (gg_lp_split4) - its own instantiation, so that the other
-// shapes do not carry its registers; two workgroups per CU in either case (both models' scan grids resident together).
-template <int NT, bool ADJ, bool SPLIT>
+// MODE 1: the Kp = 64 evaluation without both table layouts in LDS (gg_lp_split4) - its own instantiation, so that the other
+// shapes do not carry its registers.  MODE 2 ("wide"): Kp = 128 or 256 (65 <= K <= 128 blocks) - a node's lanes span two or
+// four wavefronts: the categorical draw scans through LDS (gg_group_categorical_wide) and the (node, old, new) payloads carry
+// 8-bit labels.  Two workgroups per CU in every case (both models' scan grids resident together).
+template <int NT, bool ADJ, int MODE>
 __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
+  constexpr bool WIDE = MODE == 2;
+  constexpr int LB = WIDE ? 8 : 6;                       // bits per label in a payload
+  constexpr unsigned LMASK = (1u << LB) - 1u;
   constexpr int B = gg_tB(NT);
   constexpr int NSI = gg_tNSI(NT);
   constexpr int U = 4;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   if (stage_tables == 1) off += (size_t)2 * ntab * sizeof(double);
   else if (stage_tables == 2) off += (size_t)K * RS * sizeof(double);
   double* s_acc = reinterpret_cast<double*>(s_raw + off);     // gg_lp_split4: where the chains of the four waves meet
-  constexpr bool split = SPLIT;   // (the host: stage_tables != 1 && Kp == 64)
+  constexpr bool split = MODE == 1;   // (the host: stage_tables != 1 && Kp == 64)
   if (split) off += (size_t)4 * 2 * NT * 64 * sizeof(double);
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
@@ -191,7 +196,9 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   int* s_misc = reinterpret_cast<int*>(s_raw + off); off += 16 * sizeof(int);
   short* s_H = reinterpret_cast<short*>(s_raw + off); off += (size_t)GG_SCAN_MAXWG * per * sizeof(short);   // [G per] hypothesis per node of the band: -1 none, else (old << 8 | new)
   off = (off + 3) & ~(size_t)3;
-  unsigned* s_Hm = reinterpret_cast<unsigned*>(s_raw + off);   // one bit per node of the band: a hypothesis is in place
+  unsigned* s_Hm = reinterpret_cast<unsigned*>(s_raw + off); off += (size_t)(GG_SCAN_MAXWG * per / 32 + 2) * sizeof(unsigned);   // one bit per node of the band: a hypothesis is in place
+  off = (off + 7) & ~(size_t)7;
+  double* s_cat = reinterpret_cast<double*>(s_raw + off);     // WIDE: scratch of the cross-wave categorical (2 x 256 doubles + 16 ints)
 
   const size_t dstride = (size_t)K * Np;
   // The first band's statistics: 2 K per <= 512 entries, at most two per thread.  Their loads are issued before the
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
         else if (stage_tables == 2) lp = gg_node_lp_core_t1<NT, ADJ>(x, nn, k, ld, s_T, RS, &logm_k);
         else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin, &logm_k);
         if (g.dbg) cb = wall_clock64();
-        const int lab = gg_group_categorical(lp, k, K, Kp, u_band);
+        const int lab = WIDE ? gg_group_categorical_wide(lp, k, K, Kp, u_band, s_cat) : gg_group_categorical(lp, k, K, Kp, u_band);
         if (k == 0) {
           // what the hypotheses say about this node: it moves to h's new label, or it stays
           unsigned long long dv = GG_SLOT_NONE;
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
             const int cn = s_c[i];
             const int h = s_H[n - band0];
             const int expct = h >= 0 ? (h & 0xff) : cn;
-            if (lab != expct) dv = ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab;
+            if (lab != expct) dv = ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)lab;
           }
           s_dev[i] = dv;
         }
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
         for (int w = 0; w < GG_SCAN_NW; ++w) {
           const unsigned long long v = sv[w];
           if (v == GG_SLOT_NONE || offS >= 256) continue;
-          const int f = (int)(v >> 12), old = (int)((v >> 6) & 63u), nw = (int)(v & 63u);
+          const int f = (int)(v >> (2 * LB)), old = (int)((v >> LB) & LMASK), nw = (int)(v & LMASK);
           const int h = s_H[f - band0];
           // statistics behind f hold f in block `from` (the hypothesised label, or the old one): it goes to `nw`
           s_S[offS * 3] = f; s_S[offS * 3 + 1] = h >= 0 ? (h & 0xff) : old; s_S[offS * 3 + 2] = nw;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
       }
       const long long cf = g.dbg ? wall_clock64() : 0;
       // ---- accept: the hypotheses at positions [pos, hi) - up to and including the earliest surprise - are the chain
-      const int hi = quiet ? band1 : (int)(best >> 12) + 1;
+      const int hi = quiet ? band1 : (int)(best >> (2 * LB)) + 1;
       bool cut = false;       // the list filled up before the end of the range
       {
         // (mask words of 32 nodes, contiguous runs per thread so that thread order is position order; one word per thread

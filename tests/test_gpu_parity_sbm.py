@@ -248,3 +248,75 @@ def test_joint_sbm_chain_bitexact(abi, N, K, B):
     assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
     with pytest.raises(abi.EngineError):
         abi.Model(kind=abi.SBM_JOINT, N=N, K=K, B=3, seed=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,B,special,beta", [(300, 100, 1, 1, 1.0), (520, 128, 2, 0, 1.0), (257, 65, 1, 1, 0.6), (700, 97, 3, 1, 1.0)])
+def test_more_than_64_blocks_chain_bitexact(abi, N, K, B, special, beta):
+    """65..128 blocks: a node's (node, block) lanes span two wavefronts - the wide instantiation of the resident scan (categorical
+    draw as a Kogge-Stone scan through LDS in the oracle's order, 8-bit labels in the exchange payloads) is the scan form.
+    Adjacency and weight chains against the oracle, bit for bit, from a random start (hundreds of changes per scan), in
+    uneven chunks, tempered and not; log-likelihood and step-wise parts as well."""
+    A, W, _ = planted_sbm(N, 5, B=B, seed=123)        # (few planted blocks, many model blocks: most stay sparsely populated)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=11), WState(N, K, B, seed=12)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=501, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                    special_case_self_conns=special)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=502, special_case_self_conns=special)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    w.set(abi.ST_MU_SELF, sw.mu_self); w.set(abi.ST_SIGMA_SELF, sw.sigma_self)
+    ps, done = sa.p_self, 0
+    for chunk in (1, 2, 4):
+        abi.resample_many([adj, w], d, chunk, beta)
+        for s in range(done, done + chunk):
+            ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, special, 501, s, beta=beta)
+            O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self,
+                          special, 502, s, beta=beta)
+        done += chunk
+        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), "adjacency labels after %d sweeps" % done
+        assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p) and np.array_equal(adj.get(abi.ST_M, (K,)), sa.m)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), "weight labels after %d sweeps" % done
+        assert np.array_equal(w.get(abi.ST_MU, (K, K, B)), sw.mu) and np.array_equal(w.get(abi.ST_SIGMA, (K, K, B, B)), sw.sigma)
+        assert np.array_equal(w.get(abi.ST_M, (K,)), sw.m)
+        ll = float(np.sum(abi.log_likelihood_many([adj, w], d)))
+        ref = (O.sbm_adj_loglik(A, sa.c, sa.p, ps, True, bool(special)) +
+               O.sbm_w_loglik(A, q, shift, sw.c, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, bool(special)))
+        assert abs(ll - ref) <= 1e-9 * abs(ref) + 1e-7, (ll, ref)
+    assert adj.stats()["label_changes"] > 100
+    with pytest.raises(abi.EngineError):
+        adj.node_lp(d, 0, K)
+    with pytest.raises(abi.EngineError):
+        abi.Model(kind=abi.SBM_ADJ, N=N, K=129, B=1, seed=1)
+
+
+@pytest.mark.gpu
+def test_more_than_64_blocks_through_the_host_classes(abi):
+    """The reference-shaped classes with C = 70: sweeps, log-likelihood, and the device predictive log-likelihood against the
+    reference's generic formula (graphistician_amd/abstractions.py) with m concentrated on single blocks."""
+    from graphistician_amd.abstractions import AdjacencyDistribution, GaussianWeightDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution
+    np.random.seed(8)
+    N, C, B = 90, 70, 1
+    A, W, _ = planted_sbm(N, 4, B=B, seed=9)
+    a = SBMAdjacencyDistribution(N, C=C)
+    w = SBMGaussianWeightDistribution(N, B=B, C=C)
+    for _ in range(3):
+        a.resample(A)
+        w.resample((A, W))
+    assert np.isfinite(a.log_likelihood(A)) and np.isfinite(w.log_likelihood((A, W)))
+    assert a.c.min() >= 0 and a.c.max() < C and w.c.max() < C
+    Arow, Acol = np.random.rand(N + 1) < 0.4, np.random.rand(N + 1) < 0.6
+    Acol[-1] = Arow[-1] = True
+    Wrow, Wcol = np.random.randn(N + 1, B), np.random.randn(N + 1, B)
+    Wcol[-1] = Wrow[-1]
+    for k in (0, 33, 69):
+        a.m = np.eye(C)[k]; w.m = np.eye(C)[k]
+        ref_a = AdjacencyDistribution.approx_predictive_ll(a, Arow, Acol, M=2)
+        assert abs(a.approx_predictive_ll(Arow, Acol, M=2) - ref_a) <= 1e-10 * abs(ref_a), k
+        ref_w = GaussianWeightDistribution.approx_predictive_ll(w, Arow, Acol, Wrow, Wcol, M=2)
+        assert abs(w.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=2) - ref_w) <= 1e-10 * abs(ref_w), k
