@@ -477,6 +477,12 @@ __global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restri
   }
 }
 
+// log m for more than 64 blocks (the parameter kernel's last workgroup has 192 lanes for it): all of them, after it.
+__global__ void k_logm(const double* __restrict__ m, double* __restrict__ logm, int K) {
+  const int k = threadIdx.x;
+  if (k < K) logm[k] = gg_log(m[k]);
+}
+
 // ------------------------------------------------------------------ fused parameter step
 // One workgroup per block pair (a, b) (+ one for the self parameter and log m):
 //   1. reduce the pair's sufficient statistics from the out-histograms (k_pair_tables),

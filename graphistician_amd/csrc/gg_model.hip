@@ -111,7 +111,7 @@ struct gg_model {
   short* sh_H;                  //               [GG_SHARD_WINDOW] hypothesis per node of the band
   int32_t* sh_mv;               //               moves of the last round's surprises, (node, from, to)
   int sh_hint;                  //               rounds the last scan of this model needed (+ margin): the first batch of the next
-  bool wide;                    // 65..128 blocks: a node's lanes span two wavefronts - the resident scan's wide instantiation is the
+  bool wide;                    // 65..256 blocks: a node's lanes span two or four wavefronts - the resident scan's wide instantiation is the
                                 // only scan form (no speculative / restart-round fallback, no node shards, no gg_node_lp)
   int ahead_cap;                // speculative form: sweeps enqueued ahead of the last confirmed one (64, doubling per clean batch up to 512)
   int scan_pref_saved;          // the preference a k_scan timeout suspended (0: none suspended)
@@ -256,7 +256,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->is_block = true;
   m->N = cfg->N;
   m->K = m->sbm ? cfg->K : 1;
-  if (m->K < 1 || m->K > 128) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "number of blocks C=%d not in 1..128", m->K); }
+  if (m->K < 1 || m->K > 256) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "number of blocks C=%d not in 1..256", m->K); }
   m->B = m->is_adj ? 1 : cfg->B;
   if (!m->is_adj && !(m->B >= 1 && m->B <= GG_MAXB)) {
     delete m;
@@ -815,7 +815,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   if (m->wide && m->m_pending && prep) {
     // resample_m of the previous sweep (deferred to this parameter step, which takes log m from it): more than 64 blocks do
     // not fit the one wave the parameter kernel has for it
-    k_draw_m<<<1, 128, 128 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, 256, 256 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                           m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m);
     GG_HIP(hipGetLastError());
     m->m_pending = false;
@@ -850,6 +850,10 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   else if (m->B == 3) k_params<false, 3><<<nwg, 256, 0, m->stream>>>(g);
   else k_params<false, 4><<<nwg, 256, 0, m->stream>>>(g);
   GG_HIP(hipGetLastError());
+  if (m->wide && prep) {
+    k_logm<<<1, 256, 0, m->stream>>>(m->m, m->logm, m->K);
+    GG_HIP(hipGetLastError());
+  }
   if (g.shared && draw) {   // weights.py:545-552: the shared covariance and, with it, the coefficient tables
     if (m->B == 1) k_shared_cov<1><<<1, 256, 0, m->stream>>>(g);
     else if (m->B == 2) k_shared_cov<2><<<1, 256, 0, m->stream>>>(g);
@@ -1352,7 +1356,7 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
     m->pcur = 1 - P;
   } else if (m->sbm) {
     // K == 1 SBM: resample_c returns early (adjacency.py:657-658) but m is still drawn
-    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 256 : 64, (m->K > 64 ? 256 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, sweep, m->m);
     GG_HIP(hipGetLastError());
   }
@@ -1575,7 +1579,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
   }
   m->pending = 0;
   if (m->m_pending) {
-    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 256 : 64, (m->K > 64 ? 256 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m);
     GG_HIP(hipGetLastError());
     m->m_pending = false;
@@ -1825,7 +1829,7 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   }
   if (do_m) {
     if ((rc = ensure_perm(m))) return rc;
-    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 256 : 64, (m->K > 64 ? 256 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
     GG_HIP(hipGetLastError());
   }
@@ -2292,7 +2296,7 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
       }
       m->perm_valid = false;
     }
-    k_draw_m<<<1, m->K > 64 ? 128 : 64, (m->K > 64 ? 128 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
+    k_draw_m<<<1, m->K > 64 ? 256 : 64, (m->K > 64 ? 256 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
                                                         m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->sweep, m->m);
     GG_HIP(hipGetLastError());
     m->sweep += 1;

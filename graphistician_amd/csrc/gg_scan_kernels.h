@@ -147,7 +147,7 @@ __device__ __forceinline__ bool gg_grid_exchange_multi(unsigned long long* slots
 }
 
 // MODE 1: the Kp = 64 evaluation without both table layouts in LDS (gg_lp_split4) - its own instantiation, so that the other
-// shapes do not carry its registers.  MODE 2 ("wide"): Kp = 128 or 256 (65 <= K <= 128 blocks) - a node's lanes span two or
+// shapes do not carry its registers.  MODE 2 ("wide"): Kp = 128 or 256 (65 <= K <= 256 blocks) - a node's lanes span two or
 // four wavefronts: the categorical draw scans through LDS (gg_group_categorical_wide) and the (node, old, new) payloads carry
 // 8-bit labels.  Two workgroups per CU in every case (both models' scan grids resident together).
 template <int NT, bool ADJ, int MODE>
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   int* s_S = reinterpret_cast<int*>(s_raw + off); off += 256 * 3 * sizeof(int);      // its surprises, compacted: (node, from, to)
   int* s_cntn = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * K * sizeof(int);   // block sizes as node i of the group sees them
   int* s_misc = reinterpret_cast<int*>(s_raw + off); off += 16 * sizeof(int);
-  short* s_H = reinterpret_cast<short*>(s_raw + off); off += (size_t)GG_SCAN_MAXWG * per * sizeof(short);   // [G per] hypothesis per node of the band: -1 none, else (old << 8 | new)
+  unsigned short* s_H = reinterpret_cast<unsigned short*>(s_raw + off); off += (size_t)GG_SCAN_MAXWG * per * sizeof(short);   // [G per] hypothesis per node of the band: 0xffff none, else (old << 8 | new) (old != new: never 0xffff)
   off = (off + 3) & ~(size_t)3;
   unsigned* s_Hm = reinterpret_cast<unsigned*>(s_raw + off); off += (size_t)(GG_SCAN_MAXWG * per / 32 + 2) * sizeof(unsigned);   // one bit per node of the band: a hypothesis is in place
   off = (off + 7) & ~(size_t)7;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     // the band starts without hypotheses; every node of the group sees the block sizes of the accepted labels
     const int band0 = band * G * per;
     const int band1 = (band0 + G * per < N) ? band0 + G * per : N;
-    for (int idx = tid; idx < G * per; idx += 256) s_H[idx] = (short)-1;
+    for (int idx = tid; idx < G * per; idx += 256) s_H[idx] = (unsigned short)0xffffu;
     for (int idx = tid; idx < (G * per + 31) / 32; idx += 256) s_Hm[idx] = 0u;
     for (int idx = tid; idx < per * K; idx += 256) s_cntn[idx] = s_cnt[idx % K];
     // the node's uniform is a function of (seed, site, sweep, node): drawn once per band, not once per round (ten Philox
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           if (live) {
             const int cn = s_c[i];
             const int h = s_H[n - band0];
-            const int expct = h >= 0 ? (h & 0xff) : cn;
+            const int expct = h != 0xffff ? (h & 0xff) : cn;
             if (lab != expct) dv = ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)lab;
           }
           s_dev[i] = dv;
@@ -473,8 +473,8 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           const int f = (int)(v >> (2 * LB)), old = (int)((v >> LB) & LMASK), nw = (int)(v & LMASK);
           const int h = s_H[f - band0];
           // statistics behind f hold f in block `from` (the hypothesised label, or the old one): it goes to `nw`
-          s_S[offS * 3] = f; s_S[offS * 3 + 1] = h >= 0 ? (h & 0xff) : old; s_S[offS * 3 + 2] = nw;
-          s_H[f - band0] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
+          s_S[offS * 3] = f; s_S[offS * 3 + 1] = h != 0xffff ? (h & 0xff) : old; s_S[offS * 3 + 2] = nw;
+          s_H[f - band0] = (nw == old) ? (unsigned short)0xffffu : (unsigned short)((old << 8) | nw);
           if (nw == old) atomicAnd(&s_Hm[(f - band0) >> 5], ~(1u << ((f - band0) & 31)));
           else atomicOr(&s_Hm[(f - band0) >> 5], 1u << ((f - band0) & 31));
           ++offS;

@@ -251,9 +251,10 @@ def test_joint_sbm_chain_bitexact(abi, N, K, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K,B,special,beta", [(300, 100, 1, 1, 1.0), (520, 128, 2, 0, 1.0), (257, 65, 1, 1, 0.6), (700, 97, 3, 1, 1.0)])
+@pytest.mark.parametrize("N,K,B,special,beta", [(300, 100, 1, 1, 1.0), (520, 128, 2, 0, 1.0), (257, 65, 1, 1, 0.6), (700, 97, 3, 1, 1.0),
+                                                 (600, 256, 1, 1, 1.0), (450, 193, 2, 0, 0.8), (1300, 200, 1, 1, 1.0)])
 def test_more_than_64_blocks_chain_bitexact(abi, N, K, B, special, beta):
-    """65..128 blocks: a node's (node, block) lanes span two wavefronts - the wide instantiation of the resident scan (categorical
+    """65..256 blocks: a node's (node, block) lanes span two or four wavefronts - the wide instantiation of the resident scan (categorical
     draw as a Kogge-Stone scan through LDS in the oracle's order, 8-bit labels in the exchange payloads) is the scan form.
     Adjacency and weight chains against the oracle, bit for bit, from a random start (hundreds of changes per scan), in
     uneven chunks, tempered and not; log-likelihood and step-wise parts as well."""
@@ -290,7 +291,7 @@ def test_more_than_64_blocks_chain_bitexact(abi, N, K, B, special, beta):
     with pytest.raises(abi.EngineError):
         adj.node_lp(d, 0, K)
     with pytest.raises(abi.EngineError):
-        abi.Model(kind=abi.SBM_ADJ, N=N, K=129, B=1, seed=1)
+        abi.Model(kind=abi.SBM_ADJ, N=N, K=257, B=1, seed=1)
 
 
 @pytest.mark.gpu
