@@ -490,7 +490,7 @@ def test_invalid_arguments_are_errors_not_hangs(abi):
         lambda: m.set(abi.ST_M, np.array([np.inf, 0.0, 0.0])),
         lambda: m.set(abi.ST_P, np.zeros(2)), lambda: m.set(999, np.zeros(2)), lambda: m.get(999, (2,)),
         lambda: adj(tau1=0.0), lambda: adj(tau0=-1.0), lambda: adj(tau1=float("nan")),
-        lambda: adj(K=0), lambda: adj(K=65), lambda: adj(N=0), lambda: adj(device=99),
+        lambda: adj(K=0), lambda: adj(K=257), lambda: adj(N=0), lambda: adj(device=99),
         lambda: w.resample(dA, 1),                                          # weight model, data without W
         lambda: w.set(abi.ST_SIGMA, -np.tile(eye, (K, K, 1, 1))),
         lambda: w.set(abi.ST_SIGMA, np.tile(np.array([[1.0, 2.0], [2.0, 1.0]]), (K, K, 1, 1))),   # indefinite
