@@ -667,9 +667,9 @@ def main():
     # SAME chain (GG_BENCH_CHAIN_SEED, default 1).  Independent chains differ only in this seed.
     chain_seed = int(os.environ.get("GG_BENCH_CHAIN_SEED", "1"))
     # HIP events (on the engine streams) around the launches that stream the data: every one of them for short runs (the
-    # driver's --steps 20), about 16 of them for long ones (each record costs the stream a barrier packet that drains the
-    # queue: 2-3 us of a 38 us sweep when every third launch is sampled)
-    every = max(1, args.steps // 16)
+    # (each record costs the stream a barrier packet that drains the queue: 2-3 us of a 38 us sweep when every third launch
+    # is sampled, a quarter of the timed region of the driver's --steps 20 when every launch is)
+    every = max(1, -(-args.steps // 8))     # about 8 sampled launches whatever the run length
     r = run_chain(abi, data, N, K, chain_seed, device, args.burnin, args.warmup, args.steps, every, barrier,
                   stepwise=bool(os.environ.get("GG_BENCH_STEPWISE")))
     adj, w, el, bulk, chg = r["adj"], r["w"], r["elapsed"], r["bulk"], r["changes"]

@@ -113,6 +113,8 @@ struct gg_model {
   int sh_hint;                  //               rounds the last scan of this model needed (+ margin): the first batch of the next
   bool wide;                    // 65..256 blocks: a node's lanes span two or four wavefronts - the resident scan's wide instantiation is the
                                 // only scan form (no speculative / restart-round fallback, no node shards, no gg_node_lp)
+  bool timing_dirty;            // the last call's HIP-event times have not been read yet (gg_last_stats does: each query costs
+                                // microseconds, and a caller that does not ask for them should not wait for them)
   int ahead_cap;                // speculative form: sweeps enqueued ahead of the last confirmed one (64, doubling per clean batch up to 512)
   int scan_pref_saved;          // the preference a k_scan timeout suspended (0: none suspended)
   uint64_t scan_retry_at;       // st.sweeps count from which the suspended preference is tried again
@@ -1413,6 +1415,7 @@ static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep, bool mor
 }
 
 static void begin_call(gg_model* m) {
+  m->timing_dirty = false;
   m->ev_used = 0;
   m->ev_sweep.clear(); m->ev_bytes.clear();
   m->st.bulk_bytes = 0; m->st.bulk_ms = 0; m->st.bulk_launches = 0; m->st.total_ms = 0;
@@ -1607,7 +1610,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
                       m->is_adj ? "adj" : "w", (h[1] - h[0]) * 0.01, (h[2] - h[0]) * 0.01, (h[4] - h[0]) * 0.01, (h[3] - h[0]) * 0.01);
   }
   set_pend_data(m, nullptr);   // nothing of this model is in flight on the network any more
-  if ((rc = collect_timing(m))) return rc;
+  m->timing_dirty = true;
   return GG_OK;
 }
 
@@ -1842,7 +1845,8 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
   // resample_m is the last step of a sweep (adjacency.py:615-618, weights.py:394-397): it closes the sweep index
   if (parts & GG_PART_M) { m->sweep += 1; m->parts_done = 0; }
   else m->parts_done |= parts;
-  return collect_timing(m);
+  m->timing_dirty = true;
+  return GG_OK;
 }
 
 int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
@@ -1867,7 +1871,8 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
     return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
   }
   GG_HIP(hipMemcpy(lp, m->lp_out, (size_t)m->K * 8, hipMemcpyDeviceToHost));
-  return collect_timing(m);
+  m->timing_dirty = true;
+  return GG_OK;
 }
 
 // Closed forms from the K x K tables (shared by the single-GPU and the sharded path).
@@ -2388,6 +2393,7 @@ int gg_last_stats(gg_model* m, gg_stats* out) {
   if (m->ld) return gg_latent_stats(m->ld, out);
   int rc = model_sync(m);
   if (rc) return rc;
+  if (m->timing_dirty) { m->timing_dirty = false; if ((rc = collect_timing(m))) return rc; }
   *out = m->st;
   if (m->sbm && !m->sharded && m->K > 1) {
     // rounds of the resident scans (one grid-wide exchange each), counted by k_scan itself
