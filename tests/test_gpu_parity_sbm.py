@@ -288,6 +288,16 @@ def test_more_than_64_blocks_chain_bitexact(abi, N, K, B, special, beta):
                O.sbm_w_loglik(A, q, shift, sw.c, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, bool(special)))
         assert abs(ll - ref) <= 1e-9 * abs(ref) + 1e-7, (ll, ref)
     assert adj.stats()["label_changes"] > 100
+    # the reference's step-wise calls resample_p / resample_c / resample_m (adjacency.py:615-618), one sweep index
+    for part in (abi.PART_PARAMS, abi.PART_C, abi.PART_M):
+        adj.resample_part(d, part, beta)
+        w.resample_part(d, part, beta)
+    ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, special, 501, done, beta=beta)
+    O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, special, 502, done,
+                  beta=beta)
+    assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(adj.get(abi.ST_M, (K,)), sa.m)
+    assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c) and np.array_equal(w.get(abi.ST_M, (K,)), sw.m)
+    assert np.array_equal(w.get(abi.ST_MU, (K, K, B)), sw.mu)
     with pytest.raises(abi.EngineError):
         adj.node_lp(d, 0, K)
     with pytest.raises(abi.EngineError):
