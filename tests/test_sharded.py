@@ -27,19 +27,22 @@ def test_sharded_chain_equals_single_chain(world, N, K, B, special):
 
 
 @pytest.mark.gpu
-def test_sharded_bench_is_rank_count_invariant():
-    """bench.py --shard on device-generated data: 1 rank and 2 ranks (sharing the GPU, gloo) run the same chain."""
+@pytest.mark.parametrize("N,K", [(700, 6), (8192, 16)])
+def test_sharded_bench_is_rank_count_invariant(N, K):
+    """bench.py --shard on device-generated data: 1 rank and 2 ranks (sharing the GPU, gloo) run the same chain - also at
+    N=8192 (two bands of the scan window per half-sweep, thousands of label changes in the first sweeps from the random
+    start: every rank reports 32 surprises per round)."""
     import json
     digests = []
     for world in (1, 2):
         env = dict(os.environ, GG_BENCH_BACKEND="gloo", GG_BENCH_SAME_DEVICE="1")
-        base = [os.path.join(ROOT, "bench.py"), "--shard", "--nodes", "700", "--blocks", "6", "--steps", "3", "--warmup", "2",
+        base = [os.path.join(ROOT, "bench.py"), "--shard", "--nodes", str(N), "--blocks", str(K), "--steps", "3", "--warmup", "2",
                 "--gpus", str(world)]
         if world == 1:
             cmd = [sys.executable] + base
         else:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                   "--master-addr", "127.0.0.1", "--master-port", "29561"] + base
+                   "--master-addr", "127.0.0.1", "--master-port", str(29561 + (N > 1000))] + base
         out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
         r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
