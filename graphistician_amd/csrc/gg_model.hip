@@ -1379,6 +1379,16 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
 static int enqueue_sweep_ahead(gg_model* m, const gg_data* d, uint32_t sweep, bool more) {
   int rc;
   const int a = m->cur, b = (a + 1) % 3, c = (a + 2) % 3, P = m->pcur;
+  {
+    // K > 32 without the tables in LDS: the scan's conditional keeps its table entries in registers (178 of them), the
+    // fused launch is compiled for two waves per SIMD, and riders that share it stream at half their speed.  Every sweep
+    // then runs as the two-launch form: k_params with the whole next pass as riders (full occupancy), k_spec_resolve alone.
+    static int fuse64 = -1;   // GG_FUSE64=1: the fused launch for these shapes as well
+    if (fuse64 < 0) { const char* e = getenv("GG_FUSE64"); fuse64 = e ? atoi(e) : 0; }
+    int stage = 0;
+    lds_spec(m, &stage);
+    if (!stage && m->Kp == 64 && !fuse64) more = false;
+  }
   if (!m->pre) {
     if (!(m->ahead && m->ahead_uid == d->uid)) {
       // prologue: nothing was counted ahead for this sweep (first sweep, new data or labels, after a stall)
