@@ -19,3 +19,8 @@ done
 cat $O
 echo "float-model shape sweep (tests/fuzz_float_models.py): $(timeout -k 10 900 python tests/fuzz_float_models.py 2>&1 | tail -1)" >> $O
 tail -2 $O
+echo "# larger networks and more than 64 blocks" >> $O
+for cfg in "8192 16 300" "16384 32 60" "8192 64 60" "2048 100 40" "3000 128 20" "1500 256 20"; do
+  timeout -k 10 500 python tests/soak_parity.py $cfg 2>&1 | tail -1 >> $O || echo "FAILED: $cfg" >> $O
+done
+tail -8 $O
