@@ -23,19 +23,22 @@
 #include "gg_common.h"
 #include "spec/gg_pg.h"
 #include "spec/gg_probit.h"
+#include "spec/gg_eig.h"
 
 #define EIG_T 64          // nodes per tile of the F scan
-#define EIG_CHN 4096      // neighbours per workgroup in k_eig_tile_stats (1024 threads x 4)
+#define EIG_CHN 1024      // neighbours per workgroup of the tile statistics (riders of the chain launches)
 
 struct gg_eigen {
   gg_config cfg;
   int N, D, Np, DM;
   int probit;            // GG_PROBIT_EIG: buffer S holds Z_ij + Z_ji, the pair weight is the constant 2
   double beta;           // AIS inverse temperature (logistic link only): omega ~ PG(beta, psi), kappa = beta (A - 1/2)
-  int NEG, NE, NG;        // D(D+1)/2, NEG + D, 2 + 2D + NEG
+  int NEG, NE, NG;        // D(D+1)/2, NEG + D, 2 + 2 DM + DM(DM+1)/2
+  int NEm;                // entries of a node's tile statistics, padded to DM: DM(DM+1)/2 + DM
   int NCH;
   double *F, *lmbda, *mu0, *mu_lmbda;
   double *S, *dO, *Z;
+  double *Sb, *Vb;        // tile-local pair weights / mean coefficients, [N][EIG_VW] (k_eig_vblocks)
   double *part, *gpart, *llpart;
   int* status;
   long long* dbgbuf;   // GG_EIG_DBG: cycle counters of the chain's solver wave
@@ -220,17 +223,75 @@ __global__ __launch_bounds__(256) void k_eig_z(int N, int Np, int D, const doubl
   }
 }
 
-// Gram statistics of the tile's nodes against the current F (eigenmodel.py:894-901):
-//   G_n[a,b] = sum_{nn != n} S[n,nn] ft_a ft_b,  h_n[a] = sum_{nn != n} ((A[n,nn]+A[nn,n]-1) - mu_0 S[n,nn]) ft_a,
-// ft = F[nn] * lambda.  One workgroup per (node, chunk of EIG_CHN neighbours).
+// ------------------------------------------------------------------ _resample_F (eigenmodel.py:876-908, :295-329)
+//
+// The scan over nodes is sequential with a continuous state, so nothing can be speculated; what CAN be chosen is what sits
+// on the per-node critical path.  With the draw made by perturbation (spec/gg_eig.h) node n needs  x = Lambda_n^{-1} b_n,
+//     Lambda_n = I / sigma_F + sum_{nn != n} s_{n,nn} g_nn g_nn^T,    b_n = z_n / sqrt(sigma_F) + sum_{nn != n} v_{n,nn} g_nn,
+// g = F * lambda (current), v = the pair's mean coefficient with the perturbation noise folded in (gg_eig_coef).  Inside a tile
+// of 64 nodes, node i's (Lambda, b) differ from what was known at tile start only by the rank-one terms of the tile's earlier
+// nodes - so instead of factorising Lambda_i when its turn comes (round 1-2: a D x D Cholesky and two substitutions on one
+// lane, 3400 clocks per node), the tile keeps the INVERSE of every node's precision in registers and folds each published
+// feature vector u_k = g_k(new) into the later nodes by Sherman-Morrison,
+//     q = P u,  t = u^T q,  c = s / (1 + s t),  P <- P - c q q^T,  b <- b + v u,
+// DM lanes per node (lane j owns row j of P_i and b_i[j]).  Node k+1's own turn ("closing") then needs no update of P at all:
+//     x = (P - c q q^T)(b + v u) = r + (v - c (d + v t)) q,      r = P b (prepared one step ahead),  d = u^T r,
+// one matrix-vector product, two DM-lane reductions, one reciprocal.  The precisions at tile start leave out the tile's
+// earlier nodes (their old features never enter), so every rank-one step ADDS a positive term: no downdates.
+//   * riders (workgroups > 0 of every chain launch): Gram statistics of the NEXT tile's nodes against all nodes outside
+//     both tiles (eig_tile_stats_body), the noise normals drawn on the fly;
+//   * k_eig_vblocks, once per sweep: pair weights and mean coefficients of the 128 columns around every node's own tile
+//     (previous tile | own tile), what the chain's prologue multiplies on the matrix cores;
+//   * prologue of a chain launch: previous tile (new features) and the later nodes of the own tile (old features) are added
+//     as two 64 x 64 x (NEGM + DM) products (v_mfma_f64_16x16x4_f64), then every lane factorises its node's precision
+//     (redundantly within the node's DM lanes - SIMD lockstep makes that free) and solves for ITS row of the inverse.
+
+#define EIG_VW 128   // columns per node in the tile-local blocks: [tile start - 64, tile start + 64)
+
+// Pair weights s and mean coefficients v (with the perturbation noise) of node n against the 128 nodes of its own and the
+// previous tile.  Entries outside the matrix and the diagonal are zero.
+__global__ __launch_bounds__(64) void k_eig_vblocks(int N, int Np, const double* __restrict__ S, const uint8_t* __restrict__ A,
+                                                    const uint8_t* __restrict__ AT, const double* __restrict__ mu0p,
+                                                    double* __restrict__ Sb, double* __restrict__ Vb, int probit, double ka,
+                                                    uint64_t seed, uint32_t sweep) {
+  const int n = blockIdx.x;
+  const int m0 = (n / EIG_T) * EIG_T - EIG_T + 2 * (int)threadIdx.x;   // this thread's pair of columns (m0 even)
+  const double mu0 = *mu0p;
+  double sv[2] = {0.0, 0.0}, vv[2] = {0.0, 0.0};
+  if (m0 >= 0 && m0 < N) {
+    double e[2];
+    gg_eig_noise_pair(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)(m0 >> 1), &e[0], &e[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = m0 + h;
+      if (m < N && m != n) {
+        const size_t at = (size_t)n * Np + m;
+        const double raw = S[at];
+        const double s = probit ? 2.0 : raw;
+        const double a = probit ? raw : ka * (double)((int)A[at] + (int)AT[at] - 1);
+        sv[h] = s;
+        vv[h] = gg_eig_coef(s, a, mu0, e[h]);
+      }
+    }
+  }
+  const size_t o = (size_t)n * EIG_VW + 2 * threadIdx.x;
+  Sb[o] = sv[0]; Sb[o + 1] = sv[1];
+  Vb[o] = vv[0]; Vb[o + 1] = vv[1];
+}
+
+// Gram statistics of a tile's nodes against the current F (eigenmodel.py:894-901), all nodes nn outside [ex_lo, n]: the
+// tile whose scan is still running and the earlier nodes of n's own tile are left out (the chain adds them with their new
+// features), the later nodes of the own tile enter with the features they have now - which is what node n will see:
+//   G_n[a,b] = sum_nn s[n,nn] g_a g_b,   b_n[a] = sum_nn v[n,nn] g_a,   g = F[nn] * lambda.
+// One workgroup per (node, chunk of EIG_CHN neighbours); a thread takes pairs of neighbours (one Philox block each).
+// Output layout per (node, chunk): upper triangle of the DM x DM matrix (padded to DM), then the DM mean entries.
 template <int DM>
 __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0, const double* __restrict__ S,
-                                                        const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
-                                                        const double* __restrict__ F, const double* __restrict__ lmbda,
-                                                        const double* __restrict__ mu0p, int NCH,
-                                                        double* __restrict__ part, int ex_lo, int ex_hi, int node, int c,
-                                                        int probit, double ka) {
-  // nodes [ex_lo, ex_hi) (the previous tile, whose scan is still running) are left out: the chain adds them
+                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                    const double* __restrict__ F, const double* __restrict__ lmbda,
+                                                    const double* __restrict__ mu0p, int NCH, double* __restrict__ part,
+                                                    int ex_lo, int node, int c, int probit, double ka,
+                                                    uint64_t seed, uint32_t sweep) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   const int n = t0 + node;
   if (n >= N) return;
@@ -241,24 +302,34 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
   for (int e = 0; e < NEGM; ++e) g[e] = 0.0;
 #pragma unroll
   for (int d = 0; d < DM; ++d) { h[d] = 0.0; lam[d] = d < D ? lmbda[d] : 0.0; }
-  const int lo = c * EIG_CHN, hi = (lo + EIG_CHN < N) ? lo + EIG_CHN : N;
-  for (int nn = lo + threadIdx.x; nn < hi; nn += nth) {
-    if (nn == n || (nn >= ex_lo && nn < ex_hi)) continue;
-    // logistic: s = omega_ij + omega_ji, a = kappa_ij + kappa_ji; probit (eigenmodel.py:312-321): s = 2, a = Z_ij + Z_ji
-    const double raw = S[(size_t)n * Np + nn];
-    const double s = probit ? 2.0 : raw;
-    const double a = probit ? raw : ka * (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
-    const double v = a - mu0 * s;
-    double ft[DM];
+  const int lo = c * EIG_CHN, hi = (lo + EIG_CHN < N) ? lo + EIG_CHN : N;   // EIG_CHN is even: lo is
+  for (int nn0 = lo + 2 * (int)threadIdx.x; nn0 < hi; nn0 += 2 * nth) {
+    // a pair whose both members are left out needs no normals
+    const bool out0 = nn0 >= ex_lo && nn0 <= n;
+    const bool out1 = nn0 + 1 >= hi || (nn0 + 1 >= ex_lo && nn0 + 1 <= n);
+    if (out0 && out1) continue;
+    double eps[2];
+    gg_eig_noise_pair(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)(nn0 >> 1), &eps[0], &eps[1]);
 #pragma unroll
-    for (int d = 0; d < DM; ++d) ft[d] = d < D ? F[(size_t)nn * D + d] * lam[d] : 0.0;
-    int e = 0;
+    for (int hh = 0; hh < 2; ++hh) {
+      if (hh ? out1 : out0) continue;
+      const int nn = nn0 + hh;
+      // logistic: s = omega_ij + omega_ji, a = kappa_ij + kappa_ji; probit (eigenmodel.py:312-321): s = 2, a = Z_ij + Z_ji
+      const double raw = S[(size_t)n * Np + nn];
+      const double s = probit ? 2.0 : raw;
+      const double a = probit ? raw : ka * (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
+      const double v = gg_eig_coef(s, a, mu0, eps[hh]);
+      double ft[DM];
 #pragma unroll
-    for (int a1 = 0; a1 < DM; ++a1) {
-      const double sa = s * ft[a1];
+      for (int d = 0; d < DM; ++d) ft[d] = d < D ? F[(size_t)nn * D + d] * lam[d] : 0.0;
+      int e = 0;
 #pragma unroll
-      for (int b1 = a1; b1 < DM; ++b1) g[e++] += sa * ft[b1];
-      h[a1] += v * ft[a1];
+      for (int a1 = 0; a1 < DM; ++a1) {
+        const double sa = s * ft[a1];
+#pragma unroll
+        for (int b1 = a1; b1 < DM; ++b1) g[e++] += sa * ft[b1];
+        h[a1] += v * ft[a1];
+      }
     }
   }
   __shared__ double s_red[16][NEGM + DM];
@@ -270,391 +341,308 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
     if (lane == 0) s_red[wave][e] = v;
   }
   __syncthreads();
-  // compact layout: entries of the D x D upper triangle then h, D-dependent
-  const int NEG = D * (D + 1) / 2;
   if (threadIdx.x < NEGM + DM) {
     const int e = threadIdx.x;
     double v = 0.0;
     for (int w = 0; w < (nth >> 6); ++w) v += s_red[w][e];
-    // map padded index -> compact index
-    int out = -1;
-    if (e < NEGM) {
-      int a1 = 0, rem = e;
-      while (rem >= DM - a1) { rem -= DM - a1; ++a1; }
-      int b1 = a1 + rem;
-      if (b1 < D) out = a1 * D - a1 * (a1 - 1) / 2 + (b1 - a1);
-    } else if (e - NEGM < D) {
-      out = NEG + (e - NEGM);
-    }
-    if (out >= 0) part[((size_t)node * NCH + c) * (NEG + D) + out] = v;
+    part[((size_t)node * NCH + c) * (NEGM + DM) + e] = v;
   }
 }
 
-// The sequential part of _resample_F for one tile (eigenmodel.py:884-908), one workgroup.
-// Everything the per-node loop touches is staged in LDS first (T x T block of S and of the
-// symmetrised adjacency, the tile's statistics, normals and old features).
 template <int DM>
-__global__ __launch_bounds__(1024) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
-                                                        const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
-                                                        const double* __restrict__ F, const double* __restrict__ lmbda,
-                                                        const double* __restrict__ mu0p, int NCH,
-                                                        double* __restrict__ part, int ex_lo, int ex_hi, int probit, double ka) {
-  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, ex_hi, blockIdx.x, blockIdx.y, probit, ka);
+__global__ __launch_bounds__(64 * DM) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
+                                                            const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                            const double* __restrict__ F, const double* __restrict__ lmbda,
+                                                            const double* __restrict__ mu0p, int NCH,
+                                                            double* __restrict__ part, int ex_lo, int probit, double ka,
+                                                            uint64_t seed, uint32_t sweep) {
+  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, blockIdx.x, blockIdx.y, probit, ka, seed, sweep);
 }
 
 // Order this wave's LDS operations: wait for the outstanding ones and keep the compiler from moving memory accesses across.
 // (__threadfence_block() also waits for every global store in flight - hundreds of clocks on the scan's critical path.)
 __device__ __forceinline__ void gg_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int DM, bool FULL>
-__global__ __launch_bounds__(512) void k_eig_chain(int N, int Np, int Drt, int t0, const double* __restrict__ S,
-                                                   const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
-                                                   double* __restrict__ F, const double* __restrict__ lmbda,
-                                                   const double* __restrict__ mu0p, double sigma_F, int NCH,
-                                                   const double* __restrict__ part, const double* __restrict__ Z,
-                                                   int* __restrict__ status, long long* __restrict__ dbg,
-                                                   double* __restrict__ part_next, int probit, double ka) {
-  constexpr int NEGM = DM * (DM + 1) / 2;
+// x of another lane of the same DPP row (16 lanes), pattern CTRL: the two halves of the double travel separately.
+template <int CTRL>
+__device__ __forceinline__ double gg_dpp_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the DM consecutive lanes of a node's group (DM = 4, 8, 16; groups are aligned), the same value in every lane.
+// quad_perm [1,0,3,2] and [2,3,0,1] sum a quad; row_half_mirror (lane l <-> 7 - l) and row_mirror (l <-> 15 - l) pair
+// a lane with one of the other quad / the other half.
+template <int DM>
+__device__ __forceinline__ double eig_group_sum(double x) {
+  x += gg_dpp_f64<0xB1>(x);
+  x += gg_dpp_f64<0x4E>(x);
+  if (DM >= 8) x += gg_dpp_f64<0x141>(x);
+  if (DM >= 16) x += gg_dpp_f64<0x140>(x);
+  return x;
+}
+
+// The sequential part of _resample_F for one tile (workgroup 0), riders behind it.  64 * DM threads = DM waves; node i of
+// the tile lives in wave i % DM, lanes [(i / DM) DM, (i / DM + 1) DM) - consecutive nodes in different waves, so that while
+// one wave closes node k the others fold change k - 1 into their nodes - lane j of the group owning row j of the node's
+// inverse precision and a copy of its mean term.
+template <int DM>
+__global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int t0, const double* __restrict__ S,
+                                                       const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                       double* __restrict__ F, const double* __restrict__ lmbda,
+                                                       const double* __restrict__ mu0p, double sigma_F, int NCH,
+                                                       const double* __restrict__ part, const double* __restrict__ Z,
+                                                       const double* __restrict__ Sb, const double* __restrict__ Vb,
+                                                       int* __restrict__ status, long long* __restrict__ dbg,
+                                                       double* __restrict__ part_next, int probit, double ka,
+                                                       uint64_t seed, uint32_t sweep) {
+  constexpr int NEGM = DM * (DM + 1) / 2, NEm = NEGM + DM, TS = EIG_T + 1, NTH = 64 * DM, NW = DM, NPW = 64 / DM;
   if (blockIdx.x > 0) {
-    // riders: the statistics of the NEXT tile (all nodes outside this tile and the next), computed while
-    // workgroup 0 scans this one; the next launch's chain adds this tile's nodes with their new features
+    // riders: the statistics of the NEXT tile against all nodes outside this tile and behind the node in its own
     const int idx = blockIdx.x - 1;
-    eig_tile_stats_body<DM>(N, Np, Drt, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, t0 + EIG_T, idx / NCH, idx % NCH, probit, ka);
+    eig_tile_stats_body<DM>(N, Np, D, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, idx / NCH, idx % NCH,
+                            probit, ka, seed, sweep);
     return;
   }
   extern __shared__ __align__(16) unsigned char s_chain[];
-  double* s_S = reinterpret_cast<double*>(s_chain);                 // [T][T+1]
-  double* s_dP = s_S + EIG_T * (EIG_T + 1);                         // [T][NEGM]
-  double* s_dF = s_dP + EIG_T * NEGM;                               // [T][DM]
-  double* s_part = s_dF + EIG_T * DM;                               // [T][NEGM+DM] (compact NE used)
-  double* s_Z = s_part + EIG_T * (NEGM + DM);                       // [T][DM]
-  double* s_Fo = s_Z + EIG_T * DM;                                  // [T][DM]
-  double* s_stat = s_Fo + EIG_T * DM;                               // [NEGM+DM]
-  signed char* s_a = reinterpret_cast<signed char*>(s_stat + NEGM + DM);  // [T][T]
+  double* s_S = reinterpret_cast<double*>(s_chain);   // [T][TS]   pair weights of the block being multiplied / scanned
+  double* s_V = s_S + EIG_T * TS;                     // [T][TS]   mean coefficients
+  double* s_C = s_V + EIG_T * TS;                     // [T][NEm]  precision (upper triangle) and mean term per node
+  double* s_g = s_C + EIG_T * NEm;                    // [T][DM]   f * lambda of the previous tile's nodes (new features)
+  double* s_u = s_g + EIG_T * DM;                     // [T][DM]   published new f * lambda of this tile's nodes
+  double* s_Fn = s_u + EIG_T * DM;                    // [T][DM]   new features
+  double* s_q = s_Fn + EIG_T * DM;                    // [NTH]     gather scratch, one slot per lane
+  volatile int* s_pub = reinterpret_cast<volatile int*>(s_q + NTH);
   const int tid = threadIdx.x;
   const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
-  // FULL: D == DM, every bound below is a compile-time constant (no guards, no dynamic LDS indices)
-  const int D = FULL ? DM : Drt;
-  const int NEG = FULL ? NEGM : D * (D + 1) / 2, NE = NEG + D;
-  const double mu0 = *mu0p;
+  const int p0 = t0 - EIG_T;       // first node of the previous tile (left out by the riders that ran beside its scan)
   const long long c_start = dbg ? clock64() : 0;
-  const int p0 = t0 - EIG_T;     // first node of the previous tile (left out by the statistics kernel)
-  // block loader: rows of this tile x columns [c0, c0 + W) of S and of a = A + A^T - 1, into s_S / s_a
-  auto load_block = [&](int c0, int W) {
-    // (all of a thread's loads are issued before the first LDS store: 8 x 3 loads in flight instead of 3)
-    constexpr int PER = EIG_T * EIG_T / 512;
-    double sv[PER];
-    int av[PER];
+  // ---- prologue.  Every global load is issued before the first wait: the riders' partial sums, both 64 x 64 blocks of
+  // pair weights / mean coefficients (previous tile: multiplied below; own tile: what the scan reads), the previous
+  // tile's new features.
+  constexpr int PER = EIG_T * EIG_T / NTH;            // block entries per thread
+  constexpr int UC = (EIG_T * NEm + NTH - 1) / NTH;   // statistics entries per thread
+  double sv0[PER], vv0[PER], sv1[PER], vv1[PER], cacc[UC];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int e = tid + u * 512;
-      const int i = e / W, j = e % W;
-      const bool in = e < T * W;
-      const size_t at = in ? (size_t)(t0 + i) * Np + c0 + j : (size_t)t0 * Np + c0;
-      sv[u] = S[at];
-      av[u] = (int)A[at] + (int)AT[at] - 1;
+  for (int u = 0; u < UC; ++u) cacc[u] = 0.0;
+  for (int c0 = 0; c0 < NCH; c0 += 4) {
+    double tmp[UC][4];
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      const int e = tid + u * NTH;
+      const int ii = e / NEm, q = e % NEm;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        tmp[u][cc] = (e < EIG_T * NEm && ii < T && c0 + cc < NCH) ? part[((size_t)ii * NCH + c0 + cc) * NEm + q] : 0.0;
+    }
+    if (c0 == 0) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * NTH;
+        const int ii = e >> 6, jj = e & 63;
+        const size_t at = (size_t)(t0 + (ii < T ? ii : 0)) * EIG_VW + jj;
+        sv0[u] = p0 >= 0 ? Sb[at] : 0.0;
+        vv0[u] = p0 >= 0 ? Vb[at] : 0.0;
+        sv1[u] = Sb[at + EIG_T];
+        vv1[u] = Vb[at + EIG_T];
+      }
+      if (p0 >= 0)
+        for (int e = tid; e < EIG_T * DM; e += NTH) {
+          const int m = e / DM, q = e % DM;
+          s_g[e] = q < D ? F[(size_t)(p0 + m) * D + q] * lmbda[q] : 0.0;
+        }
     }
     asm volatile("" ::: "memory");
 #pragma unroll
+    for (int u = 0; u < UC; ++u) cacc[u] += (tmp[u][0] + tmp[u][1]) + (tmp[u][2] + tmp[u][3]);
+  }
+#pragma unroll
+  for (int u = 0; u < UC; ++u) { const int e = tid + u * NTH; if (e < EIG_T * NEm) s_C[e] = cacc[u]; }
+  auto store_block = [&](const double* sv, const double* vv) {
+#pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int e = tid + u * 512;
-      if (e < T * W) {
-        const int i = e / W, j = e % W;
-        s_S[i * (EIG_T + 1) + j] = sv[u];
-        s_a[i * EIG_T + j] = (signed char)av[u];
-      }
+      const int e = tid + u * NTH;
+      const int ii = e >> 6, jj = e & 63;
+      s_S[ii * TS + jj] = ii < T ? sv[u] : 0.0;
+      s_V[ii * TS + jj] = ii < T ? vv[u] : 0.0;
     }
   };
-  if (p0 >= 0) load_block(p0, EIG_T); else load_block(t0, T);
-  if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[5], (unsigned long long)(clock64() - c_start));
-  for (int e = tid; e < T * NE; e += 512) {
-    int i = e / NE, q = e % NE;
-    double acc = 0.0;
-    for (int c = 0; c < NCH; ++c) acc += part[((size_t)i * NCH + c) * NE + q];
-    s_part[i * (NEGM + DM) + q] = acc;
-  }
-  for (int e = tid; e < T * D; e += 512) {
-    int i = e / D, q = e % D;
-    s_Z[i * DM + q] = Z[(size_t)(t0 + i) * D + q];
-    s_Fo[i * DM + q] = F[(size_t)(t0 + i) * D + q];
-  }
-  double lam[DM];
-#pragma unroll
-  for (int a1 = 0; a1 < DM; ++a1) lam[a1] = a1 < D ? lmbda[a1] : 0.0;
-  if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[6], (unsigned long long)(clock64() - c_start));
-  // The statistics kernel ran while the previous tile was still being scanned and left its nodes out: add
-  // them now, with their new features (s_dF is free until the scan starts: it holds f * lambda of those nodes).
+  if (tid == 0) *s_pub = 0;
   if (p0 >= 0) {
-    for (int e = tid; e < EIG_T * D; e += 512) {
-      int m = e / D, q = e % D;
-      s_dF[m * DM + q] = F[(size_t)(p0 + m) * D + q] * lmbda[q];
-    }
+    store_block(sv0, vv0);
     __syncthreads();
-    // C[i][e] = sum_m X[i][m] Y[m][e] over the 64 nodes m of the previous tile: a 64 x 64 x NE product, on the
-    // matrix cores (v_mfma_f64_16x16x4_f64; fragment layout as in eig_psi_tile_mfma).  Precision entries
-    // (e < NEG): X = S, Y[m][e] = g_m[a] g_m[b]; mean entries: X = a - mu_0 S, Y[m][q] = g_m[q].
-    {
-      const int wv = tid >> 6, l = tid & 63;
-      const int ncb = (NEG + 15) / 16;            // column blocks of the precision part
-      const int nblk = 4 * (ncb + 1);             // + one column block for the mean part
-      for (int blk = wv; blk < nblk; blk += 8) {
-        const int bi = blk & 3, cb = blk >> 2;
-        const bool mean = cb == ncb;
-        const int col = (mean ? 0 : cb * 16) + (l & 15);
-        int a1 = 0, b1 = 0;
-        bool cvalid;
-        if (mean) { a1 = col; cvalid = col < D; }
-        else { cvalid = col < NEG; if (cvalid) { int rem = col; while (rem >= D - a1) { rem -= D - a1; ++a1; } b1 = a1 + rem; } }
-        const int row = bi * 16 + (l & 15);
-        gg_double4 acc = {0.0, 0.0, 0.0, 0.0};
+    // s_C[i][e] += sum_m X[i][m] Y[m][e] over the 64 nodes m of the previous tile, with their new features, on the matrix
+    // cores (v_mfma_f64_16x16x4_f64; fragment layout as in eig_psi_tile_mfma).  Precision entries (e < NEGM): X = s,
+    // Y[m][e] = g_m[a] g_m[b]; mean entries: X = v, Y[m][a] = g_m[a].
+    const int wv = tid >> 6, l = tid & 63;
+    constexpr int ncb = (NEGM + 15) / 16;       // column blocks of the precision part
+    constexpr int nblk = 4 * (ncb + 1);         // + one column block for the mean part
+    for (int blk = wv; blk < nblk; blk += NTH / 64) {
+      const int bi = blk & 3, cb = blk >> 2;
+      const bool mean = cb == ncb;
+      const int col = (mean ? 0 : cb * 16) + (l & 15);
+      int a1 = 0, b1 = 0;
+      bool cvalid;
+      if (mean) { a1 = col; cvalid = col < DM; }
+      else { cvalid = col < NEGM; if (cvalid) { int rem = col; while (rem >= DM - a1) { rem -= DM - a1; ++a1; } b1 = a1 + rem; } }
+      const int row = bi * 16 + (l & 15);
+      gg_double4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-        for (int kk = 0; kk < EIG_T / 4; ++kk) {
-          const int m = kk * 4 + (l >> 4);
-          const double raw = s_S[row * (EIG_T + 1) + m];
-          const double sv = probit ? 2.0 : raw;
-          const double xa = mean ? gg_fma(-mu0, sv, probit ? raw : ka * (double)s_a[row * EIG_T + m]) : sv;
-          double yb = 0.0;
-          if (cvalid) yb = mean ? s_dF[m * DM + a1] : s_dF[m * DM + a1] * s_dF[m * DM + b1];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
-        }
-        // lane l holds C[16 bi + 4 r + l / 16][col block + l % 16] in component r
-        if (cvalid) {
-          const int e = mean ? NEG + a1 : col;
+      for (int kk = 0; kk < EIG_T / 4; ++kk) {
+        const int m = kk * 4 + (l >> 4);
+        const double xa = mean ? s_V[row * TS + m] : s_S[row * TS + m];
+        double yb = 0.0;
+        if (cvalid) yb = mean ? s_g[m * DM + a1] : s_g[m * DM + a1] * s_g[m * DM + b1];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
+      }
+      // lane l holds C[16 bi + 4 r + l / 16][col block + l % 16] in component r
+      if (cvalid) {
+        const int e = mean ? NEGM + a1 : col;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = bi * 16 + 4 * r + (l >> 4);
-            if (i < T) s_part[i * (NEGM + DM) + e] += acc[r];
-          }
-        }
+        for (int r = 0; r < 4; ++r) s_C[(bi * 16 + 4 * r + (l >> 4)) * NEm + e] += acc[r];
       }
     }
     __syncthreads();
-    if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[7], (unsigned long long)(clock64() - c_start));
-    load_block(t0, T);   // now the tile's own block, which the scan works on
   }
-  // progress words (LDS): s_prog[0] = nodes whose rank-one change is published; s_prog[1 + w] = changes
-  // updater wave w has applied
-  volatile int* s_prog = reinterpret_cast<volatile int*>(s_a + EIG_T * EIG_T);
-  if (tid < 16) s_prog[tid] = (tid == 2) ? 0xff : 0;   // bytes 8..15: one progress byte per updater wave (byte 8 unused: 255)
+  store_block(sv1, vv1);   // the own tile's block: what the scan reads
   __syncthreads();
-  volatile unsigned char* s_progb = reinterpret_cast<volatile unsigned char*>(s_prog + 2);
-  volatile unsigned long long* s_progq = reinterpret_cast<volatile unsigned long long*>(s_prog + 2);
-  // The scan is a software pipeline inside the workgroup.  Wave 0 (the solver) runs the per-node critical
-  // path only: fold the previous node's rank-one change into this node's statistics, solve the D x D
-  // Gaussian conditional, publish the new rank-one change.  Waves 1-7 (updaters) push every published
-  // change into the statistics of the nodes two or more positions later, in the background; each (node,
-  // entry) is always owned by the same updater lane, so changes reach it in ascending order, and the solver
-  // waits, before node nl, until every updater has applied change nl-2.  Accumulation order per entry is the
-  // same as before: partial sums, then the earlier nodes of the tile in ascending order.
-  const int wave = tid >> 6, lane = tid & 63;
-  const double inv_sigma_F = 1.0 / sigma_F;
   if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(clock64() - c_start));
-  if (wave == 0) {
-    // The solver wave.  The per-node critical path (Cholesky + two triangular solves: ~200 dependent fp64 operations)
-    // runs on lane 0; everything that is one independent operation per matrix entry -- folding the previous node's
-    // rank-one change into the statistics, the new outer-product change -- is spread over the lanes, lane l owning
-    // entry (l / DM, l % DM), and handed over through a small LDS scratch (same wave: program order, no barrier).
-    // A wave instruction costs the same for 1 or 64 active lanes, so this takes ~250 instructions off the path.
-    double* s_scr = s_stat;                        // [NEGM + DM] precision + mean term, then [2 DM] fn, fo
-    const int li = lane / DM, lj = lane % DM;
-    const int la = li < lj ? li : lj, lb = li < lj ? lj : li;
-    const bool lact = lane < DM * DM && (FULL || lb < D);
-    const int le = lact ? la * D - la * (la - 1) / 2 + (lb - la) : 0;   // compact upper-triangle index of (la, lb)
-    const bool lup = lact && li <= lj;             // the lanes that write their entry
-    const bool lvec = lane < D;                    // lanes that own a component of the mean term / of f
-    long long c_wait = 0, c_solve = 0;
-    double dPl = 0.0, dFl = 0.0;                   // the previous node's rank-one change, this lane's entry
-    bool ready = true;                             // "every updater has applied change nl-2", checked one node ahead
-    for (int nl = 0; nl < T; ++nl) {
-      const int n = t0 + nl;
-      const double* s_st = s_part + nl * (NEGM + DM);
-      // pair weight and centred pair value of (this node, the previous one): tile constants, read before the wait
-      double svp = 0.0, cfp = 0.0;
-      if (nl >= 1) {
-        const double raw = s_S[nl * (EIG_T + 1) + nl - 1];
-        svp = probit ? 2.0 : raw;
-        cfp = gg_fma(-mu0, svp, probit ? raw : ka * (double)s_a[nl * EIG_T + nl - 1]);
-      }
-      const long long c0 = dbg ? clock64() : 0;
-      if (!ready) {
-        for (int spin = 0;; ++spin) {
-          const unsigned long long q = *s_progq;   // one load: the seven progress bytes
-          int mn = 255;
+  // ---- every lane: Cholesky of its node's precision (the DM lanes of a node do the same arithmetic), row j of the inverse
+  const int wave = tid >> 6, grp = (tid & 63) / DM, j = tid % DM;
+  const int i = grp * NW + wave;                  // this lane's node
+  const int gbase = (tid / DM) * DM;              // first lane of the group (its slots of the gather scratch)
+  const bool live = i < T;
+  double Prow[DM], bfull[DM], rj = 0.0;
+  const double lamj = j < D ? lmbda[j] : 0.0;
+  {
+    double L[DM][DM];
+    const double inv_sigma_F = 1.0 / sigma_F;
+    {
+      int e = 0;
 #pragma unroll
-          for (int w = 1; w <= 7; ++w) { const int v = (int)((q >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
-          if (mn >= nl - 1) break;
-          if (spin > (1 << 22)) { if (lane == 0) atomicOr(status, 2); break; }   // never spin forever
-          __builtin_amdgcn_s_sleep(1);
+      for (int a1 = 0; a1 < DM; ++a1)
+#pragma unroll
+        for (int b1 = a1; b1 < DM; ++b1) {
+          double v = live ? s_C[i * NEm + e] : 0.0;
+          ++e;
+          if (a1 == b1) v += inv_sigma_F;
+          L[b1][a1] = v;   // lower triangle holds the precision
         }
+    }
+    double dmin = 1.0;     // smallest pivot: a non-positive one voids the sweep (status)
+    // right-looking Cholesky; the diagonal keeps 1 / L_jj (hardware reciprocal square root + two Newton steps)
+#pragma unroll
+    for (int c = 0; c < DM; ++c) {
+      const double dsum = L[c][c];
+      dmin = __builtin_fmin(dmin, dsum);
+      double inv = __builtin_amdgcn_rsq(dsum);
+      inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
+      inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
+      L[c][c] = inv;
+#pragma unroll
+      for (int r = c + 1; r < DM; ++r) L[r][c] = L[r][c] * inv;
+#pragma unroll
+      for (int r = c + 1; r < DM; ++r)
+#pragma unroll
+        for (int k = c + 1; k <= r; ++k) L[r][k] = gg_fma(-L[r][c], L[k][c], L[r][k]);
+    }
+    if (live && !(dmin > 0.0)) atomicOr(status, 1);
+    // row j of the inverse: L L^T p = e_j
+    double y[DM];
+#pragma unroll
+    for (int r = 0; r < DM; ++r) {
+      double v = (r == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) v = gg_fma(-L[r][k], y[k], v);
+      y[r] = v * L[r][r];
+    }
+#pragma unroll
+    for (int r = DM - 1; r >= 0; --r) {
+      double v = y[r];
+#pragma unroll
+      for (int k = r + 1; k < DM; ++k) v = gg_fma(-L[k][r], Prow[k], v);
+      Prow[r] = v * L[r][r];
+    }
+    const double isq = 1.0 / gg_sqrt(sigma_F);
+#pragma unroll
+    for (int m = 0; m < DM; ++m)
+      bfull[m] = (live && m < D) ? gg_fma(Z[(size_t)(t0 + i) * D + m], isq, s_C[i * NEm + NEGM + m]) : 0.0;
+  }
+  // r = P b, this lane's component: what a node closes with, prepared one step ahead
+  auto prepare_r = [&]() {
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < DM; ++m) acc = gg_fma(Prow[m], bfull[m], acc);
+    rj = acc;
+  };
+  prepare_r();
+  const long long c_scan = dbg ? clock64() : 0;
+  // ---- the scan.  Step k: node k closes with change k - 1 (the features node k - 1 has just published); the later nodes
+  // fold change k - 1 into their inverse.  A wave whose nodes are all closed leaves.
+  const int last = T > wave ? ((T - 1 - wave) / NW) * NW + wave : -1;   // this wave's last node
+  for (int k = 0; k <= last; ++k) {
+    const bool act = live && i >= k;
+    const bool closer = (k % NW) == wave;       // this wave holds node k
+    double u[DM], uj = 0.0, s = 0.0, v = 0.0, qj = 0.0, c = 0.0, tq = 0.0;
+    if (k >= 1) {
+      for (int spin = 0; *s_pub < k; ++spin) {
+        if (spin > (1 << 24)) { if ((tid & 63) == 0) atomicOr(status, 2); break; }   // never spin forever
+        if (!closer) __builtin_amdgcn_s_sleep(1);
+      }
+      gg_lds_wait();
+#pragma unroll
+      for (int m = 0; m < DM; ++m) u[m] = s_u[(k - 1) * DM + m];
+      uj = s_u[(k - 1) * DM + j];
+      if (act) { s = s_S[i * TS + k - 1]; v = s_V[i * TS + k - 1]; }
+#pragma unroll
+      for (int m = 0; m < DM; ++m) qj = gg_fma(Prow[m], u[m], qj);
+      tq = eig_group_sum<DM>(uj * qj);
+      const double den = gg_fma(s, tq, 1.0);
+      double rc = __builtin_amdgcn_rcp(den);
+      rc = rc * gg_fma(-den, rc, 2.0);
+      rc = rc * gg_fma(-den, rc, 2.0);
+      c = s * rc;
+    }
+    if (closer) {
+      // close node k:  x = r + (v - c (d + v t)) q,  d = u^T r
+      double x = rj;
+      if (k >= 1) {
+        const double d = eig_group_sum<DM>(uj * rj);
+        const double coef = v - c * gg_fma(v, tq, d);
+        x = gg_fma(coef, qj, rj);
+      }
+      if (act && i == k) {
+        if (!(x == x)) { atomicOr(status, 1); x = 0.0; }
+        s_u[k * DM + j] = x * lamj;
+        s_Fn[k * DM + j] = x;
       }
       gg_lds_wait();   // LDS traffic of one wave is performed in order: the data is written before the word that announces it
-      const long long c1 = dbg ? clock64() : 0;
-      // statistics of this node with the previous node's change folded in (same order as the updaters':
-      // earlier changes first, the previous node's last), one entry per lane
-      if (lup) {
-        double v = gg_fma(svp, dPl, s_st[le]);
-        if (li == lj) v += inv_sigma_F;
-        s_scr[le] = v;
-      }
-      if (lvec) s_scr[NEG + lane] = gg_fma(cfp, dFl, s_st[NEG + lane]);
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      const long long cA = dbg ? clock64() : 0;
-      if (lane == 0) {
-        // D x D Gaussian conditional in registers (fully unrolled to DM; rows/cols >= D are identity)
-        double L[DM][DM], hh[DM], x[DM];
-        {
-          int e = 0;
-#pragma unroll
-          for (int a1 = 0; a1 < DM; ++a1)
-#pragma unroll
-            for (int b1 = a1; b1 < DM; ++b1) {
-              double v = 0.0;
-              if (FULL || b1 < D) { v = s_scr[e]; ++e; }
-              else if (a1 == b1) v = 1.0;
-              L[b1][a1] = v;   // lower triangle holds the precision
-            }
-        }
-#pragma unroll
-        for (int a1 = 0; a1 < DM; ++a1) hh[a1] = (FULL || a1 < D) ? s_scr[NEG + a1] : 0.0;
-        double zz[DM], fo[DM];
-#pragma unroll
-        for (int i = 0; i < DM; ++i) {
-          zz[i] = (FULL || i < D) ? s_Z[nl * DM + i] : 0.0;
-          fo[i] = (FULL || i < D) ? s_Fo[nl * DM + i] : 0.0;
-        }
-        if (dbg) { asm volatile("" ::"v"(L[0][0]), "v"(hh[0]), "v"(zz[0]), "v"(fo[0])); atomicAdd((unsigned long long*)&dbg[8], (unsigned long long)(clock64() - cA)); }
-        const long long cB = dbg ? clock64() : 0;
-        double dmin = 1.0;           // smallest pivot: a non-positive one voids the node (checked once, off the path)
-        // Cholesky, RIGHT-looking: column j is scaled as soon as its pivot is known and its rank-one update is applied to
-        // the trailing columns at once, so that the only serial chain left is pivot -> reciprocal square root -> scale ->
-        // next pivot (one fma behind the scale); every other fma is independent work the scheduler can fill the chain's
-        // bubbles with.  Per element the updates arrive in the same order (k ascending) as in the left-looking form
-        // (gg_chol_d): the factor is the same to the bit.
-#pragma unroll
-        for (int j = 0; j < DM; ++j) {
-          const double dsum = L[j][j];
-          dmin = __builtin_fmin(dmin, dsum);
-          // one reciprocal square root per column instead of D divisions (float-tolerance path)
-          double inv = __builtin_amdgcn_rsq(dsum);               // hardware estimate, then two Newton steps
-          inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
-          inv = inv * gg_fma(-0.5 * dsum * inv, inv, 1.5);
-          L[j][j] = inv;           // the diagonal keeps 1 / L_jj: the solves only ever divide by it
-#pragma unroll
-          for (int i = j + 1; i < DM; ++i) L[i][j] = L[i][j] * inv;
-#pragma unroll
-          for (int i = j + 1; i < DM; ++i)
-#pragma unroll
-            for (int k = j + 1; k <= i; ++k) L[i][k] = gg_fma(-L[i][j], L[k][j], L[i][k]);
-        }
-        if (dbg) { asm volatile("" ::"v"(L[DM - 1][DM - 1])); atomicAdd((unsigned long long*)&dbg[9], (unsigned long long)(clock64() - cB)); }
-        const long long cC = dbg ? clock64() : 0;
-        // y = L^{-1} h + z ; x = L^{-T} y   (gg_gauss_from_precision), both substitutions in their eager form: a finished
-        // component is folded into every later right-hand side at once (forward: the same order per component as before)
-        double y[DM];
-#pragma unroll
-        for (int i = 0; i < DM; ++i) {
-          y[i] = gg_fma(hh[i], L[i][i], zz[i]);
-          const double u = y[i] - zz[i];
-#pragma unroll
-          for (int r = i + 1; r < DM; ++r) hh[r] = gg_fma(-L[r][i], u, hh[r]);
-        }
-#pragma unroll
-        for (int i = DM - 1; i >= 0; --i) {
-          x[i] = y[i] * L[i][i];
-#pragma unroll
-          for (int r = 0; r < i; ++r) y[r] = gg_fma(-L[i][r], x[i], y[r]);
-        }
-        if (dbg) { asm volatile("" ::"v"(x[0])); atomicAdd((unsigned long long*)&dbg[10], (unsigned long long)(clock64() - cC)); }
-        const bool ok = dmin > 0.0 && x[0] == x[0];   // x[0] closes the back substitution: NaN anywhere reaches it
-        if (!ok) atomicOr(status, 1);
-#pragma unroll
-        for (int a1 = 0; a1 < DM; ++a1) {
-          if (!ok) x[a1] = fo[a1];
-          if (FULL || a1 < D) {
-            // (the new feature stays in LDS, over the old one it replaces: the tile is written to global memory once, after
-            // the scan - a global store here would sit in front of every later wait of this wave)
-            s_Fo[nl * DM + a1] = x[a1];
-            s_scr[a1] = x[a1] * lam[a1];            // fn
-            s_scr[DM + a1] = fo[a1] * lam[a1];      // fo
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      // progress of the updaters for the NEXT node (needs change nl-1 applied everywhere): the words arrive while the
-      // outer product below is formed
-      const unsigned long long pq = *s_progq;
-      // rank-one change of this node's outer product, seen by the later nodes of the tile: one entry per lane
-      if (lact) {
-        const double fna = s_scr[la], fnb = s_scr[lb], foa = s_scr[DM + la], fob = s_scr[DM + lb];
-        dPl = fna * fnb - foa * fob;
-        if (lup) s_dP[nl * NEGM + le] = dPl;
-      }
-      if (lvec) {
-        dFl = s_scr[lane] - s_scr[DM + lane];
-        s_dF[nl * DM + lane] = dFl;
-      }
-      {
-        int mn = 255;
-#pragma unroll
-        for (int w = 1; w <= 7; ++w) { const int v = (int)((pq >> (8 * w)) & 255u); mn = v < mn ? v : mn; }
-        ready = (nl + 1 < 2) || (mn >= nl);
-      }
-      gg_lds_wait();   // LDS traffic of one wave is performed in order: the data is written before the word that announces it
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) s_prog[0] = nl + 1;   // change nl is published
-      if (dbg) { const long long c3 = clock64(); c_wait += c1 - c0; c_solve += c3 - c1; if (lane == 0) atomicAdd((unsigned long long*)&dbg[11], (unsigned long long)(cA - c1)); }
+      if (act && i == k && j == 0) *s_pub = k + 1;
     }
-    // the tile's new features -> global memory (nothing in this launch reads them: the riders leave this tile out)
-    gg_lds_wait();
-    for (int e = lane; e < T * D; e += 64) F[(size_t)(t0 + e / D) * D + e % D] = s_Fo[(e / D) * DM + e % D];
-    if (dbg && lane == 0) { atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)c_wait); atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)c_solve); atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T); }
-  } else {
-    // updaters: every lane owns up to RU fixed (node, entry) pairs and keeps their running values in registers;
-    // per change it needs two or three independent LDS reads per pair (issued as one batch), one fma, one store
-    constexpr int NU = 512 - 64;
-    constexpr int RU = (EIG_T * (NEGM + DM) + NU - 1) / NU;
-    const int u = tid - 64;
-    int ui[RU], ue[RU];
-    double val[RU];
+    if (k >= 1 && last > k) {
+      // the later nodes of this wave: P <- P - c q q^T, b <- b + v u
+      s_q[tid] = qj;
+      gg_lds_wait();
+      if (act && i > k) {
+        const double cq = c * qj;
 #pragma unroll
-    for (int r = 0; r < RU; ++r) {
-      const int idx = u + NU * r;
-      const bool v = idx < T * NE;
-      ui[r] = v ? idx / NE : -1;
-      ue[r] = v ? idx % NE : 0;
-      val[r] = v ? s_part[ui[r] * (NEGM + DM) + ue[r]] : 0.0;
-    }
-    for (int k = 0; k + 2 < T; ++k) {          // change k goes to nodes k+2 .. T-1 (node k+1 is the solver's)
-      for (int spin = 0; s_prog[0] < k + 1; ++spin) {
-        if (spin > (1 << 22)) { if (lane == 0) atomicOr(status, 2); break; }   // never spin forever
-        __builtin_amdgcn_s_sleep(1);
-      }
-      __threadfence_block();
-      double sv[RU], dd[RU], aa[RU];
+        for (int m = 0; m < DM; ++m) Prow[m] = gg_fma(-cq, s_q[gbase + m], Prow[m]);
 #pragma unroll
-      for (int r = 0; r < RU; ++r) {
-        const bool act = ui[r] >= k + 2;
-        const int i = act ? ui[r] : 0, e = ue[r];
-        sv[r] = s_S[i * (EIG_T + 1) + k];
-        dd[r] = (e < NEG) ? s_dP[k * NEGM + e] : s_dF[k * DM + (e - NEG)];
-        aa[r] = ka * (double)s_a[i * EIG_T + k];
+        for (int m = 0; m < DM; ++m) bfull[m] = gg_fma(v, u[m], bfull[m]);
       }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < RU; ++r) {
-        if (ui[r] >= k + 2) {
-          const double svr = probit ? 2.0 : sv[r];
-          const double coef = (ue[r] < NEG) ? svr : gg_fma(-mu0, svr, probit ? sv[r] : aa[r]);
-          val[r] = gg_fma(coef, dd[r], val[r]);
-          s_part[ui[r] * (NEGM + DM) + ue[r]] = val[r];
-        }
-      }
-      __threadfence_block();
-      if (lane == 0) s_progb[wave] = (unsigned char)(k + 1);
+      gg_lds_wait();
+      if (((k + 1) % NW) == wave) prepare_r();   // node k + 1 closes next: its r = P b with every change but the last
     }
   }
+  __syncthreads();
+  if (dbg && tid == 0) {
+    atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)(clock64() - c_scan));
+    atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)T);
+    atomicAdd((unsigned long long*)&dbg[5], (unsigned long long)(c_scan - c_start));
+  }
+  // the tile's new features -> global memory (nothing in this launch reads them: the riders leave this tile out)
+  for (int e = tid; e < T * D; e += NTH) F[(size_t)(t0 + e / D) * D + e % D] = s_Fn[(e / D) * DM + e % D];
 }
 
 // Statistics of _resample_mu_0 (eigenmodel.py:914-925) and _resample_lmbda (:938-958) over pairs i < j:
@@ -848,6 +836,7 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   e->DM = cfg->D <= 4 ? 4 : 8;
   e->NEG = e->D * (e->D + 1) / 2; e->NE = e->NEG + e->D;
   e->NG = 2 + 2 * e->DM + e->DM * (e->DM + 1) / 2;
+  e->NEm = e->DM * (e->DM + 1) / 2 + e->DM;
   e->NCH = (e->N + EIG_CHN - 1) / EIG_CHN;
   int rc;
   GG_HIP(hipStreamCreate(&e->stream));
@@ -856,7 +845,8 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   const size_t N = e->N, D = e->D;
   if ((rc = emalloc(&e->F, N * D)) || (rc = emalloc(&e->lmbda, D)) || (rc = emalloc(&e->mu0, 1)) ||
       (rc = emalloc(&e->mu_lmbda, D)) || (rc = emalloc(&e->S, N * e->Np)) || (rc = emalloc(&e->dO, N)) ||
-      (rc = emalloc(&e->Z, N * D)) || (rc = emalloc(&e->part, (size_t)2 * EIG_T * e->NCH * e->NE)) ||
+      (rc = emalloc(&e->Z, N * D)) || (rc = emalloc(&e->part, (size_t)2 * EIG_T * e->NCH * e->NEm)) ||
+      (rc = emalloc(&e->Sb, N * EIG_VW)) || (rc = emalloc(&e->Vb, N * EIG_VW)) ||
       (rc = emalloc(&e->gpart, N * e->NG)) || (rc = emalloc(&e->status, 1)) || (rc = emalloc(&e->dbgbuf, 16)))
     return rc;
   const size_t nt = (N + 31) / 32;
@@ -867,7 +857,7 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
 
 int gg_eigen_destroy(gg_eigen* e) {
   if (!e) return GG_OK;
-  void* ptrs[] = {e->F, e->lmbda, e->mu0, e->mu_lmbda, e->S, e->dO, e->Z, e->part, e->gpart, e->llpart, e->status};
+  void* ptrs[] = {e->F, e->lmbda, e->mu0, e->mu_lmbda, e->S, e->dO, e->Z, e->Sb, e->Vb, e->part, e->gpart, e->llpart, e->status, e->dbgbuf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->e0) (void)hipEventDestroy(e->e0);
   if (e->e1) (void)hipEventDestroy(e->e1);
@@ -973,26 +963,25 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
     if (dbgon < 0) { const char* ev = getenv("GG_EIG_DBG"); dbgon = ev ? atoi(ev) : 0; }
     long long* dbg = dbgon ? e->dbgbuf : nullptr;
     if (dbg) GG_HIP(hipMemsetAsync(dbg, 0, 16 * sizeof(long long), st));
-    const int DMv = e->DM, NEGMv = DMv * (DMv + 1) / 2;
-    const size_t chain_lds = (((size_t)EIG_T * (EIG_T + 1) + (size_t)EIG_T * NEGMv + 3 * (size_t)EIG_T * DMv +
-                               (size_t)EIG_T * (NEGMv + DMv) + (NEGMv + DMv)) * sizeof(double) + (size_t)EIG_T * EIG_T + 64 + 15) & ~(size_t)15;
+    const int DMv = e->DM, nth = 64 * DMv;
+    const size_t chain_lds = (((size_t)2 * EIG_T * (EIG_T + 1) + (size_t)EIG_T * e->NEm + 3 * (size_t)EIG_T * DMv + nth) * sizeof(double) + 16 + 15) & ~(size_t)15;
     static bool attr4 = false, attr8 = false;
     if (DMv == 4 && !attr4) {
-      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
-      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
       attr4 = true;
     }
     if (DMv == 8 && !attr8) {
-      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
-      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+      GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
       attr8 = true;
     }
+    // the tile-local blocks of pair weights and mean coefficients (previous tile | own tile) for every node
+    k_eig_vblocks<<<N, 64, 0, st>>>(N, Np, e->S, d->A, d->AT, e->mu0, e->Sb, e->Vb, e->probit, e->beta, e->cfg.seed, e->sweep);
     // Tile 0's statistics in a launch of their own; every chain launch then carries, as extra workgroups, the
     // statistics of the tile after it (all nodes outside both tiles), and adds the previous tile's nodes itself.
-    const size_t part_stride = (size_t)EIG_T * e->NCH * e->NE;
+    const size_t part_stride = (size_t)EIG_T * e->NCH * e->NEm;
     {
       dim3 grd(N < EIG_T ? N : EIG_T, e->NCH);
-#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 1024, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, 0, e->probit, e->beta)
+#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 64 * DMV, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, e->probit, e->beta, e->cfg.seed, e->sweep)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -1003,12 +992,9 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
       const int Tn = (t0 + EIG_T < N) ? ((N - t0 - EIG_T < EIG_T) ? (N - t0 - EIG_T) : EIG_T) : 0;
       const int grid = 1 + Tn * e->NCH;
 #define CALL(DMV)                                                                                                      \
-  if (D == DMV)                                                                                                        \
-    k_eig_chain<DMV, true><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,       \
-                                                         e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit, e->beta); \
-  else                                                                                                                 \
-    k_eig_chain<DMV, false><<<grid, 512, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,      \
-                                                          e->cfg.sigma_F, e->NCH, partb, e->Z, e->status, dbg, partn, e->probit, e->beta)
+  k_eig_chain<DMV><<<grid, 64 * DMV, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,           \
+                                                      e->cfg.sigma_F, e->NCH, partb, e->Z, e->Sb, e->Vb, e->status, dbg, \
+                                                      partn, e->probit, e->beta, e->cfg.seed, e->sweep)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -1035,8 +1021,7 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   if (getenv("GG_EIG_DBG") && (parts & GG_PART_F)) {
     long long h[16];
     (void)hipMemcpy(h, e->dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
-    if (h[3]) fprintf(stderr, "[eig chain]   solver lane per node: fold %.0f, load %.0f, cholesky %.0f, solves %.0f clocks\n", (double)h[11] / h[3], (double)h[8] / h[3], (double)h[9] / h[3], (double)h[10] / h[3]);
-    if (h[3]) fprintf(stderr, "[eig chain] per node: wait %.0f fold %.0f solve %.0f shader clocks (%lld nodes); prologue %.0f clocks per tile (block %.0f, +loads %.0f, +cross %.0f)\n", (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / ((h[3] + EIG_T - 1) / EIG_T), (double)h[5] / 64, (double)h[6] / 64, (double)h[7] / 64);
+    if (h[3]) fprintf(stderr, "[eig chain] per node: scan %.0f shader clocks (%lld nodes); per tile: prologue %.0f clocks (of which statistics + products %.0f)\n", (double)h[2] / h[3], h[3], (double)h[5] / ((h[3] + EIG_T - 1) / EIG_T), (double)h[4] / ((h[3] + EIG_T - 1) / EIG_T));
   }
   if (stv) {
     int z = 0;

@@ -367,6 +367,13 @@ def pg_frac_vec(seed, b, z, n):
     return out
 
 
+def eig_noise_row(seed, sweep, N, n):
+    """eps[n, :] of the perturbation draw of F[n] (spec/gg_eig.h)."""
+    out = np.empty(N)
+    lib().orc_eig_noise_row(C.c_uint64(seed), C.c_uint32(sweep), int(N), int(n), _f64(out))
+    return out
+
+
 def pg1_vec(seed, z, n):
     out = np.empty(n)
     lib().orc_pg1_vec(C.c_uint64(seed), C.c_double(z), _f64(out), C.c_longlong(n))

@@ -17,6 +17,7 @@
 #include "../graphistician_amd/csrc/spec/gg_math.h"
 #include "../graphistician_amd/csrc/spec/gg_draws.h"
 #include "../graphistician_amd/csrc/spec/gg_pg.h"
+#include "../graphistician_amd/csrc/spec/gg_eig.h"
 
 #define ORC_PART_OMEGA 8
 #define ORC_PART_F 16
@@ -51,27 +52,35 @@ void orc_eig_resample_omega(int N, int D, const double* F, const double* lmbda, 
     }
 }
 
-// eigenmodel.py:876-908 _resample_F: sequential over nodes, F[n] updated in place.
+// eigenmodel.py:876-908 _resample_F: sequential over nodes, F[n] updated in place.  Precision and mean term are the
+// reference's double loop; the draw F[n] ~ N(prec^{-1} h, prec^{-1}) (:908, np.random.multivariate_normal) is made by
+// perturbation (spec/gg_eig.h): b = h + z / sqrt(sigma_F) + sum_nn sqrt(O[n,nn] + O[nn,n]) eps[n,nn] f_nn * lambda,
+// x = prec^{-1} b - the same law, no matrix square root.
 int orc_eig_resample_F(int N, int D, const uint8_t* A, const double* Omega, double* F, const double* lmbda,
                        double mu_0, double sigma_F, uint64_t seed, uint32_t sweep, double beta) {
-  std::vector<double> prec((size_t)D * D), h(D), z(D), x(D);
+  std::vector<double> prec((size_t)D * D), h(D), b(D), x(D);
   for (int n = 0; n < N; ++n) {
     for (int a = 0; a < D * D; ++a) prec[a] = 0.0;
-    for (int a = 0; a < D; ++a) { prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0; }
+    for (int a = 0; a < D; ++a) {
+      prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0;
+      b[a] = gg_normal_at(seed, GG_SITE_EIG_F, sweep, (uint32_t)(n * D + a)) / gg_sqrt(sigma_F);
+    }
     for (int nn = 0; nn < N; ++nn) {
       if (nn == n) continue;
       const double o1 = Omega[(size_t)n * N + nn], o2 = Omega[(size_t)nn * N + n];
       // O * zcent = kappa - O mu_0 with kappa = A - 1/2 (eigenmodel.py:813-820,892)
       const double k1 = beta * ((A[(size_t)n * N + nn] ? 1.0 : 0.0) - 0.5) - o1 * mu_0;
       const double k2 = beta * ((A[(size_t)nn * N + n] ? 1.0 : 0.0) - 0.5) - o2 * mu_0;
+      const double w = gg_sqrt(o1 + o2) * gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
       const double* f = F + (size_t)nn * D;
       for (int a = 0; a < D; ++a) {
-        for (int b = 0; b < D; ++b) prec[a * D + b] += f[a] * f[b] * lmbda[a] * lmbda[b] * (o1 + o2);
+        for (int c = 0; c < D; ++c) prec[a * D + c] += f[a] * f[c] * lmbda[a] * lmbda[c] * (o1 + o2);
         h[a] += (k1 + k2) * f[a] * lmbda[a];
+        b[a] += w * f[a] * lmbda[a];
       }
     }
-    for (int a = 0; a < D; ++a) z[a] = gg_normal_at(seed, GG_SITE_EIG_F, sweep, (uint32_t)(n * D + a));
-    if (gg_gauss_from_precision(prec.data(), h.data(), z.data(), D, x.data())) return -5;
+    for (int a = 0; a < D; ++a) b[a] += h[a];
+    if (gg_solve_spd(prec.data(), b.data(), D, x.data())) return -5;
     for (int a = 0; a < D; ++a) F[(size_t)n * D + a] = x[a];
   }
   return 0;
@@ -155,6 +164,11 @@ void orc_pg_frac_vec(uint64_t seed, double b, double z, double* out, long long n
   }
 }
 
+// The per-pair normals of the perturbation draw (spec/gg_eig.h), row n: out[nn] for nn < N.
+void orc_eig_noise_row(uint64_t seed, uint32_t sweep, int N, int n, double* out) {
+  for (int nn = 0; nn < N; ++nn) out[nn] = gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
+}
+
 // PG(1, z) draws for distributional tests: n draws, stream index = i.
 void orc_pg1_vec(uint64_t seed, double z, double* out, long long n) {
   for (long long i = 0; i < n; ++i) {
@@ -185,25 +199,30 @@ void orc_probit_resample_Z(int N, int D, const uint8_t* A, const double* F, cons
                                              eig_psi(N, D, F, lmbda, mu_0, i, j), A[(size_t)i * N + j] ? 1 : 0);
 }
 
-// eigenmodel.py:295-329 _resample_F.
+// eigenmodel.py:295-329 _resample_F (the draw by perturbation, as in orc_eig_resample_F: pair weight 2).
 int orc_probit_resample_F(int N, int D, const double* Z, double* F, const double* lmbda, double mu_0, double sigma_F,
                           uint64_t seed, uint32_t sweep) {
-  std::vector<double> prec((size_t)D * D), h(D), z(D), x(D);
+  std::vector<double> prec((size_t)D * D), h(D), b(D), x(D);
   for (int n = 0; n < N; ++n) {
     for (int a = 0; a < D * D; ++a) prec[a] = 0.0;
-    for (int a = 0; a < D; ++a) { prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0; }
+    for (int a = 0; a < D; ++a) {
+      prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0;
+      b[a] = gg_normal_at(seed, GG_SITE_EIG_F, sweep, (uint32_t)(n * D + a)) / gg_sqrt(sigma_F);
+    }
     for (int nn = 0; nn < N; ++nn) {
       if (nn == n) continue;
       const double* f = F + (size_t)nn * D;
       const double z1 = Z[(size_t)nn * N + n] - mu_0, z2 = Z[(size_t)n * N + nn] - mu_0;
+      const double w = gg_sqrt(2.0) * gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
       for (int a = 0; a < D; ++a) {
-        for (int b = 0; b < D; ++b) prec[a * D + b] += 2.0 * f[a] * f[b] * lmbda[a] * lmbda[b];
+        for (int c = 0; c < D; ++c) prec[a * D + c] += 2.0 * f[a] * f[c] * lmbda[a] * lmbda[c];
         h[a] += z1 * f[a] * lmbda[a];
         h[a] += z2 * f[a] * lmbda[a];
+        b[a] += w * f[a] * lmbda[a];
       }
     }
-    for (int a = 0; a < D; ++a) z[a] = gg_normal_at(seed, GG_SITE_EIG_F, sweep, (uint32_t)(n * D + a));
-    if (gg_gauss_from_precision(prec.data(), h.data(), z.data(), D, x.data())) return -5;
+    for (int a = 0; a < D; ++a) b[a] += h[a];
+    if (gg_solve_spd(prec.data(), b.data(), D, x.data())) return -5;
     for (int a = 0; a < D; ++a) F[(size_t)n * D + a] = x[a];
   }
   return 0;

@@ -30,6 +30,16 @@ def gauss_from_precision(prec, h, z):
     return np.linalg.solve(L.T, y)
 
 
+def perturbation_draw(prec, h, S_row, G, n, sigma_F, seed, sweep, D):
+    """spec/gg_eig.h: x = prec^{-1} (h + z / sqrt(sigma_F) + sum_nn sqrt(s[n,nn]) eps[n,nn] g_nn), the law of
+    np.random.multivariate_normal(prec^{-1} h, prec^{-1}) (eigenmodel.py:905-908) without a matrix square root."""
+    N = G.shape[0]
+    z = np.array([O.normal_at(seed, SITE_F, sweep, n * D + d) for d in range(D)])
+    w = np.sqrt(S_row) * O.eig_noise_row(seed, sweep, N, n)
+    w[n] = 0.0
+    return np.linalg.solve(prec, h + z / np.sqrt(sigma_F) + w @ G)
+
+
 # ---------------------------------------------------------------- CPU
 def test_pg1_moments_and_law():
     """E = tanh(z/2)/(2z) (anchor at eigenmodel.py:1062-1063), Var = (sinh z - z)/(4 z^3 cosh^2(z/2));
@@ -61,8 +71,7 @@ def test_oracle_sweep_follows_the_reference_formulas():
     Fp = F_in.copy()
     for n in range(N):
         prec, h = R.eigen_F_conditional(A, Om, Fp, lmbda, mu_0, sF, n)
-        z = np.array([O.normal_at(seed, SITE_F, 3, n * D + d) for d in range(D)])
-        Fp[n] = gauss_from_precision(prec, h, z)
+        Fp[n] = perturbation_draw(prec, h, Om[n] + Om[:, n], Fp * lmbda, n, sF, seed, 3, D)
     assert np.allclose(Fo, Fp, rtol=1e-10, atol=1e-12)
     # mu_0 (eigenmodel.py:910-932)
     mu_new, _ = O.eig_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_MU0, Omega=Om)
@@ -76,6 +85,39 @@ def test_oracle_sweep_follows_the_reference_formulas():
     assert np.allclose(lo, gauss_from_precision(prec, h, z), rtol=1e-10, atol=1e-12)
     # log-likelihood (eigenmodel.py:110-129)
     assert abs(O.eig_loglik(A, Fo, lo, mu_new) - R.eigen_loglik(A, Fo, lo, mu_new)) < 1e-9
+
+
+def test_perturbation_draw_has_the_conditional_law():
+    """The draw of F[n] (spec/gg_eig.h) against the reference's np.random.multivariate_normal(Sigma h, Sigma)
+    (eigenmodel.py:903-908): over many Philox sweeps, x = prec^{-1}(h + xi) must have mean prec^{-1} h and
+    covariance prec^{-1}; the per-pair normals themselves are checked against N(0, 1)."""
+    N, D, n = 7, 3, 2
+    A, F, lmbda, mu_0 = make_case(N, D, 11)
+    rng = np.random.RandomState(3)
+    Om = rng.gamma(2.0, 0.2, size=(N, N))
+    prec, h = R.eigen_F_conditional(A, Om, F, lmbda, mu_0, 0.7, n)
+    Sigma = np.linalg.inv(prec)
+    xs = []
+    for sweep in range(6000):
+        Fo = F.copy()
+        # one node only: the oracle's scan with every other row restored afterwards would be the same draw
+        xs.append(perturbation_draw(prec, h, Om[n] + Om[:, n], F * lmbda, n, 0.7, 321, sweep, D))
+    xs = np.array(xs)
+    se = np.sqrt(np.diag(Sigma) / len(xs))
+    assert np.all(np.abs(xs.mean(0) - Sigma @ h) < 4.5 * se)
+    C = np.cov(xs.T)
+    assert np.allclose(C, Sigma, rtol=0.12, atol=0.06 * np.sqrt(np.outer(np.diag(Sigma), np.diag(Sigma))).max())
+    L = np.linalg.cholesky(prec)
+    white = (xs - Sigma @ h) @ L          # L^T (x - mean) ~ N(0, I)
+    for d in range(D):
+        assert stats.kstest(white[:, d], "norm").pvalue > 1e-3
+    # and the oracle's own scan uses exactly this draw for node 0 of a sweep
+    Fo = F.copy()
+    O.eig_sweep(A, Fo, lmbda, mu_0, np.zeros(D), 0.0, 1.0, 0.7, 1.0, 0, 321, 5, parts=O.PART_F, Omega=Om)
+    p0, h0 = R.eigen_F_conditional(A, Om, F, lmbda, mu_0, 0.7, 0)
+    assert np.allclose(Fo[0], perturbation_draw(p0, h0, Om[0] + Om[:, 0], F * lmbda, 0, 0.7, 321, 5, D), rtol=1e-10)
+    eps = np.concatenate([O.eig_noise_row(9, s, 64, 3) for s in range(400)])
+    assert stats.kstest(eps, "norm").pvalue > 1e-3 and abs(eps.mean()) < 0.03 and abs(eps.var() - 1) < 0.03
 
 
 def test_geweke_eigenmodel_prior_recovery():
@@ -308,8 +350,7 @@ def test_probit_oracle_follows_the_reference_formulas():
     Fp = F.copy()
     for n in range(N):
         prec, h = probit_F_conditional(Z, Fp, lmbda, mu_0, sF, n)
-        z = np.array([O.normal_at(seed, SITE_F, 3, n * D + d) for d in range(D)])
-        Fp[n] = gauss_from_precision(prec, h, z)
+        Fp[n] = perturbation_draw(prec, h, np.full(N, 2.0), Fp * lmbda, n, sF, seed, 3, D)
     assert np.allclose(Fo, Fp, rtol=1e-10, atol=1e-12)
     # mu_0 (eigenmodel.py:331-352)
     mu_new, _ = O.probit_sweep(A, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 3, parts=O.PART_MU0, Z=Z)
