@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
   double* s_u = s_g + EIG_T * DM;                     // [T][DM]   published new f * lambda of this tile's nodes
   double* s_Fn = s_u + EIG_T * DM;                    // [T][DM]   new features
   double* s_q = s_Fn + EIG_T * DM;                    // [NTH]     gather scratch, one slot per lane
-  volatile int* s_pub = reinterpret_cast<volatile int*>(s_q + NTH);
+  int* s_pub = reinterpret_cast<int*>(s_q + NTH);      // (plain LDS accesses behind compiler barriers: a volatile pointer here becomes flat loads)
   const int tid = threadIdx.x;
   const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
   const int p0 = t0 - EIG_T;       // first node of the previous tile (left out by the riders that ran beside its scan)
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
   __syncthreads();
   if (dbg && tid == 0) atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(clock64() - c_start));
   // ---- every lane: Cholesky of its node's precision (the DM lanes of a node do the same arithmetic), row j of the inverse
-  const int wave = tid >> 6, grp = (tid & 63) / DM, j = tid % DM;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = (tid & 63) / DM, j = tid % DM;
   const int i = grp * NW + wave;                  // this lane's node
   const int gbase = (tid / DM) * DM;              // first lane of the group (its slots of the gather scratch)
   const bool live = i < T;
@@ -586,10 +586,13 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
     const bool closer = (k % NW) == wave;       // this wave holds node k
     double u[DM], uj = 0.0, s = 0.0, v = 0.0, qj = 0.0, c = 0.0, tq = 0.0;
     if (k >= 1) {
-      for (int spin = 0; *s_pub < k; ++spin) {
+      for (int spin = 0;; ++spin) {
+        asm volatile("" ::: "memory");
+        if (*s_pub >= k) break;
         if (spin > (1 << 24)) { if ((tid & 63) == 0) atomicOr(status, 2); break; }   // never spin forever
         if (!closer) __builtin_amdgcn_s_sleep(1);
       }
+      asm volatile("" ::: "memory");
       gg_lds_wait();
 #pragma unroll
       for (int m = 0; m < DM; ++m) u[m] = s_u[(k - 1) * DM + m];
@@ -619,6 +622,7 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
       }
       gg_lds_wait();   // LDS traffic of one wave is performed in order: the data is written before the word that announces it
       if (act && i == k && j == 0) *s_pub = k + 1;
+      asm volatile("" ::: "memory");
     }
     if (k >= 1 && last > k) {
       // the later nodes of this wave: P <- P - c q q^T, b <- b + v u
