@@ -5,10 +5,17 @@ One *step* = one full sweep = FactorizedNetworkDistribution.resample((A,W))
 (reference networks.py:69-71): the SBM adjacency half (adjacency.py:615-618)
 followed by the SBM Gaussian-weight half (weights.py:394-397), on a synthetic
 planted Gaussian SBM resident in HBM.  N=1 runs BASELINE.json configs[1]
-(N=4096, K=16, B=1, dense).  With --gpus G (one process per GPU, launched by
-torch.distributed.run) every rank runs an independent chain on its own copy of
-the workload (north_star: "otherwise independent chains map one-per-GPU"), no
-data-path collective; value = total sweeps / max-over-ranks time.
+(N=4096, K=16, B=1, dense) and reports a MIX of chains: how many labels a chain
+keeps changing per sweep depends on its prior draw, so `value` = all timed sweeps /
+all timed seconds over chain seeds 1..6 (K sweeps each), the quiet chain alone in
+`quiet_chain`.  With --gpus G > 1 (one process per GPU, launched by
+torch.distributed.run) the workload is BASELINE.json configs[3] (N=65536, K=64):
+every rank runs an independent replica of the chain on its own copy of the network
+(north_star: "otherwise independent chains map one-per-GPU"), no data-path
+collective, value = total sweeps / max-over-ranks time (weak scaling) - and the
+same line carries, under `sharded_chain`, ONE chain of that network sharded over
+the G GPUs (exact; RCCL inside the library; strong scaling).  --shard prints the
+sharded chain as the line itself.
 
 Prints ONE JSON line (rank 0).  torch is used only for the multi-process
 rendezvous / barrier; the engine itself is ctypes -> libgraphgibbs.so.
@@ -201,28 +208,25 @@ def cpu_literal_extrapolated(N, K, seed=3):
                        "by operation count: %.0f s adjacency half + %.0f s weight half per sweep" % (Na, Nb, K0, N, K, t_adj, t_w))
 
 
-def pmc_traffic(N, alg_bytes, ahead):
-    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries (FETCH_SIZE and
-    WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction: tools/scripts/profile_r02.sh, tools/pmc_traffic.py).
-    Counters cannot be collected inside this process; the figure is the measurement of this very launch shape when one is on file
-    (N = 4096: the fused sweep launch), otherwise the algorithmic bytes times the ratio measured past the Infinity Cache (N = 32768)."""
+def pmc_traffic(N, K, forms):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel, FROM THE COMMITTED PROFILE of that launch shape
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction:
+    tools/scripts/profile_r02.sh, tools/pmc_traffic.py) - counters cannot be collected inside this process.  Only when the
+    run is the profiled shape (N=4096, K=16, the fused launch for most sweeps); null otherwise."""
     try:
-        here = os.path.join(ROOT, "profiles")
-        if N == 4096 and ahead:
-            e = json.load(open(os.path.join(here, "r02_pmc_traffic_n4096.json")))["k_sweep_q<3"]
-            return {"traffic": e["traffic_bytes"],
-                    "note": "measured at N=4096 on k_sweep_q<3,false,0,0> (profiles/r02_pmc_traffic_n4096.json): %.1f MB read (FETCH_SIZE x 2) + "
-                            "%.1f MB written per launch against %.1f MB algorithmic (ratio %.3f: the riders' pass plus the scan's and the "
-                            "parameter step's own reads, the zeroing of one statistics buffer and the integer atomics); at this size the 138 MB "
-                            "working set stays in the 256 MiB Infinity Cache, whose hits the memory-side counters include"
-                            % (e["hbm_read_bytes_corrected"] / 1e6, e["hbm_write_bytes"] / 1e6, e["algorithmic_bytes_per_launch"] / 1e6,
-                               e["traffic_over_algorithmic"])}
-        e = json.load(open(os.path.join(here, "r02_pmc_traffic_n32768.json")))["k_bulk_w"]
-        return {"traffic": alg_bytes * e["traffic_over_algorithmic"],
-                "note": "algorithmic bytes x %.3f, the traffic / algorithmic ratio of k_bulk_w<1,4,true> measured past the Infinity Cache at "
-                        "N=32768 (8.74 GB per launch against 8.59 GB; profiles/r02_pmc_traffic_n32768.json)" % e["traffic_over_algorithmic"]}
+        fused = forms.get("sweeps_fused", 0)
+        if (N, K) == (4096, 16) and fused > forms.get("sweeps_serial", 0) + forms.get("sweeps_two_launch", 0):
+            e = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_n4096.json")))["k_sweep_q<3"]
+            return {"traffic": e["traffic_bytes"], "traffic_source": "from_profile: profiles/r02_pmc_traffic_n4096.json (round 2, commit d9720d9)",
+                    "note": "k_sweep_q<3,false,0,0> at N=4096: %.1f MB read (FETCH_SIZE x 2) + %.1f MB written per launch against %.1f MB "
+                            "algorithmic (ratio %.3f); the 138 MB working set stays in the 256 MiB Infinity Cache, whose hits the "
+                            "memory-side counters include" % (e["hbm_read_bytes_corrected"] / 1e6, e["hbm_write_bytes"] / 1e6,
+                                                              e["algorithmic_bytes_per_launch"] / 1e6, e["traffic_over_algorithmic"])}
+        return {"traffic": None, "traffic_source": None,
+                "note": "no PMC profile of this launch shape on file (N=%d, K=%d, forms %s); profiles/r02_pmc_traffic_n32768.json holds "
+                        "k_bulk_w<1,4,true> at N=32768: 8.74 GB per launch against 8.59 GB algorithmic" % (N, K, forms)}
     except Exception as exc:
-        return {"traffic": None, "note": "no PMC summary on file (%s)" % exc}
+        return {"traffic": None, "traffic_source": None, "note": "no PMC summary on file (%s)" % exc}
 
 
 def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every, barrier=lambda: None, stepwise=False):
@@ -260,23 +264,10 @@ def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every,
                 changes=sa["label_changes"] + sw["label_changes"] - chg0,
                 rounds=sa["resolve_rounds"] + sw["resolve_rounds"] - rnd0,
                 changes_adj=sa["label_changes"], changes_w=sw["label_changes"],
-                # the quiet chain ran in the ahead form (fused launches carrying the next sweeps' pass) unless it was switched off
-                ahead=bool(os.environ.get("GG_AHEAD", "1") != "0" and os.environ.get("GG_SCAN") is None and
-                           sa["label_changes"] + sw["label_changes"] - chg0 == 0))
-
-
-def extra_mixing_chains(abi, data, N, K, device, burnin, steps=100):
-    """The headline chain (seed 1) settles into zero label changes per sweep; chains 2 and 4 keep mixing (the scan's
-    sequential machinery at work in the timed region).  Same network, same kernels, other prior draws."""
-    out = []
-    for seed in (2, 4):
-        r = run_chain(abi, data, N, K, seed, device, burnin, 10, steps, 0)
-        out.append({"chain_seed": seed, "value": steps / r["elapsed"], "unit": "sweeps/s", "ms_per_step": r["elapsed"] / steps * 1e3,
-                    "label_changes_per_sweep": r["changes"] / float(steps),
-                    # both models' scans: 1 per quiet scan, 1 per grid-wide exchange of a resident scan (hypothesis rounds)
-                    "scan_rounds_per_sweep": r["rounds"] / float(steps)})
-        del r
-    return out
+                # how the engine ran the weight model's sweeps of the timed region (gg_stats: enqueued sweeps by form)
+                forms={k: int(sw[k] - st0w[k]) for k in ("sweeps_fused", "sweeps_two_launch", "sweeps_serial")},
+                forms_adj={k: int(sa[k] - st0a[k]) for k in ("sweeps_fused", "sweeps_two_launch", "sweeps_serial")},
+                ahead=bool(sw["sweeps_fused"] - st0w["sweeps_fused"] > (sw["sweeps_serial"] - st0w["sweeps_serial"])))
 
 
 def extra_eigen(abi, device, N=4096, D=8, warmup=5, steps=20):
@@ -496,10 +487,15 @@ def bench_latent_w(args, abi, device, rank, world, barrier, max_over_ranks):
 
 
 def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
-    """One Gaussian-SBM chain sharded over the ranks (strong scaling; BASELINE.json configs[3] at --nodes 65536
-    --blocks 64): exact — the same chain for any number of ranks (graphistician_amd/sharded.py)."""
+    line = run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, args.nodes, args.blocks)
+    if rank == 0:
+        _emit(json.dumps(line))
+
+
+def run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K):
+    """One Gaussian-SBM chain sharded over the ranks (strong scaling; BASELINE.json configs[3] at N=65536, K=64):
+    exact - the same chain for any number of ranks (graphistician_amd/sharded.py).  Returns the result line (rank 0)."""
     from graphistician_amd import sharded as S
-    N, K = args.nodes, args.blocks
     # collectives: the library's own RCCL calls (one process per GPU); GG_BENCH_BACKEND=gloo (CPU-side tests, several ranks on
     # one GPU) routes them through host callbacks instead.  torch.distributed is the launcher / rendezvous only.
     # (RCCL greets with a version banner on stdout when its first communicator comes up: that goes to stderr here, stdout
@@ -550,9 +546,10 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
     rnd = adj.stats()["resolve_rounds"] + w.stats()["resolve_rounds"] - rnd0
     digest = int(np.bitwise_xor.reduce(adj.get(abi.ST_C, (N,), np.int32) * np.arange(1, N + 1, dtype=np.int32)))
     cinfo = comm.info()
+    del adj, w, data
     if rank == 0:
         sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
-        _emit(json.dumps({
+        return ({
             "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": args.steps / el,
             "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -570,7 +567,8 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
                        "sweep_algorithmic_bytes": sweep_bytes, "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9},
             "roofline": {"bound": "hbm", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": sweep_bytes * args.steps / el / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                         "note": "whole-sweep effective rate over the aggregate HBM peak of the ranks"}}))
+                         "note": "whole-sweep effective rate over the aggregate HBM peak of the ranks"}})
+    return None
 
 
 def main():
@@ -583,10 +581,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--nodes", type=int, default=4096)
-    ap.add_argument("--blocks", type=int, default=16)
+    ap.add_argument("--nodes", type=int, default=None, help="default: 4096 on one GPU (configs[1]), 65536 with --gpus G > 1 (configs[3])")
+    ap.add_argument("--blocks", type=int, default=None, help="default: 16 on one GPU, 64 with --gpus G > 1")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
-    ap.add_argument("--burnin", type=int, default=30,
+    ap.add_argument("--burnin", type=int, default=None,
                     help="sweeps run as part of chain set-up, before the W warm-up steps: the chain starts from a prior draw "
                          "and relabels thousands of nodes in its first few sweeps; the metric is the sampler's steady state")
     ap.add_argument("--no-cpu", action="store_true")
@@ -642,6 +640,12 @@ def main():
         return
 
     from graphistician_amd import _abi as abi
+    if args.nodes is None:
+        args.nodes = 4096 if (world == 1 or args.config != "sbm") else 65536
+    if args.blocks is None:
+        args.blocks = 16 if args.nodes < 32768 else 64
+    if args.burnin is None:
+        args.burnin = 30 if args.nodes < 32768 else 12
     N, K = args.nodes, args.blocks
     device = local_rank
     if os.environ.get("GG_BENCH_SAME_DEVICE"):      # several ranks on one GPU (tests on a 1-GPU box)
@@ -662,41 +666,70 @@ def main():
     truth = planted_truth(N, K, seed=1234)
     data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
                                         truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
-    # Weak scaling needs the same work on every GPU: how many labels a chain keeps changing per sweep (and so how
-    # much of the scan's slow path it exercises) depends on its prior draw, so every rank runs a replica of the
-    # SAME chain (GG_BENCH_CHAIN_SEED, default 1).  Independent chains differ only in this seed.
-    chain_seed = int(os.environ.get("GG_BENCH_CHAIN_SEED", "1"))
-    # HIP events (on the engine streams) around the launches that stream the data: every one of them for short runs (the
-    # (each record costs the stream a barrier packet that drains the queue: 2-3 us of a 38 us sweep when every third launch
-    # is sampled, a quarter of the timed region of the driver's --steps 20 when every launch is)
-    every = max(1, -(-args.steps // 8))     # about 8 sampled launches whatever the run length
-    r = run_chain(abi, data, N, K, chain_seed, device, args.burnin, args.warmup, args.steps, every, barrier,
-                  stepwise=bool(os.environ.get("GG_BENCH_STEPWISE")))
-    adj, w, el, bulk, chg = r["adj"], r["w"], r["elapsed"], r["bulk"], r["changes"]
-    if rank == 0:
-        _progress("timed region done: %d sweeps in %.3f s" % (args.steps, el))
-    el = max_over_ranks(el)
+    # How many labels a chain keeps changing per sweep - and so how much of the scan's sequential machinery runs in the timed
+    # region - depends on its prior draw: of six chain seeds at N=4096 two settle into zero changes, two change a few labels now
+    # and then, two keep mixing.  The headline is therefore the MIX: every seed runs its own burn-in,
+    # warm-up and K timed sweeps (each timed segment bracketed by the barrier), value = all timed sweeps / all timed seconds.
+    # Every rank runs the same seeds (weak scaling needs the same work on every GPU).  GG_BENCH_CHAIN_SEED=s: that chain only.
+    if os.environ.get("GG_BENCH_CHAIN_SEED"):
+        seeds = [int(os.environ["GG_BENCH_CHAIN_SEED"])]
+    elif os.environ.get("GG_BENCH_CHAIN_SEEDS"):
+        seeds = [int(x) for x in os.environ["GG_BENCH_CHAIN_SEEDS"].split(",")]
+    else:
+        seeds = [1, 2, 3, 4, 5, 6] if N < 32768 else [1]
+    # HIP events (on the engine streams) around the launches that stream the data: about 8 sampled launches per chain whatever
+    # the run length at small N (each record costs the stream a barrier packet that drains the queue: a quarter of the timed
+    # region of the driver's --steps 20 if every launch were sampled), every launch for N > 8192
+    every = 1 if N > 8192 else max(1, -(-args.steps // 8))
+    chains, total_el = [], 0.0
+    bulk = dict(w_ms=0.0, w_n=0, w_bytes=0.0, adj_ms=0.0, adj_n=0, adj_bytes=0.0)
+    forms = dict(sweeps_fused=0, sweeps_two_launch=0, sweeps_serial=0)
+    chg = 0
+    r = None
+    for seed in seeds:
+        del r
+        r = run_chain(abi, data, N, K, seed, device, args.burnin, args.warmup, args.steps, every, barrier,
+                      stepwise=bool(os.environ.get("GG_BENCH_STEPWISE")))
+        el_s = max_over_ranks(r["elapsed"])
+        total_el += el_s
+        chg += r["changes"]
+        for k in bulk:
+            bulk[k] += r["bulk"][k]
+        for k in forms:
+            forms[k] += r["forms"][k]
+        chains.append({"chain_seed": seed, "value": world * args.steps / el_s, "ms_per_step": el_s / args.steps * 1e3,
+                       "label_changes_per_sweep": r["changes"] / float(args.steps),
+                       "scan_rounds_per_sweep": r["rounds"] / float(args.steps), "weight_model_sweep_forms": r["forms"],
+                       "bulk_launch_ms": r["bulk"]["w_ms"] / max(r["bulk"]["w_n"], 1),
+                       "bulk_launch_GBs": r["bulk"]["w_bytes"] / (r["bulk"]["w_ms"] * 1e-3) / 1e9 if r["bulk"]["w_ms"] > 0 else None})
+        if rank == 0:
+            _progress("chain seed %d: %d sweeps in %.4f s (%.1f label changes per sweep)" % (seed, args.steps, el_s, r["changes"] / float(args.steps)))
+    adj, w = r["adj"], r["w"]
+    el, nsw = total_el, len(seeds) * args.steps
 
+    out = None
     if rank == 0:
         # Dominant kernel: the weight model's streaming pass over the N x N int32 weight matrix AND its stored transpose
-        # (out- and in-statistics of every node): 2 * N^2 * 4 algorithmic bytes per sweep.  While the chain is quiet the
-        # pass of sweep s+1 rides in the two launches of sweep s (k_params + riders, k_spec_resolve + riders):
-        # the events bracket exactly those launches, achieved = the bytes their riders stream / their duration.
+        # (out- and in-statistics of every node): 2 * N^2 * 4 algorithmic bytes per sweep.  While a chain is quiet the pass of
+        # sweep s+2 rides in the fused launch of sweep s (k_sweep_q), otherwise it is k_bulk_w on its own: the
+        # events bracket exactly the launches that stream the data, achieved = the bytes they stream / their duration, over
+        # the sampled launches of ALL chains of the mix.
         per_launch_ms = bulk["w_ms"] / max(bulk["w_n"], 1)
         alg_bytes = bulk["w_bytes"] / max(bulk["w_n"], 1)
         achieved = bulk["w_bytes"] / (bulk["w_ms"] * 1e-3) / 1e9 if bulk["w_ms"] > 0 else 0.0
         sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
-        pmc = pmc_traffic(N, alg_bytes, r["ahead"])
+        pmc = pmc_traffic(N, K, forms)
         sa_ms, sa_b = adj.bench_bulk(data, 20)
         sw_ms, sw_b = w.bench_bulk(data, 20)
+        quiet = [c for c in chains if c["label_changes_per_sweep"] == 0.0]
         out = {
             "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak",
-            "value": world * args.steps / el,
+            "value": world * nsw / el,
             "unit": "sweeps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3,
+            "ms_per_step": el / nsw * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -705,34 +738,45 @@ def main():
             "config": {
                 "workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1, dense adjacency (%s)" % (
                     N, K, "BASELINE.json configs[1]" if (N, K) == (4096, 16) else
-                    ("BASELINE.json configs[3] on one GPU" if (N, K) == (65536, 64) else "same recipe, other size")),
+                    ("BASELINE.json configs[3], one replica of the chain per GPU" if (N, K) == (65536, 64) else "same recipe, other size")),
                 "parallelism": "one replica of the chain per GPU, no collective" if world > 1 else "single GPU",
-                "chain_seed": chain_seed, "burn_in_sweeps": args.burnin,
-                "label_changes_in_timed_region": int(chg),
+                "chain_seeds": seeds, "timed_sweeps": nsw, "steps_per_chain": args.steps,
+                "value_is": "timed sweeps of all chains / their timed seconds (each chain: burn-in, warm-up, then `steps` timed sweeps)",
+                "burn_in_sweeps": args.burnin,
+                "label_changes_in_timed_region": int(chg), "label_changes_per_sweep": chg / float(nsw),
+                "chains": chains,
                 "sweep_algorithmic_bytes": sweep_bytes,
-                "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9,
+                "sweep_effective_GBs": sweep_bytes * nsw / el / 1e9,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_sweep_q<3,false,0,0> (scan of sweep s | gated parameter step of sweep s+1 | riders = the weight pass "
-                          "k_bulk_w<1> for sweep s+2)" if r["ahead"] else "k_bulk_w<1>",
+                "kernel": "the launches that stream W and W^T: k_sweep_q<3,false,0,0> (scan of sweep s | gated parameter step of sweep s+1 | "
+                          "riders = the weight pass for sweep s+2) for %d of the weight model's timed sweeps, its two-launch form "
+                          "(k_params + riders, k_spec_resolve + riders) for %d, k_bulk_w<1> on its own for %d (gg_stats)"
+                          % (forms["sweeps_fused"], forms["sweeps_two_launch"], forms["sweeps_serial"]),
+                "weight_model_sweep_forms": forms,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc.get("traffic"),
+                "traffic_source": pmc.get("traffic_source"),
                 "traffic_note": pmc.get("note"),
                 "launch_ms": per_launch_ms,
                 "launch_bytes": alg_bytes,
                 "sampled_launches": int(bulk["w_n"]),
                 "standalone_GBs": sw_b / sw_ms / 1e6,
                 "note": "achieved = in situ (HIP events on the engine stream around the sampled launches inside the timed "
-                        "region, with the adjacency model's kernels running concurrently on another stream); "
+                        "regions, with the adjacency model's kernels running concurrently on another stream); "
                         "standalone_GBs = the plain bulk kernel k_bulk_w<1> launched back to back alone",
                 "adj_kernel": {"kernel": "adjacency pass (k_bulk_adj, or its riders)", "launch_ms": bulk["adj_ms"] / max(bulk["adj_n"], 1),
                                "launch_bytes": bulk["adj_bytes"] / max(bulk["adj_n"], 1), "standalone_GBs": sa_b / sa_ms / 1e6},
             },
         }
+        if quiet:
+            out["quiet_chain"] = {"chain_seed": quiet[0]["chain_seed"], "value": quiet[0]["value"], "unit": "sweeps/s",
+                                  "ms_per_step": quiet[0]["ms_per_step"],
+                                  "note": "a chain of the mix that changed no label in its timed sweeps (the round-2 headline was this chain alone)"}
         # measured ceiling beside the nominal peak: a pure read stream of the same number of bytes as one
         # k_bulk_w launch (cache-resident at N=4096, like the kernel's own data) and of 4 GiB (HBM)
         if world == 1:
@@ -787,11 +831,6 @@ def main():
         if world == 1 and not args.no_extras:
             # The other configurations of BASELINE.json and the chains that keep mixing, in the same driver-run line
             # (extra keys; `value` stays the configs[1] headline).  Each leg is bounded and must never cost the line.
-            _progress("mixing chains (seeds 2 and 4)")
-            try:
-                out["mixing_chains"] = extra_mixing_chains(abi, data, N, K, device, args.burnin)
-            except Exception as exc:
-                out["mixing_chains"] = {"error": str(exc)}
             del adj, w, r, data
             legs = {}
             for name, fn in (("eigen_n4096_d8", extra_eigen), ("ais_sbm_n8192", extra_ais), ("sbm_n65536_k64_one_gpu", extra_big)):
@@ -801,6 +840,20 @@ def main():
                 except Exception as exc:
                     legs[name] = {"error": str(exc)}
             out["other_configs"] = legs
+    if world > 1 and not os.environ.get("GG_BENCH_NO_SHARD_LEG"):
+        # BASELINE.json configs[3] as written: ONE chain of the same network sharded over the G GPUs (every rank takes part)
+        adj = w = r = data = None
+        import gc
+        gc.collect()
+        if rank == 0:
+            _progress("sharded chain over %d ranks" % world)
+        try:
+            line = run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K)
+        except Exception as exc:      # (a failing leg must not cost the replica line)
+            line = {"error": str(exc)}
+        if rank == 0:
+            out["sharded_chain"] = line
+    if rank == 0:
         _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()

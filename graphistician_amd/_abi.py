@@ -48,7 +48,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("sweeps", C.c_uint64), ("label_changes", C.c_uint64), ("resolve_rounds", C.c_uint64),
                 ("bulk_bytes", C.c_double), ("bulk_ms", C.c_double), ("bulk_launches", C.c_uint64),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("sweeps_fused", C.c_uint64), ("sweeps_two_launch", C.c_uint64),
+                ("sweeps_serial", C.c_uint64)]
 
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_update", "gg_data_info",

@@ -544,7 +544,12 @@ __device__ __forceinline__ bool gg_poll_verdict(int32_t* ctl, unsigned* verdict,
     // (relaxed polls: an acquire load would invalidate the compute unit's caches, shared with the scan's workgroups, at
     // every poll; nothing this workgroup reads afterwards was written by the scan)
     const unsigned v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((v >> 1) == tag) return (v & 1u) == 0u;
+    if ((v >> 1) == tag) {
+      // one acquire fence, once per sweep, pairs with the resolver's release store: what this workgroup writes from here on
+      // (control words the resolver has written too) is ordered behind the resolver's writes
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return (v & 1u) == 0u;
+    }
     __builtin_amdgcn_s_sleep(40);
   }
   atomicOr(&ctl[3], 8);   // the resolving workgroups are dispatched ahead of this one: only a hung device gets here

@@ -9,7 +9,12 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <mutex>
+
 #include "gg_common.h"
+
+static std::mutex g_data_mu;   // guards gg_data::refs / dead (see gg_data_destroy)
+static int data_refs(gg_data* d) { std::lock_guard<std::mutex> lk(g_data_mu); return d->refs; }
 
 thread_local std::string gg_err_text;
 
@@ -170,6 +175,17 @@ static int alloc_data(gg_data* d) {
   return GG_OK;
 }
 
+static void data_free(gg_data* d);
+
+// Stream + device buffers of a fresh handle; on failure the handle (and whatever was allocated) is freed here.
+static int data_open(gg_data* d) {
+  int rc = GG_OK;
+  if (hipStreamCreate(&d->stream) != hipSuccess) { d->stream = nullptr; rc = gg_fail(GG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(hipGetLastError())); }
+  if (!rc) rc = alloc_data(d);
+  if (rc) data_free(d);
+  return rc;
+}
+
 // 32 adjacency bytes -> one word of the bit matrix (bit j of the word = byte j != 0).
 __global__ void k_pack_bits(const uint8_t* __restrict__ A, uint32_t* __restrict__ Ab, size_t nwords) {
   size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,9 +324,7 @@ int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const 
   d->B = W ? B : 1;
   d->Np = gg_round_up(N, 64);
   d->has_w = W ? 1 : 0;
-  GG_HIP(hipStreamCreate(&d->stream));
-  rc = alloc_data(d);
-  if (rc) return rc;
+  if ((rc = data_open(d))) return rc;
   rc = fill_full(d, A, W);
   if (rc) { gg_data_destroy(d); return rc; }
   *out = d;
@@ -324,7 +338,7 @@ int gg_data_update(gg_data* d, const uint8_t* A, const double* W) {
   if (!d || !A) return gg_fail(GG_ERR_INVALID, "gg_data_update: null argument");
   if (d->n0 != 0 || d->n1 != d->N) return gg_fail(GG_ERR_INVALID, "gg_data_update: not for column shards");
   if ((W != nullptr) != (d->has_w != 0)) return gg_fail(GG_ERR_INVALID, "gg_data_update: the handle was created %s weights", d->has_w ? "with" : "without");
-  if (__atomic_load_n(&d->refs, __ATOMIC_ACQUIRE) > 0)
+  if (data_refs(d) > 0)
     return gg_fail(GG_ERR_INVALID, "gg_data_update: a model still has sweeps enqueued on this network (gg_sync it first)");
   int rc = gg_ensure_device(d->device);
   if (rc) return rc;
@@ -361,9 +375,7 @@ static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c
   memset(d, 0, sizeof(*d));
   d->uid = gg_next_data_uid();
   d->device = device; d->N = N; d->n0 = n0; d->n1 = n1; d->B = 1; d->Np = gg_round_up(Nl, 64); d->has_w = 1;
-  GG_HIP(hipStreamCreate(&d->stream));
-  rc = alloc_data(d);
-  if (rc) return rc;
+  if ((rc = data_open(d))) return rc;
   // fixed-point scale from a bound on |w|: max |mu| + 8 sd (values beyond are clamped; probability < 1e-15 per edge)
   double wb = fabs(mu_self) + 8.0 * sqrt(sigma_self);
   std::vector<double> sd((size_t)K * K);
@@ -432,8 +444,7 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
   const int Nl = n1 - n0;
   d->Np = gg_round_up(Nl, 64);
   d->has_w = W ? 1 : 0;
-  GG_HIP(hipStreamCreate(&d->stream));
-  if ((rc = alloc_data(d))) return rc;
+  if ((rc = data_open(d))) return rc;
   const size_t nA = (size_t)N * d->Np;
   // column shard of A (in-edges of the owned nodes) and of A^T (their out-edges), diagonal apart
   std::vector<uint8_t> hA(nA, 0), hAT(nA, 0), hdA(Nl, 0);
@@ -497,13 +508,15 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
   return GG_OK;
 }
 
-static void data_free(gg_data* d);
+// Who frees a handle that is destroyed while sweeps are still enqueued on it is decided under one lock (the
+// lock-free rendezvous let the loser read a handle the winner had deleted): destroy with references outstanding only marks
+// it, and the release that takes the count to zero frees it.  These are per-call operations, not per sweep.
 
 int gg_data_destroy(gg_data* d) {
   if (!d) return GG_OK;
-  if (__atomic_load_n(&d->refs, __ATOMIC_ACQUIRE) > 0) {   // sweeps are still enqueued on it: freed by the last release
-    __atomic_store_n(&d->dead, 1, __ATOMIC_RELEASE);
-    if (__atomic_load_n(&d->refs, __ATOMIC_ACQUIRE) > 0) return GG_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_data_mu);
+    if (d->refs > 0) { d->dead = 1; return GG_OK; }   // sweeps are still enqueued on it: freed by the last release
   }
   data_free(d);
   return GG_OK;
@@ -512,16 +525,23 @@ int gg_data_destroy(gg_data* d) {
 }  // extern "C"
 
 void gg_data_retain(const gg_data* d) {
-  if (d) __atomic_add_fetch(&const_cast<gg_data*>(d)->refs, 1, __ATOMIC_ACQ_REL);
+  if (!d) return;
+  std::lock_guard<std::mutex> lk(g_data_mu);
+  const_cast<gg_data*>(d)->refs += 1;
 }
 void gg_data_release(const gg_data* d) {
   if (!d) return;
   gg_data* w = const_cast<gg_data*>(d);
-  if (__atomic_sub_fetch(&w->refs, 1, __ATOMIC_ACQ_REL) == 0 && __atomic_load_n(&w->dead, __ATOMIC_ACQUIRE)) data_free(w);
+  bool last;
+  {
+    std::lock_guard<std::mutex> lk(g_data_mu);
+    w->refs -= 1;
+    last = w->refs == 0 && w->dead;
+  }
+  if (last) data_free(w);
 }
 
 static void data_free(gg_data* d) {
-  if (__atomic_exchange_n(&d->dead, 2, __ATOMIC_ACQ_REL) == 2) return;   // (destroy and the last release met: free once)
   hipSetDevice(d->device);
   if (d->A) hipFree(d->A);
   if (d->AT) hipFree(d->AT);

@@ -43,6 +43,8 @@ struct gg_model {
   int N, K, Kp, B, NT, NSI, Np, NTAB;   // N = all nodes (labels, rows); Np = padded number of OWNED nodes
   int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded)
   bool sharded;
+  unsigned char* pred_buf = nullptr;    // gg_predictive_ll: grow-only device scratch (the reference calls it once per held-out node)
+  size_t pred_cap = 0;
   long long* sh_buf;                    // sharded chain: device staging of the diagonal statistics (all-reduce)
   int32_t *sh_trip, *sh_all;            // this rank's first changer {node, old, new}; the gathered ones [world][3]
   long long sh_diag[1 + GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];   // global diagonal statistics of network sh_diag_uid
@@ -435,7 +437,7 @@ int gg_model_destroy(gg_model* m) {
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
                   m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all,
-                  m->sh_cntn, m->sh_H, m->sh_mv};
+                  m->sh_cntn, m->sh_H, m->sh_mv, m->pred_buf};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -1363,6 +1365,7 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
     GG_HIP(hipGetLastError());
   }
   m->cur = nxt;
+  m->st.sweeps_serial += 1;
   return GG_OK;
 }
 
@@ -1403,10 +1406,12 @@ static int enqueue_sweep_ahead(gg_model* m, const gg_data* d, uint32_t sweep, bo
   m->m_sweep = sweep;
   if (more) {
     if ((rc = launch_sweep_q(m, d, a, b, c, sweep, P))) return rc;
+    if (m->pre) m->st.sweeps_fused += 1; else m->st.sweeps_two_launch += 1;   // (the first sweep of a run: k_params + riders in front)
     m->pre = true;
   } else {
     // last sweep of the call: the scan alone (+ the rest of the next sweep's pass when it did not ride above)
     if ((rc = launch_spec_resolve(m, d, a, sweep, 1 - P, m->pre ? -1 : b))) return rc;
+    m->st.sweeps_two_launch += 1;
     m->pre = false;
   }
   m->st.resolve_rounds += 1;
@@ -2363,15 +2368,20 @@ int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, co
   if (rc) return rc;
   const int N = m->N, K = m->K, B = m->B;
   const size_t na = (size_t)N + 1, nw = ((size_t)N + 1) * B;
-  unsigned char* dbuf = nullptr;
   const size_t bytes = 2 * na + (m->is_adj ? 0 : 2 * nw * 8) + 16;
-  GG_HIP(hipMalloc((void**)&dbuf, bytes + (size_t)(K + 1) * 8 + 64));
+  const size_t need = bytes + (size_t)(K + 1) * 8 + 64;
+  if (m->pred_cap < need) {   // (no allocation, no free and so no implicit device synchronisation per call: ADVICE r2)
+    if (m->pred_buf) { GG_HIP(hipStreamSynchronize(m->stream)); GG_HIP(hipFree(m->pred_buf)); m->pred_buf = nullptr; m->pred_cap = 0; }
+    GG_HIP(hipMalloc((void**)&m->pred_buf, need));
+    m->pred_cap = need;
+  }
+  unsigned char* dbuf = m->pred_buf;
   // layout: [w_row | w_col] (doubles first: alignment) | a_row | a_col | out[K + 1]
   double* d_w = reinterpret_cast<double*>(dbuf);
   unsigned char* d_a = dbuf + (m->is_adj ? 0 : 2 * nw * 8);
   double* d_out = reinterpret_cast<double*>(dbuf + ((bytes + 7) & ~(size_t)7));
   if (!m->is_adj) {
-    if (gg_first_nonfinite(w_row, nw) >= 0 || gg_first_nonfinite(w_col, nw) >= 0) { hipFree(dbuf); return gg_fail(GG_ERR_INVALID, "gg_predictive_ll: non-finite weight"); }
+    if (gg_first_nonfinite(w_row, nw) >= 0 || gg_first_nonfinite(w_col, nw) >= 0) return gg_fail(GG_ERR_INVALID, "gg_predictive_ll: non-finite weight");
     GG_HIP(hipMemcpyAsync(d_w, w_row, nw * 8, hipMemcpyHostToDevice, m->stream));
     GG_HIP(hipMemcpyAsync(d_w + nw, w_col, nw * 8, hipMemcpyHostToDevice, m->stream));
   }
@@ -2395,7 +2405,6 @@ int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, co
   std::vector<double> h((size_t)K + 1);
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, m->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
-  hipFree(dbuf);
   if (e != hipSuccess) return gg_fail(GG_ERR_HIP, "gg_predictive_ll failed: %s", hipGetErrorString(e));
   if (h[(size_t)K] != 0.0) return gg_fail(GG_ERR_NUMERIC, "gg_predictive_ll: a block covariance is not positive definite");
   for (int k = 0; k < K; ++k) ll_k[k] = h[(size_t)k];

@@ -425,7 +425,9 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
       g.rs[7] = 1;
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(&g.rs[10]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(0, 0, 0, 1, 0);
-      if (vtag) __hip_atomic_store(g.verdict, vtag << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (release: the control words written above are ordered before the verdict - a gated parameter workgroup that has
+      // seen it goes on to store to the same words, gg_params_body's housekeeping)
+      if (vtag) __hip_atomic_store(g.verdict, vtag << 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else if (tid == 0) {
     const int f = (int)(best >> 12), ca = (int)((best >> 6) & 63u), cb = (int)(best & 63u);
@@ -440,7 +442,7 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
     g.rs[4] = 1;
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(&g.rs[10]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(f + 1, 1, 0, 0, 0);
-    if (vtag) __hip_atomic_store(g.verdict, (vtag << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (vtag) __hip_atomic_store(g.verdict, (vtag << 1) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -19,41 +19,58 @@ from . import _abi
 
 _DATA_CACHE = collections.OrderedDict()
 _DATA_CACHE_SIZE = 4
+_IMMUTABLE = {}        # id(array) -> weakref: arrays the caller has declared read-only (identity is then the whole key)
 
 
-_SAMPLE = 4096
+def _content_hash(a):
+    """64-bit hash of the WHOLE buffer (xxh3: ~10 GB/s, 1.7 ms for a 4096 x 4096 byte adjacency).  The reference reads
+    its arrays on every call (networks.py:28,69); the engine keeps a device copy, so a copy is only reused when every
+    byte of the host array is what it was when the copy was made - one flipped entry is new data."""
+    buf = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+    view = memoryview(buf.reshape(-1).view(np.uint8))
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(view)
+    except ImportError:       # pragma: no cover
+        import zlib
+        return zlib.crc32(view)
 
 
 def _fingerprint(a):
-    """Cache key of one host array: identity (id, buffer address, shape, dtype) plus a hash of a strided sample of
-    its CONTENT (about 4096 elements spread over the whole buffer, ~10 us), so that refilling the same buffer in
-    place — `A[:] = model.rvs()`, masking a held-out row and column — is seen as new data and uploaded again.
-    The reference reads its arrays on every call (networks.py:28,69); an edit that touches only a handful of
-    entries can slip between the samples: call `invalidate(A)` (or `clear_data_cache()`) after such an edit."""
+    """Cache key of one host array: identity (id, buffer address, shape, dtype) plus a hash of its full content, so that
+    any in-place edit - `A[:] = model.rvs()`, masking a held-out row and column, one flipped entry - is seen as new data
+    and uploaded again.  Arrays registered with `declare_immutable` skip the hash (identity only): that, or passing a
+    `DeviceData` handle, is what a loop over a large fixed network should do."""
     if a is None:
         return None
-    flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
-    step = max(1, flat.size // _SAMPLE) | 1
-    if a.ndim >= 2 and a.shape[1] > 1 and step % a.shape[1] in (0, 1, a.shape[1] - 1):
-        step += 2          # never walk a single column or a diagonal of the matrix
-    sample = flat[::step].tobytes()
-    try:
-        import xxhash
-        h = xxhash.xxh3_64_intdigest(sample)
-    except ImportError:       # pragma: no cover
-        import zlib
-        h = zlib.crc32(sample)
-    return (id(a), a.shape, a.dtype.str, a.__array_interface__["data"][0], h)
+    ident = (id(a), a.shape, a.dtype.str, a.__array_interface__["data"][0])
+    ref = _IMMUTABLE.get(id(a))
+    if ref is not None and ref() is a:
+        return ident + ("immutable",)
+    return ident + (_content_hash(a),)
 
 
-def as_device_data(A, W=None, device=0):
-    """Device-resident network for (A, W); accepts an existing DeviceData."""
+def declare_immutable(*arrays):
+    """Promise that these host arrays will not be edited in place while they are used as data: their device copies are
+    then found by identity alone (no per-call hash of the buffer).  `invalidate` / `clear_data_cache` take it back."""
+    import weakref
+    for a in arrays:
+        if a is None:
+            continue
+        a = np.asarray(a)
+        _IMMUTABLE[id(a)] = weakref.ref(a, lambda _r, k=id(a): _IMMUTABLE.pop(k, None))
+
+
+def as_device_data(A, W=None, device=0, immutable=False):
+    """Device-resident network for (A, W); accepts an existing DeviceData.  immutable=True: see `declare_immutable`."""
     if isinstance(A, _abi.DeviceData):
         return A
     if isinstance(A, tuple) and W is None:
         A, W = A
     A = np.asarray(A)
     Wn = None if W is None else np.asarray(W)
+    if immutable:
+        declare_immutable(A, Wn)
     key = (_fingerprint(A), _fingerprint(Wn), device)
     hit = _DATA_CACHE.get(key)
     if hit is not None:
@@ -64,15 +81,20 @@ def as_device_data(A, W=None, device=0):
         # A loop that draws new data every iteration (`A = model.rvs(); model.resample(A)`, the reference's Geweke tests)
         # would allocate and free every device buffer each time round: recycle the least recently used handle of the same
         # shape instead (gg_data_update; refused - and then simply not recycled - while sweeps are still pending on it).
-        old_key, (old, _, oldW) = next(iter(_DATA_CACHE.items()))
+        # Only a handle nobody else holds is recycled: one that was handed to a caller keeps the network it was made from.
+        import sys
+        old_key, entry = next(iter(_DATA_CACHE.items()))
+        old, oldW = entry[0], entry[2]
         B = 1 if Wn is None else (1 if Wn.ndim == 2 else Wn.shape[2])
-        if old.N == A.shape[0] and old.device == device and (oldW is None) == (Wn is None) and old.B == B:
+        sole_owner = sys.getrefcount(old) <= 3      # the cache entry, `old`, getrefcount's argument
+        if sole_owner and old.N == A.shape[0] and old.device == device and (oldW is None) == (Wn is None) and old.B == B:
             try:
                 old.update(A, Wn)
                 d = old
                 del _DATA_CACHE[old_key]
             except _abi.EngineError:
                 d = None
+        del old, entry
     if d is None:
         d = _abi.DeviceData(A, Wn, device=device)
     _DATA_CACHE[key] = (d, A, Wn)  # keep the arrays alive so ids are not reused
@@ -83,12 +105,16 @@ def as_device_data(A, W=None, device=0):
 
 def clear_data_cache():
     _DATA_CACHE.clear()
+    _IMMUTABLE.clear()
 
 
 def invalidate(A, W=None):
-    """Forget the device copy made from these host arrays (after an in-place edit too small for the content sample)."""
+    """Forget the device copy made from these host arrays (and any `declare_immutable` promise about them)."""
     for key in [k for k, v in _DATA_CACHE.items() if v[1] is A or (W is not None and v[2] is W)]:
         del _DATA_CACHE[key]
+    for a in (A, W):
+        if a is not None:
+            _IMMUTABLE.pop(id(a), None)
 
 
 def draw_seed():

@@ -133,6 +133,11 @@ typedef struct gg_stats {
   double bulk_ms;               /* HIP-event time of those kernels, last call */
   uint64_t bulk_launches;       /* number of bulk kernel launches, last call */
   double total_ms;              /* HIP-event time of the whole last call */
+  /* sweeps ENQUEUED since creation, by execution form (block models; a sweep voided by a stalled scan and run again is
+   * counted again).  fused: one launch per sweep (scan | gated parameter step | riders); two_launch: parameter step +
+   * riders, scan + riders (the first / last sweep of a run, K > 32 without staged tables); serial: pass, parameter step,
+   * scan as separate launches (chains that keep changing labels, wide and joint models, GG_AHEAD=0) */
+  uint64_t sweeps_fused, sweeps_two_launch, sweeps_serial;
 } gg_stats;
 
 /* ---- library ------------------------------------------------------------- */

@@ -232,20 +232,34 @@ def test_stale_config_struct_is_refused_before_anything_else():
 
 
 def test_data_cache_key_sees_in_place_edits():
-    """engine.as_device_data keys its cache on a content sample as well as on identity: refilling a buffer in
-    place or masking a held-out row / column changes the key; NaN in A is refused at upload."""
+    """engine.as_device_data keys its cache on a hash of the WHOLE buffer as well as on identity: refilling a
+    buffer in place, masking a held-out row / column or flipping ONE entry changes the key - the reference reads its arrays
+    on every call (networks.py:28,69).  Arrays declared immutable are keyed by identity alone.  NaN in A is refused at upload."""
     from graphistician_amd import engine, _abi
     rng = np.random.RandomState(0)
     A = (rng.rand(512, 512) < 0.5).astype(np.float64)
     W = rng.randn(512, 512, 2)
     k0 = (engine._fingerprint(A), engine._fingerprint(W))
     assert k0 == (engine._fingerprint(A), engine._fingerprint(W))
+    A[200, 301] = 1.0 - A[200, 301]                    # one entry
+    k1 = engine._fingerprint(A)
+    assert k1 != k0[0]
+    W[17, 400, 1] += 1e-9                              # one weight, the smallest of edits
+    assert engine._fingerprint(W) != k0[1]
     A2 = A.copy()
     A2[37, :] = 0; A2[:, 37] = 0                       # hold one node out
     A[:] = A2
-    assert engine._fingerprint(A) != k0[0]
-    W[:] = rng.randn(512, 512, 2)                      # a new rvs() draw into the same buffer
-    assert engine._fingerprint(W) != k0[1]
+    assert engine._fingerprint(A) not in (k0[0], k1)
+    At = np.asfortranarray(A)                          # any memory layout is hashed through its C-order bytes
+    kt = engine._fingerprint(At)
+    At[5, 6] = 1.0 - At[5, 6]
+    assert engine._fingerprint(At) != kt
+    engine.declare_immutable(A)
+    ki = engine._fingerprint(A)
+    A[1, 2] = 1.0 - A[1, 2]
+    assert engine._fingerprint(A) == ki                # promised read-only: identity is the key
+    engine.invalidate(A)
+    assert engine._fingerprint(A) != ki
     A[3, 4] = np.nan
     with pytest.raises(ValueError):
         _abi._adjacency_u8(A)

@@ -158,6 +158,40 @@ def test_python_data_cache_and_state_roundtrip(abi):
     assert np.array_equal(m.c, c1)
 
 
+def test_one_flipped_entry_is_new_data(abi):
+    """the host classes find their device copy by a hash of the whole array - flip ONE entry of A (or edit one
+    weight) in place and the next log_likelihood is that of the edited network, as in the reference, which reads its arrays on
+    every call (networks.py:28,69).  A handle held by a caller is never recycled for other data."""
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution
+    from graphistician_amd import engine
+    engine.clear_data_cache()
+    N = 96
+    A, W, _ = planted_sbm(N, 3, seed=4, B=1)
+    A = A.astype(bool)
+    np.random.seed(2)
+    net = FactorizedNetworkDistribution(N, SBMAdjacencyDistribution, dict(C=3), SBMGaussianWeightDistribution, dict(C=3, B=1))
+    ll0 = net.log_likelihood((A, W))
+    assert net.log_likelihood((A, W)) == ll0 and len(engine._DATA_CACHE) == 1
+    i, j = [(i, j) for i in range(N) for j in range(N) if i != j and not A[i, j]][0]
+    A[i, j] = True                                        # one new edge, in place
+    ll1 = net.log_likelihood((A, W))
+    assert ll1 != ll0
+    ref = net.adjacency.log_likelihood(A.copy()) + net.weights.log_likelihood((A.copy(), W.copy()))
+    assert abs(ll1 - ref) <= 1e-9 * abs(ref)
+    W[i, j, 0] += 0.25                                    # and one weight
+    ll2 = net.log_likelihood((A, W))
+    assert ll2 != ll1
+    # a handle a caller holds keeps its network while the cache turns over
+    held = engine.as_device_data(A, W)
+    ll_held = net.adjacency.log_likelihood(held)
+    for s in range(engine._DATA_CACHE_SIZE + 2):
+        A2, W2, _ = planted_sbm(N, 3, seed=50 + s, B=1)
+        net.log_likelihood((A2, W2))
+    assert net.adjacency.log_likelihood(held) == ll_held
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ahead,split", [("0", None), (None, None), (None, "0"), (None, "1"), (None, "0.27")])
 def test_ahead_form_is_the_same_chain(abi, monkeypatch, ahead, split):
