@@ -88,6 +88,10 @@ struct gg_model {
   long long* h_tab;   // pinned staging of the K x K tables + block counts (gg_log_likelihood)
   hipStream_t stream;
   bool can_ahead;               // this model may run the ahead form (scan model, not sharded, GG_AHEAD != 0)
+  int scan_ride;                // the resident-grid scan carries the next sweep's bulk pass as riders: 0 never (default; wide, sharded, joint), 1 while the chain changes
+                                // few labels per sweep (GG_SCAN_RIDE=1), 2 always (GG_SCAN_RIDE=2: tests).  Exact, and slower: see launch_scan
+  long long ride_chg_seen;      // label changes at the last completed batch, and what that batch changed per sweep (-1: no batch yet)
+  double chg_per_sweep;
   bool ahead;                   // Gbuf[cur] holds the exact statistics of network ahead_uid under the CURRENT labels
   unsigned long long ahead_uid; // (counted by the riders of the last completed sweep, whose scan changed no label)
   unsigned* verdict;            // verdict word of the fused launch, alone on its cache line
@@ -372,7 +376,8 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     { const char* esp = getenv("GG_SCAN_SPIN"); m->scan_spin = esp && atoi(esp) > 0 ? atoi(esp) : GG_BAR_SPIN_LIMIT; }
     // The ahead form (enqueue_sweep_ahead): while the chain is quiet, the next sweep's bulk pass rides in this sweep's
     // k_params and k_spec_resolve launches.  GG_AHEAD=0 keeps every sweep in the serial form (bulk -> params -> scan).
-    const char* ea = getenv("GG_AHEAD");
+{ const char* er2 = getenv("GG_SCAN_RIDE"); m->scan_ride = (m->wide || m->joint || m->sharded) ? 0 : (er2 ? atoi(er2) : 0); m->ride_chg_seen = 0; m->chg_per_sweep = -1.0; }
+        const char* ea = getenv("GG_AHEAD");
     m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0) && !m->joint && !m->wide;   // (the joint kind runs the serial form)
     const char* ers = getenv("GG_RIDE_SPLIT");
     m->ride_split = ers ? atof(ers) : -1.0;   // (default chosen below, once the scan forms of this shape are known)
@@ -1169,8 +1174,9 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
 }
 
 // The whole scan in one launch (k_scan: resident grid, one barrier round per accepted change).
-static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw, bool resume = false) {
+static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw, bool resume = false, int ride_buf = -1) {
   gg_scan_args a;
+  memset(&a, 0, sizeof(a));
   a.resume = resume ? 1 : 0;
   a.spin_limit = m->scan_spin;
   gg_resolve_args& g = a.r;
@@ -1188,6 +1194,9 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   g.keep_L = 0;
   a.ap = m->ap; a.Gc0 = gcnt(m, buf, 0); a.Gs0 = gs(m, buf, 0); a.bar = m->bar;
   a.Lcap = m->Lcap < 1024 ? m->Lcap : 1024;   // every workgroup keeps its own copy of the list in LDS (12 KB)
+  // (with riders every workgroup of the launch is given the scan's LDS: a shorter list - flushed more often in a burn-in
+  // sweep, never in a steady one - lets a third workgroup onto the CU)
+  if (ride_buf >= 0 && a.Lcap > 256) a.Lcap = 256;
   { const char* el = getenv("GG_SCAN_LCAP"); if (el && atoi(el) >= 2 && atoi(el) < a.Lcap) a.Lcap = atoi(el); }   // (tests: flush the list often)
   const int per = 256 / m->Kp;
   const int ngroups = (m->Nl + per - 1) / per;
@@ -1197,6 +1206,17 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   if (lds > GG_LDS_LIMIT)
     return gg_fail(GG_ERR_UNSUPPORTED, "the resident-grid scan needs %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
   g.stage_tables = stage;
+  int nr = 0, ntl = 0;
+  double ride_bytes = 0.0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool timed = false;
+  if (ride_buf >= 0) {
+    // the NEXT sweep's bulk pass behind the scan workgroups, under the label sort this scan starts from (1 - pw)
+    a.ride = make_ride(m, d, ride_buf, 1 - pw, 2, a.G, &nr, &ntl, &ride_bytes);
+    a.Gn0 = gcnt(m, ride_buf, 0); a.Gsn0 = gs(m, ride_buf, 0);
+    timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+    if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
+  }
 #define SCN1(NTV, ADJV, SPV)                                                                                       \
   do {                                                                                                            \
     static bool attr_set = false;                                                                                 \
@@ -1206,7 +1226,24 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     }                                                                                                             \
     k_scan<NTV, ADJV, SPV><<<a.G, 256, lds, m->stream>>>(a);                                                       \
   } while (0)
-#define SCN(NTV, ADJV) do { if (m->Kp > 64) SCN1(NTV, ADJV, 2); else if (stage != 1 && m->Kp == 64) SCN1(NTV, ADJV, 1); else SCN1(NTV, ADJV, 0); } while (0)
+#define SCNR(NTV, ADJV, SPV, RV)                                                                                   \
+  do {                                                                                                            \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set && lds > 48 * 1024) {                                                                           \
+      GG_HIP(hipFuncSetAttribute((const void*)k_scan<NTV, ADJV, SPV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+      attr_set = true;                                                                                            \
+    }                                                                                                             \
+    k_scan<NTV, ADJV, SPV, RV><<<a.G + nr, 256, lds, m->stream>>>(a);                                              \
+  } while (0)
+#define SCN(NTV, ADJV)                                                                                             \
+  do {                                                                                                            \
+    if (ride_buf >= 0) {                                                                                          \
+      if (stage != 1 && m->Kp == 64) { if (ntl) SCNR(NTV, ADJV, 1, 2); else SCNR(NTV, ADJV, 1, 1); }              \
+      else { if (ntl) SCNR(NTV, ADJV, 0, 2); else SCNR(NTV, ADJV, 0, 1); }                                        \
+    } else if (m->Kp > 64) SCN1(NTV, ADJV, 2);                                                                    \
+    else if (stage != 1 && m->Kp == 64) SCN1(NTV, ADJV, 1);                                                       \
+    else SCN1(NTV, ADJV, 0);                                                                                      \
+  } while (0)
   if (m->is_adj) SCN(2, true);
   else if (m->joint && m->B == 1) SCN(4, false);
   else if (m->joint) SCN(7, false);
@@ -1215,8 +1252,13 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   else if (m->B == 3) SCN(10, false);
   else SCN(15, false);
 #undef SCN1
+#undef SCNR
 #undef SCN
   GG_HIP(hipGetLastError());
+  if (ride_buf >= 0) {
+    if (timed) { m->ev_bytes.push_back(ride_bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
+    m->zeroed[ride_buf] = false;
+  }
   return GG_OK;
 }
 
@@ -1335,8 +1377,10 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
   int rc;
   const bool scan = m->sbm && m->K > 1;
   const int buf = m->cur, nxt = (buf + 1) % 3, P = m->pcur;
+  bool rode = false;
   if (m->ahead && m->ahead_uid == d->uid) {
-    // the statistics of this sweep were counted ahead by the riders of the previous one (which changed no label)
+    // the statistics of this sweep were counted ahead by the riders of the previous one (which changed no label, or whose
+    // resident scan's change list was applied to them)
     m->ahead = false;
   } else {
     drop_ahead(m);
@@ -1345,7 +1389,22 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
   if ((rc = enqueue_params(m, d, buf, true, true, scan, nxt, sweep, P))) return rc;
   if (scan) {
     if (m->use_scan) {
-      if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P))) return rc;
+      // GG_SCAN_RIDE (off by default): the next sweep's bulk pass rides in the scan's launch, counting under the labels the
+      // scan starts with, and the scan's change list then moves those statistics to the labels it ends with - exact
+      // (tests/test_gpu_edge_cases.py::test_resident_grid_scan_is_the_same_chain, ride = 2), and measured SLOWER on MI355X
+      // (round 3): the scan's exchange rounds are memory-side polls, and under a pass that saturates the memory system each
+      // of them takes several times as long - N=4096, K=16, 60 changes per sweep: 192 us per sweep against 95 serial;
+      // N=65536, K=64: 11.6 ms against 8.6.  The quiet chain's fused launch overlaps the same pass with ONE verdict word
+      // polled behind a sleep; a scan that needs 5-7 grid-wide exchanges does not survive the loaded latency.
+      // (not while the chain relabels hundreds of nodes per sweep - burn-in: the riding launch keeps a short change list,
+      // and a list that overflows is flushed chip-wide)
+      const bool ride = m->Kp <= 64 && m->zeroed[nxt] &&
+                        (m->scan_ride == 2 || (m->scan_ride == 1 && m->chg_per_sweep >= 0.0 && m->chg_per_sweep <= 128.0));
+      if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P, false, ride ? nxt : -1))) return rc;
+      if (ride) {
+        if ((rc = launch_apply_L(m, d, nxt, 3, false))) return rc;
+        rode = true;
+      }
     } else if (m->scan_pref < 0) {
       // adaptive form, quiet phase: speculation and the resolution of the common case in one launch; a scan that does
       // change a label is left stalled behind its first change for the resident grid (finish_scan)
@@ -1365,6 +1424,7 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
     GG_HIP(hipGetLastError());
   }
   m->cur = nxt;
+  if (rode) { m->ahead = true; m->ahead_uid = d->uid; }   // (a scan that times out stalls the pipeline: model_sync drops it)
   m->st.sweeps_serial += 1;
   return GG_OK;
 }
@@ -1498,6 +1558,10 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
     }
     if (!m->h_rs[4]) {  // nothing stalled or flushed: every enqueued sweep completed
+      if (scan && m->pending > 0) {
+        m->chg_per_sweep = (double)((long long)m->h_rs[2] - m->ride_chg_seen) / (double)m->pending;
+        m->ride_chg_seen = (long long)m->h_rs[2];
+      }
       if (m->scan_pref < 0) {
         // adaptive scan form: stay with the resident-grid scan while labels keep changing, go back to speculate +
         // resolve after scan_hold sweeps in a row without a change

@@ -504,14 +504,17 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
                                                  int32_t* Gc1, long long* Gs0, long long* Gs1, const uint32_t* XA,
                                                  const uint32_t* XAT, const int32_t* XW, const int32_t* XWT, int mode) {
   // mode 0: flush between restart rounds (nothing to do once the scan is done); mode 1: end-of-scan flush of
-  // the incremental-statistics pipeline (nothing to do behind a stalled scan: the slow path flushes); 2: always
+  // the incremental-statistics pipeline (nothing to do behind a stalled scan: the slow path flushes); 2: always;
+  // mode 3: the changes a completed k_scan made (rs[25] entries) into the buffer its riders counted the NEXT sweep's
+  // statistics into under the labels the scan started with - every entry for every node, `ap` untouched; nothing behind a
+  // stalled scan (the slow path drops what was counted ahead)
   constexpr int B = gg_tB(NT);
   constexpr int NSI = gg_tNSI(NT);
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= x.N) return;
-  if (mode == 0 ? rs[7] != 0 : (mode == 1 ? rs[4] != 0 : false)) return;
-  const int nL = rs[1], Np = x.Np;
-  for (int e = ap[n]; e < nL; ++e) {
+  if (mode == 0 ? rs[7] != 0 : ((mode == 1 || mode == 3) ? rs[4] != 0 : false)) return;
+  const int nL = mode == 3 ? rs[25] : rs[1], Np = x.Np;
+  for (int e = mode == 3 ? 0 : ap[n]; e < nL; ++e) {
     const int n2 = L[e * 3], a = L[e * 3 + 1], b = L[e * 3 + 2];
     const size_t at = (size_t)n2 * Np + n;
     if (ADJ) {
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
       }
     }
   }
-  ap[n] = 0;
+  if (mode != 3) ap[n] = 0;
 }
 
 __global__ void k_reset_L(int32_t* rs, int mode) {

@@ -48,7 +48,14 @@ struct gg_scan_args {
   int G;                      // workgroups in the grid
   int resume;                 // 1: finish a scan that k_resolve left stalled at rs[0] (G is exact for the current labels, L empty)
   int spin_limit;             // polls before an exchange gives up (GG_BAR_SPIN_LIMIT; GG_SCAN_SPIN overrides it for tests)
+  // RIDE: the NEXT sweep's bulk pass rides behind the G scan workgroups, counting into the next statistics buffer under the
+  // labels this scan STARTS with; the scan's change list (rs[GG_RS_CARRY] entries of g.L when it ends) then turns those
+  // statistics into the ones under the labels it ends with (k_apply_L mode 3): integer moves, exact.
+  gg_ride_args ride;
+  int32_t* Gn0;               // the next sweep's statistics buffer (what the riders fill), same layout as Gc0 / Gs0
+  long long* Gsn0;
 };
+#define GG_RS_CARRY 25        // control block: entries of g.L that hold the changes of the last completed k_scan since its last flush
 
 // Grid-wide exchange that doubles as the barrier: workgroup b publishes (round tag << 48 | payload) in its own
 // slot with one write-through store; everybody polls all G slots (one coalesced load per poll, lane t reads
@@ -150,9 +157,15 @@ __device__ __forceinline__ bool gg_grid_exchange_multi(unsigned long long* slots
 // shapes do not carry its registers.  MODE 2 ("wide"): Kp = 128 or 256 (65 <= K <= 256 blocks) - a node's lanes span two or
 // four wavefronts: the categorical draw scans through LDS (gg_group_categorical_wide) and the (node, old, new) payloads carry
 // 8-bit labels.  Two workgroups per CU in every case (both models' scan grids resident together).
-template <int NT, bool ADJ, int MODE>
+template <int NT, bool ADJ, int MODE, int RIDE = 0>
 __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   constexpr bool WIDE = MODE == 2;
+  if (RIDE && (int)blockIdx.x >= a.G) {
+    // riders (the scan workgroups come first in the grid: resident before anything that shares the chip with them)
+    if (!a.resume && a.r.rs[4]) return;
+    gg_ride<ADJ, (gg_tB(NT)), RIDE == 2>(a.ride);
+    return;
+  }
   constexpr int LB = WIDE ? 8 : 6;                       // bits per label in a payload
   constexpr unsigned LMASK = (1u << LB) - 1u;
   constexpr int B = gg_tB(NT);
@@ -555,6 +568,33 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           ++it;
         }
         for (int n = b * 256 + tid; n < N; n += G * 256) {
+          if (RIDE) {
+            // the riders count the next sweep's statistics under the labels this scan started with: the list that is about
+            // to be dropped goes into that buffer too (atomics: the riders are adding to it at this moment)
+            for (int e = 0; e < nL; ++e) {
+              const int n2 = s_L[e * 3], ba = s_L[e * 3 + 1], bb = s_L[e * 3 + 2];
+              const size_t at = (size_t)n2 * Np + n;
+              for (int d = 0; d < 2; ++d) {
+                if (ADJ) {
+                  if (gg_abit(d == 0 ? g.XAT : g.XA, at)) { atomicSub(&a.Gn0[d * dstride + (size_t)ba * Np + n], 1); atomicAdd(&a.Gn0[d * dstride + (size_t)bb * Np + n], 1); }
+                } else {
+                  const int32_t* q = (d == 0 ? g.XWT : g.XW) + at * B;
+                  if (q[0] == GG_NO_EDGE) continue;
+                  atomicSub(&a.Gn0[d * dstride + (size_t)ba * Np + n], 1);
+                  atomicAdd(&a.Gn0[d * dstride + (size_t)bb * Np + n], 1);
+                  long long v[NSI > 0 ? NSI : 1];
+                  int t = 0;
+                  for (int r = 0; r < B; ++r) v[t++] = q[r];
+                  for (int r = 0; r < B; ++r)
+                    for (int s2 = r; s2 < B; ++s2) v[t++] = (long long)q[r] * (long long)q[s2];
+                  for (int s2 = 0; s2 < NSI; ++s2) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&a.Gsn0[(d * dstride + (size_t)ba * Np + n) * NSI + s2]), (unsigned long long)(-v[s2]));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&a.Gsn0[(d * dstride + (size_t)bb * Np + n) * NSI + s2]), (unsigned long long)v[s2]);
+                  }
+                }
+              }
+            }
+          }
           const int ng = n / per;
           if (ng >= band * G && ng < (band + 1) * G) { a.ap[n] = 0; continue; }   // in some workgroup's LDS
           for (int e = a.ap[n]; e < nL; ++e) {
@@ -637,6 +677,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
       g.rs[2] += nchg;
       g.rs[9] += nchg;
       g.rs[4] = 1;
+      g.rs[GG_RS_CARRY] = -1;
       // round state for the restart rounds, exactly as k_resolve leaves it for an incomplete scan
       *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(rpos, nL, 0, 0, 0);
       *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_MIN]) = GG_NO_CHANGE;
@@ -667,6 +708,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     g.rs[0] = 0;
     g.rs[1] = g.keep_L ? nL : 0;
     g.rs[GG_RS_ROUNDS] += (int)it;     // exchange rounds of this scan (gg_stats.resolve_rounds)
+    g.rs[GG_RS_CARRY] = nL;            // g.L[0, nL): the changes since the scan's last flush (what k_apply_L mode 3 applies)
     g.rs[2] += nchg;
     g.rs[9] += nchg;
     g.rs[5] += 1;

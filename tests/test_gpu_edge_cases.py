@@ -269,14 +269,20 @@ def test_ahead_form_is_the_same_chain(abi, monkeypatch, ahead, split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K,lcap", [(300, 7, 0), (1100, 64, 0), (900, 32, 0), (700, 40, 0), (300, 7, 3), (1100, 64, 5), (700, 16, 2)])
-def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, monkeypatch):
+@pytest.mark.parametrize("N,K,lcap,ride", [(300, 7, 0, 1), (1100, 64, 0, 1), (900, 32, 0, 1), (700, 40, 0, 1), (300, 7, 3, 0), (1100, 64, 5, 0),
+                                            (700, 16, 2, 0), (300, 7, 0, 2), (1100, 64, 0, 2), (900, 32, 0, 2), (300, 7, 3, 2), (1100, 64, 5, 2),
+                                            (700, 16, 2, 2), (2500, 16, 0, 2), (2500, 16, 40, 2)])
+def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, ride, monkeypatch):
     """GG_SCAN=1: the scan as one resident-grid launch (k_scan: one grid-wide exchange per round, every round accepting the
     hypothesised changes up to the earliest surprise).  Same chain bit for bit, burn-in included (random start: hundreds
     of changes per scan, several changers per workgroup); N=1100, K=64 needs two bands of node groups (lazy change list
     at band load); GG_SCAN_LCAP: a change list of 2-5 entries, so that acceptances are cut short and the chip-wide
-    flush of the list runs many times per scan."""
+    flush of the list runs many times per scan.  ride = 2 (GG_SCAN_RIDE=2): from the second sweep on the NEXT sweep's bulk
+    pass rides in the scan's launch, counting under the labels the scan starts with, and the scan's change list - flushed
+    into that buffer too whenever it overflows - moves those statistics to the labels it ends with (the default, 1, does
+    so only for chains that change few labels per sweep); 0: never."""
     monkeypatch.setenv("GG_SCAN", "1")
+    monkeypatch.setenv("GG_SCAN_RIDE", str(ride))
     if lcap:
         monkeypatch.setenv("GG_SCAN_LCAP", str(lcap))
     A, W, _ = planted_sbm(N, K, seed=31)
@@ -290,8 +296,12 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, monkeypatch):
     w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
     w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
     ps = sa.p_self
-    nsw = 4
-    abi.resample_many([adj, w], d, nsw)        # both grids resident at the same time
+    nsw = 4 if ride < 2 else 7
+    abi.resample_many([adj, w], d, nsw - 2)        # both grids resident at the same time
+    adj.resample(d, 1); w.resample(d, 1)           # (one call per sweep as well: what was counted ahead survives the call)
+    ll_mid = adj.log_likelihood(d)                 # (and serves a log-likelihood in between)
+    abi.resample_many([adj, w], d, 1)
+    assert np.isfinite(ll_mid)
     for s in range(nsw):
         ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 71, s)
         O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, 1, 72, s)
