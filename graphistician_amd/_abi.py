@@ -54,7 +54,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_update", "gg_data_info",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
-           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_predictive_ll", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
+           "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_part_many", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_predictive_ll", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
            "gg_comm_create_host", "gg_comm_destroy", "gg_comm_info", "gg_shard_sweep", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws"]
 
@@ -95,6 +95,7 @@ def lib():
         L.gg_get_state.argtypes = [vp, C.c_int32, vp, C.c_size_t]
         L.gg_resample.argtypes = [vp, vp, C.c_int32, C.c_double]
         L.gg_resample_part.argtypes = [vp, vp, C.c_int32, C.c_double]
+        L.gg_resample_part_many.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_double]
         L.gg_resample_async.argtypes = [vp, vp, C.c_int32, C.c_double]
         L.gg_sync.argtypes = [vp]
         L.gg_sync_many.argtypes = [C.POINTER(vp), C.c_int32]
@@ -138,24 +139,35 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def _adjacency_u8(A):
-    """(N, N) adjacency as uint8 {0, 1}.  NaN is refused: `NaN != 0` would silently upload a missing entry as an edge
-    (the reference's eigenmodel treats NaN as missing data, eigenmodel.py:121-127; the engine has no missing-data mask)."""
+A_MISSING = 2     # byte value of an unobserved adjacency entry (GG_A_MISSING)
+
+
+def _adjacency_u8(A, missing_ok=False):
+    """(N, N) adjacency as uint8 {0, 1}.  NaN marks missing data in the reference's eigenmodel (eigenmodel.py:121-127): with
+    missing_ok it becomes the byte A_MISSING, which the eigenmodel kernels leave out of every conditional and of the
+    log-likelihood; otherwise it is refused - `NaN != 0` would silently upload a missing entry as an edge, and the block
+    models define nothing for it (the reference's masked sums turn NaN)."""
     A = np.asarray(A)
-    if A.dtype.kind == "f" and np.isnan(A).any():
-        raise ValueError("the adjacency matrix contains NaN: missing entries are not supported by the engine")
+    if A.dtype.kind == "f":
+        nan = np.isnan(A)
+        if nan.any():
+            if not missing_ok:
+                raise ValueError("the adjacency matrix contains NaN: missing entries are defined for the eigenmodels only")
+            out = np.ascontiguousarray(np.where(nan, 0, A) != 0, dtype=np.uint8)
+            out[nan] = A_MISSING
+            return out
     return np.ascontiguousarray(A != 0, dtype=np.uint8)
 
 
 class DeviceData(object):
     """Device-resident (A, W): replaces the ndarray pair of networks.py:28,69."""
 
-    def __init__(self, A=None, W=None, device=0, handle=None, N=None, B=None):
+    def __init__(self, A=None, W=None, device=0, handle=None, N=None, B=None, missing_ok=False):
         self._h = C.c_void_p()
         if handle is not None:
             self._h = handle
         else:
-            A = _adjacency_u8(A)
+            A = _adjacency_u8(A, missing_ok)
             assert A.ndim == 2 and A.shape[0] == A.shape[1]
             N = A.shape[0]
             if W is not None:
@@ -208,9 +220,9 @@ class DeviceData(object):
                                                  int(shard[1]), device))
         return cls(handle=h, N=N, B=1, device=device)
 
-    def update(self, A, W=None):
+    def update(self, A, W=None, missing_ok=False):
         """Replace the network in place with another (A, W) of the same shape (gg_data_update)."""
-        A = _adjacency_u8(A)
+        A = _adjacency_u8(A, missing_ok)
         assert A.shape == (self.N, self.N)
         if W is not None:
             W = np.ascontiguousarray(W, dtype=np.float64)
@@ -278,6 +290,11 @@ class Model(object):
 
     def resample_part(self, data, parts, beta=1.0):
         check(lib().gg_resample_part(self._h, data.handle if data is not None else None, parts, beta))
+
+    def resample_part_many(self, datas, parts, beta=1.0):
+        """The reference's list-taking forms (gg_resample_part_many): SBM adjacency resample_p(As), eigenmodel resample(networks)."""
+        hs = (C.c_void_p * len(datas))(*[d.handle for d in datas])
+        check(lib().gg_resample_part_many(self._h, hs, len(datas), parts, beta))
 
     def log_likelihood(self, data):
         out = C.c_double(0)

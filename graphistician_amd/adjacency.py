@@ -482,8 +482,14 @@ class SBMAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacke
         self._run(A, _abi.PART_ALL, beta)
 
     def resample_p(self, As, beta=1.0):
-        assert len(As) == 1, "one adjacency matrix per model"
-        self._run(As[0], _abi.PART_PARAMS, beta)
+        """adjacency.py:620-648: the block-pair counts are summed over the graphs of the list, one Beta draw per pair."""
+        assert len(As) >= 1
+        if len(As) == 1:
+            return self._run(As[0], _abi.PART_PARAMS, beta)
+        ds = [self._data(A) for A in As]
+        assert all(d.N == self.N for d in ds)
+        self._engine().resample_part_many(ds, _abi.PART_PARAMS, beta)
+        self._mark_stale("c", "m", "p", "p_self")
 
     def resample_c(self, A, beta=1.0):
         if self.C == 1:

@@ -441,6 +441,7 @@ struct gg_adj_hyp {
   int special;       // special_case_self_conns (BB: self_connection)
   int bb;            // Beta-Bernoulli semantics (adjacency.py:153-181)
   long long d1, d0;  // diagonal edge / non-edge counts
+  int ngraphs;       // adjacency matrices the counts were summed over (resample_p(As), adjacency.py:630-634): 1 in a sweep
 };
 
 struct gg_w_hyp {
@@ -690,6 +691,7 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
           long long n1 = s_tab[0];
           long long pairs = (long long)g.cnt[a] * (long long)g.cnt[b];
           if (a == b && g.ah.special) pairs -= g.cnt[a];
+          pairs *= (long long)g.ah.ngraphs;      // (every graph of the list offers every pair: adjacency.py:633)
           long long n0 = pairs - n1;
           gg_stream s;
           gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_P : GG_SITE_ADJ_P, g.sweep, (uint32_t)t);

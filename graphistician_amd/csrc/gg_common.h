@@ -80,6 +80,8 @@ static inline int gg_nsi(int B) { return B + B * (B + 1) / 2; }
 //   Ab, AbT : uint32 [N][Np/32]   the same, bit-packed (block adjacency models: 1/8 of the bytes per pass)
 //   Wq, WqT : int32  [N][Np][B]   fixed-point weights, GG_NO_EDGE in component 0 where A == 0 / diag / pad
 //   dA, dWq : the diagonal, kept apart because the reference special-cases self connections
+#define GG_A_MISSING 2   // byte value of an unobserved adjacency entry (host input and the device byte matrices)
+
 struct gg_data {
   int device;
   int N, B, Np;      // N rows (all nodes); Np = padded number of stored columns
@@ -87,6 +89,7 @@ struct gg_data {
   int has_w;
   int shift;
   long long n_edges;
+  long long n_missing;   // entries of A given as GG_A_MISSING (unobserved: eigenmodel.py:121-127); 0 for every other network
   uint8_t *A, *AT, *dA;
   // the same off-diagonal adjacency and its transpose, one BIT per entry ([N][Np / 32] words, bit j of row i = A[i][j]):
   // what the block adjacency models read (their bulk pass counts by positional popcount, their scans test single bits);

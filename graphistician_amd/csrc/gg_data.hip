@@ -231,7 +231,7 @@ static void diag_stats_host(gg_data* d, const uint8_t* dA, const int32_t* dWq) {
   for (int s = 0; s < gg_nsi(GG_MAXB); ++s) d->dS[s] = 0;
   int B = d->B;
   for (int i = 0; i < d->N; ++i) {
-    if (!dA[i]) continue;
+    if (dA[i] != 1) continue;      // (0: no self edge; GG_A_MISSING: unobserved)
     d->d1 += 1;
     if (!d->has_w) continue;
     const int32_t* q = dWq + (size_t)i * B;
@@ -249,14 +249,18 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
   // oracle's orc_quantise: shift = qbits - frexp-exponent of max |w| over edges).
   size_t nA = (size_t)N * d->Np;
   std::vector<uint8_t> hA(nA, 0), hdA(N, 0);
-  long long nedges = 0;
+  long long nedges = 0, nmiss = 0;
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
-      uint8_t a = A[(size_t)i * N + j] ? 1 : 0;
-      nedges += a;
+      const uint8_t raw = A[(size_t)i * N + j];
+      const uint8_t a = raw == GG_A_MISSING ? (uint8_t)GG_A_MISSING : (raw ? 1 : 0);
+      nedges += a == 1;
+      nmiss += a == GG_A_MISSING;
       if (i == j) hdA[i] = a; else hA[(size_t)i * d->Np + j] = a;
     }
   d->n_edges = nedges;
+  d->n_missing = nmiss;
+  if (nmiss && W) return gg_fail(GG_ERR_UNSUPPORTED, "unobserved adjacency entries (%lld of them) with weights: missing data is defined for the eigenmodels' adjacency only (eigenmodel.py:121-127)", nmiss);
   GG_HIP(hipMemcpyAsync(d->A, hA.data(), nA, hipMemcpyHostToDevice, d->stream));
   GG_HIP(hipMemcpyAsync(d->dA, hdA.data(), N, hipMemcpyHostToDevice, d->stream));
   std::vector<int32_t> hW, hdW;

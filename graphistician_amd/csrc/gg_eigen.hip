@@ -39,6 +39,16 @@ struct gg_eigen {
   double *F, *lmbda, *mu0, *mu_lmbda;
   double *S, *dO, *Z;
   double *Sb, *Vb;        // tile-local pair weights / mean coefficients, [N][EIG_VW] (k_eig_vblocks)
+  // Several graphs per model (resample(networks), eigenmodel.py:836-857) and unobserved entries (NaN in A, :121-127): every
+  // conditional is linear in the pair's summed auxiliary variables and summed centred observations, so the general form keeps
+  //   a2[i][j]  = sum over graphs and OBSERVED directions (i->j, j->i) of (2 A - 1)   (int8; the logistic kappa sum is ka a2 / 2)
+  //   nob[i][j] = the number of those observed entries                                (uint8; the probit pair weight)
+  // and their diagonal counterparts, built by k_eig_obs when the auxiliary variables are drawn; S accumulates over the graphs.
+  // One fully observed graph (gen == 0) reads A and A^T as before.
+  int8_t *a2, *da2;
+  uint8_t *nob;
+  int gen;                // the auxiliary variables in S were drawn in the general form
+  unsigned long long omega_uid;   // the network they were drawn for (one graph), 0: a list
   double *part, *gpart, *llpart;
   int* status;
   long long* dbgbuf;   // GG_EIG_DBG: cycle counters of the chain's solver wave
@@ -49,6 +59,8 @@ struct gg_eigen {
   hipEvent_t e0, e1;
   gg_stats st;
 };
+
+int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int parts);
 
 // ------------------------------------------------------------------ kernels
 typedef double gg_double4 __attribute__((ext_vector_type(4)));
@@ -74,6 +86,48 @@ __device__ __forceinline__ void eig_psi_tile_mfma(const double (*s_fi)[DM], cons
   for (int r = 0; r < 4; ++r) s_psi[bi * 16 + 4 * r + (lane >> 4)][bj * 16 + (lane & 15)] = mu0 + acc[r];
 }
 
+// Where a pair's centred observation and (probit) weight come from: one fully observed graph reads its byte matrices, the
+// general form (several graphs, unobserved entries) the summed int8 matrices (gg_eigen::a2 / nob).
+struct eig_obs {
+  const uint8_t *A, *AT;
+  const int8_t* a2;
+  const uint8_t* nob;
+  int gen;
+};
+// Pair (i, j) at offset `at`: weight s and centred value a of the conditionals (eigenmodel.py:898-901, :312-321).
+// logistic: s = the summed omegas (raw), a = sum of kappa = ka (A - 1/2) over the observed entries; probit: s = the number of
+// observed entries (2 for one fully observed graph), a = the summed Z (raw).  ka a2 / 2 == ka (A + A^T - 1) to the bit.
+__device__ __forceinline__ void eig_pair(const eig_obs& o, int probit, double ka, double raw, size_t at, double* s, double* a) {
+  if (o.gen) {
+    *s = probit ? (double)o.nob[at] : raw;
+    *a = probit ? raw : 0.5 * ka * (double)o.a2[at];
+  } else {
+    *s = probit ? 2.0 : raw;
+    *a = probit ? raw : ka * (double)((int)o.A[at] + (int)o.AT[at] - 1);
+  }
+}
+
+// a2 / nob (and the diagonal's da2) of one graph, added to what the earlier graphs of the list left (first: stored).
+__global__ void k_eig_obs(int N, int Np, const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                          const uint8_t* __restrict__ dA, int8_t* __restrict__ a2, uint8_t* __restrict__ nob,
+                          int8_t* __restrict__ da2, int first) {
+  const size_t at = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (at >= (size_t)N * Np) return;
+  const int i = (int)(at / Np), j = (int)(at % Np);
+  int v = 0, nb = 0;
+  if (j < N && j != i) {
+    const int a = A[at], t = AT[at];
+    if (a != GG_A_MISSING) { v += 2 * a - 1; nb += 1; }
+    if (t != GG_A_MISSING) { v += 2 * t - 1; nb += 1; }
+  }
+  a2[at] = (int8_t)((first ? 0 : (int)a2[at]) + v);
+  nob[at] = (uint8_t)((first ? 0 : (int)nob[at]) + nb);
+  if (j == 0) {
+    const int d = dA[i];
+    da2[i] = (int8_t)((first ? 0 : (int)da2[i]) + (d != GG_A_MISSING ? 2 * d - 1 : 0));
+  }
+}
+
 __global__ void k_eig_normals(double* Z, int n, uint64_t seed, uint32_t site, uint32_t sweep) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) Z[i] = gg_normal_at(seed, site, sweep, (uint32_t)i);
@@ -87,11 +141,15 @@ __device__ __forceinline__ void eig_tile_pair(int b, int nt, int* I, int* J) {
 }
 
 // eigenmodel.py:859-874: omega_ij ~ PG(1, psi_ij), psi = mu_0 + (F lambda) F^T, diag psi = mu_0 (:81-82).
+// gen: entries given as GG_A_MISSING are unobserved - no omega is drawn for them (their likelihood term is absent);
+// accumulate: a further graph of the list (its own Philox site), added to S / dO.
 template <int DM>
 __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const double* __restrict__ F,
                                                    const double* __restrict__ lmbda, const double* __restrict__ mu0p,
                                                    uint64_t seed, uint32_t sweep, double* __restrict__ S,
-                                                   double* __restrict__ dO, double beta) {
+                                                   double* __restrict__ dO, double beta, const uint8_t* __restrict__ A,
+                                                   const uint8_t* __restrict__ AT, const uint8_t* __restrict__ dA, int gen,
+                                                   int accumulate, uint32_t site) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
   __shared__ double s_t[32][33];
   __shared__ double s_psi[32][33];
@@ -114,29 +172,29 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
     const int gi = I * 32 + li, gj = J * 32 + lj;
     double val = 0.0;
     if (gi < N && gj < N) {
-      if (beta != 1.0) {
-        // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
-        if (I == J && li == lj) {
+      if (I == J && li == lj) {
+        double dv = 0.0;
+        if (!gen || dA[gi] != GG_A_MISSING) {
           gg_stream s0;
-          gg_stream_init(&s0, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gi);
-          dO[gi] = beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0;
-        } else if (I < J || li < lj) {
-          const double psi = s_psi[li][lj];
-          gg_stream s1, s2;
-          gg_stream_init(&s1, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj);
-          gg_stream_init(&s2, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi);
-          val = beta > 0.0 ? gg_pg_frac(&s1, beta, psi) + gg_pg_frac(&s2, beta, psi) : 0.0;
+          gg_stream_init(&s0, seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gi);
+          // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
+          dv = beta != 1.0 ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
         }
-      } else if (I == J && li == lj) {
-        dO[gi] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gi, mu0);
+        dO[gi] = accumulate ? dO[gi] + dv : dv;
       } else if (I < J || li < lj) {
         const double psi = s_psi[li][lj];
-        // omega_ij and omega_ji see the same psi: the mixture mass is computed once for the pair
-        const double Z = 0.5 * gg_fabs(psi), ptex = gg_pg_mass_texpon(Z);
+        const size_t at = (size_t)gi * Np + gj;
+        const bool o1 = !gen || A[at] != GG_A_MISSING, o2 = !gen || AT[at] != GG_A_MISSING;   // i -> j, j -> i observed
         gg_stream s1, s2;
-        gg_stream_init(&s1, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj);
-        gg_stream_init(&s2, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi);
-        val = gg_pg1_pre(&s1, Z, ptex) + gg_pg1_pre(&s2, Z, ptex);
+        gg_stream_init(&s1, seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj);
+        gg_stream_init(&s2, seed, site, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi);
+        if (beta != 1.0) {
+          if (beta > 0.0) val = (o1 ? gg_pg_frac(&s1, beta, psi) : 0.0) + (o2 ? gg_pg_frac(&s2, beta, psi) : 0.0);
+        } else {
+          // omega_ij and omega_ji see the same psi: the mixture mass is computed once for the pair
+          const double Zh = 0.5 * gg_fabs(psi), ptex = gg_pg_mass_texpon(Zh);
+          val = (o1 ? gg_pg1_pre(&s1, Zh, ptex) : 0.0) + (o2 ? gg_pg1_pre(&s2, Zh, ptex) : 0.0);
+        }
       }
     }
     if (I < J || li <= lj) s_t[li][lj] = val;
@@ -152,13 +210,13 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
   for (int e = tid; e < 1024; e += 256) {
     const int li = e >> 5, lj = e & 31;
     const int gi = I * 32 + li, gj = J * 32 + lj;
-    if (gi < N && gj < N) S[(size_t)gi * Np + gj] = s_t[li][lj];
+    if (gi < N && gj < N) { const size_t o = (size_t)gi * Np + gj; S[o] = accumulate ? S[o] + s_t[li][lj] : s_t[li][lj]; }
   }
   if (I < J) {
     for (int e = tid; e < 1024; e += 256) {
       const int lj = e >> 5, li = e & 31;   // transposed tile, coalesced over li
       const int gi = I * 32 + li, gj = J * 32 + lj;
-      if (gi < N && gj < N) S[(size_t)gj * Np + gi] = s_t[li][lj];
+      if (gi < N && gj < N) { const size_t o = (size_t)gj * Np + gi; S[o] = accumulate ? S[o] + s_t[li][lj] : s_t[li][lj]; }
     }
   }
 }
@@ -170,7 +228,7 @@ template <int DM>
 __global__ __launch_bounds__(256) void k_eig_z(int N, int Np, int D, const double* __restrict__ F,
                                                const double* __restrict__ lmbda, const double* __restrict__ mu0p,
                                                const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
-                                               uint64_t seed, uint32_t sweep, double* __restrict__ S) {
+                                               uint64_t seed, uint32_t sweep, double* __restrict__ S, int accumulate, uint32_t site) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
   __shared__ double s_t[32][33];
   __shared__ double s_psi[32][33];
@@ -195,8 +253,10 @@ __global__ __launch_bounds__(256) void k_eig_z(int N, int Np, int D, const doubl
     if (gi < N && gj < N && (I < J || li < lj)) {
       const double psi = s_psi[li][lj];
       const size_t at = (size_t)gi * Np + gj;
-      const double z1 = gg_truncnorm_at(seed, sweep, (uint32_t)N, (uint32_t)gi, (uint32_t)gj, psi, A[at] ? 1 : 0);
-      const double z2 = gg_truncnorm_at(seed, sweep, (uint32_t)N, (uint32_t)gj, (uint32_t)gi, psi, AT[at] ? 1 : 0);
+      // (an unobserved entry has no auxiliary variable: it is absent from every conditional)
+      const int a1 = A[at], a2v = AT[at];
+      const double z1 = a1 == GG_A_MISSING ? 0.0 : gg_truncnorm(gg_uniform_at(seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj), psi, a1 ? 1 : 0);
+      const double z2 = a2v == GG_A_MISSING ? 0.0 : gg_truncnorm(gg_uniform_at(seed, site, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi), psi, a2v ? 1 : 0);
       val = z1 + z2;
     }
     if (I < J || li <= lj) s_t[li][lj] = val;
@@ -212,13 +272,13 @@ __global__ __launch_bounds__(256) void k_eig_z(int N, int Np, int D, const doubl
   for (int e = tid; e < 1024; e += 256) {
     const int li = e >> 5, lj = e & 31;
     const int gi = I * 32 + li, gj = J * 32 + lj;
-    if (gi < N && gj < N) S[(size_t)gi * Np + gj] = s_t[li][lj];
+    if (gi < N && gj < N) { const size_t o = (size_t)gi * Np + gj; S[o] = accumulate ? S[o] + s_t[li][lj] : s_t[li][lj]; }
   }
   if (I < J) {
     for (int e = tid; e < 1024; e += 256) {
       const int lj = e >> 5, li = e & 31;   // transposed tile, coalesced over li
       const int gi = I * 32 + li, gj = J * 32 + lj;
-      if (gi < N && gj < N) S[(size_t)gj * Np + gi] = s_t[li][lj];
+      if (gi < N && gj < N) { const size_t o = (size_t)gj * Np + gi; S[o] = accumulate ? S[o] + s_t[li][lj] : s_t[li][lj]; }
     }
   }
 }
@@ -250,8 +310,8 @@ __global__ __launch_bounds__(256) void k_eig_z(int N, int Np, int D, const doubl
 
 // Pair weights s and mean coefficients v (with the perturbation noise) of node n against the 128 nodes of its own and the
 // previous tile.  Entries outside the matrix and the diagonal are zero.
-__global__ __launch_bounds__(64) void k_eig_vblocks(int N, int Np, const double* __restrict__ S, const uint8_t* __restrict__ A,
-                                                    const uint8_t* __restrict__ AT, const double* __restrict__ mu0p,
+__global__ __launch_bounds__(64) void k_eig_vblocks(int N, int Np, const double* __restrict__ S, eig_obs ob,
+                                                    const double* __restrict__ mu0p,
                                                     double* __restrict__ Sb, double* __restrict__ Vb, int probit, double ka,
                                                     uint64_t seed, uint32_t sweep) {
   const int n = blockIdx.x;
@@ -266,9 +326,8 @@ __global__ __launch_bounds__(64) void k_eig_vblocks(int N, int Np, const double*
       const int m = m0 + h;
       if (m < N && m != n) {
         const size_t at = (size_t)n * Np + m;
-        const double raw = S[at];
-        const double s = probit ? 2.0 : raw;
-        const double a = probit ? raw : ka * (double)((int)A[at] + (int)AT[at] - 1);
+        double s, a;
+        eig_pair(ob, probit, ka, S[at], at, &s, &a);
         sv[h] = s;
         vv[h] = gg_eig_coef(s, a, mu0, e[h]);
       }
@@ -287,7 +346,7 @@ __global__ __launch_bounds__(64) void k_eig_vblocks(int N, int Np, const double*
 // Output layout per (node, chunk): upper triangle of the DM x DM matrix (padded to DM), then the DM mean entries.
 template <int DM>
 __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0, const double* __restrict__ S,
-                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                    const eig_obs& ob,
                                                     const double* __restrict__ F, const double* __restrict__ lmbda,
                                                     const double* __restrict__ mu0p, int NCH, double* __restrict__ part,
                                                     int ex_lo, int node, int c, int probit, double ka,
@@ -315,9 +374,8 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
       if (hh ? out1 : out0) continue;
       const int nn = nn0 + hh;
       // logistic: s = omega_ij + omega_ji, a = kappa_ij + kappa_ji; probit (eigenmodel.py:312-321): s = 2, a = Z_ij + Z_ji
-      const double raw = S[(size_t)n * Np + nn];
-      const double s = probit ? 2.0 : raw;
-      const double a = probit ? raw : ka * (double)((int)A[(size_t)n * Np + nn] + (int)AT[(size_t)n * Np + nn] - 1);
+      double s, a;
+      eig_pair(ob, probit, ka, S[(size_t)n * Np + nn], (size_t)n * Np + nn, &s, &a);
       const double v = gg_eig_coef(s, a, mu0, eps[hh]);
       double ft[DM];
 #pragma unroll
@@ -351,12 +409,12 @@ __device__ __forceinline__ void eig_tile_stats_body(int N, int Np, int D, int t0
 
 template <int DM>
 __global__ __launch_bounds__(64 * DM) void k_eig_tile_stats(int N, int Np, int D, int t0, const double* __restrict__ S,
-                                                            const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                            eig_obs ob,
                                                             const double* __restrict__ F, const double* __restrict__ lmbda,
                                                             const double* __restrict__ mu0p, int NCH,
                                                             double* __restrict__ part, int ex_lo, int probit, double ka,
                                                             uint64_t seed, uint32_t sweep) {
-  eig_tile_stats_body<DM>(N, Np, D, t0, S, A, AT, F, lmbda, mu0p, NCH, part, ex_lo, blockIdx.x, blockIdx.y, probit, ka, seed, sweep);
+  eig_tile_stats_body<DM>(N, Np, D, t0, S, ob, F, lmbda, mu0p, NCH, part, ex_lo, blockIdx.x, blockIdx.y, probit, ka, seed, sweep);
 }
 
 // Order this wave's LDS operations: wait for the outstanding ones and keep the compiler from moving memory accesses across.
@@ -389,7 +447,7 @@ __device__ __forceinline__ double eig_group_sum(double x) {
 // inverse precision and a copy of its mean term.
 template <int DM>
 __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int t0, const double* __restrict__ S,
-                                                       const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                       eig_obs ob,
                                                        double* __restrict__ F, const double* __restrict__ lmbda,
                                                        const double* __restrict__ mu0p, double sigma_F, int NCH,
                                                        const double* __restrict__ part, const double* __restrict__ Z,
@@ -401,7 +459,7 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
   if (blockIdx.x > 0) {
     // riders: the statistics of the NEXT tile against all nodes outside this tile and behind the node in its own
     const int idx = blockIdx.x - 1;
-    eig_tile_stats_body<DM>(N, Np, D, t0 + EIG_T, S, A, AT, F, lmbda, mu0p, NCH, part_next, t0, idx / NCH, idx % NCH,
+    eig_tile_stats_body<DM>(N, Np, D, t0 + EIG_T, S, ob, F, lmbda, mu0p, NCH, part_next, t0, idx / NCH, idx % NCH,
                             probit, ka, seed, sweep);
     return;
   }
@@ -654,7 +712,7 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
 // g = F_i * F_j (elementwise).  One workgroup per row i; partials reduced in k_eig_draw_globals.
 template <int DM>
 __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const double* __restrict__ S,
-                                                    const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
+                                                    eig_obs ob,
                                                     const double* __restrict__ F, double* __restrict__ gpart, int probit, double ka) {
   constexpr int NEGM = DM * (DM + 1) / 2;
   constexpr int NGM = 2 + 2 * DM + NEGM;
@@ -666,9 +724,8 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
 #pragma unroll
   for (int d = 0; d < DM; ++d) fi[d] = d < D ? F[(size_t)i * D + d] : 0.0;
   for (int j = i + 1 + threadIdx.x; j < N; j += 256) {
-    const double raw = S[(size_t)i * Np + j];
-    const double s = probit ? 2.0 : raw;
-    const double a = probit ? raw : ka * (double)((int)A[(size_t)i * Np + j] + (int)AT[(size_t)i * Np + j] - 1);
+    double s, a;
+    eig_pair(ob, probit, ka, S[(size_t)i * Np + j], (size_t)i * Np + j, &s, &a);
     double g[DM];
 #pragma unroll
     for (int d = 0; d < DM; ++d) g[d] = d < D ? fi[d] * F[(size_t)j * D + d] : 0.0;
@@ -703,6 +760,7 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
 template <int DM>
 __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, const double* __restrict__ gpart,
                                                           const double* __restrict__ dO, const uint8_t* __restrict__ dA,
+                                                          const int8_t* __restrict__ da2,
                                                           double* __restrict__ lmbda, double* __restrict__ mu0p,
                                                           const double* __restrict__ mu_lmbda, double mu_mu_0,
                                                           double sigma_mu0, double sigma_lmbda, int do_mu0, int do_lmbda,
@@ -728,7 +786,7 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, 
   // diagonal: sum omega_ii and sum (A_ii - 1/2)
   double so = 0.0, sk = 0.0;
   if (!probit)   // (the probit bias update leaves the diagonal out altogether: eigenmodel.py:339-346)
-    for (int i = tid; i < N; i += 256) { so += dO[i]; sk += ka * ((dA[i] ? 1.0 : 0.0) - 0.5); }
+    for (int i = tid; i < N; i += 256) { so += dO[i]; sk += da2 ? 0.5 * ka * (double)da2[i] : ka * ((dA[i] ? 1.0 : 0.0) - 0.5); }
   for (int dl = 32; dl >= 1; dl >>= 1) { so += __shfl_down(so, dl); sk += __shfl_down(sk, dl); }
   if ((tid & 63) == 0) { s_w[tid >> 6][0] = so; s_w[tid >> 6][1] = sk; }
   __syncthreads();
@@ -803,6 +861,7 @@ __global__ __launch_bounds__(256) void k_eig_loglik(int N, int Np, int D, const 
         psi = s_psi[li][lj];
         a = A[(size_t)gi * Np + gj];
       }
+      if (a == GG_A_MISSING) continue;                                       // eigenmodel.py:125-127: nan_to_num(ll) = 0
       double P = probit ? gg_norm_cdf(psi) : 1.0 / (1.0 + gg_exp(-psi));   // eigenmodel.py:228-237 / :803-811
       P = P < 1e-16 ? 1e-16 : (P > 1.0 - 1e-16 ? 1.0 - 1e-16 : P);
       ll += a ? gg_log(P) : gg_log(1.0 - P);
@@ -861,7 +920,7 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
 
 int gg_eigen_destroy(gg_eigen* e) {
   if (!e) return GG_OK;
-  void* ptrs[] = {e->F, e->lmbda, e->mu0, e->mu_lmbda, e->S, e->dO, e->Z, e->Sb, e->Vb, e->part, e->gpart, e->llpart, e->status, e->dbgbuf};
+  void* ptrs[] = {e->F, e->lmbda, e->mu0, e->mu_lmbda, e->S, e->dO, e->Z, e->Sb, e->Vb, e->part, e->gpart, e->llpart, e->status, e->dbgbuf, e->a2, e->nob, e->da2};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->e0) (void)hipEventDestroy(e->e0);
   if (e->e1) (void)hipEventDestroy(e->e1);
@@ -936,8 +995,23 @@ int gg_eigen_get_state(gg_eigen* e, int id, void* buf, size_t nbytes) {
 void gg_eigen_set_beta(gg_eigen* e, double beta) { e->beta = beta; }
 
 int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
-  if (!d) return gg_fail(GG_ERR_INVALID, "null data handle");
-  if (d->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, e->N);
+  return gg_eigen_resample_many(e, &d, 1, parts);
+}
+
+// resample(networks) (eigenmodel.py:836-857, :246-272): auxiliary variables for every graph of the list, then F, mu_0 and
+// lambda from the statistics summed over the graphs (every conditional is linear in them); entries given as GG_A_MISSING
+// are unobserved and take part in nothing.  One fully observed graph is the plain sweep.
+int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int parts) {
+  if (!ds || nd < 1 || !ds[0]) return gg_fail(GG_ERR_INVALID, "null data handle");
+  if (nd > 31) return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: at most 31 graphs per model (the summed observations are kept as int8)");
+  bool general = nd > 1;
+  for (int g = 0; g < nd; ++g) {
+    if (!ds[g]) return gg_fail(GG_ERR_INVALID, "null data handle");
+    if (ds[g]->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", ds[g]->N, e->N);
+    if (ds[g]->n0 != 0 || ds[g]->n1 != e->N) return gg_fail(GG_ERR_INVALID, "eigenmodel: whole networks only, not column shards");
+    if (ds[g]->n_missing) general = true;
+  }
+  const gg_data* d = ds[0];
   const int N = e->N, D = e->D, Np = e->Np;
   hipStream_t st = e->stream;
   // a part asked for a second time under the same sweep index starts a new one: fresh Philox counters (graphgibbs.h)
@@ -945,22 +1019,43 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   GG_HIP(hipEventRecord(e->e0, st));
   const bool full = (parts & (GG_PART_OMEGA | GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) ==
                     (GG_PART_OMEGA | GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA);
+  if (general && !e->a2) {
+    int rc;
+    if ((rc = emalloc(&e->a2, (size_t)N * Np)) || (rc = emalloc(&e->nob, (size_t)N * Np)) || (rc = emalloc(&e->da2, (size_t)N))) return rc;
+  }
   if (parts & GG_PART_OMEGA) {
     const int nt = (N + 31) / 32;
     const int npairs = nt * (nt + 1) / 2;
-    if (e->probit) {
-#define CALL(DMV) k_eig_z<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, d->A, d->AT, e->cfg.seed, e->sweep, e->S)
-      EIG_DISPATCH(CALL);
+    for (int g = 0; g < nd; ++g) {
+      const gg_data* dg = ds[g];
+      const int acc = g > 0 ? 1 : 0;
+      // graph g draws from its own Philox site (the plain site for the first: one graph is the plain sweep)
+      const uint32_t site = (uint32_t)(e->probit ? GG_SITE_EIG_Z : GG_SITE_EIG_OMEGA) + ((uint32_t)g << 8);
+      if (e->probit) {
+#define CALL(DMV) k_eig_z<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, dg->A, dg->AT, e->cfg.seed, e->sweep, e->S, acc, site)
+        EIG_DISPATCH(CALL);
 #undef CALL
-    } else {
-#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta)
-      EIG_DISPATCH(CALL);
+      } else {
+#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site)
+        EIG_DISPATCH(CALL);
 #undef CALL
+      }
+      if (general) {
+        const size_t cells = (size_t)N * Np;
+        k_eig_obs<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(N, Np, dg->A, dg->AT, dg->dA, e->a2, e->nob, e->da2, acc ? 0 : 1);
+      }
     }
     e->have_omega = true;
+    e->gen = general ? 1 : 0;
+    e->omega_uid = nd == 1 ? d->uid : 0;
   }
   if ((parts & (GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) && !e->have_omega)
     return gg_fail(GG_ERR_INVALID, "eigenmodel: resample F / mu_0 / lambda needs the auxiliary variables (GG_PART_OMEGA) first");
+  if ((parts & (GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) && !(parts & GG_PART_OMEGA) && (general ? 1 : 0) != e->gen)
+    return gg_fail(GG_ERR_INVALID, "eigenmodel: the auxiliary variables were drawn for a different list of networks");
+  eig_obs ob;
+  ob.A = d->A; ob.AT = d->AT; ob.a2 = e->a2; ob.nob = e->nob; ob.gen = e->gen;
+  const int8_t* da2 = e->gen ? e->da2 : nullptr;
   if (parts & GG_PART_F) {
     k_eig_normals<<<(N * D + 255) / 256, 256, 0, st>>>(e->Z, N * D, e->cfg.seed, GG_SITE_EIG_F, e->sweep);
     static int dbgon = -1;
@@ -979,13 +1074,13 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
       attr8 = true;
     }
     // the tile-local blocks of pair weights and mean coefficients (previous tile | own tile) for every node
-    k_eig_vblocks<<<N, 64, 0, st>>>(N, Np, e->S, d->A, d->AT, e->mu0, e->Sb, e->Vb, e->probit, e->beta, e->cfg.seed, e->sweep);
+    k_eig_vblocks<<<N, 64, 0, st>>>(N, Np, e->S, ob, e->mu0, e->Sb, e->Vb, e->probit, e->beta, e->cfg.seed, e->sweep);
     // Tile 0's statistics in a launch of their own; every chain launch then carries, as extra workgroups, the
     // statistics of the tile after it (all nodes outside both tiles), and adds the previous tile's nodes itself.
     const size_t part_stride = (size_t)EIG_T * e->NCH * e->NEm;
     {
       dim3 grd(N < EIG_T ? N : EIG_T, e->NCH);
-#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 64 * DMV, 0, st>>>(N, Np, D, 0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, e->probit, e->beta, e->cfg.seed, e->sweep)
+#define CALL(DMV) k_eig_tile_stats<DMV><<<grd, 64 * DMV, 0, st>>>(N, Np, D, 0, e->S, ob, e->F, e->lmbda, e->mu0, e->NCH, e->part, 0, e->probit, e->beta, e->cfg.seed, e->sweep)
       EIG_DISPATCH(CALL);
 #undef CALL
     }
@@ -996,7 +1091,7 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
       const int Tn = (t0 + EIG_T < N) ? ((N - t0 - EIG_T < EIG_T) ? (N - t0 - EIG_T) : EIG_T) : 0;
       const int grid = 1 + Tn * e->NCH;
 #define CALL(DMV)                                                                                                      \
-  k_eig_chain<DMV><<<grid, 64 * DMV, chain_lds, st>>>(N, Np, D, t0, e->S, d->A, d->AT, e->F, e->lmbda, e->mu0,           \
+  k_eig_chain<DMV><<<grid, 64 * DMV, chain_lds, st>>>(N, Np, D, t0, e->S, ob, e->F, e->lmbda, e->mu0,                   \
                                                       e->cfg.sigma_F, e->NCH, partb, e->Z, e->Sb, e->Vb, e->status, dbg, \
                                                       partn, e->probit, e->beta, e->cfg.seed, e->sweep)
       EIG_DISPATCH(CALL);
@@ -1007,8 +1102,8 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
   const int do_lm = ((parts & GG_PART_LMBDA) && !e->cfg.lmbda_given) ? 1 : 0;
   if (do_mu0 || do_lm) {
 #define CALL(DMV)                                                                                                   \
-  k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, d->A, d->AT, e->F, e->gpart, e->probit, e->beta);    \
-  k_eig_draw_globals<DMV><<<1, 256, 0, st>>>(N, (N < 512 ? N : 512), D, e->gpart, e->dO, d->dA, e->lmbda, e->mu0, e->mu_lmbda,            \
+  k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, ob, e->F, e->gpart, e->probit, e->beta);             \
+  k_eig_draw_globals<DMV><<<1, 256, 0, st>>>(N, (N < 512 ? N : 512), D, e->gpart, e->dO, d->dA, da2, e->lmbda, e->mu0, e->mu_lmbda,            \
                                              e->cfg.mu_mu_0, e->cfg.sigma_mu0, e->cfg.sigma_lmbda, do_mu0, do_lm,   \
                                              e->cfg.seed, e->sweep, e->status, e->probit, e->beta)
     EIG_DISPATCH(CALL);

@@ -562,6 +562,7 @@ int gg_latent_get_state(gg_latent* e, int id, void* buf, size_t nbytes) {
 static int ld_check_data(gg_latent* e, const gg_data* d) {
   if (!d) return gg_fail(GG_ERR_INVALID, "null data handle");
   if (d->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, e->N);
+  if (d->n_missing) return gg_fail(GG_ERR_UNSUPPORTED, "the network has %lld unobserved entries: missing data is defined for the eigenmodels only", d->n_missing);
   if (e->wmode && (!d->has_w || d->B != 1))
     return gg_fail(GG_ERR_INVALID, "latent-distance weights: the data handle must carry weights with B = 1");
   if (d->n0 != 0 || d->n1 != d->N) return gg_fail(GG_ERR_UNSUPPORTED, "latent-distance model: column-sharded data not supported");

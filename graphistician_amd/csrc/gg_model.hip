@@ -21,6 +21,7 @@ int gg_eigen_destroy(gg_eigen* e);
 int gg_eigen_set_state(gg_eigen* e, int id, const void* buf, size_t nbytes);
 int gg_eigen_get_state(gg_eigen* e, int id, void* buf, size_t nbytes);
 int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts);
+int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int parts);
 void gg_eigen_set_beta(gg_eigen* e, double beta);
 int gg_eigen_log_likelihood(gg_eigen* e, const gg_data* d, double* out);
 int gg_eigen_stats(gg_eigen* e, gg_stats* out);
@@ -43,6 +44,8 @@ struct gg_model {
   int N, K, Kp, B, NT, NSI, Np, NTAB;   // N = all nodes (labels, rows); Np = padded number of OWNED nodes
   int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded)
   bool sharded;
+  int ngraphs = 1;                      // graphs whose tables the parameter step is drawing from (gg_resample_part_many)
+  long long* tab_sum = nullptr;         // their summed K x K tables
   unsigned char* pred_buf = nullptr;    // gg_predictive_ll: grow-only device scratch (the reference calls it once per held-out node)
   size_t pred_cap = 0;
   long long* sh_buf;                    // sharded chain: device staging of the diagonal statistics (all-reduce)
@@ -442,7 +445,7 @@ int gg_model_destroy(gg_model* m) {
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
                   m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all,
-                  m->sh_cntn, m->sh_H, m->sh_mv, m->pred_buf};
+                  m->sh_cntn, m->sh_H, m->sh_mv, m->pred_buf, m->tab_sum};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -583,6 +586,7 @@ static int check_data(const gg_model* m, const gg_data* d) {
   if (d->n0 != m->n0 || d->n1 != m->n0 + m->Nl)
     return gg_fail(GG_ERR_INVALID, "data holds nodes [%d,%d), model owns [%d,%d)", d->n0, d->n1, m->n0, m->n0 + m->Nl);
   if (d->device != m->cfg.device) return gg_fail(GG_ERR_INVALID, "data on device %d, model on device %d", d->device, m->cfg.device);
+  if (d->n_missing) return gg_fail(GG_ERR_UNSUPPORTED, "the network has %lld unobserved entries: missing data is defined for the eigenmodels only (eigenmodel.py:121-127)", d->n_missing);
   if (!m->is_adj) {
     if (!d->has_w) return gg_fail(GG_ERR_INVALID, "weight model needs data created with W");
     if (d->B != m->B) return gg_fail(GG_ERR_INVALID, "data has B=%d, model has B=%d", d->B, m->B);
@@ -785,7 +789,8 @@ static gg_params_args fill_params_args(gg_model* m, const gg_data* d, int buf, b
   g.ah.tau1 = m->cfg.tau1; g.ah.tau0 = m->cfg.tau0;
   g.ah.special = m->cfg.special_case_self_conns;
   g.ah.bb = (m->kind == GG_BB_ADJ);
-  if (d) { g.ah.d1 = d->d1; g.ah.d0 = (long long)m->N - d->d1; }
+  g.ah.ngraphs = m->ngraphs;
+  if (d) { g.ah.d1 = d->d1; g.ah.d0 = (long long)m->N * m->ngraphs - d->d1; }
   if (!m->is_adj) {
     g.wh.niw = m->niw; g.wh.niw_self = m->niw_self;
     g.wh.special = m->cfg.special_case_self_conns;
@@ -2472,6 +2477,64 @@ int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, co
   if (e != hipSuccess) return gg_fail(GG_ERR_HIP, "gg_predictive_ll failed: %s", hipGetErrorString(e));
   if (h[(size_t)K] != 0.0) return gg_fail(GG_ERR_NUMERIC, "gg_predictive_ll: a block covariance is not positive definite");
   for (int k = 0; k < K; ++k) ll_k[k] = h[(size_t)k];
+  return GG_OK;
+}
+
+__global__ void k_tab_accumulate(long long* __restrict__ dst, const long long* __restrict__ src, int n, int first) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = first ? src[i] : dst[i] + src[i];
+}
+
+// The reference's list-taking forms.  SBM adjacency: resample_p(As) (adjacency.py:620-648) - the block-pair counts are summed
+// over the graphs, every graph offering every pair, then ONE Beta draw per pair (and one for p_self from the summed
+// diagonals).  Eigenmodels: resample(networks) (eigenmodel.py:836-857, :246-272) - auxiliary variables per graph, every
+// conditional from the statistics summed over the graphs (gg_eigen.hip).
+int gg_resample_part_many(gg_model* m, const gg_data* const* ds, int32_t nd, int32_t parts, double beta) {
+  if (!m || !ds || nd < 1) return gg_fail(GG_ERR_INVALID, "gg_resample_part_many: null argument or empty list");
+  for (int i = 0; i < nd; ++i) if (!ds[i]) return gg_fail(GG_ERR_INVALID, "gg_resample_part_many: null data handle in the list");
+  if (nd == 1) return gg_resample_part(m, ds[0], parts, beta);
+  GG_HIP(hipSetDevice(m->cfg.device));
+  if (!(beta >= 0.0 && beta <= 1.0)) return gg_fail(GG_ERR_INVALID, "beta must lie in [0, 1]");
+  if (m->eig) {
+    if (beta != 1.0 && m->kind == GG_PROBIT_EIG)
+      return gg_fail(GG_ERR_UNSUPPORTED, "tempered conditionals: not defined for the probit eigenmodel");
+    gg_eigen_set_beta(m->eig, beta);
+    return gg_eigen_resample_many(m->eig, ds, nd, parts);
+  }
+  if (m->kind != GG_SBM_ADJ || m->sharded || parts != GG_PART_PARAMS)
+    return gg_fail(GG_ERR_UNSUPPORTED, "gg_resample_part_many: several graphs are defined for SBM adjacency resample_p (GG_PART_PARAMS) and for the eigenmodels");
+  int rc = model_sync(m);
+  if (rc) return rc;
+  for (int i = 0; i < nd; ++i) if ((rc = check_data(m, ds[i]))) return rc;
+  m->beta = beta;
+  if (GG_PART_PARAMS & m->parts_done) { m->sweep += 1; m->parts_done = 0; }
+  begin_call(m);
+  const size_t nt = (size_t)m->K * m->K * m->NTAB;
+  if (!m->tab_sum && (rc = dmalloc(&m->tab_sum, nt))) return rc;
+  drop_ahead(m);
+  const int buf = m->cur;
+  long long d1 = 0;
+  for (int i = 0; i < nd; ++i) {
+    // this graph's K x K tables under the current labels (one out-direction pass), added to the sum
+    if ((rc = enqueue_bulk(m, ds[i], buf, 1, false))) return rc;      // (zeroes the buffer first)
+    if ((rc = enqueue_params(m, ds[i], buf, true, false, false, -1, m->sweep))) return rc;
+    k_tab_accumulate<<<(unsigned)((nt + 255) / 256), 256, 0, m->stream>>>(m->tab_sum, m->tab, (int)nt, i == 0 ? 1 : 0);
+    GG_HIP(hipGetLastError());
+    d1 += ds[i]->d1;
+  }
+  GG_HIP(hipMemcpyAsync(m->tab, m->tab_sum, nt * sizeof(long long), hipMemcpyDeviceToDevice, m->stream));
+  gg_data dg = *ds[0];      // kernel arguments take the summed diagonal counts
+  dg.d1 = d1;
+  m->ngraphs = nd;
+  m->shard_from_tab = true;
+  rc = enqueue_params(m, &dg, buf, false, true, false, -1, m->sweep);
+  m->shard_from_tab = false;
+  m->ngraphs = 1;
+  if (rc) return rc;
+  GG_HIP(hipEventRecord(m->ev_call1, m->stream));
+  if ((rc = read_ctl(m))) return rc;
+  m->parts_done |= GG_PART_PARAMS;
+  m->timing_dirty = true;
   return GG_OK;
 }
 

@@ -102,8 +102,9 @@ class LogisticEigenmodel(AdjacencyDistribution, GibbsSampling, EngineBacked):
         return lp
 
     def log_likelihood(self, A):
-        """eigenmodel.py:110-129, evaluated tile by tile on the device (P is never materialised)."""
-        d = self._data(A)
+        """eigenmodel.py:110-129, evaluated tile by tile on the device (P is never materialised).  NaN entries of A are
+        missing data: their terms are zero (:125-127)."""
+        d = self._data(A, missing_ok=True)
         assert d.N == self.N
         return self._engine().log_likelihood(d)
 
@@ -119,20 +120,32 @@ class LogisticEigenmodel(AdjacencyDistribution, GibbsSampling, EngineBacked):
         P = np.clip(1.0 / (1.0 + np.exp(-Mu)), 1e-16, 1 - 1e-16)
         return P[-1, :], P[:, -1]
 
+    def _networks(self, A):
+        """One adjacency matrix, or the reference's list of observed graphs (`resample(networks=[])`, eigenmodel.py:836-845:
+        objects with an `.A`, or the matrices themselves).  NaN entries are unobserved."""
+        if isinstance(A, list):
+            return [self._data(getattr(a, "A", a), missing_ok=True) for a in A]
+        return [self._data(getattr(A, "A", A), missing_ok=True)]
+
     def _run(self, A, parts, beta=1.0):
-        d = self._data(A)
-        assert d.N == self.N
+        ds = self._networks(A)
+        assert len(ds) >= 1 and all(d.N == self.N for d in ds)
         eng = self._engine()
-        if parts == _abi.PART_ALL:
-            eng.resample(d, 1, beta)
+        if len(ds) > 1:
+            eng.resample_part_many(ds, parts, beta)     # auxiliary variables per graph, conditionals from the summed statistics
+        elif parts == _abi.PART_ALL:
+            eng.resample(ds[0], 1, beta)
         else:
-            eng.resample_part(d, parts, beta)
+            eng.resample_part(ds[0], parts, beta)
         self._mark_stale("F", "lmbda", "_mu0")
 
     def resample(self, A, beta=1.0):
-        """eigenmodel.py:836-857: Omega -> F -> mu_0 -> lambda.  beta < 1 tempers the likelihood for AIS: BUILD-DEFINED (the
-        reference leaves it a TODO, graph_models.py:478) - omega ~ PG(beta, psi), kappa = beta (A - 1/2); the PG(beta, .)
-        draw for a real shape is the truncated gamma-sum representation (csrc/spec/gg_pg.h), approximate by construction."""
+        """eigenmodel.py:836-857: Omega -> F -> mu_0 -> lambda, for one graph or a list of them.  beta < 1 tempers the
+        likelihood for AIS: BUILD-DEFINED (the reference leaves it a TODO, graph_models.py:478) - omega ~ PG(beta, psi),
+        kappa = beta (A - 1/2); the PG(beta, .) draw for a real shape is the truncated gamma-sum representation
+        (csrc/spec/gg_pg.h), approximate by construction.  Entries of A that are NaN are missing data: the reference
+        zeroes their log-likelihood terms (:121-127) and its Gibbs updates would turn NaN on them; here they are left out
+        of every conditional (no auxiliary variable, no term in F, mu_0, lambda)."""
         self._run(A, _abi.PART_ALL, beta)
 
     def _resample_Omega(self, A, beta=1.0):

@@ -61,8 +61,9 @@ def declare_immutable(*arrays):
         _IMMUTABLE[id(a)] = weakref.ref(a, lambda _r, k=id(a): _IMMUTABLE.pop(k, None))
 
 
-def as_device_data(A, W=None, device=0, immutable=False):
-    """Device-resident network for (A, W); accepts an existing DeviceData.  immutable=True: see `declare_immutable`."""
+def as_device_data(A, W=None, device=0, immutable=False, missing_ok=False):
+    """Device-resident network for (A, W); accepts an existing DeviceData.  immutable=True: see `declare_immutable`;
+    missing_ok: NaN entries of A are unobserved (eigenmodels only, eigenmodel.py:121-127)."""
     if isinstance(A, _abi.DeviceData):
         return A
     if isinstance(A, tuple) and W is None:
@@ -71,7 +72,7 @@ def as_device_data(A, W=None, device=0, immutable=False):
     Wn = None if W is None else np.asarray(W)
     if immutable:
         declare_immutable(A, Wn)
-    key = (_fingerprint(A), _fingerprint(Wn), device)
+    key = (_fingerprint(A), _fingerprint(Wn), device, bool(missing_ok))
     hit = _DATA_CACHE.get(key)
     if hit is not None:
         _DATA_CACHE.move_to_end(key)
@@ -89,14 +90,14 @@ def as_device_data(A, W=None, device=0, immutable=False):
         sole_owner = sys.getrefcount(old) <= 3      # the cache entry, `old`, getrefcount's argument
         if sole_owner and old.N == A.shape[0] and old.device == device and (oldW is None) == (Wn is None) and old.B == B:
             try:
-                old.update(A, Wn)
+                old.update(A, Wn, missing_ok=missing_ok)
                 d = old
                 del _DATA_CACHE[old_key]
             except _abi.EngineError:
                 d = None
         del old, entry
     if d is None:
-        d = _abi.DeviceData(A, Wn, device=device)
+        d = _abi.DeviceData(A, Wn, device=device, missing_ok=missing_ok)
     _DATA_CACHE[key] = (d, A, Wn)  # keep the arrays alive so ids are not reused
     while len(_DATA_CACHE) > _DATA_CACHE_SIZE:
         _DATA_CACHE.popitem(last=False)
@@ -166,12 +167,12 @@ class EngineBacked(object):
         for n in names:
             self._stale.add(n)
 
-    def _data(self, data):
+    def _data(self, data, missing_ok=False):
         if isinstance(data, _abi.DeviceData):
             return data
         if isinstance(data, (tuple, list)):
-            return as_device_data(data[0], data[1], device=self._device)
-        return as_device_data(data, None, device=self._device)
+            return as_device_data(data[0], data[1], device=self._device, missing_ok=missing_ok)
+        return as_device_data(data, None, device=self._device, missing_ok=missing_ok)
 
     @property
     def engine_stats(self):

@@ -147,7 +147,9 @@ const char* gg_version(void);
 
 /* ---- data: replaces the (A, W) ndarray pair the reference passes to every
  * resample / log_likelihood call (networks.py:28,69).  A is (N,N) C-order,
- * A[i][j] != 0 means an edge i -> j (adjacency.py:686-692); W is (N,N,B) C-order
+ * A[i][j] != 0 means an edge i -> j (adjacency.py:686-692), except the value 2 (GG_A_MISSING): an UNOBSERVED entry - the
+ * reference's NaN, defined for the eigenmodels only (eigenmodel.py:121-127; every other kind returns GG_ERR_UNSUPPORTED for a
+ * network that has one, and so does a network with weights); W is (N,N,B) C-order
  * float64 or NULL for adjacency-only use.  The engine copies; the caller keeps
  * ownership.  Weights are stored as fixed point. */
 int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t device);
@@ -197,6 +199,11 @@ int gg_resample(gg_model* m, const gg_data* d, int32_t n_sweeps, double beta);
  * its variates.  A full gg_resample after step-wise parts starts at a fresh index as well.  GG_ST_SWEEP reads / sets
  * the index (setting it forgets which parts were drawn under it). */
 int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta);
+/* The reference's list-taking forms: SBMAdjacencyDistribution.resample_p(As) (adjacency.py:620-648; GG_PART_PARAMS: the
+ * block-pair counts summed over the nd graphs, one Beta draw per pair) and the eigenmodels' resample(networks)
+ * (eigenmodel.py:836-857, :246-272: auxiliary variables per graph, every conditional from the summed statistics).
+ * nd = 1 is gg_resample_part. */
+int gg_resample_part_many(gg_model* m, const gg_data* const* ds, int32_t nd, int32_t parts, double beta);
 /* Stream-ordered form: gg_resample_async enqueues n_sweeps sweeps on the model's HIP stream and
  * returns; gg_sync (and every call that reads state) waits for them.  gg_resample = async + sync.
  * Distinct models run on distinct streams, so the adjacency and weight halves of

@@ -314,9 +314,42 @@ def eig_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lm
     return mu.value, Omega
 
 
+def _adj_missing(A):
+    """uint8 adjacency with NaN (missing data, eigenmodel.py:121-127) as the byte 2."""
+    A = np.asarray(A)
+    if A.dtype.kind == "f" and np.isnan(A).any():
+        out = (np.where(np.isnan(A), 0, A) != 0).astype(np.uint8)
+        out[np.isnan(A)] = 2
+        return np.ascontiguousarray(out)
+    return np.ascontiguousarray(A != 0, dtype=np.uint8)
+
+
+def eig_sweep_multi(As, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given, seed, sweep,
+                    parts=PART_EIG_ALL, aux=None, beta=1.0, probit=False):
+    """resample(networks) (eigenmodel.py:836-857 / :246-272) for a list of graphs; NaN entries are unobserved.  In-place sweep
+    of (F, lmbda); returns (mu_0, aux) with aux = the per-graph auxiliary variables, shape (nG, N, N)."""
+    N, D = F.shape
+    A8 = np.ascontiguousarray(np.stack([_adj_missing(A) for A in As]))
+    nG = A8.shape[0]
+    if aux is None:
+        aux = np.zeros((nG, N, N))
+    mu = C.c_double(float(mu_0))
+    common = [_f64(np.ascontiguousarray(mu_lmbda, dtype=np.float64)), C.c_double(mu_mu_0), C.c_double(sigma_mu0), C.c_double(sigma_F),
+              C.c_double(sigma_lmbda), int(lmbda_given), C.c_uint64(seed), C.c_uint32(sweep), int(parts)]
+    pA = A8.ctypes.data_as(C.POINTER(C.c_uint8))
+    if probit:
+        rc = lib().orc_probit_sweep_multi(nG, N, D, pA, _f64(F), _f64(lmbda), C.byref(mu), _f64(aux), *common)
+    else:
+        rc = lib().orc_eig_sweep_multi(nG, N, D, pA, _f64(F), _f64(lmbda), C.byref(mu), _f64(aux), *(common + [C.c_double(beta)]))
+    if rc:
+        raise RuntimeError("oracle eig_sweep_multi failed rc=%d" % rc)
+    return mu.value, aux
+
+
 def eig_loglik(A, F, lmbda, mu_0):
     N, D = F.shape
-    A8, pA = _u8(A != 0)
+    A8 = _adj_missing(A)
+    pA = A8.ctypes.data_as(C.POINTER(C.c_uint8))
     lib().orc_eig_loglik.restype = C.c_double
     return lib().orc_eig_loglik(N, D, pA, _f64(F), _f64(lmbda), C.c_double(mu_0))
 
@@ -340,7 +373,8 @@ def probit_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma
 
 def probit_loglik(A, F, lmbda, mu_0):
     N, D = F.shape
-    A8, pA = _u8(A != 0)
+    A8 = _adj_missing(A)
+    pA = A8.ctypes.data_as(C.POINTER(C.c_uint8))
     lib().orc_probit_loglik.restype = C.c_double
     return lib().orc_probit_loglik(N, D, pA, _f64(F), _f64(lmbda), C.c_double(mu_0))
 
@@ -365,6 +399,20 @@ def pg_frac_vec(seed, b, z, n):
     out = np.empty(n)
     lib().orc_pg_frac_vec(C.c_uint64(seed), C.c_double(b), C.c_double(z), _f64(out), C.c_longlong(n))
     return out
+
+
+def sbm_adj_resample_p_multi(As, c, p, p_self, tau1, tau0, special, seed, sweep, beta=1.0):
+    """resample_p(As) for a list of graphs (adjacency.py:620-648): p is updated in place, returns p_self."""
+    A8 = np.ascontiguousarray(np.stack([np.asarray(A) != 0 for A in As]).astype(np.uint8))
+    nG, N = A8.shape[0], A8.shape[1]
+    K = p.shape[0]
+    ps = C.c_double(float(p_self))
+    cc = np.ascontiguousarray(c, dtype=np.int32)
+    rc = lib().orc_sbm_adj_resample_p_multi(nG, N, K, A8.ctypes.data_as(C.POINTER(C.c_uint8)), _i32(cc), _f64(p), C.byref(ps),
+                                            C.c_double(tau1), C.c_double(tau0), int(special), C.c_uint64(seed), C.c_uint32(sweep),
+                                            C.c_double(beta))
+    assert rc == 0
+    return ps.value
 
 
 def eig_noise_row(seed, sweep, N, n):

@@ -34,50 +34,73 @@ static double eig_psi(int N, int D, const double* F, const double* lmbda, double
   return mu_0 + v;
 }
 
-// eigenmodel.py:859-874 _resample_Omega: omega_ij ~ PG(1, Mu_ij) for all N^2 entries.
+// Several graphs per model and missing data.  The reference's Gibbs steps take lists, `for A, O in zip(As, Omegas)`
+// (eigenmodel.py:836-857, :889, :918, :946); an entry of A given as ORC_A_MISSING (2) is an unobserved one (NaN in the
+// reference, whose log-likelihood zeroes it, :121-127, and whose Gibbs updates would turn NaN on it): it has no auxiliary
+// variable and no term in any conditional.  Graph g draws from Philox site (site + (g << 8)); As is [nG][N][N].
+#define ORC_A_MISSING 2
+
+static double eig_kappa(uint8_t a, double beta) { return a == ORC_A_MISSING ? 0.0 : beta * ((a ? 1.0 : 0.0) - 0.5); }
+
+// eigenmodel.py:859-874 _resample_Omega: omega_ij ~ PG(1, Mu_ij) for all N^2 entries (of every graph).
 // beta != 1 (AIS; build-defined, the reference leaves it a TODO at graph_models.py:478): the likelihood to the power beta
 // is augmented with omega_ij ~ PG(beta, Mu_ij) and kappa = beta (A - 1/2) (spec/gg_pg.h: gg_pg_frac).
-void orc_eig_resample_omega(int N, int D, const double* F, const double* lmbda, double mu_0, uint64_t seed,
-                            uint32_t sweep, double* Omega, double beta) {
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) {
-      const double psi = eig_psi(N, D, F, lmbda, mu_0, i, j);
-      if (beta == 1.0) Omega[(size_t)i * N + j] = gg_pg1_at(seed, sweep, (uint32_t)N, (uint32_t)i, (uint32_t)j, psi);
-      else if (beta == 0.0) Omega[(size_t)i * N + j] = 0.0;
-      else {
-        gg_stream s;
-        gg_stream_init(&s, seed, GG_SITE_EIG_OMEGA, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j);
-        Omega[(size_t)i * N + j] = gg_pg_frac(&s, beta, psi);
+void orc_eig_resample_omega_multi(int nG, int N, int D, const uint8_t* As, const double* F, const double* lmbda, double mu_0,
+                                  uint64_t seed, uint32_t sweep, double* Omegas, double beta) {
+  for (int g = 0; g < nG; ++g) {
+    const uint8_t* A = As + (size_t)g * N * N;
+    double* Omega = Omegas + (size_t)g * N * N;
+    const uint32_t site = (uint32_t)GG_SITE_EIG_OMEGA + ((uint32_t)g << 8);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const double psi = eig_psi(N, D, F, lmbda, mu_0, i, j);
+        double o = 0.0;
+        if (A[(size_t)i * N + j] != ORC_A_MISSING && beta != 0.0) {
+          gg_stream s;
+          gg_stream_init(&s, seed, site, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j);
+          o = beta == 1.0 ? gg_pg1(&s, psi) : gg_pg_frac(&s, beta, psi);
+        }
+        Omega[(size_t)i * N + j] = o;
       }
-    }
+  }
 }
 
 // eigenmodel.py:876-908 _resample_F: sequential over nodes, F[n] updated in place.  Precision and mean term are the
-// reference's double loop; the draw F[n] ~ N(prec^{-1} h, prec^{-1}) (:908, np.random.multivariate_normal) is made by
-// perturbation (spec/gg_eig.h): b = h + z / sqrt(sigma_F) + sum_nn sqrt(O[n,nn] + O[nn,n]) eps[n,nn] f_nn * lambda,
-// x = prec^{-1} b - the same law, no matrix square root.
-int orc_eig_resample_F(int N, int D, const uint8_t* A, const double* Omega, double* F, const double* lmbda,
-                       double mu_0, double sigma_F, uint64_t seed, uint32_t sweep, double beta) {
-  std::vector<double> prec((size_t)D * D), h(D), b(D), x(D);
+// reference's loops (over the graphs, then over nn); the draw F[n] ~ N(prec^{-1} h, prec^{-1}) (:908,
+// np.random.multivariate_normal) is made by perturbation (spec/gg_eig.h): b = h + z / sqrt(sigma_F) +
+// sum_nn sqrt(sum of the pair's omegas) eps[n,nn] f_nn * lambda, x = prec^{-1} b - the same law, no matrix square root.
+int orc_eig_resample_F_multi(int nG, int N, int D, const uint8_t* As, const double* Omegas, double* F, const double* lmbda,
+                             double mu_0, double sigma_F, uint64_t seed, uint32_t sweep, double beta) {
+  std::vector<double> prec((size_t)D * D), h(D), b(D), x(D), wsum(N);
   for (int n = 0; n < N; ++n) {
     for (int a = 0; a < D * D; ++a) prec[a] = 0.0;
     for (int a = 0; a < D; ++a) {
       prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0;
       b[a] = gg_normal_at(seed, GG_SITE_EIG_F, sweep, (uint32_t)(n * D + a)) / gg_sqrt(sigma_F);
     }
+    for (int nn = 0; nn < N; ++nn) wsum[nn] = 0.0;
+    for (int g = 0; g < nG; ++g) {
+      const uint8_t* A = As + (size_t)g * N * N;
+      const double* Omega = Omegas + (size_t)g * N * N;
+      for (int nn = 0; nn < N; ++nn) {
+        if (nn == n) continue;
+        const double o1 = Omega[(size_t)n * N + nn], o2 = Omega[(size_t)nn * N + n];
+        // O * zcent = kappa - O mu_0 with kappa = A - 1/2 (eigenmodel.py:813-820,892)
+        const double k1 = eig_kappa(A[(size_t)n * N + nn], beta) - o1 * mu_0;
+        const double k2 = eig_kappa(A[(size_t)nn * N + n], beta) - o2 * mu_0;
+        wsum[nn] += o1 + o2;
+        const double* f = F + (size_t)nn * D;
+        for (int a = 0; a < D; ++a) {
+          for (int c = 0; c < D; ++c) prec[a * D + c] += f[a] * f[c] * lmbda[a] * lmbda[c] * (o1 + o2);
+          h[a] += (k1 + k2) * f[a] * lmbda[a];
+        }
+      }
+    }
     for (int nn = 0; nn < N; ++nn) {
       if (nn == n) continue;
-      const double o1 = Omega[(size_t)n * N + nn], o2 = Omega[(size_t)nn * N + n];
-      // O * zcent = kappa - O mu_0 with kappa = A - 1/2 (eigenmodel.py:813-820,892)
-      const double k1 = beta * ((A[(size_t)n * N + nn] ? 1.0 : 0.0) - 0.5) - o1 * mu_0;
-      const double k2 = beta * ((A[(size_t)nn * N + n] ? 1.0 : 0.0) - 0.5) - o2 * mu_0;
-      const double w = gg_sqrt(o1 + o2) * gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
+      const double w = gg_sqrt(wsum[nn]) * gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
       const double* f = F + (size_t)nn * D;
-      for (int a = 0; a < D; ++a) {
-        for (int c = 0; c < D; ++c) prec[a * D + c] += f[a] * f[c] * lmbda[a] * lmbda[c] * (o1 + o2);
-        h[a] += (k1 + k2) * f[a] * lmbda[a];
-        b[a] += w * f[a] * lmbda[a];
-      }
+      for (int a = 0; a < D; ++a) b[a] += w * f[a] * lmbda[a];
     }
     for (int a = 0; a < D; ++a) b[a] += h[a];
     if (gg_solve_spd(prec.data(), b.data(), D, x.data())) return -5;
@@ -87,60 +110,76 @@ int orc_eig_resample_F(int N, int D, const uint8_t* A, const double* Omega, doub
 }
 
 // eigenmodel.py:910-932 _resample_mu_0.
-double orc_eig_resample_mu0(int N, int D, const uint8_t* A, const double* Omega, const double* F,
-                            const double* lmbda, double mu_mu_0, double sigma_mu0, uint64_t seed, uint32_t sweep, double beta) {
+double orc_eig_resample_mu0_multi(int nG, int N, int D, const uint8_t* As, const double* Omegas, const double* F,
+                                  const double* lmbda, double mu_mu_0, double sigma_mu0, uint64_t seed, uint32_t sweep, double beta) {
   double prec = 1.0 / sigma_mu0, h = mu_mu_0 / sigma_mu0;
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) {
-      const double o = Omega[(size_t)i * N + j];
-      prec += o;
-      const double fdf = (i == j) ? 0.0 : eig_psi(N, D, F, lmbda, 0.0, i, j);
-      h += beta * ((A[(size_t)i * N + j] ? 1.0 : 0.0) - 0.5) - o * fdf;
-    }
+  for (int g = 0; g < nG; ++g) {
+    const uint8_t* A = As + (size_t)g * N * N;
+    const double* Omega = Omegas + (size_t)g * N * N;
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const double o = Omega[(size_t)i * N + j];
+        prec += o;
+        const double fdf = (i == j) ? 0.0 : eig_psi(N, D, F, lmbda, 0.0, i, j);
+        h += eig_kappa(A[(size_t)i * N + j], beta) - o * fdf;
+      }
+  }
   const double var = 1.0 / prec;
   return var * h + gg_sqrt(var) * gg_normal_at(seed, GG_SITE_EIG_MU0, sweep, 0u);
 }
 
 // eigenmodel.py:934-965 _resample_lmbda.
-int orc_eig_resample_lmbda(int N, int D, const uint8_t* A, const double* Omega, const double* F, double* lmbda,
-                           double mu_0, const double* mu_lmbda, double sigma_lmbda, uint64_t seed, uint32_t sweep, double beta) {
+int orc_eig_resample_lmbda_multi(int nG, int N, int D, const uint8_t* As, const double* Omegas, const double* F, double* lmbda,
+                                 double mu_0, const double* mu_lmbda, double sigma_lmbda, uint64_t seed, uint32_t sweep, double beta) {
   std::vector<double> prec((size_t)D * D, 0.0), h(D), z(D), x(D);
   for (int a = 0; a < D; ++a) { prec[a * D + a] = 1.0 / sigma_lmbda; h[a] = mu_lmbda[a] / sigma_lmbda; }
-  for (int n1 = 0; n1 < N; ++n1)
-    for (int n2 = n1 + 1; n2 < N; ++n2) {
-      const double o12 = Omega[(size_t)n1 * N + n2], o21 = Omega[(size_t)n2 * N + n1];
-      const double k12 = beta * ((A[(size_t)n1 * N + n2] ? 1.0 : 0.0) - 0.5) - o12 * mu_0;
-      const double k21 = beta * ((A[(size_t)n2 * N + n1] ? 1.0 : 0.0) - 0.5) - o21 * mu_0;
-      const double* f1 = F + (size_t)n1 * D;
-      const double* f2 = F + (size_t)n2 * D;
-      for (int a = 0; a < D; ++a) {
-        for (int b = 0; b < D; ++b) prec[a * D + b] += (o21 + o12) * f1[a] * f1[b] * f2[a] * f2[b];
-        h[a] += (k12 + k21) * f1[a] * f2[a];
+  for (int g = 0; g < nG; ++g) {
+    const uint8_t* A = As + (size_t)g * N * N;
+    const double* Omega = Omegas + (size_t)g * N * N;
+    for (int n1 = 0; n1 < N; ++n1)
+      for (int n2 = n1 + 1; n2 < N; ++n2) {
+        const double o12 = Omega[(size_t)n1 * N + n2], o21 = Omega[(size_t)n2 * N + n1];
+        const double k12 = eig_kappa(A[(size_t)n1 * N + n2], beta) - o12 * mu_0;
+        const double k21 = eig_kappa(A[(size_t)n2 * N + n1], beta) - o21 * mu_0;
+        const double* f1 = F + (size_t)n1 * D;
+        const double* f2 = F + (size_t)n2 * D;
+        for (int a = 0; a < D; ++a) {
+          for (int b = 0; b < D; ++b) prec[a * D + b] += (o21 + o12) * f1[a] * f1[b] * f2[a] * f2[b];
+          h[a] += (k12 + k21) * f1[a] * f2[a];
+        }
       }
-    }
+  }
   for (int a = 0; a < D; ++a) z[a] = gg_normal_at(seed, GG_SITE_EIG_LMBDA, sweep, (uint32_t)a);
   if (gg_gauss_from_precision(prec.data(), h.data(), z.data(), D, x.data())) return -5;
   for (int a = 0; a < D; ++a) lmbda[a] = x[a];
   return 0;
 }
 
-// eigenmodel.py:836-857 resample: Omega -> F -> mu_0 -> lambda.  Omega is an output
-// (N x N) so that tests can inspect it.
-int orc_eig_sweep(int N, int D, const uint8_t* A, double* F, double* lmbda, double* mu_0, double* Omega,
-                  const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
-                  int lmbda_given, uint64_t seed, uint32_t sweep, int parts, double beta) {
+// eigenmodel.py:836-857 resample(networks): Omega -> F -> mu_0 -> lambda.  Omegas is an output ([nG][N][N]) so that tests
+// can inspect it.
+int orc_eig_sweep_multi(int nG, int N, int D, const uint8_t* As, double* F, double* lmbda, double* mu_0, double* Omegas,
+                        const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
+                        int lmbda_given, uint64_t seed, uint32_t sweep, int parts, double beta) {
   if (D > GG_MAXD) return -1;
-  if (parts & ORC_PART_OMEGA) orc_eig_resample_omega(N, D, F, lmbda, *mu_0, seed, sweep, Omega, beta);
+  if (parts & ORC_PART_OMEGA) orc_eig_resample_omega_multi(nG, N, D, As, F, lmbda, *mu_0, seed, sweep, Omegas, beta);
   if (parts & ORC_PART_F) {
-    int rc = orc_eig_resample_F(N, D, A, Omega, F, lmbda, *mu_0, sigma_F, seed, sweep, beta);
+    int rc = orc_eig_resample_F_multi(nG, N, D, As, Omegas, F, lmbda, *mu_0, sigma_F, seed, sweep, beta);
     if (rc) return rc;
   }
-  if (parts & ORC_PART_MU0) *mu_0 = orc_eig_resample_mu0(N, D, A, Omega, F, lmbda, mu_mu_0, sigma_mu0, seed, sweep, beta);
+  if (parts & ORC_PART_MU0) *mu_0 = orc_eig_resample_mu0_multi(nG, N, D, As, Omegas, F, lmbda, mu_mu_0, sigma_mu0, seed, sweep, beta);
   if ((parts & ORC_PART_LMBDA) && !lmbda_given) {
-    int rc = orc_eig_resample_lmbda(N, D, A, Omega, F, lmbda, *mu_0, mu_lmbda, sigma_lmbda, seed, sweep, beta);
+    int rc = orc_eig_resample_lmbda_multi(nG, N, D, As, Omegas, F, lmbda, *mu_0, mu_lmbda, sigma_lmbda, seed, sweep, beta);
     if (rc) return rc;
   }
   return 0;
+}
+
+// One graph: the same sweep (graph 0 draws from the plain sites).
+int orc_eig_sweep(int N, int D, const uint8_t* A, double* F, double* lmbda, double* mu_0, double* Omega,
+                  const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
+                  int lmbda_given, uint64_t seed, uint32_t sweep, int parts, double beta) {
+  return orc_eig_sweep_multi(1, N, D, A, F, lmbda, mu_0, Omega, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given,
+                             seed, sweep, parts, beta);
 }
 
 // eigenmodel.py:110-129 log_likelihood with P = clip(logistic(Mu), 1e-16, 1 - 1e-16) (:803-811).
@@ -148,6 +187,7 @@ double orc_eig_loglik(int N, int D, const uint8_t* A, const double* F, const dou
   double ll = 0.0;
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
+      if (A[(size_t)i * N + j] == ORC_A_MISSING) continue;      // eigenmodel.py:125-127: nan_to_num(ll) = 0
       double P = 1.0 / (1.0 + exp(-eig_psi(N, D, F, lmbda, mu_0, i, j)));
       P = P < 1e-16 ? 1e-16 : (P > 1 - 1e-16 ? 1 - 1e-16 : P);
       ll += A[(size_t)i * N + j] ? log(P) : log(1.0 - P);
@@ -189,37 +229,59 @@ void orc_pg1_vec(uint64_t seed, double z, double* out, long long n) {
 
 extern "C" {
 
+// Lists of graphs and unobserved entries as for the logistic model above: `for A, Z in zip(As, Zs)`; an entry given as
+// ORC_A_MISSING has no auxiliary variable (Z = 0 there and it is counted nowhere).
 // eigenmodel.py:274-293 _resample_Z: truncated normals around Mu (diagonal Mu = mu_0), lower bound 0 where
 // A == 1, upper bound 0 where A == 0.
-void orc_probit_resample_Z(int N, int D, const uint8_t* A, const double* F, const double* lmbda, double mu_0,
-                           uint64_t seed, uint32_t sweep, double* Z) {
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j)
-      Z[(size_t)i * N + j] = gg_truncnorm_at(seed, sweep, (uint32_t)N, (uint32_t)i, (uint32_t)j,
-                                             eig_psi(N, D, F, lmbda, mu_0, i, j), A[(size_t)i * N + j] ? 1 : 0);
+void orc_probit_resample_Z_multi(int nG, int N, int D, const uint8_t* As, const double* F, const double* lmbda, double mu_0,
+                                 uint64_t seed, uint32_t sweep, double* Zs) {
+  for (int g = 0; g < nG; ++g) {
+    const uint8_t* A = As + (size_t)g * N * N;
+    double* Z = Zs + (size_t)g * N * N;
+    const uint32_t site = (uint32_t)GG_SITE_EIG_Z + ((uint32_t)g << 8);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const uint8_t a = A[(size_t)i * N + j];
+        Z[(size_t)i * N + j] = a == ORC_A_MISSING ? 0.0
+            : gg_truncnorm(gg_uniform_at(seed, site, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j), eig_psi(N, D, F, lmbda, mu_0, i, j), a ? 1 : 0);
+      }
+  }
 }
 
-// eigenmodel.py:295-329 _resample_F (the draw by perturbation, as in orc_eig_resample_F: pair weight 2).
-int orc_probit_resample_F(int N, int D, const double* Z, double* F, const double* lmbda, double mu_0, double sigma_F,
-                          uint64_t seed, uint32_t sweep) {
-  std::vector<double> prec((size_t)D * D), h(D), b(D), x(D);
+// eigenmodel.py:295-329 _resample_F (the draw by perturbation, as in orc_eig_resample_F_multi: pair weight = the number of
+// observed entries of the pair, 2 per fully observed graph).
+int orc_probit_resample_F_multi(int nG, int N, int D, const uint8_t* As, const double* Zs, double* F, const double* lmbda,
+                                double mu_0, double sigma_F, uint64_t seed, uint32_t sweep) {
+  std::vector<double> prec((size_t)D * D), h(D), b(D), x(D), wsum(N);
   for (int n = 0; n < N; ++n) {
     for (int a = 0; a < D * D; ++a) prec[a] = 0.0;
     for (int a = 0; a < D; ++a) {
       prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0;
       b[a] = gg_normal_at(seed, GG_SITE_EIG_F, sweep, (uint32_t)(n * D + a)) / gg_sqrt(sigma_F);
     }
+    for (int nn = 0; nn < N; ++nn) wsum[nn] = 0.0;
+    for (int g = 0; g < nG; ++g) {
+      const uint8_t* A = As + (size_t)g * N * N;
+      const double* Z = Zs + (size_t)g * N * N;
+      for (int nn = 0; nn < N; ++nn) {
+        if (nn == n) continue;
+        const double* f = F + (size_t)nn * D;
+        const bool ob1 = A[(size_t)nn * N + n] != ORC_A_MISSING, ob2 = A[(size_t)n * N + nn] != ORC_A_MISSING;
+        const double z1 = ob1 ? Z[(size_t)nn * N + n] - mu_0 : 0.0, z2 = ob2 ? Z[(size_t)n * N + nn] - mu_0 : 0.0;
+        const double cnt = (ob1 ? 1.0 : 0.0) + (ob2 ? 1.0 : 0.0);
+        wsum[nn] += cnt;
+        for (int a = 0; a < D; ++a) {
+          for (int c = 0; c < D; ++c) prec[a * D + c] += cnt * f[a] * f[c] * lmbda[a] * lmbda[c];
+          h[a] += z1 * f[a] * lmbda[a];
+          h[a] += z2 * f[a] * lmbda[a];
+        }
+      }
+    }
     for (int nn = 0; nn < N; ++nn) {
       if (nn == n) continue;
+      const double w = gg_sqrt(wsum[nn]) * gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
       const double* f = F + (size_t)nn * D;
-      const double z1 = Z[(size_t)nn * N + n] - mu_0, z2 = Z[(size_t)n * N + nn] - mu_0;
-      const double w = gg_sqrt(2.0) * gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
-      for (int a = 0; a < D; ++a) {
-        for (int c = 0; c < D; ++c) prec[a * D + c] += 2.0 * f[a] * f[c] * lmbda[a] * lmbda[c];
-        h[a] += z1 * f[a] * lmbda[a];
-        h[a] += z2 * f[a] * lmbda[a];
-        b[a] += w * f[a] * lmbda[a];
-      }
+      for (int a = 0; a < D; ++a) b[a] += w * f[a] * lmbda[a];
     }
     for (int a = 0; a < D; ++a) b[a] += h[a];
     if (gg_solve_spd(prec.data(), b.data(), D, x.data())) return -5;
@@ -228,55 +290,75 @@ int orc_probit_resample_F(int N, int D, const double* Z, double* F, const double
   return 0;
 }
 
-// eigenmodel.py:331-352 _resample_mu_0: N^2 - N observations, residual Z - F Lambda F^T off the diagonal.
-double orc_probit_resample_mu0(int N, int D, const double* Z, const double* F, const double* lmbda, double mu_mu_0,
-                               double sigma_mu0, uint64_t seed, uint32_t sweep) {
-  double prec = 1.0 / sigma_mu0 + ((double)N * N - N), h = mu_mu_0 / sigma_mu0;
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j)
-      if (i != j) h += Z[(size_t)i * N + j] - eig_psi(N, D, F, lmbda, 0.0, i, j);
+// eigenmodel.py:331-352 _resample_mu_0: one observation per observed off-diagonal entry, residual Z - F Lambda F^T.
+double orc_probit_resample_mu0_multi(int nG, int N, int D, const uint8_t* As, const double* Zs, const double* F, const double* lmbda,
+                                     double mu_mu_0, double sigma_mu0, uint64_t seed, uint32_t sweep) {
+  double prec = 1.0 / sigma_mu0, h = mu_mu_0 / sigma_mu0;
+  for (int g = 0; g < nG; ++g) {
+    const uint8_t* A = As + (size_t)g * N * N;
+    const double* Z = Zs + (size_t)g * N * N;
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j)
+        if (i != j && A[(size_t)i * N + j] != ORC_A_MISSING) {
+          prec += 1.0;
+          h += Z[(size_t)i * N + j] - eig_psi(N, D, F, lmbda, 0.0, i, j);
+        }
+  }
   const double var = 1.0 / prec;
   return var * h + gg_sqrt(var) * gg_normal_at(seed, GG_SITE_EIG_MU0, sweep, 0u);
 }
 
 // eigenmodel.py:354-379 _resample_lmbda.
-int orc_probit_resample_lmbda(int N, int D, const double* Z, const double* F, double* lmbda, double mu_0,
-                              const double* mu_lmbda, double sigma_lmbda, uint64_t seed, uint32_t sweep) {
+int orc_probit_resample_lmbda_multi(int nG, int N, int D, const uint8_t* As, const double* Zs, const double* F, double* lmbda,
+                                    double mu_0, const double* mu_lmbda, double sigma_lmbda, uint64_t seed, uint32_t sweep) {
   std::vector<double> prec((size_t)D * D, 0.0), h(D), z(D), x(D);
   for (int a = 0; a < D; ++a) { prec[a * D + a] = 1.0 / sigma_lmbda; h[a] = mu_lmbda[a] / sigma_lmbda; }
-  for (int n1 = 0; n1 < N; ++n1)
-    for (int n2 = n1 + 1; n2 < N; ++n2) {
-      const double* f1 = F + (size_t)n1 * D;
-      const double* f2 = F + (size_t)n2 * D;
-      const double z12 = Z[(size_t)n1 * N + n2] - mu_0, z21 = Z[(size_t)n2 * N + n1] - mu_0;
-      for (int a = 0; a < D; ++a) {
-        for (int b = 0; b < D; ++b) prec[a * D + b] += 2.0 * f1[a] * f1[b] * f2[a] * f2[b];
-        h[a] += z12 * f1[a] * f2[a];
-        h[a] += z21 * f1[a] * f2[a];
+  for (int g = 0; g < nG; ++g) {
+    const uint8_t* A = As + (size_t)g * N * N;
+    const double* Z = Zs + (size_t)g * N * N;
+    for (int n1 = 0; n1 < N; ++n1)
+      for (int n2 = n1 + 1; n2 < N; ++n2) {
+        const double* f1 = F + (size_t)n1 * D;
+        const double* f2 = F + (size_t)n2 * D;
+        const bool ob12 = A[(size_t)n1 * N + n2] != ORC_A_MISSING, ob21 = A[(size_t)n2 * N + n1] != ORC_A_MISSING;
+        const double z12 = ob12 ? Z[(size_t)n1 * N + n2] - mu_0 : 0.0, z21 = ob21 ? Z[(size_t)n2 * N + n1] - mu_0 : 0.0;
+        const double cnt = (ob12 ? 1.0 : 0.0) + (ob21 ? 1.0 : 0.0);
+        for (int a = 0; a < D; ++a) {
+          for (int b = 0; b < D; ++b) prec[a * D + b] += cnt * f1[a] * f1[b] * f2[a] * f2[b];
+          h[a] += z12 * f1[a] * f2[a];
+          h[a] += z21 * f1[a] * f2[a];
+        }
       }
-    }
+  }
   for (int a = 0; a < D; ++a) z[a] = gg_normal_at(seed, GG_SITE_EIG_LMBDA, sweep, (uint32_t)a);
   if (gg_gauss_from_precision(prec.data(), h.data(), z.data(), D, x.data())) return -5;
   for (int a = 0; a < D; ++a) lmbda[a] = x[a];
   return 0;
 }
 
-// eigenmodel.py:246-272 resample: Z -> F -> mu_0 -> lambda.  Z is an output (N x N).
-int orc_probit_sweep(int N, int D, const uint8_t* A, double* F, double* lmbda, double* mu_0, double* Z,
-                     const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
-                     int lmbda_given, uint64_t seed, uint32_t sweep, int parts) {
+// eigenmodel.py:246-272 resample(networks): Z -> F -> mu_0 -> lambda.  Zs is an output ([nG][N][N]).
+int orc_probit_sweep_multi(int nG, int N, int D, const uint8_t* As, double* F, double* lmbda, double* mu_0, double* Zs,
+                           const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
+                           int lmbda_given, uint64_t seed, uint32_t sweep, int parts) {
   if (D > GG_MAXD) return -1;
-  if (parts & ORC_PART_OMEGA) orc_probit_resample_Z(N, D, A, F, lmbda, *mu_0, seed, sweep, Z);
+  if (parts & ORC_PART_OMEGA) orc_probit_resample_Z_multi(nG, N, D, As, F, lmbda, *mu_0, seed, sweep, Zs);
   if (parts & ORC_PART_F) {
-    int rc = orc_probit_resample_F(N, D, Z, F, lmbda, *mu_0, sigma_F, seed, sweep);
+    int rc = orc_probit_resample_F_multi(nG, N, D, As, Zs, F, lmbda, *mu_0, sigma_F, seed, sweep);
     if (rc) return rc;
   }
-  if (parts & ORC_PART_MU0) *mu_0 = orc_probit_resample_mu0(N, D, Z, F, lmbda, mu_mu_0, sigma_mu0, seed, sweep);
+  if (parts & ORC_PART_MU0) *mu_0 = orc_probit_resample_mu0_multi(nG, N, D, As, Zs, F, lmbda, mu_mu_0, sigma_mu0, seed, sweep);
   if ((parts & ORC_PART_LMBDA) && !lmbda_given) {
-    int rc = orc_probit_resample_lmbda(N, D, Z, F, lmbda, *mu_0, mu_lmbda, sigma_lmbda, seed, sweep);
+    int rc = orc_probit_resample_lmbda_multi(nG, N, D, As, Zs, F, lmbda, *mu_0, mu_lmbda, sigma_lmbda, seed, sweep);
     if (rc) return rc;
   }
   return 0;
+}
+
+int orc_probit_sweep(int N, int D, const uint8_t* A, double* F, double* lmbda, double* mu_0, double* Z,
+                     const double* mu_lmbda, double mu_mu_0, double sigma_mu0, double sigma_F, double sigma_lmbda,
+                     int lmbda_given, uint64_t seed, uint32_t sweep, int parts) {
+  return orc_probit_sweep_multi(1, N, D, A, F, lmbda, mu_0, Z, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given,
+                                seed, sweep, parts);
 }
 
 // eigenmodel.py:110-129 log_likelihood with P = clip(Phi(Mu), 1e-16, 1 - 1e-16) (:228-237).
@@ -284,6 +366,7 @@ double orc_probit_loglik(int N, int D, const uint8_t* A, const double* F, const 
   double ll = 0.0;
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
+      if (A[(size_t)i * N + j] == ORC_A_MISSING) continue;
       double P = gg_norm_cdf(eig_psi(N, D, F, lmbda, mu_0, i, j));
       P = P < 1e-16 ? 1e-16 : (P > 1 - 1e-16 ? 1 - 1e-16 : P);
       ll += A[(size_t)i * N + j] ? log(P) : log(1.0 - P);

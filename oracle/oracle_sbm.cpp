@@ -170,6 +170,39 @@ static void resample_m(int N, int K, const int32_t* c, const double* pi, double*
   gg_dirichlet_at(seed, site, sweep, alpha.data(), K, m);
 }
 
+// adjacency.py:620-648 resample_p(As) for a LIST of graphs: `n_conns = sum([A[mask].sum() for A in As])`, the same for the
+// non-connections and for the diagonal; As is [nG][N][N].
+int orc_sbm_adj_resample_p_multi(int nG, int N, int K, const uint8_t* As, const int32_t* c, double* p, double* p_self,
+                                 double tau1, double tau0, int special, uint64_t seed, uint32_t sweep, double beta) {
+  std::vector<long long> n1((size_t)K * K, 0), n0((size_t)K * K, 0);
+  long long d1 = 0, d0 = 0;
+  for (int g = 0; g < nG; ++g) {
+    const uint8_t* A = As + (size_t)g * N * N;
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        int a = A[(size_t)i * N + j] ? 1 : 0;
+        if (i == j) {
+          d1 += a; d0 += 1 - a;
+          if (special) continue;
+        }
+        n1[(size_t)c[i] * K + c[j]] += a;
+        n0[(size_t)c[i] * K + c[j]] += 1 - a;
+      }
+  }
+  for (int c1 = 0; c1 < K; ++c1)
+    for (int c2 = 0; c2 < K; ++c2) {
+      gg_stream s;
+      gg_stream_init(&s, seed, GG_SITE_ADJ_P, sweep, (uint32_t)(c1 * K + c2));
+      p[c1 * K + c2] = gg_beta(&s, tau1 + beta * (double)n1[c1 * K + c2], tau0 + beta * (double)n0[c1 * K + c2]);
+    }
+  if (special) {
+    gg_stream s;
+    gg_stream_init(&s, seed, GG_SITE_ADJ_PSELF, sweep, 0u);
+    *p_self = gg_beta(&s, tau1 + beta * (double)d1, tau0 + beta * (double)d0);
+  }
+  return 0;
+}
+
 // adjacency.py:615-618 resample = resample_p -> resample_c -> resample_m.
 int orc_sbm_adj_sweep_beta(int N, int K, const uint8_t* A, int32_t* c, double* m, double* p,
                            double* p_self, const double* pi, double tau1, double tau0, int special,

@@ -443,3 +443,146 @@ def test_probit_engine_chain_matches_oracle():
     ref = O.probit_loglik(A, Fo, lo, mo)
     assert abs(m.log_likelihood(A) - ref) <= 1e-7 * abs(ref)
     assert m.P.min() >= 1e-16 and np.isfinite(m.log_probability(A))
+
+
+# ================================================================ several graphs per model, missing data
+def make_list_case(N, D, seed, nG=3, frac_missing=0.15):
+    """nG graphs drawn from one eigenmodel; a share of the entries of each (diagonal included) is NaN = unobserved."""
+    rng = np.random.RandomState(seed)
+    F = rng.randn(N, D)
+    lmbda = rng.randn(D)
+    mu_0 = -0.4
+    P = 1.0 / (1.0 + np.exp(-R.eigen_Mu(F, lmbda, mu_0)))
+    As = []
+    for g in range(nG):
+        A = (rng.rand(N, N) < P).astype(np.float64)
+        A[rng.rand(N, N) < frac_missing] = np.nan
+        As.append(A)
+    return As, np.ascontiguousarray(rng.randn(N, D) * 0.8), np.ascontiguousarray(rng.randn(D)), 0.2
+
+
+def test_oracle_list_of_graphs_and_missing_entries_follow_the_reference_loops():
+    """resample(networks) (eigenmodel.py:836-857: `for A, O in zip(As, Omegas)` inside every conditional) with NaN entries
+    left out: the oracle's list form against the numpy transliteration applied graph by graph (an unobserved entry has
+    omega = 0 and kappa = 0, i.e. A = 1/2 in the transliteration's kappa = A - 1/2), and - one fully observed graph - against
+    the single-graph oracle bit for bit."""
+    N, D, seed = 8, 2, 13
+    As, F, lmbda, mu_0 = make_list_case(N, D, 4)
+    sF, sm, sl, mm, ml = 1.3, 0.9, 1.1, -0.4, np.zeros(D) + 0.2
+    _, Oms = O.eig_sweep_multi(As, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 2, parts=O.PART_OMEGA)
+    for A, Om in zip(As, Oms):
+        assert np.all(Om[np.isnan(A)] == 0.0) and np.all(Om[~np.isnan(A)] > 0.0)
+    assert not np.array_equal(Oms[0][~np.isnan(As[0]) & ~np.isnan(As[1])], Oms[1][~np.isnan(As[0]) & ~np.isnan(As[1])])   # own streams
+    Ah = [np.where(np.isnan(A), 0.5, A) for A in As]        # kappa = 0 where unobserved
+    # (the transliteration divides kappa by omega like the reference does, :892: a vanishing omega instead of 0 there)
+    Ol = [np.where(np.isnan(A), 1e-300, Om) for A, Om in zip(As, Oms)]
+    Fo = F.copy()
+    O.eig_sweep_multi(As, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 2, parts=O.PART_F, aux=Oms)
+    Fp = F.copy()
+    for n in range(N):
+        prec, h = np.zeros((D, D)), np.zeros(D)
+        for A, Om in zip(Ah, Ol):
+            pg, hg = R.eigen_F_conditional(A, Om, Fp, lmbda, mu_0, sF, n)
+            prec += pg - np.eye(D) / sF
+            h += hg
+        prec += np.eye(D) / sF
+        Ssum = sum(Om[n] + Om[:, n] for Om in Oms)
+        Fp[n] = perturbation_draw(prec, h, Ssum, Fp * lmbda, n, sF, seed, 2, D)
+    assert np.allclose(Fo, Fp, rtol=1e-10, atol=1e-12)
+    mu_new, _ = O.eig_sweep_multi(As, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 2, parts=O.PART_MU0, aux=Oms)
+    prec, h = 1.0 / sm, mm / sm
+    for A, Om in zip(Ah, Ol):
+        pg, hg = R.eigen_mu0_conditional(A, Om, Fo, lmbda, mm, sm)
+        prec += pg - 1.0 / sm
+        h += hg - mm / sm
+    assert abs(mu_new - (h / prec + np.sqrt(1 / prec) * O.normal_at(seed, SITE_MU0, 2, 0))) < 1e-12
+    lo = lmbda.copy()
+    O.eig_sweep_multi(As, Fo, lo, mu_new, ml, mm, sm, sF, sl, 0, seed, 2, parts=O.PART_LMBDA, aux=Oms)
+    prec, h = np.eye(D) / sl, ml / sl
+    for A, Om in zip(Ah, Ol):
+        pg, hg = R.eigen_lmbda_conditional(A, Om, Fo, mu_new, ml, sl)
+        prec = prec + pg - np.eye(D) / sl
+        h = h + hg - ml / sl
+    z = np.array([O.normal_at(seed, SITE_LMBDA, 2, d) for d in range(D)])
+    assert np.allclose(lo, gauss_from_precision(prec, h, z), rtol=1e-10, atol=1e-12)
+    # log-likelihood: NaN terms are zero (eigenmodel.py:121-127)
+    P = np.clip(1.0 / (1.0 + np.exp(-R.eigen_Mu(Fo, lo, mu_new))), 1e-16, 1 - 1e-16)
+    A0 = As[0]
+    ref = np.nan_to_num(A0 * np.log(P) + (1 - A0) * np.log(1 - P)).sum()
+    assert abs(O.eig_loglik(A0, Fo, lo, mu_new) - ref) < 1e-9
+    # one fully observed graph: the plain sweep, bit for bit
+    A1 = (np.nan_to_num(As[0]) != 0).astype(np.uint8)
+    Fa, la, Fb, lb = F.copy(), lmbda.copy(), F.copy(), lmbda.copy()
+    ma, _ = O.eig_sweep(A1, Fa, la, mu_0, ml, mm, sm, sF, sl, 0, seed, 5)
+    mb, _ = O.eig_sweep_multi([A1], Fb, lb, mu_0, ml, mm, sm, sF, sl, 0, seed, 5)
+    assert np.array_equal(Fa, Fb) and np.array_equal(la, lb) and ma == mb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("probit", [False, True])
+@pytest.mark.parametrize("N,D,nG,miss", [(70, 3, 3, 0.15), (150, 8, 2, 0.05), (90, 5, 1, 0.3), (64, 4, 2, 0.0)])
+def test_engine_list_of_graphs_and_missing_entries_match_oracle(N, D, nG, miss, probit):
+    """gg_resample_part_many on the eigenmodels: auxiliary variables per graph, F / mu_0 / lambda from the summed statistics,
+    unobserved entries (NaN) left out of everything - part by part and over two full sweeps through the host class, against
+    the oracle's restatement of the reference's loops; the per-graph log-likelihood skips NaN terms."""
+    from graphistician_amd import _abi as abi
+    from graphistician_amd.eigenmodel import LogisticEigenmodel, ProbitEigenmodel
+    As, F, lmbda, mu_0 = make_list_case(N, D, N + nG, nG=nG, frac_missing=miss)
+    sF, sm, sl, mm, ml = 1.2, 0.8, 1.5, -0.3, np.zeros(D) + 0.1
+    seed = 91
+    ds = [abi.DeviceData(A, None, missing_ok=True) for A in As]
+    m = abi.Model(kind=abi.PROBIT_EIG if probit else abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=seed, sigma_mu0=sm, sigma_F=sF,
+                  sigma_lmbda=sl, mu_mu_0=mm, lmbda_given=0)
+    m.set(abi.ST_F, F); m.set(abi.ST_LMBDA, lmbda); m.set(abi.ST_MU0, np.array([mu_0])); m.set(abi.ST_MU_LMBDA, ml)
+    m.resample_part_many(ds, abi.PART_OMEGA)
+    _, aux = O.eig_sweep_multi(As, F, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_OMEGA, probit=probit)
+    S = m.get(abi.ST_OMEGA_S, (N, N))
+    ref = sum(a + a.T for a in aux)
+    np.fill_diagonal(ref, 0.0 if probit else sum(np.diag(a) for a in aux))
+    if probit:
+        np.fill_diagonal(S, 0.0)
+    assert np.allclose(S, ref, rtol=1e-9, atol=1e-12)
+    m.resample_part_many(ds, abi.PART_F)
+    Fo = F.copy()
+    O.eig_sweep_multi(As, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_F, aux=aux, probit=probit)
+    assert np.allclose(m.get(abi.ST_F, (N, D)), Fo, rtol=1e-8, atol=1e-10)
+    m.resample_part_many(ds, abi.PART_MU0)
+    mu_new, _ = O.eig_sweep_multi(As, Fo, lmbda, mu_0, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_MU0, aux=aux, probit=probit)
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - mu_new) < 1e-9
+    m.resample_part_many(ds, abi.PART_LMBDA)
+    lo = lmbda.copy()
+    O.eig_sweep_multi(As, Fo, lo, mu_new, ml, mm, sm, sF, sl, 0, seed, 0, parts=O.PART_LMBDA, aux=aux, probit=probit)
+    assert np.allclose(m.get(abi.ST_LMBDA, (D,)), lo, rtol=1e-8, atol=1e-10)
+    for d, A in zip(ds, As):
+        ll = m.log_likelihood(d)
+        ref = (O.probit_loglik if probit else O.eig_loglik)(A, Fo, lo, mu_new)
+        assert abs(ll - ref) <= 1e-9 * abs(ref)
+    # two full sweeps through the reference-shaped class: resample(list of networks)
+    np.random.seed(0)
+    h = (ProbitEigenmodel if probit else LogisticEigenmodel)(N, D, p=0.3, seed=777)
+    h.F, h.lmbda, h.mu_0 = F, lmbda, mu_0
+    Fo, lo, mo = F.copy(), lmbda.copy(), mu_0
+    for s in range(2):
+        h.resample(As if nG > 1 else As[0])
+        mo, _ = O.eig_sweep_multi(As, Fo, lo, mo, np.zeros(D), h.mu_mu_0, 1.0, 1.0, 1.0, 0, 777, s, probit=probit)
+    assert np.allclose(h.F, Fo, rtol=1e-6, atol=1e-8) and np.allclose(h.lmbda, lo, rtol=1e-6, atol=1e-8) and abs(h.mu_0 - mo) < 1e-7
+    tot = sum(h.log_likelihood(A) for A in As)
+    ref = sum((O.probit_loglik if probit else O.eig_loglik)(A, Fo, lo, mo) for A in As)
+    assert abs(tot - ref) <= 1e-7 * abs(ref)
+
+
+@pytest.mark.gpu
+def test_missing_entries_are_refused_by_the_block_models():
+    """NaN in A is missing data for the eigenmodels (eigenmodel.py:121-127); the block models' masked sums turn NaN in the
+    reference and the engine refuses such a network for them instead of counting the entry as an edge."""
+    from graphistician_amd import _abi as abi
+    A = (np.random.RandomState(0).rand(40, 40) < 0.3).astype(np.float64)
+    A[3, 5] = np.nan
+    with pytest.raises(ValueError):
+        abi.DeviceData(A, None)
+    d = abi.DeviceData(A, None, missing_ok=True)
+    m = abi.Model(kind=abi.SBM_ADJ, N=40, K=3, B=1, seed=1, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+    with pytest.raises(abi.EngineError):
+        m.resample(d, 1)
+    with pytest.raises(abi.EngineError):
+        abi.DeviceData(A, np.zeros((40, 40, 1)), missing_ok=True)

@@ -331,3 +331,42 @@ def test_more_than_64_blocks_through_the_host_classes(abi):
         assert abs(a.approx_predictive_ll(Arow, Acol, M=2) - ref_a) <= 1e-10 * abs(ref_a), k
         ref_w = GaussianWeightDistribution.approx_predictive_ll(w, Arow, Acol, Wrow, Wcol, M=2)
         assert abs(w.approx_predictive_ll(Arow, Acol, Wrow, Wcol, M=2) - ref_w) <= 1e-10 * abs(ref_w), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,special,beta", [(4, 1, 1.0), (7, 0, 1.0), (3, 1, 0.4)])
+def test_resample_p_over_a_list_of_graphs(K, special, beta):
+    """SBMAdjacencyDistribution.resample_p(As) (adjacency.py:620-648): the block-pair counts - and the diagonal's, for
+    p_self - are summed over the graphs of the list, every graph offering every pair, then one Beta draw per pair: bit for
+    bit against the oracle's restatement, through the C ABI (gg_resample_part_many) and through the host class."""
+    from graphistician_amd import _abi as abi
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from oracle import oracle as O
+    from tests.helpers import planted_sbm, AdjState
+    N = 120
+    As = [planted_sbm(N, K, seed=40 + g)[0] for g in range(3)]
+    st = AdjState(N, K, seed=9)
+    m = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=55, tau1=1.5, tau0=0.7, allow_self_connections=1, special_case_self_conns=special)
+    m.set(abi.ST_C, st.c, np.int32); m.set(abi.ST_M, st.m); m.set(abi.ST_PI, st.pi); m.set(abi.ST_P, st.p)
+    m.set(abi.ST_P_SELF, np.array([st.p_self]))
+    ds = [abi.DeviceData(A, None) for A in As]
+    m.resample_part_many(ds, abi.PART_PARAMS, beta)
+    p = st.p.copy()
+    ps = O.sbm_adj_resample_p_multi(As, st.c, p, st.p_self, 1.5, 0.7, special, 55, 0, beta)
+    assert np.array_equal(m.get(abi.ST_P, (K, K)), p)
+    if special:
+        assert m.get(abi.ST_P_SELF, (1,))[0] == ps
+    # asked for again: a new sweep index (fresh variates), still the summed counts
+    m.resample_part_many(ds, abi.PART_PARAMS, beta)
+    p2 = st.p.copy()
+    O.sbm_adj_resample_p_multi(As, st.c, p2, st.p_self, 1.5, 0.7, special, 55, 1, beta)
+    assert np.array_equal(m.get(abi.ST_P, (K, K)), p2) and not np.array_equal(p, p2)
+    # the host class
+    np.random.seed(1)
+    h = SBMAdjacencyDistribution(N, C=K, tau0=0.7, tau1=1.5, special_case_self_conns=bool(special), seed=66)
+    c0 = h.c.copy()
+    h.resample_p(As, beta)
+    p3 = np.ones((K, K))
+    O.sbm_adj_resample_p_multi(As, c0, p3, 0.5, 1.5, 0.7, special, 66, 0, beta)
+    assert np.array_equal(h.p, p3)
+    h.resample(As[0])          # and a plain sweep afterwards still runs
