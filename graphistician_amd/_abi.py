@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("sweeps_serial", C.c_uint64)]
 
 
-EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_update", "gg_data_info",
+EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "gg_data_destroy", "gg_data_update", "gg_data_info", "gg_data_quantisation",
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
            "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_part_many", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_predictive_ll", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
            "gg_comm_create_host", "gg_comm_destroy", "gg_comm_info", "gg_shard_sweep", "gg_shard_log_likelihood",
@@ -86,6 +86,7 @@ def lib():
         L.gg_data_update.argtypes = [vp, vp, vp]
         L.gg_data_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int64)]
+        L.gg_data_quantisation.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.gg_data_create_sbm.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp, C.c_double,
                                          C.c_double, C.c_uint64, C.c_int32]
         L.gg_data_download.argtypes = [vp, vp, vp]
@@ -182,6 +183,26 @@ class DeviceData(object):
                 check(lib().gg_data_create(C.byref(self._h), N, 1, _ptr(A), None, device))
         self.N, self.B, self.device = N, B, device
         self.has_w = W is not None or handle is not None
+        if handle is None and W is not None:
+            self._warn_if_coarse()
+
+    LOW_BITS_WARN = 12
+
+    def quantisation(self):
+        """(w_max, w_low, low_bits, shift) of the stored weights (gg_data_quantisation): the fixed-point scale is set by the
+        largest |w| on an edge; low_bits = the significant bits the 5 % quantile of |w| keeps (-1: not measured)."""
+        wmax, wlow, bits, shift = C.c_double(0), C.c_double(0), C.c_int32(0), C.c_int32(0)
+        check(lib().gg_data_quantisation(self._h, C.byref(wmax), C.byref(wlow), C.byref(bits), C.byref(shift)))
+        return wmax.value, wlow.value, bits.value, shift.value
+
+    def _warn_if_coarse(self):
+        wmax, wlow, bits, shift = self.quantisation()
+        if 0 <= bits < self.LOW_BITS_WARN:
+            import warnings
+            warnings.warn("graphistician_amd: the weights span a wide dynamic range (max |w| = %.3g, 5%% quantile %.3g): stored as "
+                          "fixed point with one scale, the small ones keep only %d significant bits (the reference computes in "
+                          "float64). Rescale, clip or transform W if its small entries matter." % (wmax, wlow, bits),
+                          RuntimeWarning, stacklevel=3)
 
     @classmethod
     def shard(cls, A, W, n0, n1, device=0):
@@ -230,6 +251,8 @@ class DeviceData(object):
                 W = W[:, :, None].copy()
             assert W.shape == (self.N, self.N, self.B)
         check(lib().gg_data_update(self._h, _ptr(A), _ptr(W) if W is not None else None))
+        if W is not None:
+            self._warn_if_coarse()
 
     @property
     def handle(self):

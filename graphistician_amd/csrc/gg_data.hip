@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "gg_common.h"
@@ -278,6 +279,29 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
     int e;
     frexp(wmax, &e);
     d->shift = gg_qbits(N) - e;
+    {
+      // Dynamic-range guard: the shift is set by the largest |w|; report what a small weight keeps.  5 %
+      // quantile of |w| over the edges' non-zero components (all of them up to 2^22 values, a strided sample beyond).
+      std::vector<float> mags;
+      size_t nval = 0;
+      for (size_t ij = 0; ij < (size_t)N * N; ++ij) if (A[ij] == 1 || (A[ij] && A[ij] != GG_A_MISSING)) nval += B;
+      const size_t stride = nval > ((size_t)1 << 22) ? nval / ((size_t)1 << 22) : 1;
+      size_t seen = 0;
+      for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
+        if (!A[ij] || A[ij] == GG_A_MISSING) continue;
+        for (int b = 0; b < B; ++b, ++seen)
+          if (seen % stride == 0) { const double a = fabs(W[ij * B + b]); if (a > 0.0) mags.push_back((float)a); }
+      }
+      d->w_max = wmax; d->w_low = 0.0; d->low_bits = -1;
+      if (!mags.empty()) {
+        const size_t k = mags.size() / 20;
+        std::nth_element(mags.begin(), mags.begin() + k, mags.end());
+        d->w_low = mags[k];
+        int el;
+        frexp(ldexp(d->w_low, d->shift), &el);      // w_low 2^shift in [2^(el-1), 2^el)
+        d->low_bits = el - 1 < 0 ? 0 : el - 1;
+      }
+    }
     hW.assign(nA * B, 0);
     hdW.assign((size_t)N * B, 0);
     for (size_t x = 0; x < nA; ++x) hW[x * B] = GG_NO_EDGE;
@@ -483,6 +507,29 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
     int e;
     frexp(wmax, &e);
     d->shift = gg_qbits(N) - e;
+    {
+      // Dynamic-range guard: the shift is set by the largest |w|; report what a small weight keeps.  5 %
+      // quantile of |w| over the edges' non-zero components (all of them up to 2^22 values, a strided sample beyond).
+      std::vector<float> mags;
+      size_t nval = 0;
+      for (size_t ij = 0; ij < (size_t)N * N; ++ij) if (A[ij] == 1 || (A[ij] && A[ij] != GG_A_MISSING)) nval += B;
+      const size_t stride = nval > ((size_t)1 << 22) ? nval / ((size_t)1 << 22) : 1;
+      size_t seen = 0;
+      for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
+        if (!A[ij] || A[ij] == GG_A_MISSING) continue;
+        for (int b = 0; b < B; ++b, ++seen)
+          if (seen % stride == 0) { const double a = fabs(W[ij * B + b]); if (a > 0.0) mags.push_back((float)a); }
+      }
+      d->w_max = wmax; d->w_low = 0.0; d->low_bits = -1;
+      if (!mags.empty()) {
+        const size_t k = mags.size() / 20;
+        std::nth_element(mags.begin(), mags.begin() + k, mags.end());
+        d->w_low = mags[k];
+        int el;
+        frexp(ldexp(d->w_low, d->shift), &el);      // w_low 2^shift in [2^(el-1), 2^el)
+        d->low_bits = el - 1 < 0 ? 0 : el - 1;
+      }
+    }
     hW.assign(nA * B, 0); hWT.assign(nA * B, 0); hdW.assign((size_t)Nl * B, 0);
     for (size_t x = 0; x < nA; ++x) { hW[x * B] = GG_NO_EDGE; hWT[x * B] = GG_NO_EDGE; }
     for (int nl = 0; nl < Nl; ++nl) hdW[(size_t)nl * B] = GG_NO_EDGE;
@@ -567,6 +614,15 @@ int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64
   if (B) *B = d->B;
   if (shift) *shift = d->shift;
   if (n_edges) *n_edges = d->n_edges;
+  return GG_OK;
+}
+
+int gg_data_quantisation(const gg_data* d, double* w_max, double* w_low, int32_t* low_bits, int32_t* shift) {
+  if (!d) return gg_fail(GG_ERR_INVALID, "null data");
+  if (w_max) *w_max = d->w_max;
+  if (w_low) *w_low = d->w_low;
+  if (low_bits) *low_bits = (d->has_w && d->w_max > 0.0) ? d->low_bits : -1;     // (w_max == 0: never measured)
+  if (shift) *shift = d->shift;
   return GG_OK;
 }
 

@@ -611,3 +611,32 @@ def test_predictive_ll_on_the_device_matches_the_reference_formula(abi):
     niw = NIWGaussianWeightDistribution(N, B=B)
     ref = GaussianWeightDistribution.approx_predictive_ll(niw, Arow, Acol, Wrow, Wcol, M=2)
     assert abs(niw.approx_predictive_ll(Arow, Acol, Wrow, Wcol) - ref) <= 1e-10 * abs(ref)
+
+
+def test_quantisation_guard_reports_a_coarse_scale(abi):
+    """the weights are stored as 24-bit fixed point with ONE shift, fixed by the largest |w| on an edge - 24 bits
+    absolute where the reference's float64 keeps 53 relative (abstractions.py:261).  One outlier edge (|w| = 1e3 among
+    N(0, 0.01)) leaves the bulk of the data a handful of bits: gg_data_quantisation reports it and the binding warns; well-scaled
+    weights keep >= 20 bits and are silent.  The log-likelihood then shows the loss the guard is there to announce."""
+    import warnings
+    from oracle import oracle as O
+    N, K = 96, 3
+    A, W, c = planted_sbm(N, K, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        d = abi.DeviceData(A, W)                      # N(mu, 0.7^2): silent
+    wmax, wlow, bits, shift = d.quantisation()
+    assert bits >= 14 and wmax > wlow > 0
+    W2 = W * 0.01
+    i, j = np.argwhere(A == 1)[5]
+    W2[i, j, 0] = 1.0e3                               # one outlier sets the scale
+    with pytest.warns(RuntimeWarning, match="significant bits"):
+        d2 = abi.DeviceData(A, W2)
+    wmax2, wlow2, bits2, shift2 = d2.quantisation()
+    assert wmax2 == 1.0e3 and bits2 < 12 and shift2 < shift
+    # what the stored network is worth: round-trip error of a typical weight, relative
+    A_back, W_back = d2.download()
+    typical = (A == 1) & (np.abs(W2[:, :, 0]) < 1.0)
+    rel = np.abs(W_back[:, :, 0][typical] - W2[:, :, 0][typical]) / np.abs(W2[:, :, 0][typical]).clip(1e-9)
+    assert np.median(rel) > 1e-4                      # (24 bits relative would be 6e-8)
+    assert abi.DeviceData(A, None).quantisation()[2] == -1
