@@ -441,6 +441,15 @@ __device__ __forceinline__ double eig_group_sum(double x) {
   return x;
 }
 
+// The same for two values at once (the two dependent chains interleave).
+template <int DM>
+__device__ __forceinline__ void eig_group_sum2(double& x, double& y) {
+  x += gg_dpp_f64<0xB1>(x); y += gg_dpp_f64<0xB1>(y);
+  x += gg_dpp_f64<0x4E>(x); y += gg_dpp_f64<0x4E>(y);
+  if (DM >= 8) { x += gg_dpp_f64<0x141>(x); y += gg_dpp_f64<0x141>(y); }
+  if (DM >= 16) { x += gg_dpp_f64<0x140>(x); y += gg_dpp_f64<0x140>(y); }
+}
+
 // The sequential part of _resample_F for one tile (workgroup 0), riders behind it.  64 * DM threads = DM waves; node i of
 // the tile lives in wave i % DM, lanes [(i / DM) DM, (i / DM + 1) DM) - consecutive nodes in different waves, so that while
 // one wave closes node k the others fold change k - 1 into their nodes - lane j of the group owning row j of the node's
@@ -571,7 +580,8 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
   const int i = grp * NW + wave;                  // this lane's node
   const int gbase = (tid / DM) * DM;              // first lane of the group (its slots of the gather scratch)
   const bool live = i < T;
-  double Prow[DM], bfull[DM], rj = 0.0;
+  double Prow[DM], rj = 0.0;
+  bool bad_x = false;
   const double lamj = j < D ? lmbda[j] : 0.0;
   {
     double L[DM][DM];
@@ -622,19 +632,14 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
       for (int k = r + 1; k < DM; ++k) v = gg_fma(-L[k][r], Prow[k], v);
       Prow[r] = v * L[r][r];
     }
+    // r = P b, this lane's component; b = the mean term + z / sqrt(sigma_F)
     const double isq = 1.0 / gg_sqrt(sigma_F);
 #pragma unroll
-    for (int m = 0; m < DM; ++m)
-      bfull[m] = (live && m < D) ? gg_fma(Z[(size_t)(t0 + i) * D + m], isq, s_C[i * NEm + NEGM + m]) : 0.0;
+    for (int m = 0; m < DM; ++m) {
+      const double bm = (live && m < D) ? gg_fma(Z[(size_t)(t0 + i) * D + m], isq, s_C[i * NEm + NEGM + m]) : 0.0;
+      rj = gg_fma(Prow[m], bm, rj);
+    }
   }
-  // r = P b, this lane's component: what a node closes with, prepared one step ahead
-  auto prepare_r = [&]() {
-    double acc = 0.0;
-#pragma unroll
-    for (int m = 0; m < DM; ++m) acc = gg_fma(Prow[m], bfull[m], acc);
-    rj = acc;
-  };
-  prepare_r();
   const long long c_scan = dbg ? clock64() : 0;
   // ---- the scan.  Step k: node k closes with change k - 1 (the features node k - 1 has just published); the later nodes
   // fold change k - 1 into their inverse.  A wave whose nodes are all closed leaves.
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
   for (int k = 0; k <= last; ++k) {
     const bool act = live && i >= k;
     const bool closer = (k % NW) == wave;       // this wave holds node k
-    double u[DM], uj = 0.0, s = 0.0, v = 0.0, qj = 0.0, c = 0.0, tq = 0.0;
+    double u[DM], uj = 0.0, s = 0.0, v = 0.0, qj = 0.0, c = 0.0;
     if (k >= 1) {
       for (int spin = 0;; ++spin) {
         asm volatile("" ::: "memory");
@@ -656,25 +661,26 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
       for (int m = 0; m < DM; ++m) u[m] = s_u[(k - 1) * DM + m];
       uj = s_u[(k - 1) * DM + j];
       if (act) { s = s_S[i * TS + k - 1]; v = s_V[i * TS + k - 1]; }
+      // fold change k - 1 into r = P b (the P half follows below, behind the publication):
+      //   r' = (P - c q q^T)(b + v u) = r + q (v - s d) / (1 + s t),   t = u^T q,  d = u^T r
+      double qa = 0.0, qb = 0.0;
 #pragma unroll
-      for (int m = 0; m < DM; ++m) qj = gg_fma(Prow[m], u[m], qj);
-      tq = eig_group_sum<DM>(uj * qj);
+      for (int m = 0; m < DM / 2; ++m) { qa = gg_fma(Prow[m], u[m], qa); qb = gg_fma(Prow[DM / 2 + m], u[DM / 2 + m], qb); }
+      qj = qa + qb;
+      double tq = uj * qj, d = uj * rj;
+      eig_group_sum2<DM>(tq, d);
       const double den = gg_fma(s, tq, 1.0);
       double rc = __builtin_amdgcn_rcp(den);
       rc = rc * gg_fma(-den, rc, 2.0);
       rc = rc * gg_fma(-den, rc, 2.0);
       c = s * rc;
+      rj = gg_fma(gg_fma(-s, d, v) * rc, qj, rj);
     }
     if (closer) {
-      // close node k:  x = r + (v - c (d + v t)) q,  d = u^T r
-      double x = rj;
-      if (k >= 1) {
-        const double d = eig_group_sum<DM>(uj * rj);
-        const double coef = v - c * gg_fma(v, tq, d);
-        x = gg_fma(coef, qj, rj);
-      }
+      // node k's new features are its r with every earlier change of the tile folded in
       if (act && i == k) {
-        if (!(x == x)) { atomicOr(status, 1); x = 0.0; }
+        double x = rj;
+        if (!(x == x)) { bad_x = true; x = 0.0; }
         s_u[k * DM + j] = x * lamj;
         s_Fn[k * DM + j] = x;
       }
@@ -683,20 +689,16 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
       asm volatile("" ::: "memory");
     }
     if (k >= 1 && last > k) {
-      // the later nodes of this wave: P <- P - c q q^T, b <- b + v u
+      // the later nodes of this wave: P <- P - c q q^T (lanes of closed nodes compute on, nobody reads them)
       s_q[tid] = qj;
       gg_lds_wait();
-      if (act && i > k) {
-        const double cq = c * qj;
+      const double cq = c * qj;
 #pragma unroll
-        for (int m = 0; m < DM; ++m) Prow[m] = gg_fma(-cq, s_q[gbase + m], Prow[m]);
-#pragma unroll
-        for (int m = 0; m < DM; ++m) bfull[m] = gg_fma(v, u[m], bfull[m]);
-      }
+      for (int m = 0; m < DM; ++m) Prow[m] = gg_fma(-cq, s_q[gbase + m], Prow[m]);
       gg_lds_wait();
-      if (((k + 1) % NW) == wave) prepare_r();   // node k + 1 closes next: its r = P b with every change but the last
     }
   }
+  if (bad_x) atomicOr(status, 1);
   __syncthreads();
   if (dbg && tid == 0) {
     atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)(clock64() - c_scan));
