@@ -190,7 +190,7 @@ class DeviceData(object):
 
     def quantisation(self):
         """(w_max, w_low, low_bits, shift) of the stored weights (gg_data_quantisation): the fixed-point scale is set by the
-        largest |w| on an edge; low_bits = the significant bits the 5 % quantile of |w| keeps (-1: not measured)."""
+        largest |w| on an edge; low_bits = the significant bits the median of |w| keeps (-1: not measured)."""
         wmax, wlow, bits, shift = C.c_double(0), C.c_double(0), C.c_int32(0), C.c_int32(0)
         check(lib().gg_data_quantisation(self._h, C.byref(wmax), C.byref(wlow), C.byref(bits), C.byref(shift)))
         return wmax.value, wlow.value, bits.value, shift.value
@@ -199,8 +199,8 @@ class DeviceData(object):
         wmax, wlow, bits, shift = self.quantisation()
         if 0 <= bits < self.LOW_BITS_WARN:
             import warnings
-            warnings.warn("graphistician_amd: the weights span a wide dynamic range (max |w| = %.3g, 5%% quantile %.3g): stored as "
-                          "fixed point with one scale, the small ones keep only %d significant bits (the reference computes in "
+            warnings.warn("graphistician_amd: the weights span a wide dynamic range (max |w| = %.3g, median %.3g): stored as "
+                          "fixed point with one scale, a typical one keeps only %d significant bits (the reference computes in "
                           "float64). Rescale, clip or transform W if its small entries matter." % (wmax, wlow, bits),
                           RuntimeWarning, stacklevel=3)
 

@@ -90,8 +90,8 @@ struct gg_data {
   int shift;
   long long n_edges;
   // dynamic range of the stored weights (gg_data_quantisation): the largest |w| on an edge fixes ONE shift for the whole
-  // matrix, so an edge whose |w| is far below it keeps few significant bits.  w_low = the 5 % quantile of |w| over the edges'
-  // components, low_bits = floor(log2(w_low 2^shift)) (what that quantile keeps; < 0: not measured - device-generated data)
+  // matrix, so an edge whose |w| is far below it keeps few significant bits.  w_low = the MEDIAN of |w| over the edges'
+  // components, low_bits = floor(log2(w_low 2^shift)) (what a typical weight keeps; < 0: not measured - device-generated data)
   double w_max, w_low;
   int low_bits;
   long long n_missing;   // entries of A given as GG_A_MISSING (unobserved: eigenmodel.py:121-127); 0 for every other network

@@ -280,8 +280,9 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
     frexp(wmax, &e);
     d->shift = gg_qbits(N) - e;
     {
-      // Dynamic-range guard: the shift is set by the largest |w|; report what a small weight keeps.  5 %
-      // quantile of |w| over the edges' non-zero components (all of them up to 2^22 values, a strided sample beyond).
+      // Dynamic-range guard: the shift is set by the largest |w|; report what a TYPICAL weight keeps: the
+      // median of |w| over the edges' non-zero components - the sums the sampler forms (w, w w^T) carry the absolute error, so it
+      // is the data's scale that has to stand clear of the step, not its smallest entries (all of them up to 2^22 values, a strided sample beyond).
       std::vector<float> mags;
       size_t nval = 0;
       for (size_t ij = 0; ij < (size_t)N * N; ++ij) if (A[ij] == 1 || (A[ij] && A[ij] != GG_A_MISSING)) nval += B;
@@ -294,7 +295,7 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
       }
       d->w_max = wmax; d->w_low = 0.0; d->low_bits = -1;
       if (!mags.empty()) {
-        const size_t k = mags.size() / 20;
+        const size_t k = mags.size() / 2;
         std::nth_element(mags.begin(), mags.begin() + k, mags.end());
         d->w_low = mags[k];
         int el;
@@ -508,8 +509,9 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
     frexp(wmax, &e);
     d->shift = gg_qbits(N) - e;
     {
-      // Dynamic-range guard: the shift is set by the largest |w|; report what a small weight keeps.  5 %
-      // quantile of |w| over the edges' non-zero components (all of them up to 2^22 values, a strided sample beyond).
+      // Dynamic-range guard: the shift is set by the largest |w|; report what a TYPICAL weight keeps: the
+      // median of |w| over the edges' non-zero components - the sums the sampler forms (w, w w^T) carry the absolute error, so it
+      // is the data's scale that has to stand clear of the step, not its smallest entries (all of them up to 2^22 values, a strided sample beyond).
       std::vector<float> mags;
       size_t nval = 0;
       for (size_t ij = 0; ij < (size_t)N * N; ++ij) if (A[ij] == 1 || (A[ij] && A[ij] != GG_A_MISSING)) nval += B;
@@ -522,7 +524,7 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
       }
       d->w_max = wmax; d->w_low = 0.0; d->low_bits = -1;
       if (!mags.empty()) {
-        const size_t k = mags.size() / 20;
+        const size_t k = mags.size() / 2;
         std::nth_element(mags.begin(), mags.begin() + k, mags.end());
         d->w_low = mags[k];
         int el;

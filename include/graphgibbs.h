@@ -164,7 +164,7 @@ int gg_data_update(gg_data* d, const uint8_t* A, const double* W);
 int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64_t* n_edges);
 /* Dynamic range of the stored weights.  W is kept as 24-bit fixed point with ONE shift for the whole matrix, fixed by the
  * largest |w| on an edge (exact, order-independent integer sums: DESIGN.md section 2) - 24 bits ABSOLUTE where the
- * reference's float64 (abstractions.py:261) keeps 53 relative.  w_max: that largest |w|; w_low: the 5 % quantile of |w| over
+ * reference's float64 (abstractions.py:261) keeps 53 relative.  w_max: that largest |w|; w_low: the median of |w| over
  * the edges' components; low_bits: the significant bits a weight of size w_low keeps, floor(log2(w_low 2^shift)) (-1: not
  * measured - no weights, or data generated on the device).  low_bits < 12: a few outliers have set the scale and the bulk of
  * the data is stored coarsely - the Python binding warns; rescale, clip or transform the weights (a wider storage mode is not
