@@ -143,8 +143,10 @@ __device__ __forceinline__ void eig_tile_pair(int b, int nt, int* I, int* J) {
 // eigenmodel.py:859-874: omega_ij ~ PG(1, psi_ij), psi = mu_0 + (F lambda) F^T, diag psi = mu_0 (:81-82).
 // gen: entries given as GG_A_MISSING are unobserved - no omega is drawn for them (their likelihood term is absent);
 // accumulate: a further graph of the list (its own Philox site), added to S / dO.
-template <int DM>
-__global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const double* __restrict__ F,
+// TEMP: the tempered draw PG(beta, psi), beta != 1 (its 64-term gamma sum would otherwise set the register count of the plain
+// sweep's kernel, which runs at four waves per SIMD: 2.40 -> 1.96 ms at N=4096 against two).
+template <int DM, bool TEMP>
+__global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, const double* __restrict__ F,
                                                    const double* __restrict__ lmbda, const double* __restrict__ mu0p,
                                                    uint64_t seed, uint32_t sweep, double* __restrict__ S,
                                                    double* __restrict__ dO, double beta, const uint8_t* __restrict__ A,
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
           gg_stream s0;
           gg_stream_init(&s0, seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gi);
           // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
-          dv = beta != 1.0 ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
+          dv = TEMP ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
         }
         dO[gi] = accumulate ? dO[gi] + dv : dv;
       } else if (I < J || li < lj) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
         gg_stream s1, s2;
         gg_stream_init(&s1, seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj);
         gg_stream_init(&s2, seed, site, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi);
-        if (beta != 1.0) {
+        if (TEMP) {
           if (beta > 0.0) val = (o1 ? gg_pg_frac(&s1, beta, psi) : 0.0) + (o2 ? gg_pg_frac(&s2, beta, psi) : 0.0);
         } else {
           // omega_ij and omega_ji see the same psi: the mixture mass is computed once for the pair
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void k_eig_omega(int N, int Np, int D, const d
 // A_ij = 0.  Z enters the conditionals only through Z_ij + Z_ji off the diagonal (:312-321, :339-346, :363-372),
 // which is what this kernel stores in S (symmetric, diagonal 0): same tiling as k_eig_omega.
 template <int DM>
-__global__ __launch_bounds__(256) void k_eig_z(int N, int Np, int D, const double* __restrict__ F,
+__global__ __launch_bounds__(256, 4) void k_eig_z(int N, int Np, int D, const double* __restrict__ F,
                                                const double* __restrict__ lmbda, const double* __restrict__ mu0p,
                                                const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
                                                uint64_t seed, uint32_t sweep, double* __restrict__ S, int accumulate, uint32_t site) {
@@ -1038,7 +1040,9 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
         EIG_DISPATCH(CALL);
 #undef CALL
       } else {
-#define CALL(DMV) k_eig_omega<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site)
+#define CALL(DMV)                                                                                                                  \
+  if (e->beta != 1.0) k_eig_omega<DMV, true><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site); \
+  else k_eig_omega<DMV, false><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site)
         EIG_DISPATCH(CALL);
 #undef CALL
       }

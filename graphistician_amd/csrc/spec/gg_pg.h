@@ -45,6 +45,17 @@ GG_HD double gg_pg_a(int n, double x) {
   }
   return 0.0;
 }
+// The same with the logarithms that do not depend on n taken out of the series loop (lx = log x, lhp = log(pi / 2): the
+// caller computes them once per proposal): the same expression, the same value.
+GG_HD double gg_pg_a_pre(int n, double x, double lx, double lhp) {
+  const double K = ((double)n + 0.5) * GG_PI;
+  if (x > GG_PG_TRUNC) return K * GG_PG_EXP(-0.5 * K * K * x);
+  if (x > 0.0) {
+    double expnt = -1.5 * (lhp + lx) + GG_PG_LOG(K) - 2.0 * ((double)n + 0.5) * ((double)n + 0.5) / x;
+    return GG_PG_EXP(expnt);
+  }
+  return 0.0;
+}
 
 // probability mass of the truncated-exponential component
 GG_HD double gg_pg_mass_texpon(double Z) {
@@ -94,16 +105,18 @@ GG_HD double gg_pg1_pre(gg_stream* s, double Z, double ptex) {
     double X;
     if (gg_stream_uniform(s) < ptex) X = GG_PG_TRUNC + gg_expon(s) / fz;
     else X = gg_pg_rtigauss(s, Z);
-    double S = gg_pg_a(0, X);
+    // (log x and log(pi / 2) once per proposal, not once per term of the series: two of the three logarithms of a term)
+    const double lx = (X > 0.0 && !(X > GG_PG_TRUNC)) ? GG_PG_LOG(X) : 0.0, lhp = GG_PG_LOG(0.5 * GG_PI);
+    double S = gg_pg_a_pre(0, X, lx, lhp);
     const double Y = gg_stream_uniform(s) * S;
     int n = 0;
     for (;;) {
       ++n;
       if (n & 1) {
-        S -= gg_pg_a(n, X);
+        S -= gg_pg_a_pre(n, X, lx, lhp);
         if (Y <= S) return 0.25 * X;
       } else {
-        S += gg_pg_a(n, X);
+        S += gg_pg_a_pre(n, X, lx, lhp);
         if (Y > S) break;
       }
       if (n > 200) return 0.25 * X;  // numerically converged series
