@@ -781,7 +781,15 @@ __global__ __launch_bounds__(256) void k_eig_draw_globals(int N, int NP, int D, 
     if (e < NGM) {
       const int lo = (int)((long long)NP * q / 4), hi = (int)((long long)NP * (q + 1) / 4);
       double v = 0.0;
-      for (int i = lo; i < hi; ++i) v += gpart[(size_t)i * NGM + e];
+      int i = lo;
+      for (; i + 8 <= hi; i += 8) {        // (eight loads in flight, added in the same order as one by one)
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = gpart[(size_t)(i + u) * NGM + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += w[u];
+      }
+      for (; i < hi; ++i) v += gpart[(size_t)i * NGM + e];
       s_q[q][e] = v;
     }
     __syncthreads();
