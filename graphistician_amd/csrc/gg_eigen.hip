@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
   double* s_Fn = s_u + EIG_T * DM;                    // [T][DM]   new features
   double* s_q = s_Fn + EIG_T * DM;                    // [NTH]     gather scratch, one slot per lane
   int* s_pub = reinterpret_cast<int*>(s_q + NTH);      // (plain LDS accesses behind compiler barriers: a volatile pointer here becomes flat loads)
+  double* s_Y = s_q + NTH + 2;                        // [T][NEm]  previous tile: g_a g_b (upper triangle) and g_a per node (prologue only)
   const int tid = threadIdx.x;
   const int T = (N - t0 < EIG_T) ? (N - t0) : EIG_T;
   const int p0 = t0 - EIG_T;       // first node of the previous tile (left out by the riders that ran beside its scan)
@@ -544,34 +545,59 @@ __global__ __launch_bounds__(64 * DM) void k_eig_chain(int N, int Np, int D, int
     // s_C[i][e] += sum_m X[i][m] Y[m][e] over the 64 nodes m of the previous tile, with their new features, on the matrix
     // cores (v_mfma_f64_16x16x4_f64; fragment layout as in eig_psi_tile_mfma).  Precision entries (e < NEGM): X = s,
     // Y[m][e] = g_m[a] g_m[b]; mean entries: X = v, Y[m][a] = g_m[a].
+    {
+      // Y[m][e]: the products the matrix cores multiply the previous tile's block with - thread (m, a) writes g_a g_b for
+      // b >= a (upper triangle, row a) and the mean entry g_a (the scan's gather scratch and feature buffers are free: s_Y
+      // lies over s_u .. s_q and beyond, see the LDS map)
+      for (int e = tid; e < EIG_T * DM; e += NTH) {
+        const int m = e / DM, a1 = e % DM;
+        double g[DM];
+#pragma unroll
+        for (int q = 0; q < DM; ++q) g[q] = s_g[m * DM + q];
+        double ga = 0.0;
+#pragma unroll
+        for (int q = 0; q < DM; ++q) ga = (q == a1) ? g[q] : ga;
+        const int rowstart = a1 * DM - a1 * (a1 - 1) / 2;     // index of (a1, a1) in the padded upper triangle
+#pragma unroll
+        for (int b1 = 0; b1 < DM; ++b1)
+          if (b1 >= a1) s_Y[m * NEm + rowstart + (b1 - a1)] = ga * g[b1];
+        s_Y[m * NEm + NEGM + a1] = ga;
+      }
+    }
+    __syncthreads();
     const int wv = tid >> 6, l = tid & 63;
     constexpr int ncb = (NEGM + 15) / 16;       // column blocks of the precision part
     constexpr int nblk = 4 * (ncb + 1);         // + one column block for the mean part
-    for (int blk = wv; blk < nblk; blk += NTH / 64) {
-      const int bi = blk & 3, cb = blk >> 2;
-      const bool mean = cb == ncb;
-      const int col = (mean ? 0 : cb * 16) + (l & 15);
-      int a1 = 0, b1 = 0;
-      bool cvalid;
-      if (mean) { a1 = col; cvalid = col < DM; }
-      else { cvalid = col < NEGM; if (cvalid) { int rem = col; while (rem >= DM - a1) { rem -= DM - a1; ++a1; } b1 = a1 + rem; } }
-      const int row = bi * 16 + (l & 15);
-      gg_double4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-      for (int kk = 0; kk < EIG_T / 4; ++kk) {
-        const int m = kk * 4 + (l >> 4);
-        const double xa = mean ? s_V[row * TS + m] : s_S[row * TS + m];
-        double yb = 0.0;
-        if (cvalid) yb = mean ? s_g[m * DM + a1] : s_g[m * DM + a1] * s_g[m * DM + b1];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
-      }
-      // lane l holds C[16 bi + 4 r + l / 16][col block + l % 16] in component r
-      if (cvalid) {
-        const int e = mean ? NEGM + a1 : col;
+    constexpr int NB = nblk / (NTH / 64);       // 16 x 16 blocks per wave, accumulated side by side
+    static_assert(nblk == NB * (NTH / 64), "whole blocks per wave");
+    const double* X[NB];
+    int yo[NB], eo[NB], ro[NB];
+    bool cv[NB];
+    gg_double4 acc[NB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_C[(bi * 16 + 4 * r + (l >> 4)) * NEm + e] += acc[r];
-      }
+    for (int h = 0; h < NB; ++h) {
+      const int blk = wv + h * (NTH / 64), bi = blk & 3, cb = blk >> 2;
+      const bool mean = cb == ncb;
+      const int col = l & 15;
+      eo[h] = mean ? NEGM + col : cb * 16 + col;
+      cv[h] = mean ? col < DM : cb * 16 + col < NEGM;
+      X[h] = (mean ? s_V : s_S) + (bi * 16 + (l & 15)) * TS;
+      yo[h] = cv[h] ? eo[h] : 0;     // (lanes of columns that do not exist read entry 0 and store nothing)
+      ro[h] = bi * 16 + (l >> 4);
+      acc[h] = gg_double4{0.0, 0.0, 0.0, 0.0};
     }
+#pragma unroll 4
+    for (int kk = 0; kk < EIG_T / 4; ++kk) {
+      const int m = kk * 4 + (l >> 4);
+#pragma unroll
+      for (int h = 0; h < NB; ++h) acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[h][m], s_Y[m * NEm + yo[h]], acc[h], 0, 0, 0);
+    }
+    // lane l holds C[16 bi + 4 r + l / 16][col block + l % 16] in component r
+#pragma unroll
+    for (int h = 0; h < NB; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (cv[h]) s_C[(ro[h] + 4 * r) * NEm + eo[h]] += acc[h][r];
     __syncthreads();
   }
   store_block(sv1, vv1);   // the own tile's block: what the scan reads
@@ -1077,7 +1103,7 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
     long long* dbg = dbgon ? e->dbgbuf : nullptr;
     if (dbg) GG_HIP(hipMemsetAsync(dbg, 0, 16 * sizeof(long long), st));
     const int DMv = e->DM, nth = 64 * DMv;
-    const size_t chain_lds = (((size_t)2 * EIG_T * (EIG_T + 1) + (size_t)EIG_T * e->NEm + 3 * (size_t)EIG_T * DMv + nth) * sizeof(double) + 16 + 15) & ~(size_t)15;
+    const size_t chain_lds = (((size_t)2 * EIG_T * (EIG_T + 1) + 2 * (size_t)EIG_T * e->NEm + 3 * (size_t)EIG_T * DMv + nth + 2) * sizeof(double) + 16 + 15) & ~(size_t)15;
     static bool attr4 = false, attr8 = false;
     if (DMv == 4 && !attr4) {
       GG_HIP(hipFuncSetAttribute((const void*)k_eig_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
