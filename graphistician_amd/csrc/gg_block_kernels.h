@@ -465,9 +465,13 @@ __device__ inline void gg_unpack_wstats(const long long* hl /* hi,lo pairs */, i
 }
 
 // adjacency.py:697-702 / weights.py:493-498 resample_m.
+// ctl: the pipeline's control block, or null - behind a stalled scan the launch is a no-op like every other kernel of the
+// pipeline (more than 64 blocks, speculative form: a draw from the half-scanned block sizes would hand the resumed scan the
+// wrong log m).
 __global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restrict__ pi, int K, uint64_t seed,
-                         uint32_t site, uint32_t sweep, double* __restrict__ m) {
+                         uint32_t site, uint32_t sweep, double* __restrict__ m, const int32_t* __restrict__ ctl = nullptr) {
   extern __shared__ double s_g[];
+  if (ctl && ctl[4]) return;
   int k = threadIdx.x;
   if (k < K) s_g[k] = gg_dirichlet_gamma_at(seed, site, sweep, k, pi[k] + (double)cnt[k]);
   __syncthreads();
@@ -479,7 +483,8 @@ __global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restri
 }
 
 // log m for more than 64 blocks (the parameter kernel's last workgroup has 192 lanes for it): all of them, after it.
-__global__ void k_logm(const double* __restrict__ m, double* __restrict__ logm, int K) {
+__global__ void k_logm(const double* __restrict__ m, double* __restrict__ logm, int K, const int32_t* __restrict__ ctl = nullptr) {
+  if (ctl && ctl[4]) return;
   const int k = threadIdx.x;
   if (k < K) logm[k] = gg_log(m[k]);
 }
@@ -1302,6 +1307,12 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
   double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
   *n_out = n;
   *live_out = live;
+  if (SPLIT == 2) {
+    // more than 64 blocks: a node's lanes span two or four wavefronts and the categorical scans through LDS (scratch behind
+    // the statistics; the tables are never staged at this size)
+    double* s_cat = s_st + (size_t)2 * K * per * NT;
+    return gg_group_categorical_wide(lp, k, K, Kp, u, s_cat);
+  }
   return gg_group_categorical(lp, k, K, Kp, u);
 }
 

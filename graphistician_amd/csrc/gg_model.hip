@@ -186,6 +186,7 @@ static size_t lds_spec(const gg_model* m, int* stage_out) {
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
   else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+  if (m->Kp > 64) lds += (size_t)2 * 256 * sizeof(double) + 16 * sizeof(int) + 8;   // the cross-wave categorical's scratch
   if (stage_out) *stage_out = stage;
   return lds;
 }
@@ -371,7 +372,9 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     const char* es = getenv("GG_SCAN");
     const bool can_scan = m->sbm && m->K > 1 && !m->sharded;
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
-    if (m->wide) m->scan_pref = 1;      // the wide instantiation of k_scan is the one scan form of 65..128 blocks
+    // more than 64 blocks: the resident scan (wide instantiation) and, round 3, the speculative one-launch form for quiet chains
+    // (k_spec_resolve<.., 2>); no restart rounds, so GG_SCAN=0 means the resident form there
+    if (m->wide && can_scan) m->scan_pref = es ? 1 : -1;
     m->use_scan = m->scan_pref == 1;
     m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
     m->scan_pref_saved = 0; m->scan_retry_at = 0; m->ahead_cap = 64;
@@ -381,7 +384,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     // k_params and k_spec_resolve launches.  GG_AHEAD=0 keeps every sweep in the serial form (bulk -> params -> scan).
 { const char* er2 = getenv("GG_SCAN_RIDE"); m->scan_ride = (m->wide || m->joint || m->sharded) ? 0 : (er2 ? atoi(er2) : 0); m->ride_chg_seen = 0; m->chg_per_sweep = -1.0; }
         const char* ea = getenv("GG_AHEAD");
-    m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0) && !m->joint && !m->wide;   // (the joint kind runs the serial form)
+    m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0) && !m->joint;   // (the joint kind runs the serial form)
     const char* ers = getenv("GG_RIDE_SPLIT");
     m->ride_split = ers ? atof(ers) : -1.0;   // (default chosen below, once the scan forms of this shape are known)
     if (can_scan) {
@@ -408,7 +411,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
       // registers does not, so there the whole pass rides with k_params.
       int stage = 0;
       lds_spec(m, &stage);
-      m->ride_split = (!stage && m->Kp == 64) ? 1.0 : 0.5;
+      m->ride_split = ((!stage && m->Kp == 64) || m->wide) ? 1.0 : 0.5;
     }
   }
   // defaults: uniform m, pi = 1, p = 0.5, standard NIW
@@ -830,7 +833,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
     // resample_m of the previous sweep (deferred to this parameter step, which takes log m from it): more than 64 blocks do
     // not fit the one wave the parameter kernel has for it
     k_draw_m<<<1, 256, 256 * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
-                                                          m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m);
+                                                          m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m, m->rs);
     GG_HIP(hipGetLastError());
     m->m_pending = false;
   }
@@ -865,7 +868,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   else k_params<false, 4><<<nwg, 256, 0, m->stream>>>(g);
   GG_HIP(hipGetLastError());
   if (m->wide && prep) {
-    k_logm<<<1, 256, 0, m->stream>>>(m->m, m->logm, m->K);
+    k_logm<<<1, 256, 0, m->stream>>>(m->m, m->logm, m->K, m->rs);
     GG_HIP(hipGetLastError());
   }
   if (g.shared && draw) {   // weights.py:545-552: the shared covariance and, with it, the coefficient tables
@@ -1029,7 +1032,11 @@ static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t 
   } while (0)
 #define SPR(NTV, ADJV)                                                                                                     \
   do {                                                                                                                     \
-    if (split64) {                                                                                                         \
+    if (m->Kp > 64) {                                                                                                      \
+      if (ride == 0) SPR1(NTV, ADJV, 0, 2);                                                                                \
+      else if (ride == 1) SPR1(NTV, ADJV, 1, 2);                                                                           \
+      else SPR1(NTV, ADJV, 2, 2);                                                                                          \
+    } else if (split64) {                                                                                                  \
       if (ride == 0) SPR1(NTV, ADJV, 0, 1);                                                                                \
       else if (ride == 1) SPR1(NTV, ADJV, 1, 1);                                                                           \
       else SPR1(NTV, ADJV, 2, 1);                                                                                          \
@@ -1455,7 +1462,7 @@ static int enqueue_sweep_ahead(gg_model* m, const gg_data* d, uint32_t sweep, bo
     if (fuse64 < 0) { const char* e = getenv("GG_FUSE64"); fuse64 = e ? atoi(e) : 0; }
     int stage = 0;
     lds_spec(m, &stage);
-    if (!stage && m->Kp == 64 && !fuse64) more = false;
+    if ((!stage && m->Kp == 64 && !fuse64) || m->wide) more = false;   // (more than 64 blocks: the two-launch form as well)
   }
   if (!m->pre) {
     if (!(m->ahead && m->ahead_uid == d->uid)) {

@@ -379,6 +379,8 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
                                                      const unsigned nfront, const unsigned vtag) {
   const gg_node_ctx& x = g.x;
   const int tid = threadIdx.x, N = x.N, K = x.K;
+  constexpr int LB = SPLIT == 2 ? 8 : 6;
+  constexpr unsigned LMASK = (1u << LB) - 1u;
   __shared__ unsigned long long s_fmin;
   __shared__ int s_last, s_any;
   if (tid == 0) s_fmin = GG_NO_CHANGE;
@@ -392,7 +394,8 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
   if (live && tid % x.Kp == 0) {
     ap[n] = 0;   // no entry of this scan's change list is applied to the node yet
     const int cn = cn_pre;
-    if (lab != cn) atomicMin(&s_fmin, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
+    // (node, old, new) with 6-bit labels, 8-bit for more than 64 blocks (SPLIT == 2)
+    if (lab != cn) atomicMin(&s_fmin, ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)lab);
   }
   if (g.tail_sort)
     for (int n2 = blockIdx.x * 256 + tid; n2 < N; n2 += nfront * 256) g.perm[n2] = g.perm_prev[n2];
@@ -430,7 +433,7 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
       if (vtag) __hip_atomic_store(g.verdict, vtag << 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else if (tid == 0) {
-    const int f = (int)(best >> 12), ca = (int)((best >> 6) & 63u), cb = (int)(best & 63u);
+    const int f = (int)(best >> (2 * LB)), ca = (int)((best >> LB) & LMASK), cb = (int)(best & LMASK);
     g.c[f] = cb;
     atomicSub(&g.cnt[ca], 1);
     atomicAdd(&g.cnt[cb], 1);

@@ -370,3 +370,47 @@ def test_resample_p_over_a_list_of_graphs(K, special, beta):
     O.sbm_adj_resample_p_multi(As, c0, p3, 0.5, 1.5, 0.7, special, 66, 0, beta)
     assert np.array_equal(h.p, p3)
     h.resample(As[0])          # and a plain sweep afterwards still runs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,B,special", [(400, 100, 1, 1), (300, 70, 2, 0), (500, 200, 1, 1)])
+def test_more_than_64_blocks_quiet_form_is_the_same_chain(abi, N, K, B, special):
+    """Round 3: 65..256 blocks run the adaptive form too - the resident scan while labels keep changing, and once the chain is
+    quiet the speculative one-launch scan (k_spec_resolve with the cross-wave categorical and 8-bit label payloads) in the
+    two-launch ahead form (k_params + the whole next pass as riders, then the scan).  Strongly planted network, 80 sweeps in
+    uneven chunks: both switches are crossed; labels and parameters bit for bit against the oracle at every checkpoint."""
+    rng = np.random.RandomState(N)
+    Kp_true = 4
+    ctrue = rng.choice(Kp_true, size=N)
+    ptrue = np.full((Kp_true, Kp_true), 0.08) + np.eye(Kp_true) * 0.8
+    A = (rng.rand(N, N) < ptrue[np.ix_(ctrue, ctrue)]).astype(np.uint8)
+    W = (rng.randn(Kp_true, Kp_true, B) * 3.0)[ctrue][:, ctrue] + 0.3 * rng.randn(N, N, B)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=21), WState(N, K, B, seed=22)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=601, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=special)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=602, special_case_self_conns=special)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    w.set(abi.ST_MU_SELF, sw.mu_self); w.set(abi.ST_SIGMA_SELF, sw.sigma_self)
+    ps, done = sa.p_self, 0
+    for chunk in (3, 1, 12, 2, 25, 1, 36):
+        abi.resample_many([adj, w], d, chunk)
+        for s in range(done, done + chunk):
+            ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, special, 601, s)
+            O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, special, 602, s)
+        done += chunk
+        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), "adjacency labels after %d sweeps" % done
+        assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p) and np.array_equal(adj.get(abi.ST_M, (K,)), sa.m)
+        assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), "weight labels after %d sweeps" % done
+        assert np.array_equal(w.get(abi.ST_MU, (K, K, B)), sw.mu) and np.array_equal(w.get(abi.ST_M, (K,)), sw.m)
+    ll = float(np.sum(abi.log_likelihood_many([adj, w], d)))
+    ref = (O.sbm_adj_loglik(A, sa.c, sa.p, ps, True, bool(special)) +
+           O.sbm_w_loglik(A, q, shift, sw.c, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, bool(special)))
+    assert abs(ll - ref) <= 1e-9 * abs(ref) + 1e-7
+    sta, stw = adj.stats(), w.stats()
+    # (which forms a chain went through depends on when it went quiet: at least one of the two must have used the new one)
+    assert sta["sweeps_two_launch"] + stw["sweeps_two_launch"] > 0, (sta, stw)
+    assert sta["sweeps_serial"] + stw["sweeps_serial"] > 0
