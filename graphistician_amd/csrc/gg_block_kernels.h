@@ -846,10 +846,8 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g, gg_ride_args r
   gg_params_body<ADJ, B, JOINT>(g, (int)blockIdx.x, nfront, 0u);
 }
 
-#define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index)
-#define GG_RS_NTOT 23        //                total number of nodes
-#define GG_RS_WBASE 21       //                first node of the band the scan stands in
-#define GG_RS_NMV 20         //                moves the last round's surprises made (k_shard_fold -> k_shard_moves)
+#define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index) - for the host; the device
+                             //                reads gg_shard_state
 #define GG_RS_ROUNDS 14      //                rounds of the sharded scan that did something
 #define GG_SHARD_M 32        // surprises a rank reports per round
 #define GG_SHARD_WINDOW 4096
@@ -1320,7 +1318,7 @@ template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
                                                    uint32_t sweep, int32_t* __restrict__ cand, int lp_node,
                                                    double* __restrict__ lp_out, const int32_t* __restrict__ ctl,
-                                                   int stage_tables, int shard_mode, int round_mode, int32_t* __restrict__ ap) {
+                                                   int stage_tables, int round_mode, int32_t* __restrict__ ap) {
   if (round_mode) {            // device-driven restart round: start where the scan stands, unless it is done
     if (ctl[7]) return;
     n_begin = ctl[0];
@@ -1329,18 +1327,6 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
     if (ctl[8] > 0 && first >= ctl[8]) return;   // adaptive window chosen by the last resolve
   } else if (ctl && ctl[4]) {
     return;
-  }
-  if (shard_mode) {
-    // device-driven sharded scan: the window [spos, spos + GG_SHARD_WINDOW) of GLOBAL node indices, of which this rank
-    // evaluates its own nodes; the position lives in the control block (gg_shard_sweep)
-    const int spos = ctl[GG_RS_SPOS], ntot = ctl[GG_RS_NTOT], wbase = ctl[GG_RS_WBASE];
-    if (spos >= ntot) return;
-    const int wend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;   // the band the scan stands in
-    int lo = spos - x.n0, hi = wend - x.n0;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > x.N ? x.N : hi;
-    if (hi <= lo || lo + (int)blockIdx.x * (256 / x.Kp) >= hi) return;
-    n_begin = lo;
   }
   int n;
   bool live;
@@ -1399,105 +1385,173 @@ __global__ __launch_bounds__(256) void k_shared_cov(gg_params_args g) {
 // position before theirs, and what a rank reports are the first GG_SHARD_M SURPRISES among its own nodes - decisions that
 // differ from what H says.  Ranks own contiguous node ranges, so the gathered reports are in position order; everything of
 // H before the earliest one, and that one itself, is the sequential chain.  One all-gather per ROUND, not per change.
-__global__ __launch_bounds__(1024) void k_shard_surprises(const int32_t* __restrict__ c, const int32_t* __restrict__ cand,
-                                                          const short* __restrict__ H, int n0, int Nl,
-                                                          const int32_t* __restrict__ rs, int32_t* __restrict__ trip) {
-  __shared__ int s_scan[1024];
-  const int t = (int)threadIdx.x;
-  if (t < GG_SHARD_M) { trip[3 * t] = GG_SHARD_NONE; trip[3 * t + 1] = 0; trip[3 * t + 2] = 0; }
-  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT], wbase = rs[GG_RS_WBASE];
+//
+// A round is TWO launches around the all-gather (round 3; four before):
+//   k_shard_eval   the rank's own nodes of the band behind the scan position evaluated under the hypotheses; the workgroup
+//                  that finishes last compacts the first GG_SHARD_M surprises, in position order, into `trip`
+//   [all-gather of trip]
+//   k_shard_apply  every workgroup derives the round's moves from the gathered reports and applies them to the statistics of
+//                  the rank's nodes behind each moved node; workgroup 0 also folds the reports into the hypotheses, accepts
+//                  everything up to the earliest surprise into labels and block sizes and moves the scan on.
+// The scan state (position, band start) and the hypotheses are kept TWICE and used alternately (round r reads copy r & 1,
+// workgroup 0 of k_shard_apply writes copy (r + 1) & 1), so that no workgroup of a launch reads a word another one writes.
+struct gg_shard_state {
+  int32_t st[2][2];   // [copy][spos, wbase]
+  int32_t ticket;     // workgroups of the running k_shard_eval that are done
+  int32_t pad[3];
+};
+
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, uint64_t seed, uint32_t site, uint32_t sweep,
+                                                    int32_t* __restrict__ cand, const int32_t* __restrict__ c,
+                                                    const short* __restrict__ Hb, gg_shard_state* __restrict__ S, int round,
+                                                    int ntot, int stage_tables, int32_t* __restrict__ trip) {
+  __shared__ int s_scan[256];
+  __shared__ int s_last;
+  const int t = (int)threadIdx.x, per = 256 / x.Kp;
+  const int spos = S->st[round & 1][0], wbase = S->st[round & 1][1];
+  const short* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;
   int lo = 0, hi = 0;
   if (spos < ntot) {
-    const int wend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;
-    lo = spos - n0; hi = wend - n0;
+    const int wend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;   // the band the scan stands in
+    lo = spos - x.n0; hi = wend - x.n0;
     lo = lo < 0 ? 0 : lo;
-    hi = hi > Nl ? Nl : hi;
+    hi = hi > x.N ? x.N : hi;
   }
-  const int len = hi > lo ? hi - lo : 0;
-  const int chunk = (len + 1023) / 1024;
-  const int my_lo = lo + t * chunk, my_hi = (my_lo + chunk < hi) ? my_lo + chunk : hi;
-  auto deviates = [&](int nl) {
-    const int h = H[n0 + nl - wbase];
-    return cand[nl] != (h >= 0 ? (h & 0xff) : c[n0 + nl]);
-  };
-  int cnt = 0;
-  for (int nl = my_lo; nl < my_hi; ++nl) cnt += deviates(nl) ? 1 : 0;
-  s_scan[t] = cnt;
+  if (hi > lo && lo + (int)blockIdx.x * per < hi) {        // (uniform over the workgroup)
+    int n;
+    bool live;
+    const int lab = gg_spec_eval<NT, ADJ>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live);
+    if (live && n < hi && t % x.Kp == 0) {
+      // (an atomic exchange at agent scope: performed at the memory side, and its return value holds the wave until it has
+      // been - the decision is out before the workgroup's ticket is drawn.  No fence: a release fence per workgroup writes
+      // back every dirty line of the XCD's L2, megabytes of statistics - measured at +115 us per round)
+      const int old = atomicExch(&cand[n], lab);
+      asm volatile("" ::"v"(old) : "memory");
+    }
+  }
+  // last workgroup out: it sees every decision (read with agent-scope loads, not through a stale cache line)
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int v = t >= d ? s_scan[t - d] : 0;
-    __syncthreads();
-    s_scan[t] += v;
-    __syncthreads();
+  if (t == 0) {
+    const int tk = atomicAdd(&S->ticket, 1);
+    s_last = tk == (int)gridDim.x - 1 ? 1 : 0;
+    if (s_last) __hip_atomic_store(&S->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  int idx = s_scan[t] - cnt;
-  for (int nl = my_lo; nl < my_hi && idx < GG_SHARD_M; ++nl)
-    if (deviates(nl)) { trip[3 * idx] = n0 + nl; trip[3 * idx + 1] = c[n0 + nl]; trip[3 * idx + 2] = cand[nl]; ++idx; }
+  __syncthreads();
+  if (!s_last) return;
+  if (t < GG_SHARD_M) { trip[3 * t] = GG_SHARD_NONE; trip[3 * t + 1] = 0; trip[3 * t + 2] = 0; }
+  __syncthreads();
+  // The first GG_SHARD_M deviations in position order.  Thread t looks at the nodes lo + 256 i + t (i < 16: the band has at
+  // most 4096 nodes), all of its loads in flight together - the decisions are read with agent-scope loads, a memory-side
+  // round trip each, and sixteen of them one after the other were most of this launch; a node's rank is the number of
+  // deviations in the stripes before its own plus those of the lanes before it in its stripe.
+  constexpr int NS = GG_SHARD_WINDOW / 256;
+  int cv[NS], hv[NS], ov[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int nl = lo + i * 256 + t;
+    const bool in = nl < hi;
+    cv[i] = in ? __hip_atomic_load(&cand[nl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    hv[i] = in ? (int)H[x.n0 + nl - wbase] : 0;
+    ov[i] = in ? c[x.n0 + nl] : 0;
+  }
+  unsigned dev = 0;
+  const int wv = t >> 6, ln = t & 63;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const bool d = lo + i * 256 + t < hi && cv[i] != (hv[i] >= 0 ? (hv[i] & 0xff) : ov[i]);
+    dev |= d ? (1u << i) : 0u;
+    const unsigned long long bal = __ballot(d);
+    if (ln == 0) s_scan[i * 4 + wv] = __popcll(bal);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const bool d = (dev >> i) & 1u;
+    const unsigned long long bal = __ballot(d);
+    if (d) {
+      int rk = __popcll(bal & ((1ull << ln) - 1ull));
+      for (int q = 0; q < i * 4 + wv; ++q) rk += s_scan[q];
+      if (rk < GG_SHARD_M) { trip[3 * rk] = x.n0 + lo + i * 256 + t; trip[3 * rk + 1] = ov[i]; trip[3 * rk + 2] = cv[i]; }
+    }
+  }
 }
 
-// Every rank folds the gathered surprises into H (writing the statistics moves they imply: node f leaves block `from` - its
-// hypothesised label, or its old one - for block `to`), accepts the hypotheses at positions up to and including the earliest
-// surprise (all of the band's when there is none) into its copy of the labels and counts, and moves the scan on.
-__global__ __launch_bounds__(256) void k_shard_fold(int32_t* c, int32_t* cnt, short* H, int32_t* rs, const int32_t* __restrict__ all,
-                                                    int world, int32_t* __restrict__ mv) {
-  __shared__ int s_hi, s_quiet, s_acc;
-  const int spos = rs[GG_RS_SPOS], ntot = rs[GG_RS_NTOT], wbase = rs[GG_RS_WBASE];
-  if (spos >= ntot) { if (threadIdx.x == 0) rs[GG_RS_NMV] = 0; return; }
-  const int bend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;
-  if (threadIdx.x == 0) {
-    int nmv = 0, pstar = GG_SHARD_NONE;
-    for (int e = 0; e < world * GG_SHARD_M; ++e) {
+// all: the gathered reports [world][GG_SHARD_M][3] (node, label it has, label it draws), in position order.
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, int32_t* cnt, short* Hb, int32_t* rs,
+                                                     gg_shard_state* S, int round, int ntot, const int32_t* __restrict__ all,
+                                                     int world, int32_t* __restrict__ cntn, int32_t* Gc0, int32_t* Gc1,
+                                                     long long* Gs0, long long* Gs1, const uint32_t* XA, const uint32_t* XAT,
+                                                     const int32_t* XW, const int32_t* XWT) {
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
+  extern __shared__ int s_mv[];                // [world][GG_SHARD_M][3]
+  __shared__ short s_H[GG_SHARD_WINDOW];
+  __shared__ int s_pstar, s_acc;
+  const int t = (int)threadIdx.x;
+  const int spos = S->st[round & 1][0], wbase = S->st[round & 1][1];
+  const short* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  if (spos >= ntot) {          // the scan is over: the state is handed on as it is
+    if (first && t == 0) { S->st[(round + 1) & 1][0] = spos; S->st[(round + 1) & 1][1] = wbase; }
+    return;
+  }
+  const int nrep = world * GG_SHARD_M;
+  // the moves the reports imply: node f leaves the block its hypothesis put it in (or its old one) for the one it draws
+  for (int e = t; e < nrep; e += 256) {
+    const int f = all[3 * e];
+    int from = 0;
+    if (f != GG_SHARD_NONE) { const int h = H[f - wbase]; from = h >= 0 ? (h & 0xff) : all[3 * e + 1]; }
+    s_mv[3 * e] = f; s_mv[3 * e + 1] = from; s_mv[3 * e + 2] = all[3 * e + 2];
+  }
+  if (first) {
+    if (t == 0) { s_pstar = GG_SHARD_NONE; s_acc = 0; }
+    for (int i = t; i < GG_SHARD_WINDOW; i += 256) s_H[i] = H[i];
+  }
+  __syncthreads();
+  if (first) {
+    // ---- fold, accept, move the scan on (one workgroup; everything it writes is read by LATER launches only)
+    const int bend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;
+    for (int e = t; e < nrep; e += 256) {
       const int f = all[3 * e];
       if (f == GG_SHARD_NONE) continue;
       const int old = all[3 * e + 1], nw = all[3 * e + 2];
-      if (pstar == GG_SHARD_NONE) pstar = f;        // (position order: the first is the earliest)
-      const int h = H[f - wbase];
-      mv[3 * nmv] = f; mv[3 * nmv + 1] = h >= 0 ? (h & 0xff) : old; mv[3 * nmv + 2] = nw;
-      ++nmv;
-      H[f - wbase] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
+      s_H[f - wbase] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
+      atomicMin(&s_pstar, f);
     }
-    rs[GG_RS_NMV] = nmv;
-    rs[GG_RS_ROUNDS] += 1;
-    s_quiet = pstar == GG_SHARD_NONE ? 1 : 0;
-    s_hi = s_quiet ? bend : pstar + 1;
-    s_acc = 0;
+    __syncthreads();
+    const bool quiet = s_pstar == GG_SHARD_NONE;
+    const int hi = quiet ? bend : s_pstar + 1;
+    int mine = 0;
+    for (int n = spos + t; n < hi; n += 256) {
+      const int h = s_H[n - wbase];
+      if (h < 0) continue;
+      c[n] = h & 0xff;
+      atomicSub(&cnt[h >> 8], 1);
+      atomicAdd(&cnt[h & 0xff], 1);
+      ++mine;
+    }
+    if (mine) atomicAdd(&s_acc, mine);
+    short* Hn = Hb + (size_t)((round + 1) & 1) * GG_SHARD_WINDOW;
+    // (a final band starts the next one without hypotheses)
+    for (int i = t; i < GG_SHARD_WINDOW; i += 256) Hn[i] = quiet ? (short)-1 : s_H[i];
+    __syncthreads();
+    if (t == 0) {
+      rs[2] += s_acc;
+      rs[GG_RS_ROUNDS] += 1;
+      rs[GG_RS_SPOS] = hi;        // (for the host: the device reads the state copies)
+      S->st[(round + 1) & 1][0] = hi;
+      S->st[(round + 1) & 1][1] = quiet ? bend : wbase;
+    }
   }
-  __syncthreads();
-  const int hi = s_hi;
-  int mine = 0;
-  for (int n = spos + (int)threadIdx.x; n < hi; n += (int)blockDim.x) {
-    const int h = H[n - wbase];
-    if (h < 0) continue;
-    c[n] = h & 0xff;
-    atomicSub(&cnt[h >> 8], 1);
-    atomicAdd(&cnt[h & 0xff], 1);
-    ++mine;
-  }
-  if (mine) atomicAdd(&s_acc, mine);
-  __syncthreads();
-  if (s_quiet)     // the band is final: the next one starts without hypotheses
-    for (int i = (int)threadIdx.x; i < GG_SHARD_WINDOW; i += (int)blockDim.x) H[i] = (short)-1;
-  if (threadIdx.x == 0) {
-    rs[2] += s_acc;
-    rs[GG_RS_SPOS] = hi;
-    if (s_quiet) rs[GG_RS_WBASE] = bend;
-  }
-}
-
-// The moves of the last round applied to the statistics (and the block sizes) of this rank's nodes BEHIND the moved node.
-template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_shard_moves(gg_node_ctx x, const int32_t* __restrict__ mv, const int32_t* __restrict__ rs,
-                                                     int32_t* __restrict__ cntn, int32_t* Gc0, int32_t* Gc1, long long* Gs0,
-                                                     long long* Gs1, const uint32_t* XA, const uint32_t* XAT, const int32_t* XW,
-                                                     const int32_t* XWT) {
-  constexpr int B = gg_tB(NT);
-  constexpr int NSI = gg_tNSI(NT);
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  // ---- the moves applied to the statistics (and the block sizes) of this rank's nodes BEHIND the moved node
+  const int n = blockIdx.x * blockDim.x + t;
   if (n >= x.N) return;
-  const int nmv = rs[GG_RS_NMV], Np = x.Np, K = x.K;
-  for (int e = blockIdx.y; e < nmv; e += gridDim.y) {
-    const int f = mv[3 * e], a = mv[3 * e + 1], b = mv[3 * e + 2];
-    if (x.n0 + n <= f) continue;
+  const int Np = x.Np, K = x.K;
+  for (int e = blockIdx.y; e < nrep; e += gridDim.y) {
+    const int f = s_mv[3 * e], a = s_mv[3 * e + 1], b = s_mv[3 * e + 2];
+    if (f == GG_SHARD_NONE || x.n0 + n <= f) continue;
     atomicSub(&cntn[(size_t)n * K + a], 1);
     atomicAdd(&cntn[(size_t)n * K + b], 1);
     const size_t at = (size_t)f * Np + n;
@@ -1517,13 +1571,13 @@ __global__ __launch_bounds__(256) void k_shard_moves(gg_node_ctx x, const int32_
         atomicSub(&Gc[(size_t)a * Np + n], 1);
         atomicAdd(&Gc[(size_t)b * Np + n], 1);
         long long v[NSI > 0 ? NSI : 1];
-        int t = 0;
+        int tt = 0;
 #pragma unroll
-        for (int r = 0; r < B; ++r) v[t++] = qq[r];
+        for (int r = 0; r < B; ++r) v[tt++] = qq[r];
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
-          for (int s = r; s < B; ++s) v[t++] = (long long)qq[r] * (long long)qq[s];
+          for (int s = r; s < B; ++s) v[tt++] = (long long)qq[r] * (long long)qq[s];
 #pragma unroll
         for (int s = 0; s < NSI; ++s) {
           atomicAdd(reinterpret_cast<unsigned long long*>(&Gs[((size_t)a * Np + n) * NSI + s]), (unsigned long long)(-v[s]));
@@ -1536,9 +1590,9 @@ __global__ __launch_bounds__(256) void k_shard_moves(gg_node_ctx x, const int32_
 
 // start of a sharded scan: no hypotheses, every own node sees the block sizes of the labels as they are
 __global__ void k_shard_init(const int32_t* __restrict__ cnt, int32_t* __restrict__ cntn, short* __restrict__ H, int Nl, int K,
-                             int32_t* __restrict__ rs) {
+                             int32_t* __restrict__ rs, gg_shard_state* __restrict__ S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) rs[GG_RS_ROUNDS] = 0;
+  if (i == 0) { rs[GG_RS_ROUNDS] = 0; rs[GG_RS_SPOS] = 0; S->st[0][0] = 0; S->st[0][1] = 0; S->ticket = 0; }
   if (i < (size_t)Nl * K) cntn[i] = cnt[i % K];
   if (i < GG_SHARD_WINDOW) H[i] = (short)-1;
 }

@@ -117,8 +117,8 @@ struct gg_model {
   long long chg_seen;           // label changes (control word 2) at the last decision
   long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
   int32_t* sh_cntn;             // sharded scan: [Nl][K] block sizes as own node n sees them
-  short* sh_H;                  //               [GG_SHARD_WINDOW] hypothesis per node of the band
-  int32_t* sh_mv;               //               moves of the last round's surprises, (node, from, to)
+  short* sh_H;                  //               [2][GG_SHARD_WINDOW] hypothesis per node of the band, two copies used alternately
+  gg_shard_state* sh_state;     //               scan position / band start (two copies) + the evaluation launch's ticket
   int sh_hint;                  //               rounds the last scan of this model needed (+ margin): the first batch of the next
   bool wide;                    // 65..256 blocks: a node's lanes span two or four wavefronts - the resident scan's wide instantiation is the
                                 // only scan form (no speculative / restart-round fallback, no node shards, no gg_node_lp)
@@ -448,7 +448,7 @@ int gg_model_destroy(gg_model* m) {
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
                   m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all,
-                  m->sh_cntn, m->sh_H, m->sh_mv, m->pred_buf, m->tab_sum};
+                  m->sh_cntn, m->sh_H, m->sh_state, m->pred_buf, m->tab_sum};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -882,16 +882,15 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
 }
 
 static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin, int lp_node, uint32_t sweep, bool pipelined,
-                            int round_window = 0, int explicit_count = 0, bool shard_mode = false) {
+                            int round_window = 0, int explicit_count = 0) {
   gg_node_ctx x = node_ctx(m, d, buf);
-  if (shard_mode) x.cntn = m->sh_cntn;   // block sizes as each own node sees them (hypotheses at earlier positions included)
   const int K = m->K, per = 256 / m->Kp;
   const int count = round_window > 0 ? round_window : (explicit_count > 0 ? explicit_count : (m->Nl - n_begin));
   int nb = (count + per - 1) / per;
   if (nb < 1) nb = 1;
   uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
   double* lpo = lp_node >= 0 ? m->lp_out : nullptr;
-  const int32_t* ctl = (pipelined || round_window > 0 || shard_mode) ? m->rs : nullptr;
+  const int32_t* ctl = (pipelined || round_window > 0) ? m->rs : nullptr;
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
@@ -904,7 +903,7 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
     k_speculate<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, n_begin, m->cfg.seed, site, sweep, m->cand, lp_node, lpo, ctl,    \
-                                                        stage, shard_mode ? 1 : 0, round_window > 0 ? 1 : 0, m->ap);      \
+                                                        stage, round_window > 0 ? 1 : 0, m->ap);                          \
   } while (0)
   if (m->is_adj) SPEC(2, true);
   else if (m->joint && m->B == 1) SPEC(4, false);
@@ -2303,18 +2302,53 @@ static int shard_global_tables(gg_model* m, const gg_data* d, gg_comm* c, int di
   return comm_allreduce_i64(c, m->tab, (size_t)m->K * m->K * m->NTAB, m->stream);
 }
 
-static int launch_shard_moves(gg_model* m, const gg_data* d, int buf) {
+// One round of the sharded scan = these two launches around the all-gather (gg_block_kernels.h).
+static int launch_shard_eval(gg_model* m, const gg_data* d, int buf, int round) {
   gg_node_ctx x = node_ctx(m, d, buf);
-  dim3 grd((m->Nl + 255) / 256, 8);
-#define SHM(NTV, ADJV)                                                                                                 \
-  k_shard_moves<NTV, ADJV><<<grd, 256, 0, m->stream>>>(x, m->sh_mv, m->rs, m->sh_cntn, gcnt(m, buf, 0), gcnt(m, buf, 1),  \
-                                                       gs(m, buf, 0), gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT)
-  if (m->is_adj) SHM(2, true);
-  else if (m->B == 1) SHM(3, false);
-  else if (m->B == 2) SHM(6, false);
-  else if (m->B == 3) SHM(10, false);
-  else SHM(15, false);
-#undef SHM
+  x.cntn = m->sh_cntn;   // block sizes as each own node sees them (hypotheses at earlier positions included)
+  const int K = m->K, per = 256 / m->Kp;
+  const int count = m->Nl < GG_SHARD_WINDOW ? m->Nl : GG_SHARD_WINDOW;
+  int nb = (count + per - 1) / per;
+  if (nb < 1) nb = 1;                    // (a rank without nodes still reports "no surprise")
+  const uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
+  size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
+  const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
+  if (stage) lds += table_bytes(m);
+  else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+#define SHE(NTV, ADJV)                                                                                                     \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set && lds > 48 * 1024) {                                                                                    \
+      GG_HIP(hipFuncSetAttribute((const void*)k_shard_eval<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    k_shard_eval<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, m->cfg.seed, site, m->sweep, m->cand, m->c, m->sh_H, m->sh_state, \
+                                                         round, m->N, stage, m->sh_trip);                                  \
+  } while (0)
+  if (m->is_adj) SHE(2, true);
+  else if (m->B == 1) SHE(3, false);
+  else if (m->B == 2) SHE(6, false);
+  else if (m->B == 3) SHE(10, false);
+  else SHE(15, false);
+#undef SHE
+  GG_HIP(hipGetLastError());
+  return GG_OK;
+}
+
+static int launch_shard_apply(gg_model* m, const gg_data* d, int buf, int round, const int32_t* all, int world) {
+  gg_node_ctx x = node_ctx(m, d, buf);
+  dim3 grd((m->Nl + 255) / 256 > 0 ? (m->Nl + 255) / 256 : 1, 8);
+  const size_t lds = (size_t)3 * GG_SHARD_M * world * sizeof(int);
+#define SHA(NTV, ADJV)                                                                                                 \
+  k_shard_apply<NTV, ADJV><<<grd, 256, lds, m->stream>>>(x, m->c, m->cnt, m->sh_H, m->rs, m->sh_state, round, m->N, all, world, \
+                                                         m->sh_cntn, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0),  \
+                                                         gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT)
+  if (m->is_adj) SHA(2, true);
+  else if (m->B == 1) SHA(3, false);
+  else if (m->B == 2) SHA(6, false);
+  else if (m->B == 3) SHA(10, false);
+  else SHA(15, false);
+#undef SHA
   GG_HIP(hipGetLastError());
   return GG_OK;
 }
@@ -2336,8 +2370,8 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
     m->sh_world = c->world;
   }
   if (!m->sh_cntn) {
-    if ((rc = dmalloc(&m->sh_cntn, (size_t)(m->Nl > 0 ? m->Nl : 1) * m->K)) || (rc = dmalloc(&m->sh_H, (size_t)GG_SHARD_WINDOW)) ||
-        (rc = dmalloc(&m->sh_mv, (size_t)3 * GG_SHARD_M * c->world + 4)))
+    if ((rc = dmalloc(&m->sh_cntn, (size_t)(m->Nl > 0 ? m->Nl : 1) * m->K)) || (rc = dmalloc(&m->sh_H, (size_t)2 * GG_SHARD_WINDOW)) ||
+        (rc = dmalloc(&m->sh_state, 1)))
       return rc;
   }
   if (m->sh_world != c->world) return gg_fail(GG_ERR_INVALID, "gg_shard_sweep: the communicator's size changed");
@@ -2355,32 +2389,27 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
     m->shard_from_tab = false;
     if (rc) return rc;
     if (m->K > 1) {
-      // control words 20..23: moves of the last round, band start, scan position, number of nodes
-      m->h_rs[24] = 0; m->h_rs[25] = 0; m->h_rs[26] = 0; m->h_rs[27] = m->N;
-      GG_HIP(hipMemcpyAsync(m->rs + GG_RS_NMV, m->h_rs + 24, 4 * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
       {
         const size_t cells = (size_t)m->Nl * m->K > (size_t)GG_SHARD_WINDOW ? (size_t)m->Nl * m->K : (size_t)GG_SHARD_WINDOW;
-        k_shard_init<<<(unsigned)((cells + 255) / 256), 256, 0, m->stream>>>(m->cnt, m->sh_cntn, m->sh_H, m->Nl, m->K, m->rs);
+        k_shard_init<<<(unsigned)((cells + 255) / 256), 256, 0, m->stream>>>(m->cnt, m->sh_cntn, m->sh_H, m->Nl, m->K, m->rs, m->sh_state);
         GG_HIP(hipGetLastError());
       }
       // Rounds are enqueued in batches without host synchronisation; a round beyond the scan's end is a no-op on the device
       // but still a collective on the wire, so the first batch is what the previous scan needed plus a margin (the same
       // number on every rank: it comes from the replicated control block), later ones a quarter of that.
       int batch = m->sh_hint > 0 ? m->sh_hint : 8;
+      int round = 0;      // (selects the copy of the scan state a round reads: the same sequence on every rank)
+      // one rank: the "gathered" reports are the rank's own - no copy
+      const int32_t* all = c->world == 1 ? m->sh_trip : m->sh_all;
       for (;;) {
-        for (int r = 0; r < batch; ++r) {
-          // one round: own nodes of the band behind the scan position evaluated under the hypotheses -> the first
-          // GG_SHARD_M surprises -> ALL-GATHER -> fold into the hypotheses, accept up to the earliest surprise -> moves
-          if (m->Nl > 0) {
-            const int count = m->Nl < GG_SHARD_WINDOW ? m->Nl : GG_SHARD_WINDOW;
-            if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false, 0, count, true))) return rc;
-          }
-          k_shard_surprises<<<1, 1024, 0, m->stream>>>(m->c, m->cand, m->sh_H, m->n0, m->Nl, m->rs, m->sh_trip);
-          GG_HIP(hipGetLastError());
-          if ((rc = comm_allgather_i32(c, m->sh_trip, m->sh_all, 3 * GG_SHARD_M, m->stream))) return rc;
-          k_shard_fold<<<1, 256, 0, m->stream>>>(m->c, m->cnt, m->sh_H, m->rs, m->sh_all, c->world, m->sh_mv);
-          GG_HIP(hipGetLastError());
-          if (m->Nl > 0 && (rc = launch_shard_moves(m, d, buf))) return rc;   // statistics of the owned nodes
+        for (int r = 0; r < batch; ++r, ++round) {
+          // one round: own nodes of the band behind the scan position evaluated under the hypotheses, the first GG_SHARD_M
+          // surprises compacted by the launch's last workgroup -> ALL-GATHER -> fold into the hypotheses, accept up to the
+          // earliest surprise, moves of the owned nodes' statistics
+          if ((rc = launch_shard_eval(m, d, buf, round))) return rc;
+          if (c->world > 1) { if ((rc = comm_allgather_i32(c, m->sh_trip, m->sh_all, 3 * GG_SHARD_M, m->stream))) return rc; }
+          else c->collectives += 1;
+          if ((rc = launch_shard_apply(m, d, buf, round, all, c->world))) return rc;
         }
         GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 24 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
         GG_HIP(hipStreamSynchronize(m->stream));
