@@ -463,23 +463,36 @@ def bench_stream(nbytes, reps=20, mode=0, device=0):
     return (2 if mode == 1 else 1) * float(nbytes) / ms.value / 1e6
 
 
-def log_likelihood_many(models, datas):
-    """log_likelihood of several independent models at once (enqueued together, then collected); returns the list of values."""
+_many_args = {}
+
+
+def _handles(models, datas):
+    """ctypes arrays of the models' and the networks' handles, kept per (models, networks) combination: the reference's loop
+    calls `resample` and `log_probability` with the same objects thousands of times, and building the arrays is a few
+    microseconds of a call that takes a few tens."""
     if not isinstance(datas, (list, tuple)):
         datas = [datas] * len(models)
-    marr = (C.c_void_p * len(models))(*[m._h for m in models])
-    darr = (C.c_void_p * len(models))(*[d.handle for d in datas])
-    out = (C.c_double * len(models))()
+    key = (tuple(m._h.value if hasattr(m._h, "value") else m._h for m in models), tuple(d.handle.value if hasattr(d.handle, "value") else d.handle for d in datas))
+    hit = _many_args.get(key)
+    if hit is None:
+        if len(_many_args) > 64:
+            _many_args.clear()
+        hit = ((C.c_void_p * len(models))(*[m._h for m in models]), (C.c_void_p * len(models))(*[d.handle for d in datas]),
+               (C.c_double * len(models))())
+        _many_args[key] = hit
+    return hit
+
+
+def log_likelihood_many(models, datas):
+    """log_likelihood of several independent models at once (enqueued together, then collected); returns the list of values."""
+    marr, darr, out = _handles(models, datas)
     check(lib().gg_log_likelihood_many(marr, darr, len(models), out))
     return [float(v) for v in out]
 
 
 def resample_many(models, datas, n_sweeps=1, beta=1.0):
     """n_sweeps x resample for several independent models (one host thread each)."""
-    if not isinstance(datas, (list, tuple)):
-        datas = [datas] * len(models)
-    marr = (C.c_void_p * len(models))(*[m._h for m in models])
-    darr = (C.c_void_p * len(models))(*[d.handle for d in datas])
+    marr, darr, _ = _handles(models, datas)
     check(lib().gg_resample_many(marr, darr, len(models), n_sweeps, beta))
 
 

@@ -497,6 +497,182 @@ __global__ __launch_bounds__(256, (SPLIT ? 1 : GG_RIDE_WAVES)) void k_sweep_q(gg
   if (ride.dbg && threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&ride.dbg[role]), (unsigned long long)wall_clock64());
 }
 
+// ---- The call's LAST sweep with its epilogue in the same launch (round 3; the reference's loop `model.resample(data);
+// lps.append(model.log_probability(data))`, examples/demo_model_comparison.py:69-72, one sweep per call).  Block ranges:
+//   [0, nspec)              the speculative scan of the sweep                     (gg_spec_resolve_body, publishes the verdict)
+//   [nspec, nspec + K K)    one workgroup per block pair: the pair's table from the statistics the riders of the previous
+//                           launch counted for the NEXT sweep (= the labels this scan leaves, iff it changes none) and the
+//                           pair's log-likelihood term (abstractions.py:111-115 / weights.py:316-331, as k_loglik forms it)
+//   nspec + K K             resample_m (adjacency.py:697-702; as k_draw_m)
+// all of them gated on the scan's verdict.  The pair workgroup that finishes last sums the terms in k_loglik's order (same
+// bits), adds the diagonal term and writes, into PINNED HOST memory: the log-likelihood, the control block as the resolver
+// left it and the launch's tag - the host then needs no copy of the control block, no k_draw_m and no log-likelihood launch:
+// one stream synchronisation completes `resample` and answers the `log_likelihood` that follows.  A scan that changes a
+// label stalls the pipeline as ever; nothing of the epilogue is written and the host takes the usual path.
+struct gg_epi_args {
+  double* terms;              // [K K] device scratch: the pairs' terms
+  int32_t* ticket;            // device: pair workgroups done
+  int32_t* bad;               // device: a covariance was not positive definite
+  double* out;                // pinned host: [0] log-likelihood, [1] bad flag, [2] tag, then 24 control words (as int32) from [4] on
+  int want_ll;                // 0: only resample_m and the control block's mirror
+  int npair;                  // pair workgroups in the launch: K K, or 1 without the log-likelihood
+  uint32_t m_site;
+};
+
+template <bool ADJ, int B>
+__device__ __forceinline__ void gg_epilogue_body(const gg_params_args& g, const gg_ll_args& la, const gg_epi_args& ep, const int t,
+                                                 const unsigned tag) {
+  const int K = g.K, KK = K * K, tid = (int)threadIdx.x;
+  constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
+  constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;
+  __shared__ long long s_red[4][NTAB];
+  __shared__ long long s_tab[NTAB];
+  __shared__ double s_part[256];
+  __shared__ int s_flag;
+  if (t == ep.npair) {
+    // resample_m: the block sizes are final once the scan is known to have changed nothing
+    if (!gg_wait_verdict(g.ctl, g.verdict, tag)) return;
+    __shared__ double s_g[256];
+    if (tid < K) s_g[tid] = gg_dirichlet_gamma_at(g.seed, ep.m_site, g.sweep, tid, g.pi[tid] + (double)g.cnt[tid]);
+    __syncthreads();
+    if (tid < K) {
+      double tot = 0.0;
+      for (int j = 0; j < K; ++j) tot += s_g[j];
+      g.m[tid] = s_g[tid] / tot;
+    }
+    return;
+  }
+  const int a = t / K, b = t % K;
+  double term = 0.0;
+  bool bad = false;
+  if (ep.want_ll) {
+    // the pair's table, reduced as gg_params_body reduces it (the same integers whatever the order)
+    const int s0 = g.lab_start[a], s1 = g.lab_start[a + 1];
+    long long acc[NTAB];
+#pragma unroll
+    for (int q = 0; q < NTAB; ++q) acc[q] = 0;
+    for (int r = s0 + tid; r < s1; r += 256) {
+      const int n = g.perm[r];
+      acc[0] += g.Gcnt0[(size_t)b * g.Np + n];
+      if (!ADJ)
+#pragma unroll
+        for (int s2 = 0; s2 < NSI; ++s2) {
+          const long long v = g.GS0[((size_t)b * g.Np + n) * NSI + s2];
+          acc[1 + 2 * s2] += (v >> 32);
+          acc[2 + 2 * s2] += (v & 0xffffffffll);
+        }
+      if (g.add_diag && a == b && g.dA[n]) {
+        acc[0] += 1;
+        if (!ADJ) {
+          const int32_t* q = g.dWq + (size_t)n * B;
+          int tt = 0;
+          for (int r1 = 0; r1 < B; ++r1, ++tt) {
+            const long long v = q[r1];
+            acc[1 + 2 * tt] += (v >> 32);
+            acc[2 + 2 * tt] += (v & 0xffffffffll);
+          }
+          for (int r1 = 0; r1 < B; ++r1)
+            for (int r2 = r1; r2 < B; ++r2, ++tt) {
+              const long long v = (long long)q[r1] * (long long)q[r2];
+              acc[1 + 2 * tt] += (v >> 32);
+              acc[2 + 2 * tt] += (v & 0xffffffffll);
+            }
+        }
+      }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < NTAB; ++q) {
+      const long long v = gg_wave_sum_ll(acc[q]);
+      if (lane == 0) s_red[wave][q] = v;
+    }
+    __syncthreads();
+    if (tid < NTAB) s_tab[tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    __syncthreads();
+    if (tid == 0) {
+      if (ADJ) {
+        const long long n1 = s_tab[0];
+        const long long pairs = (long long)la.cnt[a] * la.cnt[b] - ((a == b && la.special) ? la.cnt[a] : 0);
+        term = gg_ll_bern(la.p[t], n1, pairs - n1);
+      } else {
+        const double sc1 = gg_pow2i(-la.shift), sc2 = gg_pow2i(-2 * la.shift);
+        term = gg_ll_gauss(la.mu + (size_t)t * B, la.sigma + (size_t)t * B * B, B, NSI, (double)s_tab[0], s_tab + 1, sc1, sc2, &bad);
+      }
+    }
+  }
+  if (tid == 0) {
+    // The terms do not wait for the verdict (the scratch they go to is this launch's own): only the workgroup that sums
+    // them does, so one lane polls instead of K K and the exchange below runs while the scan is still being resolved.
+    // (exchanges at agent scope, performed at the memory side; their return values hold the wave until they have been -
+    // the term is out before the ticket is drawn.  No fence: gg_block_kernels.h, k_shard_eval)
+    unsigned long long o1 = atomicExch(reinterpret_cast<unsigned long long*>(&ep.terms[t]), (unsigned long long)__double_as_longlong(term));
+    int o2 = bad ? atomicOr(ep.bad, 1) : 0;
+    asm volatile("" ::"v"(o1), "v"(o2) : "memory");
+    s_flag = atomicAdd(ep.ticket, 1) == ep.npair - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  // ---- the last pair workgroup: the sum in k_loglik's order, the diagonal term, the host's copy of the control block
+  double acc = 0.0;
+  if (ep.want_ll)
+    for (int ab = tid; ab < KK; ab += 256)
+      acc += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&ep.terms[ab]), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+  s_part[tid] = acc;
+  __syncthreads();
+  for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+    if (tid < s2) s_part[tid] += s_part[tid + s2];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __hip_atomic_store(ep.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (re-armed whatever the verdict)
+    s_flag = gg_poll_verdict(g.ctl, g.verdict, tag, 0) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_flag) {      // the scan changed a label: no record (the host copies the control block and takes its usual path)
+    if (tid == 0) __hip_atomic_store(ep.bad, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (tid < 24) {
+    const int v = __hip_atomic_load(&g.ctl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    reinterpret_cast<int32_t*>(ep.out + 4)[tid] = v;
+  }
+  if (tid == 0) {
+    double ll = s_part[0];
+    int isbad = __hip_atomic_load(ep.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ep.want_ll) {
+      if (ADJ) {
+        if (la.diag_zero) ll += gg_ll_bern(0.0, la.d1, la.d0);
+        else if (la.special) ll += gg_ll_bern(*la.p_self, la.d1, la.d0);
+      } else if (la.special) {
+        const double sc1 = gg_pow2i(-la.shift), sc2 = gg_pow2i(-2 * la.shift);
+        long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+        for (int s2 = 0; s2 < la.NSI; ++s2) { hl[2 * s2] = la.dS[s2] >> 32; hl[2 * s2 + 1] = la.dS[s2] & 0xffffffffll; }
+        bool b2 = false;
+        ll += gg_ll_gauss(la.mu_self, la.sigma_self, la.B, la.NSI, (double)la.d1, hl, sc1, sc2, &b2);
+        if (b2) isbad = 1;
+      }
+    }
+    if (isbad) __hip_atomic_store(ep.bad, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ep.out[0] = ll;
+    ep.out[1] = isbad ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  __threadfence_system();
+  if (tid == 0) ep.out[2] = (double)tag;      // (last: the host takes the record only with its launch's tag on it)
+}
+
+template <int NT, bool ADJ, int SPLIT>
+__global__ __launch_bounds__(256) void k_spec_resolve_epi(gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap,
+                                                          gg_params_args pg, gg_ll_args la, gg_epi_args ep, int nspec, unsigned vtag) {
+  if (g.rs[4]) return;   // behind a stalled scan of this pipeline: no-op (uniform)
+  if ((int)blockIdx.x >= nspec) {
+    gg_epilogue_body<ADJ, (gg_tB(NT))>(pg, la, ep, (int)blockIdx.x - nspec, vtag);
+    return;
+  }
+  gg_spec_resolve_body<NT, ADJ, 0, SPLIT>(g, stage_tables, ap, (unsigned)nspec, vtag);
+}
+
 // Apply the change list to the resident statistics of every node (chip-wide):
 // after it G is again the exact block histogram under the current labels.
 // Node n has entries [0, ap[n]) applied already (restart rounds apply L lazily to the nodes they

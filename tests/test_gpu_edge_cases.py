@@ -640,3 +640,59 @@ def test_quantisation_guard_reports_a_coarse_scale(abi):
     rel = np.abs(W_back[:, :, 0][typical] - W2[:, :, 0][typical]) / np.abs(W2[:, :, 0][typical]).clip(1e-9)
     assert np.median(rel) > 1e-4                      # (24 bits relative would be 6e-8)
     assert abi.DeviceData(A, None).quantisation()[2] == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,B,special", [(300, 4, 1, 1), (257, 5, 2, 0), (400, 70, 1, 1)])
+def test_call_epilogue_is_the_plain_chain_and_the_plain_log_likelihood(abi, N, K, B, special):
+    """The reference's loop `model.resample(data); lps.append(model.log_probability(data))` (examples/
+    demo_model_comparison.py:69-72), one sweep per call: a quiet call's last launch carries the call's epilogue - resample_m,
+    the control block for the host and, once the caller has asked for a log-likelihood right after a resample, the
+    log-likelihood of the state the call leaves (k_spec_resolve_epi).  Labels, m and parameters stay the oracle's chain bit
+    for bit through burn-in and the quiet phase; the value the epilogue leaves is, to the last bit, the one the plain
+    evaluation (fresh pass, k_loglik) gives for the same state; a state change in between drops it."""
+    rng = np.random.RandomState(N + K)
+    Kt = 3
+    ctrue = rng.choice(Kt, size=N)
+    ptrue = np.full((Kt, Kt), 0.08) + np.eye(Kt) * 0.8
+    A = (rng.rand(N, N) < ptrue[np.ix_(ctrue, ctrue)]).astype(np.uint8)
+    W = (rng.randn(Kt, Kt, B) * 3.0)[ctrue][:, ctrue] + 0.3 * rng.randn(N, N, B)
+    q, shift = O.quantise(A, W)
+    sa, sw = AdjState(N, K, seed=31), WState(N, K, B, seed=32)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=701, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=special)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=B, seed=702, special_case_self_conns=special)
+    w.set(abi.ST_C, sw.c, np.int32); w.set(abi.ST_M, sw.m); w.set(abi.ST_PI, sw.pi)
+    w.set(abi.ST_MU, sw.mu); w.set(abi.ST_SIGMA, sw.sigma); w.set(abi.ST_NIW, sw.niw); w.set(abi.ST_NIW_SELF, sw.niw_self)
+    w.set(abi.ST_MU_SELF, sw.mu_self); w.set(abi.ST_SIGMA_SELF, sw.sigma_self)
+    ps = sa.p_self
+    lls = []
+    for it in range(45):
+        abi.resample_many([adj, w], d, 1)
+        ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, special, 701, it)
+        O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, special, 702, it)
+        ll = abi.log_likelihood_many([adj, w], d)
+        lls.append(ll)
+        ref = (O.sbm_adj_loglik(A, sa.c, sa.p, ps, True, bool(special)),
+               O.sbm_w_loglik(A, q, shift, sw.c, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, bool(special)))
+        assert abs(ll[0] - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-7 and abs(ll[1] - ref[1]) <= 1e-9 * abs(ref[1]) + 1e-7, (it, ll, ref)
+        if it % 7 == 6 or it >= 40:
+            assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), it
+            assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), it
+            assert np.array_equal(adj.get(abi.ST_M, (K,)), sa.m) and np.array_equal(w.get(abi.ST_M, (K,)), sw.m), it
+            assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p) and np.array_equal(w.get(abi.ST_MU, (K, K, B)), sw.mu), it
+    # the same state evaluated the plain way: setting the labels again (to what they are) drops everything counted ahead
+    # and the epilogue's value with it
+    adj.set(abi.ST_C, sa.c, np.int32); w.set(abi.ST_C, sw.c, np.int32)
+    plain = abi.log_likelihood_many([adj, w], d)
+    assert plain[0] == lls[-1][0] and plain[1] == lls[-1][1], (plain, lls[-1])
+    # ... and a changed state is not answered from the record: move one node, compare with the oracle
+    c2 = sa.c.copy(); c2[0] = (c2[0] + 1) % K
+    adj.set(abi.ST_C, c2, np.int32)
+    ll2 = adj.log_likelihood(d)
+    ref2 = O.sbm_adj_loglik(A, c2, sa.p, ps, True, bool(special))
+    assert abs(ll2 - ref2) <= 1e-9 * abs(ref2) + 1e-7 and ll2 != plain[0]
+    st = adj.stats()
+    assert st["sweeps_two_launch"] > 0     # the quiet phase was reached: calls ended in the epilogue form
