@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libgraphgibbs.so")
+LIB_PATH = os.environ.get("GG_LIB_PATH") or os.path.join(_HERE, "_build", "libgraphgibbs.so")   # (GG_LIB_PATH: kernel-tuning builds, tools/scripts/sweepq_variants.sh)
 
 # enums of include/graphgibbs.h
 SBM_ADJ, BB_ADJ, BERN_ADJ, SBM_GAUSS_W, NIW_W, FIXED_W, LOGISTIC_EIG, PROBIT_EIG, LATENT_DIST, SBM_GAUSS_SHCOV_W = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10

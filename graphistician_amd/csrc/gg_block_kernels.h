@@ -43,6 +43,7 @@ __device__ __forceinline__ long long gg_wave_sum_ll(long long v) {
 // ------------------------------------------------------------------ label sort
 // Counting sort of the labels: perm groups node indices by block, lab_start[k]
 // is the first position of block k, cnt[k] its size.  One workgroup.
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ __launch_bounds__(1024) void k_sort_labels(const int32_t* __restrict__ c, int N, int K,
                                                       int32_t* __restrict__ perm, int32_t* __restrict__ lab_start,
                                                       int32_t* __restrict__ cnt) {
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(1024) void k_sort_labels(const int32_t* __restrict_
     perm[pos] = n;
   }
 }
+#endif
 
 // ------------------------------------------------------------------ BULK kernels
 // G[k][n] = sum over rows i with label k of X[i][n]  (column sums grouped by the
@@ -381,6 +383,7 @@ __device__ __forceinline__ void gg_ride(const gg_ride_args& r) {
 // that N^2 terms of 46 bits cannot overflow (gg_hilo_to_double rounds once).
 // Layout: adjacency NTAB = 1 {ones}; weights NTAB = 1 + 2 NSI {cnt, hi_s, lo_s ...}.
 // When the diagonal is not special-cased it belongs to pair (c_i, c_i).
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ __launch_bounds__(256) void k_pair_tables(const int32_t* __restrict__ Gcnt0,
                                                      const long long* __restrict__ GS0, int Np, int K, int NSI,
                                                      const int32_t* __restrict__ perm,
@@ -434,6 +437,7 @@ __global__ __launch_bounds__(256) void k_pair_tables(const int32_t* __restrict__
     tab[(size_t)blockIdx.x * NTAB + threadIdx.x] = v;
   }
 }
+#endif
 
 // ------------------------------------------------------------------ parameter draws
 struct gg_adj_hyp {
@@ -468,6 +472,7 @@ __device__ inline void gg_unpack_wstats(const long long* hl /* hi,lo pairs */, i
 // ctl: the pipeline's control block, or null - behind a stalled scan the launch is a no-op like every other kernel of the
 // pipeline (more than 64 blocks, speculative form: a draw from the half-scanned block sizes would hand the resumed scan the
 // wrong log m).
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restrict__ pi, int K, uint64_t seed,
                          uint32_t site, uint32_t sweep, double* __restrict__ m, const int32_t* __restrict__ ctl = nullptr) {
   extern __shared__ double s_g[];
@@ -481,13 +486,16 @@ __global__ void k_draw_m(const int32_t* __restrict__ cnt, const double* __restri
     m[k] = s_g[k] / tot;
   }
 }
+#endif
 
 // log m for more than 64 blocks (the parameter kernel's last workgroup has 192 lanes for it): all of them, after it.
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ void k_logm(const double* __restrict__ m, double* __restrict__ logm, int K, const int32_t* __restrict__ ctl = nullptr) {
   if (ctl && ctl[4]) return;
   const int k = threadIdx.x;
   if (k < K) logm[k] = gg_log(m[k]);
 }
+#endif
 
 // ------------------------------------------------------------------ fused parameter step
 // One workgroup per block pair (a, b) (+ one for the self parameter and log m):
@@ -1589,6 +1597,7 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, 
 }
 
 // start of a sharded scan: no hypotheses, every own node sees the block sizes of the labels as they are
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ void k_shard_init(const int32_t* __restrict__ cnt, int32_t* __restrict__ cntn, short* __restrict__ H, int Nl, int K,
                              int32_t* __restrict__ rs, gg_shard_state* __restrict__ S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1596,6 +1605,7 @@ __global__ void k_shard_init(const int32_t* __restrict__ cnt, int32_t* __restric
   if (i < (size_t)Nl * K) cntn[i] = cnt[i % K];
   if (i < GG_SHARD_WINDOW) H[i] = (short)-1;
 }
+#endif
 
 // ------------------------------------------------------------------ log-likelihood from the K x K tables, on the device
 // abstractions.py:111-115 (adjacency: sum_ab n1 log p + n0 log(1 - clip(p)) + diagonal) and weights.py:316-331 (weights:
@@ -1633,6 +1643,7 @@ __device__ __forceinline__ double gg_ll_gauss(const double* mu, const double* si
   return v;
 }
 
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ __launch_bounds__(256) void k_loglik(gg_ll_args g) {
   __shared__ double s_part[256];
   __shared__ int s_bad;
@@ -1677,6 +1688,7 @@ __global__ __launch_bounds__(256) void k_loglik(gg_ll_args g) {
     g.out[1] = s_bad ? 1.0 : 0.0;
   }
 }
+#endif
 
 // ------------------------------------------------------------------ predictive log-likelihood of a held-out node
 // abstractions.py:157-182 (adjacency) / :313-357 (Gaussian weights): the log-likelihood of an (N+1)-th node's row and
@@ -1698,6 +1710,7 @@ struct gg_pred_args {
   double* out;                      // [K]; out[K] = 1.0 if a covariance was not positive definite
 };
 
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ __launch_bounds__(256) void k_pred_ll(gg_pred_args g) {
   extern __shared__ double s_tabs[];      // adjacency: [4][K] log terms; weights: [2][K][NT] Gaussian coefficient tables
   __shared__ double s_part[256];
@@ -1771,3 +1784,4 @@ __global__ __launch_bounds__(256) void k_pred_ll(gg_pred_args g) {
     if (s_bad) g.out[K] = 1.0;
   }
 }
+#endif

@@ -16,6 +16,7 @@
 #include "gg_block_kernels.h"
 #include "gg_resolve_kernels.h"
 #include "gg_scan_kernels.h"
+#include "gg_sweepq.h"
 
 struct gg_eigen;  // gg_eigen.hip
 int gg_eigen_create(gg_eigen** out, const gg_config* cfg);
@@ -983,27 +984,13 @@ static int launch_sweep_q(gg_model* m, const gg_data* d, int a, int b, int c, ui
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
   if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
-#define SWQ1(NTV, ADJV, LV, SV)                                                                                            \
-  do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set && lds > 40 * 1024) {                                                                                    \
-      GG_HIP(hipFuncSetAttribute((const void*)k_sweep_q<NTV, ADJV, LV, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
-    k_sweep_q<NTV, ADJV, LV, SV><<<nspec + nparams + nr, 256, lds, m->stream>>>(g, stage, m->ap, pg, r, nspec, vtag);        \
-  } while (0)
-#define SWQ(NTV, ADJV)                                                                                                     \
-  do {                                                                                                                     \
-    if (split64) { if (ntl) SWQ1(NTV, ADJV, 1, 1); else SWQ1(NTV, ADJV, 0, 1); }                                          \
-    else { if (ntl) SWQ1(NTV, ADJV, 1, 0); else SWQ1(NTV, ADJV, 0, 0); }                                                  \
-  } while (0)
-  if (m->is_adj) SWQ(2, true);
-  else if (m->B == 1) SWQ(3, false);
-  else if (m->B == 2) SWQ(6, false);
-  else if (m->B == 3) SWQ(10, false);
-  else SWQ(15, false);
-#undef SWQ
-#undef SWQ1
+  // (the fused kernel is compiled in a translation unit of its own, gg_sweepq.hip: its rider loop's schedule then depends on
+  // nothing that changes in this file)
+  {
+    const int rcq = gg_launch_sweep_q(m->is_adj ? 2 : m->NT, m->is_adj ? 1 : 0, ntl ? 1 : 0, split64 ? 1 : 0, nspec + nparams + nr, lds, m->stream,
+                                      g, stage, m->ap, pg, r, nspec, vtag);
+    if (rcq) return rcq;
+  }
   if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
   GG_HIP(hipGetLastError());
   if (pg.shared) {

@@ -723,6 +723,7 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
   if (mode != 3) ap[n] = 0;
 }
 
+#ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ void k_reset_L(int32_t* rs, int mode) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && !(mode == 0 ? rs[7] != 0 : (mode == 1 ? rs[4] != 0 : false))) {
     rs[1] = 0;
@@ -732,6 +733,7 @@ __global__ void k_reset_L(int32_t* rs, int mode) {
     *st = gg_pack_state(pos, 0, wlen, fin, seq);
   }
 }
+#endif
 
 // One device-driven restart round in a single launch.  The scan stands at pos = rs[0] with the change
 // list L[0, nL) (nL = rs[1]); the round covers the window [pos, pos + wlen):
