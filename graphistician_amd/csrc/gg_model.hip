@@ -214,6 +214,7 @@ static size_t lds_round(const gg_model* m, int* stage_out) {
   else if (m->Kp == 64 && !m->is_adj) lds += gsb > meet ? gsb : meet;   // k_round: the meeting place reuses the dead integer statistics
   else if (m->Kp == 64) lds += gsb + meet;
   else lds += gsb;
+  if (m->Kp > 64) lds += (size_t)2 * 256 * sizeof(double) + 16 * sizeof(int) + 16;   // the cross-wave categorical's scratch
   if (stage_out) *stage_out = stage;
   return lds;
 }
@@ -388,9 +389,9 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     const char* es = getenv("GG_SCAN");
     const bool can_scan = m->sbm && m->K > 1 && !m->sharded;
     m->scan_pref = !can_scan ? 0 : (es ? (atoi(es) == 1 ? 1 : 0) : -1);
-    // more than 64 blocks: the resident scan (wide instantiation) and, round 3, the speculative one-launch form for quiet chains
-    // (k_spec_resolve<.., 2>); no restart rounds, so GG_SCAN=0 means the resident form there
-    if (m->wide && can_scan) m->scan_pref = es ? 1 : -1;
+    // (more than 64 blocks, round 3: every form - the resident scan's wide instantiation, the speculative one-launch scan
+    // k_spec_resolve<.., 2> for quiet chains, restart rounds as the fallback; the two-kernel form k_speculate + k_resolve is
+    // the one they do not have, k_spec_resolve stands in for it)
     m->use_scan = m->scan_pref == 1;
     m->chg_seen = 0; m->clean_run = 0; m->scan_hold = 4; m->since_revert = 1 << 30;
     m->scan_pref_saved = 0; m->scan_retry_at = 0; m->ahead_cap = 64;
@@ -411,12 +412,6 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
         const size_t need = lds_round(m, nullptr);
         gg_model_destroy(m);
         return gg_fail(GG_ERR_UNSUPPORTED, "K=%d with B=%d needs %zu KB of LDS per workgroup for the node scan (150 KB available)",
-                       cfg->K, cfg->B, need / 1024);
-      }
-      if (!fit_scan && m->wide) {
-        const size_t need = lds_scan(m, 1024, nullptr);
-        gg_model_destroy(m);
-        return gg_fail(GG_ERR_UNSUPPORTED, "K=%d with B=%d needs %zu KB of LDS per workgroup for the resident scan, the one scan form of more than 64 blocks (150 KB available)",
                        cfg->K, cfg->B, need / 1024);
       }
       if (!fit_scan) { m->scan_pref = 0; m->use_scan = false; m->can_ahead = false; }   // restart rounds only (their meeting place reuses dead statistics)
@@ -1525,9 +1520,10 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
         if ((rc = launch_apply_L(m, d, nxt, 3, false))) return rc;
         rode = true;
       }
-    } else if (m->scan_pref < 0) {
+    } else if (m->scan_pref < 0 || m->wide) {
       // adaptive form, quiet phase: speculation and the resolution of the common case in one launch; a scan that does
-      // change a label is left stalled behind its first change for the resident grid (finish_scan)
+      // change a label is left stalled behind its first change for the resident grid (finish_scan) - or, for more than 64
+      // blocks without the resident grid (GG_SCAN=0, or suspended after a timeout), for the restart rounds
       if ((rc = launch_spec_resolve(m, d, buf, sweep, 1 - P))) return rc;
     } else {
       if ((rc = launch_speculate(m, d, buf, 0, -1, sweep, true))) return rc;
@@ -1676,13 +1672,6 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
     if (m->h_rs[3] == 2) {
       // A k_scan exchange timed out (the resident grid could not assemble - a device shared with other processes, say)
       // and left the scan as a stalled one at a consistent position: carry on with the launch-per-change form, for good.
-      if (m->wide) {
-        write_ctl_word(m, 3, 0);
-        m->pending = 0; m->todo = 0;
-        m->zeroed[0] = m->zeroed[1] = m->zeroed[2] = false;
-        set_pend_data(m, nullptr);
-        return gg_fail(GG_ERR_HIP, "k_scan: the resident grid timed out and C=%d has no other scan form (a device shared with other processes?)", m->K);
-      }
       if ((rc = write_ctl_word(m, 3, 0))) return rc;
       if (m->scan_pref != 0) fprintf(stderr, "graphgibbs: the resident-grid scan timed out at node %d (%d changes in its list); this model continues with restart rounds for %llu sweeps\n", m->h_rs[0], m->h_rs[1], (unsigned long long)m->scan_backoff);
       scan_suspend(m);
@@ -1775,8 +1764,12 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
         // nothing of this scan is decided yet (statistics, parameters and tables of the sweep are in place): run it in
         // the speculative form; what that leaves unfinished is finished below like any other stalled scan
         if ((rc = write_ctl_word(m, 4, 0))) return rc;
-        if ((rc = launch_speculate(m, d, buf_s, 0, -1, m->sweep + (uint32_t)s_idx, true))) return rc;
-        if ((rc = launch_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
+        if (m->wide) {
+          if ((rc = launch_spec_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, 1 - P_s))) return rc;
+        } else {
+          if ((rc = launch_speculate(m, d, buf_s, 0, -1, m->sweep + (uint32_t)s_idx, true))) return rc;
+          if ((rc = launch_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
+        }
       }
       if ((rc = finish_scan(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
     } else {
@@ -2061,24 +2054,15 @@ int gg_resample_part(gg_model* m, const gg_data* d, int32_t parts, double beta) 
     if ((rc = enqueue_params(m, d, buf, do_params, do_params, do_c, -1, m->sweep))) return rc;
     if (do_c) { m->ahead = false; m->zeroed[buf] = false; }   // the scan below may change labels: not the next sweep's statistics
   }
-  if (do_c && m->wide) {
-    // more than 64 blocks: the resident scan is the one scan form
+  if (do_c) {
     const int pw = 1 - m->pcur;
-    if ((rc = launch_scan(m, d, buf, m->sweep, true, pw))) return rc;
-    if ((rc = read_ctl(m))) return rc;
-    if (m->h_rs[3]) {
-      const int st3 = m->h_rs[3];
-      write_ctl_word(m, 3, 0);
-      if (st3 & 1) return gg_fail(GG_ERR_NUMERIC, "a block covariance is not positive definite");
-      return gg_fail(GG_ERR_HIP, "k_scan: the resident grid timed out and C=%d has no other scan form", m->K);
+    if (m->wide) {
+      // (more than 64 blocks: the one-launch speculative scan stands in for the two kernels below)
+      if ((rc = launch_spec_resolve(m, d, buf, m->sweep, pw))) return rc;
+    } else {
+      if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false))) return rc;
+      if ((rc = launch_resolve(m, d, buf, m->sweep, false, true, pw))) return rc;
     }
-    m->pcur = pw;
-    m->done_base = m->h_rs[5];
-    m->st.label_changes = (uint64_t)m->h_rs[2];
-  } else if (do_c) {
-    if ((rc = launch_speculate(m, d, buf, 0, -1, m->sweep, false))) return rc;
-    const int pw = 1 - m->pcur;
-    if ((rc = launch_resolve(m, d, buf, m->sweep, false, true, pw))) return rc;
     m->st.resolve_rounds += 1;
     if ((rc = finish_scan(m, d, buf, m->sweep, false, true, pw))) return rc;
     m->pcur = pw;   // the completed scan left the sort of the final labels there

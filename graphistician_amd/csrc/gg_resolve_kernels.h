@@ -776,8 +776,14 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
   else if (Kp == 64 && !alias_meet) off += meet_bytes;   // the split chains meet here (gg_lp_split4)
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_ap = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
+  off = (off + 7) & ~(size_t)7;   // (s_ctl[0..1] is a 64-bit word for the LDS atomics: one node per workgroup - 129..256 blocks - left it on a 4-byte boundary)
   int* s_ctl = reinterpret_cast<int*>(s_raw + off); off += 8 * sizeof(int);
-  int* s_cnt = reinterpret_cast<int*>(s_raw + off);   // [K] (resolver only)
+  int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);   // [K] (resolver only)
+  off = (off + 7) & ~(size_t)7;
+  double* s_cat = reinterpret_cast<double*>(s_raw + off);   // more than 64 blocks: scratch of the cross-wave categorical
+  // (node, old, new) payloads: 6-bit labels, 8-bit for more than 64 blocks
+  const int LB = Kp > 64 ? 8 : 6;
+  const unsigned LMASK = (1u << LB) - 1u;
   unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_ctl);   // s_ctl[0..1]
 
   // The whole round state is one 64-bit word: a workgroup that starts after this round's resolver has
@@ -959,11 +965,12 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
       else if (Kp == 64) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_T, nn);
       else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin);
       double u = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + nn));
-      int lab = gg_group_categorical(lp, k, K, Kp, u);
+      // (more than 64 blocks: a node's lanes span two or four wavefronts - round 3: the restart rounds serve that shape too)
+      int lab = Kp > 64 ? gg_group_categorical_wide(lp, k, K, Kp, u, s_cat) : gg_group_categorical(lp, k, K, Kp, u);
       if (live && k == 0) {
         const int cn = x.c[x.n0 + n];
         if (lab != cn)
-          atomicMin(s_min, ((unsigned long long)(unsigned)n << 12) | ((unsigned long long)(unsigned)cn << 6) | (unsigned)lab);
+          atomicMin(s_min, ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)lab);
       }
     }
   }
@@ -996,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_round(gg_resolve_args g, int32_t* __res
     newpos = wend;                              // the whole window is final, unchanged
     wnext = 0;                                  // quiet stretch: full window next
   } else {
-    const int ns = (int)(best >> 12), a = (int)((best >> 6) & 63u), b = (int)(best & 63u);
+    const int ns = (int)(best >> (2 * LB)), a = (int)((best >> LB) & LMASK), b = (int)(best & LMASK);
     if (tid == 0) {
       g.c[ns] = b;
       atomicSub(&g.cnt[a], 1);

@@ -74,8 +74,8 @@ def run(cases, seed0, verbose=False, extended=False):
     bad = []
     for case in range(cases):
         N = int(rng.choice([5, 17, 33, 64, 65, 100, 129, 200, 257, 300]))
-        # (more than 64 blocks run the wide resident scan, which has no fallback form: not under forced exchange timeouts)
-        ks = [2, 3, 4, 7, 16, 17, 33, 40, 64] + ([] if os.environ.get("GG_SCAN_SPIN") else [65, 100, 128, 200, 256])
+        # (more than 64 blocks: every scan form since round 3, also under forced exchange timeouts)
+        ks = [2, 3, 4, 7, 16, 17, 33, 40, 64, 65, 100, 128, 200, 256]
         K = min(int(rng.choice(ks)), N)
         B = int(rng.choice([1, 1, 1, 2, 3, 4]))
         special = int(rng.rand() < 0.7)

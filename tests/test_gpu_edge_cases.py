@@ -355,6 +355,36 @@ def test_resident_scan_timeout_falls_back_exactly(abi, monkeypatch, capfd, spin,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"GG_SCAN_SPIN": "1"}, {"GG_SCAN": "0"}, {"GG_SCAN": "1", "GG_SCAN_SPIN": "2", "GG_SCAN_RETRY": "2"},
+                                 {"GG_SCAN": "0", "GG_AHEAD": "0"}])
+def test_more_than_64_blocks_fall_back_to_restart_rounds(abi, monkeypatch, capfd, env):
+    """Round 3: 65..256 blocks have the restart rounds too (k_round with the cross-wave categorical
+    and 8-bit label payloads; k_spec_resolve stands in for the two-kernel form) - a resident-grid exchange that times out
+    (GG_SCAN_SPIN) is no longer an error for them, and GG_SCAN=0 runs them without the resident grid at all.  Same chain as the
+    oracle's, bit for bit, through burn-in (hundreds of restart rounds) and the step-wise parts."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from tests.fuzz_parity import one_case
+    assert one_case(150, 70, 1, 1, 4242, (1, 2, 6)) is None
+    assert one_case(130, 129, 2, 0, 4243, (2, 5)) is None
+    N, K = 140, 100
+    A, W, _ = planted_sbm(N, 3, seed=23)
+    sa = AdjState(N, K, seed=27)
+    d = abi.DeviceData(A, W)
+    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=83, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+    adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+    adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+    ps = sa.p_self
+    for s in range(3):      # the reference's step-wise calls (adjacency.py:615-618)
+        adj.resample_part(d, abi.PART_PARAMS); adj.resample_part(d, abi.PART_C); adj.resample_part(d, abi.PART_M)
+        ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 83, s)
+        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c), s
+        assert np.array_equal(adj.get(abi.ST_M, (K,)), sa.m) and np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p), s
+    if env.get("GG_SCAN_SPIN") == "1":
+        assert "timed out" in capfd.readouterr().err
+
+
+@pytest.mark.gpu
 def test_adaptive_scan_form_is_the_same_chain(abi, monkeypatch):
     """Default (GG_SCAN unset): the engine runs the scan as k_scan while the chain keeps changing labels and as
     k_speculate + k_resolve after a run of quiet sweeps (4 at first), deciding batch by batch.  A strongly planted network burns in within a
