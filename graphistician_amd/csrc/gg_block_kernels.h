@@ -1338,7 +1338,9 @@ __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, u
   }
   int n;
   bool live;
-  const int lab = gg_spec_eval<NT, ADJ>(x, n_begin, seed, site, sweep, lp_node, lp_out, stage_tables, &n, &live);
+  // (more than 64 blocks: the evaluation with the cross-wave categorical - gg_node_lp and the step-wise forms reach this kernel)
+  const int lab = x.Kp > 64 ? gg_spec_eval<NT, ADJ, 0, 2>(x, n_begin, seed, site, sweep, lp_node, lp_out, stage_tables, &n, &live)
+                            : gg_spec_eval<NT, ADJ>(x, n_begin, seed, site, sweep, lp_node, lp_out, stage_tables, &n, &live);
   if (live && threadIdx.x % x.Kp == 0) {
     cand[n] = lab;
     if (ap) ap[n] = 0;   // no entry of this scan's change list is applied to the node yet
@@ -1412,13 +1414,13 @@ struct gg_shard_state {
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, uint64_t seed, uint32_t site, uint32_t sweep,
                                                     int32_t* __restrict__ cand, const int32_t* __restrict__ c,
-                                                    const short* __restrict__ Hb, gg_shard_state* __restrict__ S, int round,
+                                                    const int32_t* __restrict__ Hb, gg_shard_state* __restrict__ S, int round,
                                                     int ntot, int stage_tables, int32_t* __restrict__ trip) {
   __shared__ int s_scan[256];
   __shared__ int s_last;
   const int t = (int)threadIdx.x, per = 256 / x.Kp;
   const int spos = S->st[round & 1][0], wbase = S->st[round & 1][1];
-  const short* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;
+  const int32_t* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;   // -1 none, else (old << 8 | new): 8-bit labels, up to 256 blocks
   int lo = 0, hi = 0;
   if (spos < ntot) {
     const int wend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;   // the band the scan stands in
@@ -1429,7 +1431,8 @@ __global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, uint64_t seed
   if (hi > lo && lo + (int)blockIdx.x * per < hi) {        // (uniform over the workgroup)
     int n;
     bool live;
-    const int lab = gg_spec_eval<NT, ADJ>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live);
+    const int lab = x.Kp > 64 ? gg_spec_eval<NT, ADJ, 0, 2>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live)
+                              : gg_spec_eval<NT, ADJ>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live);
     if (live && n < hi && t % x.Kp == 0) {
       // (an atomic exchange at agent scope: performed at the memory side, and its return value holds the wave until it has
       // been - the decision is out before the workgroup's ticket is drawn.  No fence: a release fence per workgroup writes
@@ -1487,7 +1490,7 @@ __global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, uint64_t seed
 
 // all: the gathered reports [world][GG_SHARD_M][3] (node, label it has, label it draws), in position order.
 template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, int32_t* cnt, short* Hb, int32_t* rs,
+__global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, int32_t* cnt, int32_t* Hb, int32_t* rs,
                                                      gg_shard_state* S, int round, int ntot, const int32_t* __restrict__ all,
                                                      int world, int32_t* __restrict__ cntn, int32_t* Gc0, int32_t* Gc1,
                                                      long long* Gs0, long long* Gs1, const uint32_t* XA, const uint32_t* XAT,
@@ -1495,11 +1498,11 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, 
   constexpr int B = gg_tB(NT);
   constexpr int NSI = gg_tNSI(NT);
   extern __shared__ int s_mv[];                // [world][GG_SHARD_M][3]
-  __shared__ short s_H[GG_SHARD_WINDOW];
+  __shared__ int32_t s_H[GG_SHARD_WINDOW];
   __shared__ int s_pstar, s_acc;
   const int t = (int)threadIdx.x;
   const int spos = S->st[round & 1][0], wbase = S->st[round & 1][1];
-  const short* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;
+  const int32_t* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;   // -1 none, else (old << 8 | new): 8-bit labels, up to 256 blocks
   const bool first = blockIdx.x == 0 && blockIdx.y == 0;
   if (spos >= ntot) {          // the scan is over: the state is handed on as it is
     if (first && t == 0) { S->st[(round + 1) & 1][0] = spos; S->st[(round + 1) & 1][1] = wbase; }
@@ -1525,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, 
       const int f = all[3 * e];
       if (f == GG_SHARD_NONE) continue;
       const int old = all[3 * e + 1], nw = all[3 * e + 2];
-      s_H[f - wbase] = (nw == old) ? (short)-1 : (short)((old << 8) | nw);
+      s_H[f - wbase] = (nw == old) ? -1 : ((old << 8) | nw);
       atomicMin(&s_pstar, f);
     }
     __syncthreads();
@@ -1541,9 +1544,9 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, 
       ++mine;
     }
     if (mine) atomicAdd(&s_acc, mine);
-    short* Hn = Hb + (size_t)((round + 1) & 1) * GG_SHARD_WINDOW;
+    int32_t* Hn = Hb + (size_t)((round + 1) & 1) * GG_SHARD_WINDOW;
     // (a final band starts the next one without hypotheses)
-    for (int i = t; i < GG_SHARD_WINDOW; i += 256) Hn[i] = quiet ? (short)-1 : s_H[i];
+    for (int i = t; i < GG_SHARD_WINDOW; i += 256) Hn[i] = quiet ? -1 : s_H[i];
     __syncthreads();
     if (t == 0) {
       rs[2] += s_acc;
@@ -1598,12 +1601,12 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, 
 
 // start of a sharded scan: no hypotheses, every own node sees the block sizes of the labels as they are
 #ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
-__global__ void k_shard_init(const int32_t* __restrict__ cnt, int32_t* __restrict__ cntn, short* __restrict__ H, int Nl, int K,
+__global__ void k_shard_init(const int32_t* __restrict__ cnt, int32_t* __restrict__ cntn, int32_t* __restrict__ H, int Nl, int K,
                              int32_t* __restrict__ rs, gg_shard_state* __restrict__ S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { rs[GG_RS_ROUNDS] = 0; rs[GG_RS_SPOS] = 0; S->st[0][0] = 0; S->st[0][1] = 0; S->ticket = 0; }
   if (i < (size_t)Nl * K) cntn[i] = cnt[i % K];
-  if (i < GG_SHARD_WINDOW) H[i] = (short)-1;
+  if (i < GG_SHARD_WINDOW) H[i] = -1;
 }
 #endif
 

@@ -120,7 +120,7 @@ struct gg_model {
   long long chg_seen;           // label changes (control word 2) at the last decision
   long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
   int32_t* sh_cntn;             // sharded scan: [Nl][K] block sizes as own node n sees them
-  short* sh_H;                  //               [2][GG_SHARD_WINDOW] hypothesis per node of the band, two copies used alternately
+  int32_t* sh_H;                //               [2][GG_SHARD_WINDOW] hypothesis per node of the band, two copies used alternately
   gg_shard_state* sh_state;     //               scan position / band start (two copies) + the evaluation launch's ticket
   int sh_hint;                  //               rounds the last scan of this model needed (+ margin): the first batch of the next
   bool wide;                    // 65..256 blocks: a node's lanes span two or four wavefronts - the resident scan's wide instantiation is the
@@ -313,9 +313,9 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if (m->joint) m->cfg.special_case_self_conns = 0;   // stochastic_block_model.py:291-296: the diagonal belongs to pair (c_n, c_n)
   if (m->joint && m->sharded) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "GG_SBM_JOINT: not for node shards"); }
   m->wide = m->K > 64;
-  if (m->wide && (m->sharded || m->joint)) {
+  if (m->wide && m->joint) {
     delete m;
-    return gg_fail(GG_ERR_UNSUPPORTED, "C=%d: more than 64 blocks are supported for the SBM adjacency / weight kinds on one GPU (not for node shards or the joint model)", m->K);
+    return gg_fail(GG_ERR_UNSUPPORTED, "C=%d: more than 64 blocks are supported for the SBM adjacency / weight kinds (not for the joint model)", m->K);
   }
   if (m->kind == GG_SBM_GAUSS_SHCOV_W && !m->cfg.special_case_self_conns && m->sharded) {
     delete m;
@@ -910,6 +910,7 @@ static int launch_speculate(gg_model* m, const gg_data* d, int buf, int n_begin,
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
   else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+  if (m->Kp > 64) lds += (size_t)2 * 256 * sizeof(double) + 16 * sizeof(int) + 8;   // the cross-wave categorical's scratch
 #define SPEC(NTV, ADJV)                                                                                                    \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
@@ -2092,7 +2093,6 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
   if (!m || !lp) return gg_fail(GG_ERR_INVALID, "gg_node_lp: null argument");
   GG_HIP(hipSetDevice(m->cfg.device));
   if (m->eig || m->ld) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: block models only");
-  if (m->wide) return gg_fail(GG_ERR_UNSUPPORTED, "gg_node_lp: not for more than 64 blocks (the per-node evaluation kernel gives a node one wavefront)");
   int rc = model_sync(m);
   if (rc) return rc;
   if ((rc = check_data(m, d))) return rc;
@@ -2453,6 +2453,7 @@ static int launch_shard_eval(gg_model* m, const gg_data* d, int buf, int round) 
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
   else if (m->Kp == 64) lds += (size_t)4 * 2 * m->NT * 64 * sizeof(double);   // gg_lp_split4's meeting place
+  if (m->Kp > 64) lds += (size_t)2 * 256 * sizeof(double) + 16 * sizeof(int) + 8;   // the cross-wave categorical's scratch
 #define SHE(NTV, ADJV)                                                                                                     \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \

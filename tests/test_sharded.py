@@ -13,12 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,N,K,B,special", [(1, 150, 4, 1, 1), (2, 200, 5, 1, 1), (3, 330, 7, 1, 1), (2, 257, 33, 2, 0),
-                                                 (3, 160, 64, 4, 1), (2, 129, 17, 1, 0), (2, 4500, 6, 1, 1), (1, 8192, 16, 1, 1)])
+                                                 (3, 160, 64, 4, 1), (2, 129, 17, 1, 0), (2, 4500, 6, 1, 1), (1, 8192, 16, 1, 1),
+                                                 (2, 210, 100, 1, 1), (1, 300, 70, 2, 0), (3, 270, 256, 1, 1)])
 def test_sharded_chain_equals_single_chain(world, N, K, B, special):
     """One chain, its nodes sharded over `world` ranks, against the oracle's sequential chain, bit for bit, from a random
     start (thousands of label changes in the first scans: every rank reports its first 32 surprises per round, the hypotheses
     are amended and accepted in bulk; N = 4500 crosses a band boundary of the 4096-node scan window; N = 8192, K = 16 - the
-    network size of configs[4], two bands per scan - runs through the RCCL communicator)."""
+    network size of configs[4], two bands per scan - runs through the RCCL communicator; the last three: more than 64 blocks,
+    a node's lanes spanning two or four wavefronts - round 3)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(29600 + world + 4 * B + 16 * special), os.path.join(ROOT, "tests", "shard_worker.py"),
            str(N), str(K), "3", str(B), str(special)]
