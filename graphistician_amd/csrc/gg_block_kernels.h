@@ -81,8 +81,18 @@ __global__ __launch_bounds__(1024) void k_sort_labels(const int32_t* __restrict_
 // transactions of a contiguous row segment: coalesced regardless of perm.
 //
 // slot -> (label k, sub-chunk): labels with more than RW rows span several slots.
+// Every lane of the calling wavefront must be active (the slots of 64 labels at a time are counted by a wave-wide prefix sum:
+// the serial walk this replaces was K dependent loads per work item - 6 us at 100 blocks, 13 us at 256).
+// SERIAL: the walk - for the WEIGHT riders of the fused kernel's translation unit (gg_sweepq.hip, GG_FIND_SLOT_SERIAL_W):
+// there the prefix sum moved the rider loop's schedule (32.2 -> 38.8 us per launch at 16 blocks), and that kernel only runs
+// shapes with few blocks; its adjacency instantiation gains from the prefix sum (23.5 -> 20.1 us alone) and keeps it.
+#ifndef GG_FIND_SLOT_SERIAL_W
+#define GG_FIND_SLOT_SERIAL_W false
+#endif
+template <bool SERIAL = false>
 __device__ __forceinline__ bool gg_find_slot(const int32_t* __restrict__ lab_start, int K, int RW, int slot,
                                              int* k_out, int* row0, int* nrows) {
+  if (SERIAL) {
   for (int k = 0; k < K; ++k) {
     int s0 = lab_start[k], n = lab_start[k + 1] - s0;
     int ns = (n + RW - 1) / RW;
@@ -94,6 +104,31 @@ __device__ __forceinline__ bool gg_find_slot(const int32_t* __restrict__ lab_sta
       return true;
     }
     slot -= ns;
+  }
+  return false;
+  }
+  const int lane = (int)(threadIdx.x & 63u);
+  int base = 0;                                   // slots of the labels before the current group of 64
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int k = k0 + lane;
+    int s0 = 0, n = 0;
+    if (k < K) { s0 = lab_start[k]; n = lab_start[k + 1] - s0; }
+    const int ns = (n + RW - 1) / RW;
+    int incl = ns;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const int total = __shfl(incl, 63);
+    if (slot < base + total) {
+      const unsigned long long bal = __ballot(base + incl > slot);   // (the first such lane holds the slot's label)
+      const int src = __ffsll((long long)bal) - 1;
+      const int sub = slot - base - __shfl(incl - ns, src);
+      const int s0s = __shfl(s0, src), ns_n = __shfl(n, src);
+      *k_out = k0 + src;
+      *row0 = s0s + sub * RW;
+      const int rem = ns_n - sub * RW;
+      *nrows = rem < RW ? rem : RW;
+      return true;
+    }
+    base += total;
   }
   return false;
 }
@@ -224,7 +259,7 @@ __device__ __forceinline__ void gg_bulk_w_body(const int32_t* __restrict__ XT, c
   int32_t* __restrict__ Gcnt = dir == 0 ? Gc0 : Gc1;
   long long* __restrict__ GS = dir == 0 ? Gs0 : Gs1;
   int k, row0, nrows;
-  if (!gg_find_slot(lab_start, K, RW, slot, &k, &row0, &nrows)) return;
+  if (!gg_find_slot<GG_FIND_SLOT_SERIAL_W>(lab_start, K, RW, slot, &k, &row0, &nrows)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col0 = strip * SC + lane * EPL;
   for (int i = tid; i < SC; i += 256) s_cnt[i] = 0;

@@ -1271,7 +1271,7 @@ static int fetch_ctl(gg_model* m) {
     const volatile double* rec = m->h_epi;
     for (unsigned spin = 1;; ++spin) {
       if ((unsigned)rec[2] == m->epi_tag) break;
-      if ((spin & 4095u) == 0u && hipStreamQuery(m->stream) == hipSuccess) break;
+      if ((spin & 4095u) == 0u && hipStreamQuery(m->stream) != hipErrorNotReady) break;   // (drained, or failed: read_ctl reports it)
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     if ((unsigned)m->h_epi[2] == m->epi_tag) {

@@ -438,13 +438,19 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
     atomicSub(&g.cnt[ca], 1);
     atomicAdd(&g.cnt[cb], 1);
     g.L[0] = f; g.L[1] = ca; g.L[2] = cb;
-    g.rs[0] = f + 1;
+    // (more than 64 blocks may be finished by restart rounds, which have nothing to do for a scan that stands behind its
+    // last node: when the LAST node changed, stand on it again - its conditional does not depend on its own label, the
+    // round redraws the same one, finds the window final and runs the tail; found by the release soak under GG_SCAN=0.
+    // The other shapes are finished by the resident scan, which runs its tail from any position: their code is left as it
+    // is - it is inlined into k_sweep_q)
+    const int npos = (SPLIT == 2 && f + 1 >= N) ? N - 1 : f + 1;
+    g.rs[0] = npos;
     g.rs[1] = 1;
     g.rs[2] += 1;
     g.rs[9] += 1;
     g.rs[4] = 1;
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(&g.rs[10]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(f + 1, 1, 0, 0, 0);
+    *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(npos, 1, 0, 0, 0);
     if (vtag) __hip_atomic_store(g.verdict, (vtag << 1) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

@@ -7,6 +7,7 @@
 #include <math.h>
 #include "../../include/graphgibbs.h"
 #define GG_ONLY_SWEEPQ 1
+#define GG_FIND_SLOT_SERIAL_W true   // (gg_block_kernels.h: the walk over the labels keeps the weight riders' schedule)
 #include "gg_common.h"
 #include "gg_block_kernels.h"
 #include "gg_resolve_kernels.h"
