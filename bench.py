@@ -677,10 +677,12 @@ def main():
         seeds = [int(x) for x in os.environ["GG_BENCH_CHAIN_SEEDS"].split(",")]
     else:
         seeds = [1, 2, 3, 4, 5, 6] if N < 32768 else [1]
-    # HIP events (on the engine streams) around the launches that stream the data: about 8 sampled launches per chain whatever
-    # the run length at small N (each record costs the stream a barrier packet that drains the queue: a quarter of the timed
-    # region of the driver's --steps 20 if every launch were sampled), every launch for N > 8192
-    every = 1 if N > 8192 else max(1, -(-args.steps // 8))
+    # HIP events (on the engine streams) around the launches that stream the data: about 18 sampled launches over the whole
+    # mix whatever the run length at small N - 3 per chain of a six-chain mix, 8 for a single chain (each record costs the
+    # stream a barrier packet that drains the queue: the instrumentation, not the engine - with 7 of a chain's 20 sweeps
+    # bracketed the quiet chains lost 4-9 us per sweep to it), every launch for N > 8192
+    per_chain = 8 if len(seeds) < 4 else 3
+    every = 1 if N > 8192 else max(1, -(-args.steps // per_chain))
     chains, total_el = [], 0.0
     bulk = dict(w_ms=0.0, w_n=0, w_bytes=0.0, adj_ms=0.0, adj_n=0, adj_bytes=0.0)
     forms = dict(sweeps_fused=0, sweeps_two_launch=0, sweeps_serial=0)
