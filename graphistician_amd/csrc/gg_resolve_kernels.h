@@ -478,6 +478,12 @@ __global__ __launch_bounds__(256, ((RIDE && !SPLIT) ? GG_RIDE_WAVES : 1)) void k
 // change one raises the stall flag as ever, the parameter workgroups of sweep s+1 drop what they computed, and the host
 // resumes in the serial form.  The scan workgroups come first in the grid, so they are resident before any workgroup that
 // waits for them.
+#ifndef GG_W_RIDER_PRIO
+#define GG_W_RIDER_PRIO 0    // issue priority of the weight model's riders in the fused launch (0: left alone)
+#endif
+#ifndef GG_ADJ_FRONT_PRIO
+#define GG_ADJ_FRONT_PRIO 0   // issue priority of the adjacency model's front workgroups in the fused launch (its chain has slack)
+#endif
 template <int NT, bool ADJ, int NTL, int SPLIT>
 __global__ __launch_bounds__(256, (SPLIT ? 1 : GG_RIDE_WAVES)) void k_sweep_q(gg_resolve_args g, int stage_tables, int32_t* __restrict__ ap,
                                                                                  gg_params_args pg, gg_ride_args ride, int nspec, unsigned vtag) {
@@ -490,14 +496,15 @@ __global__ __launch_bounds__(256, (SPLIT ? 1 : GG_RIDE_WAVES)) void k_sweep_q(gg
   if (bid >= ride.front) {
     role = 3;
     if (ride.dbg && threadIdx.x == 0) atomicMin(reinterpret_cast<unsigned long long*>(&ride.dbg[4]), (unsigned long long)t0);
+    if (!ADJ && GG_W_RIDER_PRIO) __builtin_amdgcn_s_setprio(GG_W_RIDER_PRIO);
     gg_ride<ADJ, B, NTL == 1>(ride);
   } else if (bid >= nspec) {
     role = 2;
-    __builtin_amdgcn_s_setprio(2);   // the latency chain goes first at every issue slot it can use
+    __builtin_amdgcn_s_setprio(ADJ ? GG_ADJ_FRONT_PRIO : 2);   // the latency chain goes first at every issue slot it can use
     gg_params_body<ADJ, B>(pg, bid - nspec, (unsigned)(ride.front - nspec), vtag);
   } else {
     role = 1;
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(ADJ ? GG_ADJ_FRONT_PRIO : 2);
     gg_spec_resolve_body<NT, ADJ, GG_RIDE_UJ, SPLIT>(g, stage_tables, ap, (unsigned)nspec, vtag);
   }
   if (ride.dbg && threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&ride.dbg[role]), (unsigned long long)wall_clock64());
