@@ -1357,6 +1357,97 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
   return gg_group_categorical(lp, k, K, Kp, u);
 }
 
+// More than 64 blocks, the quiet scan's evaluation (k_spec_resolve / k_spec_resolve_epi, SPLIT == 2): a node's lanes span two or
+// four wavefronts, so a workgroup holds only 256 / Kp = 2 or 1 nodes per pass - and every pass reads both coefficient tables
+// (2 K NT Kp doubles: 600 KB at 100 blocks) from L2.  Here a workgroup evaluates GG_WIDE_P(NT) passes' worth of nodes at once:
+// lane (i, k) keeps the chains of nodes i, i + per, i + 2 per, ... and every table entry it fetches serves all of them.
+// Same chains per node, same order, same bits as gg_spec_eval.  Nodes of the workgroup: [blockIdx.x per P, + per P).
+#define GG_WIDE_P(NT) ((NT) <= 3 ? 4 : ((NT) <= 6 ? 2 : 1))
+template <int NT, bool ADJ, int P>
+__device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t seed, uint32_t site, uint32_t sweep, int* labs,
+                                                  int* nodes, bool* lives) {
+  constexpr int NSI = ADJ ? 0 : gg_tNSI(NT);
+  extern __shared__ __align__(16) unsigned char s_spec[];
+  const int K = x.K, Kp = x.Kp;
+  const int per = 256 / Kp, nwg = per * P;
+  double* s_st = reinterpret_cast<double*>(s_spec);                       // [dir][j][node of the workgroup][NT]
+  double* s_cat = s_st + (size_t)2 * K * nwg * NT;                       // the cross-wave categorical's scratch
+  const int n0 = (int)blockIdx.x * nwg;
+  const int tid = threadIdx.x;
+  const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  for (int idx = tid; idx < 2 * K * nwg; idx += 256) {
+    const int i = idx % nwg, j = (idx / nwg) % K, d = idx / (nwg * K);
+    const int n = (n0 + i < x.N) ? n0 + i : x.N - 1;
+    const size_t gd = (size_t)d * K * x.Np + (size_t)j * x.Np + n;        // direction 1 follows direction 0 in the buffer
+    const int gc = x.Gcnt[0][gd];
+    double* dst = s_st + ((size_t)(d * K + j) * nwg + i) * NT;
+    if (ADJ) {
+      const int cx = (x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0);
+      dst[0] = (double)gc;
+      dst[1] = (double)(cx - gc);
+    } else {
+      constexpr int B = gg_tB(NT);
+      dst[0] = (double)gc;
+#pragma unroll
+      for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
+      if (gg_tJ(NT)) dst[NT - 1] = (double)((x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0));
+    }
+  }
+  __syncthreads();
+  const int i0 = tid / Kp, k = tid % Kp;
+  double acc_o[P][NT], acc_i[P][NT];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc_o[p][t] = 0.0; acc_i[p][t] = 0.0; }
+  if (k < K) {
+    constexpr int UJ = NT <= 3 ? 4 : 2;
+    auto step = [&](int j, const double* to, const double* ti) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const double* a = s_st + ((size_t)(0 * K + j) * nwg + p * per + i0) * NT;
+        const double* b = s_st + ((size_t)(1 * K + j) * nwg + p * per + i0) * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc_o[p][t] = gg_fma(to[t], a[t], acc_o[p][t]);
+          acc_i[p][t] = gg_fma(ti[t], b[t], acc_i[p][t]);
+        }
+      }
+    };
+    int j = 0;
+    for (; j + UJ <= K; j += UJ) {
+      double to[UJ][NT], ti[UJ][NT];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          to[u][t] = x.Tout[((size_t)(j + u) * NT + t) * Kp + k];
+          ti[u][t] = x.Tin[((size_t)(j + u) * NT + t) * Kp + k];
+        }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) step(j + u, to[u], ti[u]);
+    }
+    for (; j < K; ++j) {
+      double to[NT], ti[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { to[t] = x.Tout[((size_t)j * NT + t) * Kp + k]; ti[t] = x.Tin[((size_t)j * NT + t) * Kp + k]; }
+      step(j, to, ti);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int n = n0 + p * per + i0;
+    const bool live = n < x.N;
+    const int nn = live ? n : x.N - 1;
+    const double lp = gg_node_lp_finish<NT, ADJ>(x, nn, k, acc_o[p], acc_i[p]);
+    const double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
+    labs[p] = gg_group_categorical_wide(lp, k, K, Kp, u, s_cat);    // (synchronises: every thread, every pass)
+    nodes[p] = n;
+    lives[p] = live;
+  }
+}
+
 template <int NT, bool ADJ>
 __global__ __launch_bounds__(256) void k_speculate(gg_node_ctx x, int n_begin, uint64_t seed, uint32_t site,
                                                    uint32_t sweep, int32_t* __restrict__ cand, int lp_node,

@@ -193,8 +193,12 @@ static size_t table_bytes(const gg_model* m) { return (size_t)2 * m->K * m->NT *
 // launch sites and for the capacity check at model creation: 150 KB is what a workgroup may ask for next to the few
 // static words these kernels keep.
 #define GG_LDS_LIMIT ((size_t)150 * 1024)
+// nodes a workgroup of the quiet scan evaluates (k_spec_resolve, k_spec_resolve_epi, k_sweep_q): one pass of 256 / Kp nodes, or
+// GG_WIDE_P passes' worth for more than 64 blocks (gg_spec_eval_wide)
+static int spec_nodes_per_wg(const gg_model* m) { return (256 / m->Kp) * (m->Kp > 64 ? GG_WIDE_P(m->NT) : 1); }
+
 static size_t lds_spec(const gg_model* m, int* stage_out) {
-  const int K = m->K, per = 256 / m->Kp;
+  const int K = m->K, per = spec_nodes_per_wg(m);
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
   if (stage) lds += table_bytes(m);
@@ -1008,7 +1012,7 @@ static int launch_sweep_q(gg_model* m, const gg_data* d, int a, int b, int c, ui
 // one this sweep started with).
 static int launch_spec_resolve(gg_model* m, const gg_data* d, int buf, uint32_t sweep, int pw, int ride_next = -1) {
   gg_resolve_args g = fill_spec_args(m, d, buf, sweep, pw);
-  const int per = 256 / m->Kp;
+  const int per = spec_nodes_per_wg(m);
   const int nb = (m->Nl + per - 1) / per;
   int stage;
   const size_t lds = lds_spec(m, &stage);
@@ -1104,7 +1108,7 @@ static int launch_spec_resolve_epi(gg_model* m, const gg_data* d, int buf, int n
   ep.want_ll = want_ll ? 1 : 0;
   ep.npair = want_ll ? m->K * m->K : 1;
   ep.m_site = m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M;
-  const int per = 256 / m->Kp;
+  const int per = spec_nodes_per_wg(m);
   const int nspec = (m->Nl + per - 1) / per;
   int stage;
   const size_t lds = lds_spec(m, &stage);

@@ -384,6 +384,24 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
   __shared__ unsigned long long s_fmin;
   __shared__ int s_last, s_any;
   if (tid == 0) s_fmin = GG_NO_CHANGE;
+  if (SPLIT == 2) {
+    // more than 64 blocks: several passes' worth of nodes per workgroup, one fetch of a coefficient-table entry for all of
+    // them (gg_spec_eval_wide); the grid is sized accordingly (launch_spec_resolve)
+    constexpr int P = GG_WIDE_P(NT);
+    int labs[P], nodes[P];
+    bool lives[P];
+    __syncthreads();   // (s_fmin is initialised before anyone reports)
+    gg_spec_eval_wide<NT, ADJ, P>(x, g.seed, g.site, g.sweep, labs, nodes, lives);
+    if (tid % x.Kp == 0) {
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (lives[p]) {
+          const int n = nodes[p], cn = x.c[x.n0 + n];
+          ap[n] = 0;
+          if (labs[p] != cn) atomicMin(&s_fmin, ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)labs[p]);
+        }
+    }
+  } else {
   int n;
   bool live;
   // the node's current label: fetched now, compared after the evaluation (one dependent round trip less at the end)
@@ -396,6 +414,7 @@ __device__ __forceinline__ void gg_spec_resolve_body(const gg_resolve_args& g, i
     const int cn = cn_pre;
     // (node, old, new) with 6-bit labels, 8-bit for more than 64 blocks (SPLIT == 2)
     if (lab != cn) atomicMin(&s_fmin, ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)lab);
+  }
   }
   if (g.tail_sort)
     for (int n2 = blockIdx.x * 256 + tid; n2 < N; n2 += nfront * 256) g.perm[n2] = g.perm_prev[n2];
