@@ -889,6 +889,161 @@ __global__ __launch_bounds__(256) void k_params(gg_params_args g, gg_ride_args r
   gg_params_body<ADJ, B, JOINT>(g, (int)blockIdx.x, nfront, 0u);
 }
 
+// The parameter step for more than 64 blocks (round 3): K K + 1 workgroups of 256 threads are 10 001 workgroups at 100 blocks,
+// each reducing a pair's table over the ~N / K = 41 nodes of a block - one wavefront's worth.  Here a WAVE owns a pair (four
+// pairs per workgroup, no workgroup barrier anywhere): the same integer tables, the same draws from the same Philox streams as
+// gg_params_body (plain SBM kinds: not the joint model, not the shared covariance), and the last workgroup forms log m for all
+// K <= 256 blocks itself (no k_logm launch behind it).  nfront = ceil(K K / 4) + 1 workgroups.
+template <bool ADJ, int B>
+__device__ __forceinline__ void gg_params_body_w(gg_params_args& g, const int bid, const unsigned nfront) {
+  const int K = g.K, KK = K * K;
+  constexpr int NSI = ADJ ? 0 : B + B * (B + 1) / 2;
+  constexpr int NTAB = ADJ ? 1 : 1 + 2 * NSI;
+  constexpr int NT = ADJ ? 2 : 1 + B + B * (B + 1) / 2;
+  // housekeeping, as gg_params_body's
+  if (g.do_prep && bid == 0 && threadIdx.x == 0) { g.ctl[7] = 0; g.ctl[8] = 0; g.ctl[9] = 0; }
+  if (g.do_prep && g.bar)
+    for (unsigned sl = bid * blockDim.x + threadIdx.x; sl < 512u * 4u; sl += nfront * blockDim.x) g.bar[(size_t)(sl >> 2) * GG_SLOT_PAD + (sl & 3u)] = 0ull;
+  if (g.zero_ptr) {
+    size_t i = (size_t)bid * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)nfront * blockDim.x;
+    for (; i < g.zero_words; i += stride) g.zero_ptr[i] = 0ull;
+  }
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  if (bid == (int)nfront - 1) {
+    // last workgroup: the self parameter (one lane) and log m
+    if (threadIdx.x == 0 && g.do_draw) {
+      if (ADJ) {
+        if (g.ah.special) {
+          gg_stream s;
+          gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_PSELF : GG_SITE_ADJ_PSELF, g.sweep, 0u);
+          *g.p_self = gg_beta(&s, g.ah.tau1 + g.beta * (double)g.ah.d1, g.ah.tau0 + g.beta * (double)g.ah.d0);
+        }
+      } else if (g.wh.special) {
+        long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
+        for (int i = 0; i < NSI; ++i) { hl[2 * i] = g.wh.dS[i] >> 32; hl[2 * i + 1] = g.wh.dS[i] & 0xffffffffll; }
+        double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB], mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
+        gg_unpack_wstats(hl, B, g.wh.shift, s1, s2);
+        gg_stream s;
+        gg_stream_init(&s, g.seed, GG_SITE_W_NIW_SELF, g.sweep, 0u);
+        for (int i = 0; i < B; ++i) s1[i] *= g.beta;
+        for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
+        gg_niw_posterior_draw(&s, &g.wh.niw_self, B, g.beta * (double)g.wh.d1, s1, s2, mo, so);
+        for (int i = 0; i < B; ++i) g.mu_self[i] = mo[i];
+        for (int i = 0; i < B * B; ++i) g.sigma_self[i] = so[i];
+      }
+    }
+    if (g.do_prep && (int)threadIdx.x < K) g.logm[threadIdx.x] = gg_log(g.m[threadIdx.x]);   // (m: drawn by k_draw_m in front of this launch)
+    return;
+  }
+  const int t = bid * 4 + wave;
+  if (t >= KK) return;                 // (wave-uniform)
+  const int a = t / K, b = t % K;
+  long long tabv[NTAB];
+#pragma unroll
+  for (int q = 0; q < NTAB; ++q) tabv[q] = 0;
+  if (g.do_tables) {
+    const int s0 = g.lab_start[a], s1 = g.lab_start[a + 1];
+    for (int r = s0 + lane; r < s1; r += 64) {
+      const int n = g.perm[r] - g.n0;
+      if (n < 0 || n >= g.Nl) continue;   // not an owned node
+      tabv[0] += g.Gcnt0[(size_t)b * g.Np + n];
+      if (!ADJ)
+#pragma unroll
+        for (int s = 0; s < NSI; ++s) {
+          const long long v = g.GS0[((size_t)b * g.Np + n) * NSI + s];
+          tabv[1 + 2 * s] += (v >> 32);
+          tabv[2 + 2 * s] += (v & 0xffffffffll);
+        }
+      if (g.add_diag && a == b && g.dA[n]) {
+        tabv[0] += 1;
+        if (!ADJ) {
+          const int32_t* q = g.dWq + (size_t)n * B;
+          int tt = 0;
+          for (int r1 = 0; r1 < B; ++r1, ++tt) {
+            const long long v = q[r1];
+            tabv[1 + 2 * tt] += (v >> 32);
+            tabv[2 + 2 * tt] += (v & 0xffffffffll);
+          }
+          for (int r1 = 0; r1 < B; ++r1)
+            for (int r2 = r1; r2 < B; ++r2, ++tt) {
+              const long long v = (long long)q[r1] * (long long)q[r2];
+              tabv[1 + 2 * tt] += (v >> 32);
+              tabv[2 + 2 * tt] += (v & 0xffffffffll);
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NTAB; ++q) tabv[q] = gg_wave_sum_ll(tabv[q]);     // (lane 0 holds the sums)
+    if (lane == 0)
+#pragma unroll
+      for (int q = 0; q < NTAB; ++q) g.tab[(size_t)t * NTAB + q] = tabv[q];
+  } else if (g.tables_from_tab) {
+#pragma unroll
+    for (int q = 0; q < NTAB; ++q) tabv[q] = g.tab[(size_t)t * NTAB + q];
+  }
+  if (lane != 0) return;
+  double e[GG_MAXNT];
+  bool bad = false;
+  if (ADJ) {
+    double pv;
+    if (g.do_draw) {
+      const long long n1 = tabv[0];
+      long long pairs = (long long)g.cnt[a] * (long long)g.cnt[b];
+      if (a == b && g.ah.special) pairs -= g.cnt[a];
+      pairs *= (long long)g.ah.ngraphs;
+      const long long n0 = pairs - n1;
+      gg_stream s;
+      gg_stream_init(&s, g.seed, g.ah.bb ? GG_SITE_BB_P : GG_SITE_ADJ_P, g.sweep, (uint32_t)t);
+      pv = gg_beta(&s, g.ah.tau1 + g.beta * (double)n1, g.ah.tau0 + g.beta * (double)n0);
+      g.p[t] = pv;
+    } else {
+      pv = g.p[t];
+    }
+    e[0] = gg_log(pv);
+    e[1] = gg_log(1.0 - pv);
+  } else {
+    double mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
+    if (g.do_draw) {
+      double s1[GG_MAXB], s2[GG_MAXB * GG_MAXB];
+      gg_unpack_wstats(tabv + 1, B, g.wh.shift, s1, s2);
+      gg_stream s;
+      gg_stream_init(&s, g.seed, GG_SITE_W_NIW, g.sweep, (uint32_t)t);
+      for (int i = 0; i < B; ++i) s1[i] *= g.beta;
+      for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
+      gg_niw_posterior_draw(&s, &g.wh.niw, B, g.beta * (double)tabv[0], s1, s2, mo, so);
+      for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
+      for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
+    } else {
+      for (int i = 0; i < B; ++i) mo[i] = g.mu[(size_t)t * B + i];
+      for (int i = 0; i < B * B; ++i) so[i] = g.sigma[(size_t)t * B * B + i];
+    }
+    if (g.do_prep && gg_gauss_table(mo, so, B, e)) {
+      bad = true;
+      for (int i = 0; i < NT; ++i) e[i] = gg_nan();
+    }
+    if (bad) atomicOr(&g.ctl[3], 1);
+  }
+  if (g.do_prep)
+    for (int i = 0; i < NT; ++i) {
+      g.T[(size_t)t * NT + i] = e[i];
+      g.Tout[((size_t)b * NT + i) * g.Kp + a] = e[i];
+      g.Tin[((size_t)a * NT + i) * g.Kp + b] = e[i];
+    }
+}
+
+template <bool ADJ, int B, int RIDE = 0>   // RIDE as k_params'
+__global__ __launch_bounds__(256) void k_params_w(gg_params_args g, gg_ride_args ride = gg_ride_args()) {
+  if (g.ctl[4]) return;
+  if (RIDE && (int)blockIdx.x >= ride.front) {
+    gg_ride<ADJ, B, RIDE == 2>(ride);
+    return;
+  }
+  const unsigned nfront = RIDE ? (unsigned)ride.front : gridDim.x;
+  gg_params_body_w<ADJ, B>(g, (int)blockIdx.x, nfront);
+}
+
 #define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index) - for the host; the device
                              //                reads gg_shard_state
 #define GG_RS_ROUNDS 14      //                rounds of the sharded scan that did something

@@ -857,7 +857,11 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
     m->m_pending = false;
   }
   gg_params_args g = fill_params_args(m, d, buf, tables, draw, prep, zero_buf, sweep, pidx);
-  const int nwg = m->K * m->K + 1;
+  // more than 64 blocks (plain SBM kinds): a wave per block pair, four pairs per workgroup, log m in the same launch
+  static int pw_on = -1;
+  if (pw_on < 0) { const char* e = getenv("GG_PARAMS_W"); pw_on = e ? atoi(e) : 1; }
+  const bool wave_pairs = pw_on && m->wide && !m->joint && !g.shared;
+  const int nwg = wave_pairs ? (m->K * m->K + 3) / 4 + 1 : m->K * m->K + 1;
   if (ride_next >= 0) {
     int nr, ntl;
     double bytes;
@@ -867,7 +871,10 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
     if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
 #define PRM(ADJV, BV)                                                                          \
   do {                                                                                         \
-    if (ntl) k_params<ADJV, BV, 2><<<nwg + nr, 256, 0, m->stream>>>(g, r);                     \
+    if (wave_pairs) {                                                                          \
+      if (ntl) k_params_w<ADJV, BV, 2><<<nwg + nr, 256, 0, m->stream>>>(g, r);                 \
+      else k_params_w<ADJV, BV, 1><<<nwg + nr, 256, 0, m->stream>>>(g, r);                     \
+    } else if (ntl) k_params<ADJV, BV, 2><<<nwg + nr, 256, 0, m->stream>>>(g, r);              \
     else k_params<ADJV, BV, 1><<<nwg + nr, 256, 0, m->stream>>>(g, r);                         \
   } while (0)
     if (m->is_adj) PRM(true, 1);
@@ -878,6 +885,12 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
 #undef PRM
     if (timed) { m->ev_bytes.push_back(bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
     m->zeroed[ride_next] = false;
+  } else if (wave_pairs) {
+    if (m->is_adj) k_params_w<true, 1><<<nwg, 256, 0, m->stream>>>(g);
+    else if (m->B == 1) k_params_w<false, 1><<<nwg, 256, 0, m->stream>>>(g);
+    else if (m->B == 2) k_params_w<false, 2><<<nwg, 256, 0, m->stream>>>(g);
+    else if (m->B == 3) k_params_w<false, 3><<<nwg, 256, 0, m->stream>>>(g);
+    else k_params_w<false, 4><<<nwg, 256, 0, m->stream>>>(g);
   } else if (m->is_adj) k_params<true, 1><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->joint && m->B == 1) k_params<false, 1, 0, true><<<nwg, 256, 0, m->stream>>>(g);
   else if (m->joint) k_params<false, 2, 0, true><<<nwg, 256, 0, m->stream>>>(g);
@@ -886,7 +899,7 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
   else if (m->B == 3) k_params<false, 3><<<nwg, 256, 0, m->stream>>>(g);
   else k_params<false, 4><<<nwg, 256, 0, m->stream>>>(g);
   GG_HIP(hipGetLastError());
-  if (m->wide && prep) {
+  if (m->wide && prep && !wave_pairs) {     // (k_params_w forms log m itself)
     k_logm<<<1, 256, 0, m->stream>>>(m->m, m->logm, m->K, m->rs);
     GG_HIP(hipGetLastError());
   }

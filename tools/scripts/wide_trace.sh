@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d /tmp/wide_tr -- python3 $R/tools/wide_probe.py ${1:-4096} ${2:-100} 100 > $R/gpurun_out/wide_probe.out 2> $R/gpurun_out/wide_tr.err
+rocprofv3 --kernel-trace --output-format csv -d /tmp/wide_tr -- python3 $R/tools/wide_probe.py ${1:-4096} ${2:-100} ${3:-400} > $R/gpurun_out/wide_probe.out 2> $R/gpurun_out/wide_tr.err
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("/tmp/wide_tr/**/*kernel_trace.csv", recursive=True)[0]
