@@ -1517,7 +1517,13 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
 // (2 K NT Kp doubles: 600 KB at 100 blocks) from L2.  Here a workgroup evaluates GG_WIDE_P(NT) passes' worth of nodes at once:
 // lane (i, k) keeps the chains of nodes i, i + per, i + 2 per, ... and every table entry it fetches serves all of them.
 // Same chains per node, same order, same bits as gg_spec_eval.  Nodes of the workgroup: [blockIdx.x per P, + per P).
-#define GG_WIDE_P(NT) ((NT) <= 3 ? 4 : ((NT) <= 6 ? 2 : 1))
+#ifndef GG_WIDE_P3
+#define GG_WIDE_P3 4
+#endif
+#ifndef GG_WIDE_UJ3
+#define GG_WIDE_UJ3 4
+#endif
+#define GG_WIDE_P(NT) ((NT) <= 3 ? GG_WIDE_P3 : ((NT) <= 6 ? 2 : 1))
 template <int NT, bool ADJ, int P>
 __device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t seed, uint32_t site, uint32_t sweep, int* labs,
                                                   int* nodes, bool* lives) {
@@ -1525,7 +1531,9 @@ __device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t
   extern __shared__ __align__(16) unsigned char s_spec[];
   const int K = x.K, Kp = x.Kp;
   const int per = 256 / Kp, nwg = per * P;
-  double* s_st = reinterpret_cast<double*>(s_spec);                       // [dir][j][node of the workgroup][NT]
+  // statistics [dir][j][t][i0][p] (node of the workgroup = p per + i0): the P nodes a lane serves are one contiguous read per
+  // (j, t) - the reads are wave-uniform broadcasts, and their NUMBER is what the LDS pipe charges for
+  double* s_st = reinterpret_cast<double*>(s_spec);
   double* s_cat = s_st + (size_t)2 * K * nwg * NT;                       // the cross-wave categorical's scratch
   const int n0 = (int)blockIdx.x * nwg;
   const int tid = threadIdx.x;
@@ -1535,17 +1543,18 @@ __device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t
     const int n = (n0 + i < x.N) ? n0 + i : x.N - 1;
     const size_t gd = (size_t)d * K * x.Np + (size_t)j * x.Np + n;        // direction 1 follows direction 0 in the buffer
     const int gc = x.Gcnt[0][gd];
-    double* dst = s_st + ((size_t)(d * K + j) * nwg + i) * NT;
+    double* dst = s_st + (((size_t)(d * K + j) * NT) * per + (i % per)) * P + i / per;     // + t * per * P
+    const size_t ts = (size_t)per * P;                                                        // stride of t
     if (ADJ) {
       const int cx = (x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0);
       dst[0] = (double)gc;
-      dst[1] = (double)(cx - gc);
+      dst[ts] = (double)(cx - gc);
     } else {
       constexpr int B = gg_tB(NT);
       dst[0] = (double)gc;
 #pragma unroll
-      for (int s = 0; s < NSI; ++s) dst[1 + s] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
-      if (gg_tJ(NT)) dst[NT - 1] = (double)((x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0));
+      for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
+      if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)((x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0));
     }
   }
   __syncthreads();
@@ -1556,18 +1565,22 @@ __device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc_o[p][t] = 0.0; acc_i[p][t] = 0.0; }
   if (k < K) {
-    constexpr int UJ = NT <= 3 ? 4 : 2;
+    constexpr int UJ = NT <= 3 ? GG_WIDE_UJ3 : 2;
     auto step = [&](int j, const double* to, const double* ti) {
+      const double* a = s_st + (((size_t)(0 * K + j) * NT) * per + i0) * P;
+      const double* b = s_st + (((size_t)(1 * K + j) * NT) * per + i0) * P;
+      double av[NT][P], bv[NT][P];
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const double* a = s_st + ((size_t)(0 * K + j) * nwg + p * per + i0) * NT;
-        const double* b = s_st + ((size_t)(1 * K + j) * nwg + p * per + i0) * NT;
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < P; ++p) { av[t][p] = a[(size_t)t * per * P + p]; bv[t][p] = b[(size_t)t * per * P + p]; }
+#pragma unroll
+      for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          acc_o[p][t] = gg_fma(to[t], a[t], acc_o[p][t]);
-          acc_i[p][t] = gg_fma(ti[t], b[t], acc_i[p][t]);
+          acc_o[p][t] = gg_fma(to[t], av[t][p], acc_o[p][t]);
+          acc_i[p][t] = gg_fma(ti[t], bv[t][p], acc_i[p][t]);
         }
-      }
     };
     int j = 0;
     for (; j + UJ <= K; j += UJ) {
