@@ -1524,6 +1524,7 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
 #define GG_WIDE_UJ3 4
 #endif
 #define GG_WIDE_P(NT) ((NT) <= 3 ? GG_WIDE_P3 : ((NT) <= 6 ? 2 : 1))
+#define GG_SCAN_WIDE_P(NT) ((NT) <= 3 ? 2 : 1)   // the resident scan's (k_scan, MODE 2): both models' grids share a CU's LDS
 template <int NT, bool ADJ, int P>
 __device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t seed, uint32_t site, uint32_t sweep, int* labs,
                                                   int* nodes, bool* lives) {

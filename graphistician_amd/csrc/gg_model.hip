@@ -222,8 +222,11 @@ static size_t lds_round(const gg_model* m, int* stage_out) {
   if (stage_out) *stage_out = stage;
   return lds;
 }
+// nodes of a group of the resident scan (k_scan): 256 / Kp, twice that for more than 64 blocks with NT <= 3
+static int scan_nodes_per_wg(const gg_model* m) { return (256 / m->Kp) * (m->Kp > 64 ? GG_SCAN_WIDE_P(m->NT) : 1); }
+
 static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
-  const int K = m->K, per = 256 / m->Kp;
+  const int K = m->K, per = scan_nodes_per_wg(m);
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
                (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)lcap * 3 * sizeof(int);
   // deviations, the round's surprises, per-node block sizes, scratch, one hypothesis per node of a band
@@ -1331,7 +1334,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   // sweep, never in a steady one - lets a third workgroup onto the CU)
   if (ride_buf >= 0 && a.Lcap > 256) a.Lcap = 256;
   { const char* el = getenv("GG_SCAN_LCAP"); if (el && atoi(el) >= 2 && atoi(el) < a.Lcap) a.Lcap = atoi(el); }   // (tests: flush the list often)
-  const int per = 256 / m->Kp;
+  const int per = scan_nodes_per_wg(m);
   const int ngroups = (m->Nl + per - 1) / per;
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
   int stage;

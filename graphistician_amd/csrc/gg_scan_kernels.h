@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   const long long t_kernel0 = g.dbg ? wall_clock64() : 0;
   if (!a.resume && g.rs[4]) return;   // an earlier scan of this pipeline is unfinished (uniform: set by a previous launch)
   const int N = x.N, K = x.K, Kp = x.Kp, Np = x.Np;
-  const int per = 256 / Kp;
+  // nodes per group: one pass of 256 / Kp nodes; more than 64 blocks with NT <= 3: TWO passes' worth (GG_SCAN_WIDE_P) - a lane
+  // keeps the chains of two nodes and a coefficient-table entry fetched from L2 serves both (the quiet scan's
+  // gg_spec_eval_wide takes four; here both models' grids must fit a CU's LDS together).  Half the bands, half the rounds.
+  constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : 1;
+  const int per = (256 / Kp) * PW;
   const int tid = threadIdx.x, b = blockIdx.x, G = a.G;
   const int ngroups = (N + per - 1) / per;
   const int stage_tables = g.stage_tables;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     __syncthreads();
     if (has) {
       // the group's statistics as the bulk pass left them, plus every change accepted so far
-      if (band == band_first) {
+      if (!WIDE && band == band_first) {     // (more than 64 blocks: a group's 2 K per entries are more than two per thread)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {        // prefetched at kernel start
           const int idx = tid + u * 256;
@@ -368,8 +372,13 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     for (int idx = tid; idx < per * K; idx += 256) s_cntn[idx] = s_cnt[idx % K];
     // the node's uniform is a function of (seed, site, sweep, node): drawn once per band, not once per round (ten Philox
     // rounds are a tenth of a round's evaluation)
-    const double u_band = gg_uniform_at(g.seed, g.site, g.sweep,
-                                        (uint32_t)(x.n0 + ((has && n0 + tid / Kp < N) ? n0 + tid / Kp : N - 1)));
+    double u_bandp[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+      const int nb = n0 + (tid / Kp) * PW + p;
+      u_bandp[p] = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + ((has && nb < N) ? nb : N - 1)));
+    }
+    const double u_band = u_bandp[0];
     // ---- iterate until the band holds no further surprise
     // Spec-order doubles of the statistics: all of them when the band starts and after a round with several surprises;
     // after a single one (f: ca -> cb) only the entries of blocks ca and cb can differ - edges to / from f moved between
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
       const int i = idx % per, j = (idx / per) % K;
       const int gc = s_gc[idx];
       int ts;
-      double* dst = s_st + gg_st_slot(split, idx / per, i, per, NT, &ts);
+      double* dst = s_st + gg_st_slot(split || WIDE, idx / per, i, per, NT, &ts);   // (WIDE: [dir][j][t][node] - a lane's nodes are one read)
       if (ADJ) {
         const int cx = s_cntn[i * K + j] - (s_c[i] == j ? 1 : 0);
         dst[0] = (double)gc;
@@ -409,7 +418,75 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
       __syncthreads();
       const long long ca = g.dbg ? wall_clock64() : 0;
       long long cb = 0;
-      {
+      if (WIDE) {
+        // lane (i0, k) keeps the chains of nodes i0 PW + p: one fetch of a coefficient-table entry (L2: the tables are never
+        // staged at this size) for all of them; statistics [dir][j][t][node]: the lane's nodes are one LDS read per (j, t)
+        const int i0 = tid / Kp, k = tid % Kp;
+        double acc_o[PW][NT], acc_i[PW][NT];
+#pragma unroll
+        for (int p = 0; p < PW; ++p)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) { acc_o[p][t] = 0.0; acc_i[p][t] = 0.0; }
+        if (k < K) {
+          constexpr int UJ = NT <= 3 ? 4 : 2;
+          auto step = [&](int j, const double* to, const double* ti) {
+            const double* pa = s_st + ((size_t)(0 * K + j) * NT) * per + i0 * PW;
+            const double* pb = s_st + ((size_t)(1 * K + j) * NT) * per + i0 * PW;
+            double av[NT][PW], bv[NT][PW];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int p = 0; p < PW; ++p) { av[t][p] = pa[(size_t)t * per + p]; bv[t][p] = pb[(size_t)t * per + p]; }
+#pragma unroll
+            for (int p = 0; p < PW; ++p)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                acc_o[p][t] = gg_fma(to[t], av[t][p], acc_o[p][t]);
+                acc_i[p][t] = gg_fma(ti[t], bv[t][p], acc_i[p][t]);
+              }
+          };
+          int j = 0;
+          for (; j + UJ <= K; j += UJ) {
+            double to[UJ][NT], ti[UJ][NT];
+#pragma unroll
+            for (int u = 0; u < UJ; ++u)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                to[u][t] = x.Tout[((size_t)(j + u) * NT + t) * Kp + k];
+                ti[u][t] = x.Tin[((size_t)(j + u) * NT + t) * Kp + k];
+              }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < UJ; ++u) step(j + u, to[u], ti[u]);
+          }
+          for (; j < K; ++j) {
+            double to[NT], ti[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { to[t] = x.Tout[((size_t)j * NT + t) * Kp + k]; ti[t] = x.Tin[((size_t)j * NT + t) * Kp + k]; }
+            step(j, to, ti);
+          }
+        }
+        if (g.dbg) cb = wall_clock64();
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+          const int i = i0 * PW + p;
+          const int n = n0 + i;
+          const bool live = has && n < N && n >= pos;
+          const int nn = (has && n < N) ? n : N - 1;
+          const double lp = gg_node_lp_finish<NT, ADJ>(x, nn, k, acc_o[p], acc_i[p], &logm_k);
+          const int lab = gg_group_categorical_wide(lp, k, K, Kp, u_bandp[p], s_cat);
+          if (k == 0) {
+            unsigned long long dv = GG_SLOT_NONE;
+            if (live) {
+              const int cn = s_c[i];
+              const int h = s_H[n - band0];
+              const int expct = h != 0xffff ? (h & 0xff) : cn;
+              if (lab != expct) dv = ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)lab;
+            }
+            s_dev[i] = dv;
+          }
+        }
+      } else {
         const int i = tid / Kp, k = tid % Kp;
         const int n = n0 + i;
         const bool live = has && n < N && n >= pos;
@@ -426,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
         else if (stage_tables == 2) lp = gg_node_lp_core_t1<NT, ADJ>(x, nn, k, ld, s_T, RS, &logm_k);
         else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin, &logm_k);
         if (g.dbg) cb = wall_clock64();
-        const int lab = WIDE ? gg_group_categorical_wide(lp, k, K, Kp, u_band, s_cat) : gg_group_categorical(lp, k, K, Kp, u_band);
+        const int lab = gg_group_categorical(lp, k, K, Kp, u_band);
         if (k == 0) {
           // what the hypotheses say about this node: it moves to h's new label, or it stays
           unsigned long long dv = GG_SLOT_NONE;
