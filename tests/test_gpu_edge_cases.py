@@ -385,6 +385,45 @@ def test_more_than_64_blocks_fall_back_to_restart_rounds(abi, monkeypatch, capfd
 
 
 @pytest.mark.gpu
+def test_timeout_behind_a_flush_is_a_clean_error(abi, monkeypatch):
+    """VERDICT r2 "smaller" (ADVICE r1): a resident scan whose change list overflowed (flushed into the statistics chip-wide) and
+    whose grid then cannot assemble has no consistent stalled scan to hand to the restart rounds - the band that was in LDS at
+    the flush is not in G any more.  That is reported as an error (GG_ERR_HIP, "flush"), never resumed from stale statistics
+    and never a hang; the library stays usable.  Forced here with a 2-entry list and exchanges that give up after one poll;
+    when the workgroups do meet in time the chain must be the oracle's."""
+    monkeypatch.setenv("GG_SCAN", "1")
+    monkeypatch.setenv("GG_SCAN_LCAP", "2")
+    N, K = 600, 8
+    A, W, _ = planted_sbm(N, K, seed=29)
+    d = abi.DeviceData(A, W)
+    outcomes = []
+    for trial, spin in enumerate((1, 2, 3, 5, 8, 13, 21, 34)):      # (from "never meets" to "mostly meets": timeouts at any point of a scan)
+        monkeypatch.setenv("GG_SCAN_SPIN", str(spin))
+        sa = AdjState(N, K, seed=40 + trial)
+        adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=90 + trial, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+        adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
+        adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
+        try:
+            adj.resample(d, 2)
+        except abi.EngineError as exc:
+            assert "flush" in str(exc) or "timed out" in str(exc), str(exc)
+            outcomes.append("error")
+            continue
+        ps = sa.p_self
+        for s in range(2):
+            ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 90 + trial, s)
+        assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c)
+        outcomes.append("exact")
+    # the library is usable afterwards: the plain forms on the same data
+    print("outcomes by spin limit:", outcomes)
+    for k in ("GG_SCAN", "GG_SCAN_LCAP", "GG_SCAN_SPIN"):
+        monkeypatch.delenv(k)
+    sa = AdjState(N, K, seed=44)
+    run_adj(abi, A, sa, 95, 2)      # (asserts the chain against the oracle itself)
+    assert outcomes and all(o in ("error", "exact") for o in outcomes)
+
+
+@pytest.mark.gpu
 def test_adaptive_scan_form_is_the_same_chain(abi, monkeypatch):
     """Default (GG_SCAN unset): the engine runs the scan as k_scan while the chain keeps changing labels and as
     k_speculate + k_resolve after a run of quiet sweeps (4 at first), deciding batch by batch.  A strongly planted network burns in within a
