@@ -406,8 +406,12 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     { const char* esp = getenv("GG_SCAN_SPIN"); m->scan_spin = esp && atoi(esp) > 0 ? atoi(esp) : GG_BAR_SPIN_LIMIT; }
     // The ahead form (enqueue_sweep_ahead): while the chain is quiet, the next sweep's bulk pass rides in this sweep's
     // k_params and k_spec_resolve launches.  GG_AHEAD=0 keeps every sweep in the serial form (bulk -> params -> scan).
-{ const char* er2 = getenv("GG_SCAN_RIDE"); m->scan_ride = (m->wide || m->joint || m->sharded) ? 0 : (er2 ? atoi(er2) : 0); m->ride_chg_seen = 0; m->chg_per_sweep = -1.0; }
-        const char* ea = getenv("GG_AHEAD");
+    {
+      const char* er2 = getenv("GG_SCAN_RIDE");
+      m->scan_ride = (m->wide || m->joint || m->sharded) ? 0 : (er2 ? atoi(er2) : 0);
+      m->ride_chg_seen = 0; m->chg_per_sweep = -1.0;
+    }
+    const char* ea = getenv("GG_AHEAD");
     m->can_ahead = can_scan && m->scan_pref < 0 && !(ea && atoi(ea) == 0) && !m->joint;   // (the joint kind runs the serial form)
     const char* ers = getenv("GG_RIDE_SPLIT");
     m->ride_split = ers ? atof(ers) : -1.0;   // (default chosen below, once the scan forms of this shape are known)
