@@ -1289,7 +1289,10 @@ __device__ __forceinline__ size_t gg_st_slot(bool split, int dj /* d * K + j */,
 // workgroup instead of once per node; the chains meet in LDS and wave i combines those of node i in the
 // order of gg_block_lp.  Same chains, same order, same bits.  s_st: [dir][j][NT][4] (gg_st_slot with split = true),
 // s_acc: [4][2 NT][64].
-template <int NT, bool ADJ>
+// PER: nodes per (j, t) of the statistics' split layout [dir][j][t][PER] (4, or 8 when a group of the resident scan holds two
+// passes' worth: the caller then hands in s_st + 4 p for pass p; a compile-time stride - as a run-time one it cost the chains
+// a quarter more).
+template <int NT, bool ADJ, int PER = 4>
 __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const double* s_st, double* s_acc, int n,
                                                const double* T1 = nullptr, int RS = 0) {
   constexpr int NCH = 2 * NT;
@@ -1345,7 +1348,7 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
         if (ch < NCH) {
           const int d = ch / NT, t = ch % NT;
           // split layout of the statistics: [dir][j][t][node] - the four nodes of a (j, t) are one 32-byte read
-          const double* sb = s_st + ((size_t)d * K * NT + t) * 4;
+          const double* sb = s_st + ((size_t)d * K * NT + t) * PER;
           // the four nodes' statistics of UB steps are read before the first of them is used (left to itself the compiler
           // reads each step's 32 bytes right in front of its four fma and waits for them: one LDS latency per step)
           constexpr int UB = UJ < 4 ? UJ : 4;
@@ -1355,7 +1358,7 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
 #pragma unroll
             for (int b2 = 0; b2 < UB; ++b2) {
               const int jj = (FULL || j + u0 + b2 < K) ? j + u0 + b2 : K - 1;
-              const double* sp = sb + (size_t)jj * NT * 4;
+              const double* sp = sb + (size_t)jj * NT * PER;
 #pragma unroll
               for (int i = 0; i < 4; ++i) spv[b2][i] = sp[i];
             }
@@ -1525,6 +1528,7 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
 #endif
 #define GG_WIDE_P(NT) ((NT) <= 3 ? GG_WIDE_P3 : ((NT) <= 6 ? 2 : 1))
 #define GG_SCAN_WIDE_P(NT) ((NT) <= 3 ? 2 : 1)   // the resident scan's (k_scan, MODE 2): both models' grids share a CU's LDS
+#define GG_SCAN_SPLIT_P(NT) ((NT) <= 3 ? 2 : 1)  // ... and for 33..64 blocks (MODE 1): two passes of four nodes per group
 template <int NT, bool ADJ, int P>
 __device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t seed, uint32_t site, uint32_t sweep, int* labs,
                                                   int* nodes, bool* lives) {

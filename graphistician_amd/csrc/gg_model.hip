@@ -223,7 +223,10 @@ static size_t lds_round(const gg_model* m, int* stage_out) {
   return lds;
 }
 // nodes of a group of the resident scan (k_scan): 256 / Kp, twice that for more than 64 blocks with NT <= 3
-static int scan_nodes_per_wg(const gg_model* m) { return (256 / m->Kp) * (m->Kp > 64 ? GG_SCAN_WIDE_P(m->NT) : 1); }
+// (and for 33..64 blocks: Kp = 64 never has both table layouts in LDS, so it always runs the split form, MODE 1)
+static int scan_nodes_per_wg(const gg_model* m) {
+  return (256 / m->Kp) * (m->Kp > 64 ? GG_SCAN_WIDE_P(m->NT) : (m->Kp == 64 ? GG_SCAN_SPLIT_P(m->NT) : 1));
+}
 
 static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
   const int K = m->K, per = scan_nodes_per_wg(m);

@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   // nodes per group: one pass of 256 / Kp nodes; more than 64 blocks with NT <= 3: TWO passes' worth (GG_SCAN_WIDE_P) - a lane
   // keeps the chains of two nodes and a coefficient-table entry fetched from L2 serves both (the quiet scan's
   // gg_spec_eval_wide takes four; here both models' grids must fit a CU's LDS together).  Half the bands, half the rounds.
-  constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : 1;
+  // 33..64 blocks (MODE 1), NT <= 3: two passes of four nodes (gg_lp_split4 per pass; the evaluation doubles, the exchanges
+  // and the band starts do not: N=65536, K=64: 128 rounds of 9.5 + 7.2 us became 64 of 19 + 7.2).
+  constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : (MODE == 1 ? GG_SCAN_SPLIT_P(NT) : 1);
   const int per = (256 / Kp) * PW;
   const int tid = threadIdx.x, b = blockIdx.x, G = a.G;
   const int ngroups = (N + per - 1) / per;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     __syncthreads();
     if (has) {
       // the group's statistics as the bulk pass left them, plus every change accepted so far
-      if (!WIDE && band == band_first) {     // (more than 64 blocks: a group's 2 K per entries are more than two per thread)
+      if (PW == 1 && band == band_first) {   // (two passes' worth per group: its 2 K per entries are more than two per thread)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {        // prefetched at kernel start
           const int idx = tid + u * 256;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     double u_bandp[PW];
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
-      const int nb = n0 + (tid / Kp) * PW + p;
+      const int nb = n0 + (MODE == 1 ? 4 * p + (tid >> 6) : (tid / Kp) * PW + p);
       u_bandp[p] = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + ((has && nb < N) ? nb : N - 1)));
     }
     const double u_band = u_bandp[0];
@@ -475,6 +477,30 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           const int nn = (has && n < N) ? n : N - 1;
           const double lp = gg_node_lp_finish<NT, ADJ>(x, nn, k, acc_o[p], acc_i[p], &logm_k);
           const int lab = gg_group_categorical_wide(lp, k, K, Kp, u_bandp[p], s_cat);
+          if (k == 0) {
+            unsigned long long dv = GG_SLOT_NONE;
+            if (live) {
+              const int cn = s_c[i];
+              const int h = s_H[n - band0];
+              const int expct = h != 0xffff ? (h & 0xff) : cn;
+              if (lab != expct) dv = ((unsigned long long)(unsigned)n << (2 * LB)) | ((unsigned long long)(unsigned)cn << LB) | (unsigned)lab;
+            }
+            s_dev[i] = dv;
+          }
+        }
+      } else if (MODE == 1 && PW > 1) {
+        // two passes of four nodes: wave w evaluates node 4 p + w in pass p (the split chains of a pass meet in s_acc)
+        const int w4 = tid >> 6, k = tid & 63;
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+          if (p) __syncthreads();      // (the previous pass's meeting place has been read)
+          const int i = 4 * p + w4;
+          const int n = n0 + i;
+          const bool live = has && n < N && n >= pos;
+          const int nn = (has && n < N) ? n : N - 1;
+          const double lp = gg_lp_split4<NT, ADJ, 4 * PW>(x, s_st + 4 * p, s_acc, nn, stage_tables == 2 ? s_T : nullptr, RS);
+          if (g.dbg && p == PW - 1) cb = wall_clock64();
+          const int lab = gg_group_categorical(lp, k, K, Kp, u_bandp[p]);
           if (k == 0) {
             unsigned long long dv = GG_SLOT_NONE;
             if (live) {
