@@ -1515,6 +1515,56 @@ __device__ __forceinline__ int gg_spec_eval(const gg_node_ctx& x, int n_begin, u
   return gg_group_categorical(lp, k, K, Kp, u);
 }
 
+// 33..64 blocks, the sharded scan's evaluation (k_shard_eval): EIGHT nodes per workgroup in two passes of four - the statistics of
+// all eight are staged once ([dir][j][t][8]), gg_lp_split4 runs per pass on its half; the launch has half the workgroups and
+// (the table entries of a pass still come from L2 per pass) the staging, the uniform and the launch's fixed part are paid once
+// for eight nodes.  Same chains, same bits.  Nodes of the workgroup: n_begin + 8 blockIdx.x + 4 p + wave.
+template <int NT, bool ADJ>
+__device__ __forceinline__ void gg_spec_eval_split8(const gg_node_ctx& x, int n_begin, uint64_t seed, uint32_t site, uint32_t sweep,
+                                                    int* labs, int* nodes, bool* lives) {
+  constexpr int NSI = ADJ ? 0 : gg_tNSI(NT);
+  extern __shared__ __align__(16) unsigned char s_spec[];
+  const int K = x.K;
+  double* s_st = reinterpret_cast<double*>(s_spec);
+  double* s_acc = s_st + (size_t)2 * K * 8 * NT;      // the split chains of a pass meet here
+  const int n0 = n_begin + (int)blockIdx.x * 8;
+  const int tid = threadIdx.x;
+  const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  for (int idx = tid; idx < 2 * K * 8; idx += 256) {
+    const int i = idx % 8, j = (idx / 8) % K, d = idx / (8 * K);
+    const int n = (n0 + i < x.N) ? n0 + i : x.N - 1;
+    const size_t gd = (size_t)d * K * x.Np + (size_t)j * x.Np + n;
+    const int gc = x.Gcnt[0][gd];
+    int ts;
+    double* dst = s_st + gg_st_slot(true, idx / 8, i, 8, NT, &ts);
+    if (ADJ) {
+      const int cx = (x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0);
+      dst[0] = (double)gc;
+      dst[ts] = (double)(cx - gc);
+    } else {
+      constexpr int B = gg_tB(NT);
+      dst[0] = (double)gc;
+#pragma unroll
+      for (int s = 0; s < NSI; ++s) dst[(1 + s) * ts] = (double)x.GS[0][gd * NSI + s] * (s < B ? sc1 : sc2);
+      if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)((x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0));
+    }
+  }
+  __syncthreads();
+  const int w = tid >> 6, k = tid & 63;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (p) __syncthreads();       // (the previous pass's meeting place has been read)
+    const int n = n0 + 4 * p + w;
+    const bool live = n < x.N;
+    const int nn = live ? n : x.N - 1;
+    const double lp = gg_lp_split4<NT, ADJ, 8>(x, s_st + 4 * p, s_acc, nn);
+    const double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
+    labs[p] = gg_group_categorical(lp, k, K, 64, u);
+    nodes[p] = n;
+    lives[p] = live;
+  }
+}
+
 // More than 64 blocks, the quiet scan's evaluation (k_spec_resolve / k_spec_resolve_epi, SPLIT == 2): a node's lanes span two or
 // four wavefronts, so a workgroup holds only 256 / Kp = 2 or 1 nodes per pass - and every pass reads both coefficient tables
 // (2 K NT Kp doubles: 600 KB at 100 blocks) from L2.  Here a workgroup evaluates GG_WIDE_P(NT) passes' worth of nodes at once:
@@ -1727,15 +1777,27 @@ __global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, uint64_t seed
     lo = lo < 0 ? 0 : lo;
     hi = hi > x.N ? x.N : hi;
   }
-  if (hi > lo && lo + (int)blockIdx.x * per < hi) {        // (uniform over the workgroup)
+  // (an atomic exchange at agent scope publishes a decision: performed at the memory side, and its return value holds the wave
+  // until it has been - the decision is out before the workgroup's ticket is drawn.  No fence: a release fence per workgroup
+  // writes back every dirty line of the XCD's L2, megabytes of statistics - measured at +115 us per round)
+  if (x.Kp == 64 && NT <= 3) {
+    if (hi > lo && lo + (int)blockIdx.x * 8 < hi) {        // eight nodes per workgroup, two passes of four
+      int labs[2], nodes[2];
+      bool lives[2];
+      gg_spec_eval_split8<NT, ADJ>(x, lo, seed, site, sweep, labs, nodes, lives);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        if (lives[p] && nodes[p] < hi && (t & 63) == 0) {
+          const int old = atomicExch(&cand[nodes[p]], labs[p]);
+          asm volatile("" ::"v"(old) : "memory");
+        }
+    }
+  } else if (hi > lo && lo + (int)blockIdx.x * per < hi) {        // (uniform over the workgroup)
     int n;
     bool live;
     const int lab = x.Kp > 64 ? gg_spec_eval<NT, ADJ, 0, 2>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live)
                               : gg_spec_eval<NT, ADJ>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live);
     if (live && n < hi && t % x.Kp == 0) {
-      // (an atomic exchange at agent scope: performed at the memory side, and its return value holds the wave until it has
-      // been - the decision is out before the workgroup's ticket is drawn.  No fence: a release fence per workgroup writes
-      // back every dirty line of the XCD's L2, megabytes of statistics - measured at +115 us per round)
       const int old = atomicExch(&cand[n], lab);
       asm volatile("" ::"v"(old) : "memory");
     }

@@ -2471,7 +2471,8 @@ static int shard_global_tables(gg_model* m, const gg_data* d, gg_comm* c, int di
 static int launch_shard_eval(gg_model* m, const gg_data* d, int buf, int round) {
   gg_node_ctx x = node_ctx(m, d, buf);
   x.cntn = m->sh_cntn;   // block sizes as each own node sees them (hypotheses at earlier positions included)
-  const int K = m->K, per = 256 / m->Kp;
+  // (33..64 blocks, NT <= 3: eight nodes per workgroup in two passes of four - gg_spec_eval_split8)
+  const int K = m->K, per = (m->Kp == 64 && m->NT <= 3) ? 8 : 256 / m->Kp;
   const int count = m->Nl < GG_SHARD_WINDOW ? m->Nl : GG_SHARD_WINDOW;
   int nb = (count + per - 1) / per;
   if (nb < 1) nb = 1;                    // (a rank without nodes still reports "no surprise")
