@@ -1298,7 +1298,10 @@ static int fetch_ctl(gg_model* m) {
     const volatile double* rec = m->h_epi;
     for (unsigned spin = 1;; ++spin) {
       if ((unsigned)rec[2] == m->epi_tag) break;
-      if ((spin & 4095u) == 0u && hipStreamQuery(m->stream) != hipErrorNotReady) break;   // (drained, or failed: read_ctl reports it)
+      if ((spin & 4095u) == 0u) {
+        if (hipStreamQuery(m->stream) != hipErrorNotReady) break;   // (drained, or failed: read_ctl reports it)
+        if (spin > (1u << 16)) std::this_thread::yield();           // (a long batch: do not hold the core against other threads)
+      }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     if ((unsigned)m->h_epi[2] == m->epi_tag) {
