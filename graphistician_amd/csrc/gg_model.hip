@@ -135,7 +135,8 @@ struct gg_model {
   bool epi_hit;                 // the control block just fetched came from the epilogue's record
   unsigned epi_tag;             // tag of the epilogue launch the current batch ends with (0: none - the control block is copied)
   bool epi_ll;                  // ... and it evaluates the log-likelihood
-  bool ll_asked; int calls_since_ll;   // the caller's pattern: log_likelihood right after resample (then the epilogue computes it)
+  bool ll_asked; int calls_since_ll;   // the caller's pattern: a log_likelihood every ll_period resample calls (the epilogue of
+  int ll_period;                       // the call it is expected behind computes it: 1 = the demo loop, 2 = the AIS loop, ...)
   bool ll_from_cache;           // the pending log_likelihood call is answered from ll_val
   bool ll_cached; double ll_val; bool ll_bad; uint64_t ll_uid;   // the log-likelihood of the state as it is, from the last epilogue
   int32_t done_base;            // control word 5 (scans completed, a running count on the device) when the current batch was enqueued
@@ -1123,7 +1124,7 @@ static bool epi_ok(const gg_model* m) {
 static int launch_spec_resolve_epi(gg_model* m, const gg_data* d, int buf, int nbuf, uint32_t sweep, int P) {
   gg_resolve_args g = fill_spec_args(m, d, buf, sweep, 1 - P);
   gg_params_args pg = fill_params_args(m, d, nbuf, true, false, false, -1, sweep, P);
-  const bool want_ll = m->ll_asked && m->calls_since_ll <= 1 && !ll_is_host_form(m);
+  const bool want_ll = m->ll_asked && m->calls_since_ll == m->ll_period && !ll_is_host_form(m);
   gg_ll_args la = fill_ll_args(m, d, nullptr);
   gg_epi_args ep;
   memset(&ep, 0, sizeof(ep));
@@ -2227,7 +2228,8 @@ static int ll_enqueue(gg_model* m, const gg_data* d) {
   if (rc) return rc;
   if ((rc = check_data(m, d))) return rc;
   // the caller's pattern: asked right after a resample call -> the next call's epilogue evaluates it (launch_spec_resolve_epi)
-  m->ll_asked = true;
+  // (how many resample calls lay between the last two requests: the next one is expected after as many)
+  if (m->calls_since_ll >= 1) { m->ll_asked = true; m->ll_period = m->calls_since_ll; }
   m->calls_since_ll = 0;
   m->ll_from_cache = m->ll_cached && m->ll_uid == d->uid;
   if (m->ll_from_cache) return GG_OK;   // the last call's epilogue left the value of exactly this state
