@@ -752,6 +752,20 @@ def test_call_epilogue_is_the_plain_chain_and_the_plain_log_likelihood(abi, N, K
             assert np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c), it
             assert np.array_equal(adj.get(abi.ST_M, (K,)), sa.m) and np.array_equal(w.get(abi.ST_M, (K,)), sw.m), it
             assert np.array_equal(adj.get(abi.ST_P, (K, K)), sa.p) and np.array_equal(w.get(abi.ST_MU, (K, K, B)), sw.mu), it
+    # a request every SECOND call (the AIS loop's pattern, graphistician_amd/ais.py): the epilogue follows the period
+    it = 45
+    for rep in range(5):
+        for _ in range(2):
+            abi.resample_many([adj, w], d, 1)
+            ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, special, 701, it)
+            O.sbm_w_sweep(A, q, shift, sw.c, sw.m, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, sw.pi, sw.niw, sw.niw_self, special, 702, it)
+            it += 1
+        ll = abi.log_likelihood_many([adj, w], d)
+        lls.append(ll)
+        ref = (O.sbm_adj_loglik(A, sa.c, sa.p, ps, True, bool(special)),
+               O.sbm_w_loglik(A, q, shift, sw.c, sw.mu, sw.sigma, sw.mu_self, sw.sigma_self, bool(special)))
+        assert abs(ll[0] - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-7 and abs(ll[1] - ref[1]) <= 1e-9 * abs(ref[1]) + 1e-7, (rep, ll, ref)
+    assert np.array_equal(adj.get(abi.ST_C, (N,), np.int32), sa.c) and np.array_equal(w.get(abi.ST_C, (N,), np.int32), sw.c)
     # the same state evaluated the plain way: setting the labels again (to what they are) drops everything counted ahead
     # and the epilogue's value with it
     adj.set(abi.ST_C, sa.c, np.int32); w.set(abi.ST_C, sw.c, np.int32)
