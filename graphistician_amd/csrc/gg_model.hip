@@ -1321,9 +1321,16 @@ static int write_ctl_word(gg_model* m, int idx, int32_t v) {
 }
 
 // The whole scan in one launch (k_scan: resident grid, one barrier round per accepted change).
-static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw, bool resume = false, int ride_buf = -1) {
+static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_sort, int pw, bool resume = false, int ride_buf = -1,
+                       bool record = false) {
   gg_scan_args a;
   memset(&a, 0, sizeof(a));
+  if (record) {    // the call's last scan leaves the control block in pinned memory (the host watches for the tag)
+    m->vtag += 1u;
+    if (m->vtag == 0u || m->vtag >= 0x7fffffffu) m->vtag = 1u;
+    a.epi_out = m->h_epi; a.epi_tag = m->vtag;
+    m->epi_tag = m->vtag; m->epi_ll = false;
+  }
   a.resume = resume ? 1 : 0;
   a.spin_limit = m->scan_spin;
   gg_resolve_args& g = a.r;
@@ -1520,7 +1527,7 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
 // Serial form, everything on the model's stream:
 //   bulk -> params (+ zero the next buffer) -> scan (k_scan, or k_spec_resolve while the chain is quiet and the ahead
 //   form is off) [K = 1 kinds: bulk -> params]
-static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
+static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep, bool last = false) {
   int rc;
   const bool scan = m->sbm && m->K > 1;
   const int buf = m->cur, nxt = (buf + 1) % 3, P = m->pcur;
@@ -1547,7 +1554,9 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep) {
       // and a list that overflows is flushed chip-wide)
       const bool ride = m->Kp <= 64 && m->zeroed[nxt] &&
                         (m->scan_ride == 2 || (m->scan_ride == 1 && m->chg_per_sweep >= 0.0 && m->chg_per_sweep <= 128.0));
-      if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P, false, ride ? nxt : -1))) return rc;
+      static int rec_on = -1;
+      if (rec_on < 0) { const char* e = getenv("GG_EPILOGUE"); rec_on = e ? atoi(e) : 1; }
+      if ((rc = launch_scan(m, d, buf, sweep, true, 1 - P, false, ride ? nxt : -1, last && !ride && rec_on))) return rc;
       if (ride) {
         if ((rc = launch_apply_L(m, d, nxt, 3, false))) return rc;
         rode = true;
@@ -1646,7 +1655,7 @@ static int enqueue_sweep(gg_model* m, const gg_data* d, uint32_t sweep, bool mor
   int rc;
   m->epi_tag = 0;     // (set by the launch that ends a batch with the epilogue record)
   if (m->can_ahead && !m->use_scan && m->scan_pref < 0) rc = enqueue_sweep_ahead(m, d, sweep, more);
-  else rc = enqueue_sweep_serial(m, d, sweep);
+  else rc = enqueue_sweep_serial(m, d, sweep, !more);
   if (rc) return rc;
   if (!more && m->m_pending) {
     // The call's last sweep: resample_m (adjacency.py:697-702) is enqueued right behind its scan - a no-op if that scan

@@ -54,6 +54,8 @@ struct gg_scan_args {
   gg_ride_args ride;
   int32_t* Gn0;               // the next sweep's statistics buffer (what the riders fill), same layout as Gc0 / Gs0
   long long* Gsn0;
+  double* epi_out;      // pinned host record for the call's last scan (control block + tag, as k_spec_resolve_epi leaves it), or null
+  unsigned epi_tag;
 };
 #define GG_RS_CARRY 25        // control block: entries of g.L that hold the changes of the last completed k_scan since its last flush
 
@@ -817,5 +819,14 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     g.rs[5] += 1;
     g.rs[7] = 1;
     *reinterpret_cast<unsigned long long*>(&g.rs[GG_RS_STATE]) = gg_pack_state(0, g.keep_L ? nL : 0, 0, 1, 0);
+  }
+  if (a.epi_out) {
+    // the call's last scan: the control block as it stands now goes to pinned host memory, the launch's tag last - the host
+    // watches for it instead of copying the block and synchronising the stream (gg_model.hip, fetch_ctl)
+    __syncthreads();
+    if (tid < 24) reinterpret_cast<int32_t*>(a.epi_out + 4)[tid] = __hip_atomic_load(&g.rs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    __threadfence_system();
+    if (tid == 0) a.epi_out[2] = (double)a.epi_tag;
   }
 }
