@@ -229,45 +229,61 @@ def pmc_traffic(N, K, forms):
         return {"traffic": None, "traffic_source": None, "note": "no PMC summary on file (%s)" % exc}
 
 
-def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every, barrier=lambda: None, stepwise=False):
-    """One Gaussian-SBM chain (adjacency + weight models) on `data`: set-up burn-in, `warmup` untimed sweeps, `steps`
-    timed sweeps.  One step = one FactorizedNetworkDistribution.resample((A,W)): the two halves are independent models
-    (networks.py:69-71) enqueued stream-ordered on their own HIP streams; the timed region ends when both
-    streams have drained (gg_sync)."""
+def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every, barrier=lambda: None, stepwise=False, repeats=1,
+              max_over_ranks=lambda x: x):
+    """One Gaussian-SBM chain (adjacency + weight models) on `data`: set-up burn-in, `warmup` untimed sweeps, then `repeats`
+    timed BLOCKS of exactly `steps` sweeps each (with repeats > 1 one more block of `steps` runs untimed in front of them).
+    One step = one FactorizedNetworkDistribution.resample((A,W)): the two halves are independent models (networks.py:69-71,
+    SURVEY.md 3.1) enqueued stream-ordered on their own HIP streams; a timed block is bracketed by the barrier on both sides
+    and ends when both streams have drained (gg_sync).  A 20-sweep block lasts about a millisecond, so a single one is
+    start / stop sensitive (VERDICT r3 #8): the caller takes the MEDIAN block and reports the spread."""
     adj, w = build_models(abi, N, K, chain_seed=chain_seed, device=device)
     if burnin > 0:          # set-up: out of the prior draw's transient (SBM config: --burnin)
         abi.resample_many([adj, w], data, burnin)
     for _ in range(warmup):
         adj.resample(data, 1)
         w.resample(data, 1)
+
+    def block():
+        if stepwise:
+            for _ in range(steps):
+                adj.resample_async(data, 1)
+                w.resample_async(data, 1)
+            abi.sync_many([adj, w])
+        else:
+            abi.resample_many([adj, w], data, steps)
+
+    if repeats > 1:
+        block()             # one warm block: the engine's run-ahead depth and scan form have settled for this call length
     st0a, st0w = adj.stats(), w.stats()
     chg0 = st0a["label_changes"] + st0w["label_changes"]
     rnd0 = st0a["resolve_rounds"] + st0w["resolve_rounds"]
     adj.set_timing(every)
     w.set_timing(every)
-    barrier()
-    t0 = time.perf_counter()
-    if stepwise:
-        for _ in range(steps):
-            adj.resample_async(data, 1)
-            w.resample_async(data, 1)
-        abi.sync_many([adj, w])
-    else:
-        abi.resample_many([adj, w], data, steps)
-    barrier()
-    el = time.perf_counter() - t0
+    blocks = []
+    bulk = dict(adj_ms=0.0, adj_n=0, adj_bytes=0.0, w_ms=0.0, w_n=0, w_bytes=0.0)
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        block()
+        barrier()
+        blocks.append(max_over_ranks(time.perf_counter() - t0))
+        ba, bw = adj.stats(), w.stats()       # (bulk_* describe the last call)
+        for k, v in (("adj_ms", ba["bulk_ms"]), ("adj_n", ba["bulk_launches"]), ("adj_bytes", ba["bulk_bytes"]),
+                     ("w_ms", bw["bulk_ms"]), ("w_n", bw["bulk_launches"]), ("w_bytes", bw["bulk_bytes"])):
+            bulk[k] += v
     sa, sw = adj.stats(), w.stats()
     adj.set_timing(0); w.set_timing(0)
-    return dict(adj=adj, w=w, elapsed=el,
-                bulk=dict(adj_ms=sa["bulk_ms"], adj_n=sa["bulk_launches"], adj_bytes=sa["bulk_bytes"],
-                          w_ms=sw["bulk_ms"], w_n=sw["bulk_launches"], w_bytes=sw["bulk_bytes"]),
-                changes=sa["label_changes"] + sw["label_changes"] - chg0,
-                rounds=sa["resolve_rounds"] + sw["resolve_rounds"] - rnd0,
+    nsw = float(steps * repeats)
+    return dict(adj=adj, w=w, elapsed=float(np.median(blocks)), blocks=blocks, bulk=bulk,
+                changes=(sa["label_changes"] + sw["label_changes"] - chg0) / float(repeats),
+                rounds=(sa["resolve_rounds"] + sw["resolve_rounds"] - rnd0) / float(repeats),
                 changes_adj=sa["label_changes"], changes_w=sw["label_changes"],
-                # how the engine ran the weight model's sweeps of the timed region (gg_stats: enqueued sweeps by form)
+                # how the engine ran the weight model's sweeps of the timed blocks (gg_stats: enqueued sweeps by form)
                 forms={k: int(sw[k] - st0w[k]) for k in ("sweeps_fused", "sweeps_two_launch", "sweeps_serial")},
                 forms_adj={k: int(sa[k] - st0a[k]) for k in ("sweeps_fused", "sweeps_two_launch", "sweeps_serial")},
-                ahead=bool(sw["sweeps_fused"] - st0w["sweeps_fused"] > (sw["sweeps_serial"] - st0w["sweeps_serial"])))
+                ahead=bool(sw["sweeps_fused"] - st0w["sweeps_fused"] > (sw["sweeps_serial"] - st0w["sweeps_serial"])),
+                total_timed_s=float(sum(blocks)), sweeps_run=nsw)
 
 
 def extra_eigen(abi, device, N=4096, D=8, warmup=5, steps=20):
@@ -341,6 +357,132 @@ def extra_ais(abi, device, N=8192, R=3, B=100, steps_per_B=2):
             "value": nsweeps / el, "unit": "sweeps/s (including the per-temperature log-likelihood)", "seconds_per_chain": el,
             "tempered_sweeps": nsweeps, "log_likelihood_evaluations": B - 1, "log_Z_one_chain": float(logZ),
             "sweep_algorithmic_bytes": 2.0 * N * N / 8.0, "log_likelihood_algorithmic_bytes": 1.0 * N * N / 8.0}
+
+
+def extra_ais_eigen(abi, device, N=8192, D=8, B=12, steps_per_B=2):
+    """BASELINE.json configs[4], the eigenmodel's chain: AIS with the tempered logistic eigenmodel (D = 8) at N = 8192 through
+    the host class (examples/demo_ais.py:10-62; tempering build-defined: omega ~ PG(beta, psi)).  Few
+    temperatures: a tempered sweep draws 67 M PG(beta, psi) variates by the 64-term gamma series."""
+    from graphistician_amd.eigenmodel import LogisticEigenmodel
+    from graphistician_amd import ais as AIS
+    rng = np.random.RandomState(4321)
+    Ft, lt, mu_t = rng.randn(N, D) * 0.6, rng.randn(D), -1.3
+    A = np.empty((N, N), dtype=np.uint8)
+    for i0 in range(0, N, 1024):
+        Mu = mu_t + (Ft[i0:i0 + 1024] * lt).dot(Ft.T)
+        A[i0:i0 + 1024] = rng.rand(*Mu.shape) < 1.0 / (1.0 + np.exp(-Mu))
+    data = abi.DeviceData(A, None, device=device)
+    del A
+    np.random.seed(5)
+    m = LogisticEigenmodel(N, D, p=0.1, device=device, seed=21)
+    AIS.estimate_marginal_likelihood(m, data, N_samples=1, B=3, steps_per_B=1)      # warm-up
+    t0 = time.perf_counter()
+    logZ = AIS.estimate_marginal_likelihood(m, data, N_samples=1, B=B, steps_per_B=steps_per_B)
+    el = time.perf_counter() - t0
+    nsweeps = (B - 2) * steps_per_B
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.resample(data)
+    m.mu_0
+    plain = (time.perf_counter() - t0) / 3
+    return {"workload": "AIS, logistic eigenmodel D=%d, N=%d, one chain: %d temperatures x %d tempered sweeps + 1 log-likelihood each "
+                        "(BASELINE.json configs[4])" % (D, N, B, steps_per_B),
+            "value": nsweeps / el, "unit": "sweeps/s (including the per-temperature log-likelihood)", "seconds_per_chain": el,
+            "tempered_sweeps": nsweeps, "log_likelihood_evaluations": B - 1, "log_Z_one_chain": float(logZ),
+            "ms_per_plain_sweep_beta_1": plain * 1e3,
+            "bound": "the PG(beta, psi) draws of a tempered sweep (64 gamma variates per pair); at beta = 1 the exact PG(1, psi) sampler "
+                     "and the sequential feature scan (DESIGN.md 7)"}
+
+
+def extra_ais_latent(abi, device, N=8192, dim=2, B=30, steps_per_B=2):
+    """BASELINE.json configs[4], the latent-distance model's chain: AIS with tempered HMC resamples (dim = 2) at N = 8192 through
+    the host class (examples/demo_ais.py:10-62; adjacency.py:360-421)."""
+    from graphistician_amd.adjacency import LatentDistanceAdjacencyDistribution
+    from graphistician_amd import ais as AIS
+    rng = np.random.RandomState(7)
+    Lt = rng.randn(N, dim) * 1.3
+    A = np.empty((N, N), dtype=np.uint8)
+    for i0 in range(0, N, 1024):
+        X = -((Lt[i0:i0 + 1024, None, :] - Lt[None, :, :]) ** 2).sum(2) + 1.0
+        A[i0:i0 + 1024] = rng.rand(*X.shape) < 1.0 / (1.0 + np.exp(-X))
+    data = abi.DeviceData(A, None, device=device)
+    del A
+    np.random.seed(6)
+    m = LatentDistanceAdjacencyDistribution(N, dim=dim, sigma=2.0, device=device, seed=22)
+    AIS.estimate_marginal_likelihood(m, data, N_samples=1, B=3, steps_per_B=1)      # warm-up
+    t0 = time.perf_counter()
+    logZ = AIS.estimate_marginal_likelihood(m, data, N_samples=1, B=B, steps_per_B=steps_per_B)
+    el = time.perf_counter() - t0
+    nres = (B - 2) * steps_per_B
+    passes = 22
+    res_bytes = (11 * 2.0 + 11 * 1.0) * N * N
+    return {"workload": "AIS, latent-distance adjacency model dim=%d (HMC), N=%d, one chain: %d temperatures x %d tempered resamples + 1 "
+                        "log-likelihood each (BASELINE.json configs[4])" % (dim, N, B, steps_per_B),
+            "value": nres / el, "unit": "resamples/s (including the per-temperature log-likelihood)", "seconds_per_chain": el,
+            "tempered_resamples": nres, "log_likelihood_evaluations": B - 1, "log_Z_one_chain": float(logZ),
+            "resample_algorithmic_bytes": res_bytes, "effective_GBs": res_bytes * nres / el / 1e9,
+            "bound": "%d passes per resample, each N^2 fp64 sigmoids (exp), softplus (log) at the trajectory ends (DESIGN.md 7d)" % passes}
+
+
+def extra_host_classes(abi, device, N=4096, K=16, iters=40):
+    """the reference's OWN loop on PLAIN NDARRAYS through the host classes -
+    `model.resample((A, W)); lps.append(model.log_probability((A, W)))` (examples/demo_model_comparison.py:69-72, networks.py:28,69)
+    - at N=4096, K=16.  The engine keeps a device copy per (A, W) pair; a writeable array may have been edited in place since the
+    last call, so its whole buffer is hashed on EVERY call (exactness: tests/test_abi_and_host.py::test_one_flipped_entry_is_new_data);
+    an array that cannot be written (`A.setflags(write=False)` and no writeable base) or was declared immutable is found by
+    identity alone."""
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution
+    from graphistician_amd import engine as E
+    truth = planted_truth(N, K, seed=1234)
+    dd = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                      truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
+    A, W = dd.download()
+    del dd
+    np.random.seed(11)
+    model = FactorizedNetworkDistribution(N, SBMAdjacencyDistribution, dict(C=K, device=device, seed=31),
+                                          SBMGaussianWeightDistribution, dict(B=1, C=K, device=device, seed=32))
+    out = {}
+
+    def loop(data, n):
+        lps = []
+        t0 = time.perf_counter()
+        for _ in range(n):
+            model.resample(data)
+            lps.append(model.log_probability(data))
+        return (time.perf_counter() - t0) / n, lps
+
+    E.clear_data_cache()
+    for _ in range(60):                      # out of the prior draw's transient (the chain must be the same in all variants' timing)
+        model.resample((A, W))
+    t_w, _ = loop((A, W), max(5, iters // 4))
+    Ar, Wr = A.copy(), W.copy()
+    Ar.setflags(write=False); Wr.setflags(write=False)
+    loop((Ar, Wr), 5)
+    t_r, lps = loop((Ar, Wr), iters)
+    E.clear_data_cache()
+    E.declare_immutable(A, W)
+    loop((A, W), 5)
+    t_i, _ = loop((A, W), iters)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        model.resample((Ar, Wr))
+    t_res = (time.perf_counter() - t0) / iters
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        model.log_prior()
+    t_prior = (time.perf_counter() - t0) / iters
+    E.clear_data_cache()
+    return {"workload": "FactorizedNetworkDistribution(SBMAdjacencyDistribution, SBMGaussianWeightDistribution).resample((A, W)); "
+                        "log_probability((A, W)) on numpy arrays, N=%d, K=%d (examples/demo_model_comparison.py:69-72)" % (N, K),
+            "us_per_iteration_read_only_arrays": t_r * 1e6, "us_per_iteration_declare_immutable": t_i * 1e6,
+            "us_per_iteration_writeable_arrays": t_w * 1e6,
+            "us_per_resample_read_only_arrays": t_res * 1e6, "us_per_log_prior": t_prior * 1e6,
+            "last_log_probability": float(lps[-1]),
+            "note": "writeable arrays: the buffers of A (uint8, %.0f MB) and W (float64, %.0f MB) are hashed on every call (xxh3, in "
+                    "parallel chunks) so that an in-place edit is new data; read-only / declared arrays: identity only"
+                    % (A.nbytes / 1e6, W.nbytes / 1e6)}
 
 
 def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
@@ -492,53 +634,75 @@ def bench_sharded(args, abi, device, rank, world, barrier, max_over_ranks):
         _emit(json.dumps(line))
 
 
-def run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K):
+def run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K, all_ok=None, steps=None, warmup=None):
     """One Gaussian-SBM chain sharded over the ranks (strong scaling; BASELINE.json configs[3] at N=65536, K=64):
-    exact - the same chain for any number of ranks (graphistician_amd/sharded.py).  Returns the result line (rank 0)."""
+    exact - the same chain for any number of ranks (graphistician_amd/sharded.py).  Returns the result line (rank 0).
+    all_ok(flag) -> bool: agreement of all ranks: set-up (communicator, the rank's shard of the network, the
+    models) may fail on ONE rank - out of memory beside the replica's network, an RCCL initialisation error - and the
+    others would then wait in the library's collectives for ever; so every rank reports how its set-up went and the
+    chain runs only if all of them are ready."""
     from graphistician_amd import sharded as S
-    # collectives: the library's own RCCL calls (one process per GPU); GG_BENCH_BACKEND=gloo (CPU-side tests, several ranks on
-    # one GPU) routes them through host callbacks instead.  torch.distributed is the launcher / rendezvous only.
-    # (RCCL greets with a version banner on stdout when its first communicator comes up: that goes to stderr here, stdout
-    # carries the one JSON line)
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    err = None
     try:
-        if world > 1:
-            import torch.distributed as tdist
-            comm = S.rccl_comm(tdist, device) if os.environ.get("GG_BENCH_BACKEND", "nccl") == "nccl" else S.host_comm(tdist, device)
-        else:
-            comm = S.local_comm(device)
-    finally:
+        # collectives: the library's own RCCL calls (one process per GPU); GG_BENCH_BACKEND=gloo (CPU-side tests, several ranks on
+        # one GPU) routes them through host callbacks instead.  torch.distributed is the launcher / rendezvous only.
+        # (RCCL greets with a version banner on stdout when its first communicator comes up: that goes to stderr here, stdout
+        # carries the one JSON line)
         sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
-    n0, n1 = S.shard_range(N, rank, world)
-    truth = planted_truth(N, K, seed=1234)
-    data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
-                                        truth["mu_self"], truth["sigma_self"], seed=1234, device=device, shard=(n0, n1))
-    rng = np.random.RandomState(1)                      # the same chain on every rank
-    adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=3, tau1=1.0, tau0=1.0, allow_self_connections=1,
-                    special_case_self_conns=1, device=device, shard_begin=n0, shard_end=n1)
-    m_a = rng.dirichlet(np.ones(K))
-    adj.set(abi.ST_PI, np.ones(K)); adj.set(abi.ST_M, m_a)
-    adj.set(abi.ST_C, rng.choice(K, p=m_a, size=N).astype(np.int32), np.int32)
-    adj.set(abi.ST_P, rng.beta(1.0, 1.0, size=(K, K))); adj.set(abi.ST_P_SELF, np.array([rng.beta(1.0, 1.0)]))
-    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=4, special_case_self_conns=1, device=device,
-                  shard_begin=n0, shard_end=n1)
-    m_w = rng.dirichlet(np.ones(K) * 10.0)
-    w.set(abi.ST_PI, np.ones(K) * 10.0); w.set(abi.ST_M, m_w)
-    w.set(abi.ST_C, rng.choice(K, p=m_w, size=N).astype(np.int32), np.int32)
-    w.set(abi.ST_MU, rng.randn(K, K, 1)); w.set(abi.ST_SIGMA, np.ones((K, K, 1, 1)))
-    niw = np.array([0.0, 1.0, 3.0, 1.0])
-    w.set(abi.ST_NIW, niw); w.set(abi.ST_NIW_SELF, niw)
-    for _ in range(args.warmup):
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if world > 1:
+                import torch.distributed as tdist
+                comm = S.rccl_comm(tdist, device) if os.environ.get("GG_BENCH_BACKEND", "nccl") == "nccl" else S.host_comm(tdist, device)
+            else:
+                comm = S.local_comm(device)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+        # ownership: blocks of 256 nodes dealt out round-robin (every band of the scan spreads over all ranks);
+        # GG_BENCH_SHARD_RANGE=1: contiguous node ranges, the round-3 form
+        truth = planted_truth(N, K, seed=1234)
+        if os.environ.get("GG_BENCH_SHARD_RANGE"):
+            n0, n1 = S.shard_range(N, rank, world)
+            own, own_txt = dict(shard_begin=n0, shard_end=n1), "contiguous node ranges"
+            data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                                truth["mu_self"], truth["sigma_self"], seed=1234, device=device, shard=(n0, n1))
+        else:
+            o = S.Ownership(N, rank, world)
+            own, own_txt = o.config, "blocks of %d nodes dealt out round-robin" % o.block
+            data = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                                truth["mu_self"], truth["sigma_self"], seed=1234, device=device, blocks=o.blocks)
+        rng = np.random.RandomState(1)                      # the same chain on every rank
+        adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=3, tau1=1.0, tau0=1.0, allow_self_connections=1,
+                        special_case_self_conns=1, device=device, **own)
+        m_a = rng.dirichlet(np.ones(K))
+        adj.set(abi.ST_PI, np.ones(K)); adj.set(abi.ST_M, m_a)
+        adj.set(abi.ST_C, rng.choice(K, p=m_a, size=N).astype(np.int32), np.int32)
+        adj.set(abi.ST_P, rng.beta(1.0, 1.0, size=(K, K))); adj.set(abi.ST_P_SELF, np.array([rng.beta(1.0, 1.0)]))
+        w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=4, special_case_self_conns=1, device=device, **own)
+        m_w = rng.dirichlet(np.ones(K) * 10.0)
+        w.set(abi.ST_PI, np.ones(K) * 10.0); w.set(abi.ST_M, m_w)
+        w.set(abi.ST_C, rng.choice(K, p=m_w, size=N).astype(np.int32), np.int32)
+        w.set(abi.ST_MU, rng.randn(K, K, 1)); w.set(abi.ST_SIGMA, np.ones((K, K, 1, 1)))
+        niw = np.array([0.0, 1.0, 3.0, 1.0])
+        w.set(abi.ST_NIW, niw); w.set(abi.ST_NIW_SELF, niw)
+    except Exception as exc:
+        err = "rank %d: set-up failed: %s" % (rank, exc)
+    if all_ok is not None and not all_ok(err is None):
+        return {"error": err or "set-up failed on another rank: the sharded chain was skipped on every rank"} if rank == 0 else None
+    if err is not None:
+        raise RuntimeError(err)
+    for _ in range(warmup):
         S.half_sweep(adj, data, comm); S.half_sweep(w, data, comm)
     chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
     rnd0 = adj.stats()["resolve_rounds"] + w.stats()["resolve_rounds"]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         S.half_sweep(adj, data, comm); S.half_sweep(w, data, comm)
     barrier()
     el = max_over_ranks(time.perf_counter() - t0)
@@ -550,23 +714,25 @@ def run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K):
     if rank == 0:
         sweep_bytes = 2.0 * N * N * (0.125 + 4.0)
         return ({
-            "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": args.steps / el,
-            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": "full Gibbs sweeps/sec on N-node graph; achieved HBM GB/s vs peak", "value": steps / el,
+            "unit": "sweeps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64 statistics / f64 conditionals (bit-packed adjacency, 24-bit fixed-point weights in int32)",
             "data": "synthetic",
             "config": {"workload": "ONE Gaussian SBM chain, N=%d, K=%d, B=1, node-sharded over %d rank(s)" % (N, K, world),
-                       "parallelism": "exact node sharding: all-reduce of K x K integer tables + one all-gather of surprises per scan round "
-                                      "(%s, %d ranks seen by the communicator)" % ("RCCL, device buffers on the engine stream" if cinfo["rccl"]
-                                                                                  else "host callbacks (gloo)", cinfo["world"]),
-                       "collectives_in_run": int(cinfo["collectives"]),
+                       "parallelism": "exact node sharding (%s): all-reduce of K x K integer tables + one all-gather of surprises per scan "
+                                      "round (%s, %d ranks seen by the communicator)" % (own_txt, "RCCL, device buffers on the engine stream"
+                                                                                         if cinfo["rccl"] else "host callbacks (gloo)", cinfo["world"]),
+                       "ranks": int(cinfo["world"]),
+                       "collectives_on_the_wire_in_run": int(cinfo["collectives"]), "scan_rounds_in_run": int(cinfo["rounds"]),
+                       "note_one_rank": None if world > 1 else "one rank: the all-reduce and the all-gathers are bypassed, nothing travels",
                        "us_per_label_change": (el / max(chg, 1)) * 1e6 if chg else None,
-                       "scan_rounds_in_timed_region": int(rnd),
+                       "scan_rounds_in_timed_region": int(rnd), "scan_rounds_per_sweep": rnd / float(steps),
                        "us_per_scan_round": (el / max(rnd, 1)) * 1e6 if rnd else None,
                        "label_changes_in_timed_region": int(chg), "labels_digest": digest,
-                       "sweep_algorithmic_bytes": sweep_bytes, "sweep_effective_GBs": sweep_bytes * args.steps / el / 1e9},
-            "roofline": {"bound": "hbm", "achieved": sweep_bytes * args.steps / el / 1e9, "peak": HBM_PEAK_GBS * world,
-                         "unit": "GB/s", "frac": sweep_bytes * args.steps / el / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                       "sweep_algorithmic_bytes": sweep_bytes, "sweep_effective_GBs": sweep_bytes * steps / el / 1e9},
+            "roofline": {"bound": "hbm", "achieved": sweep_bytes * steps / el / 1e9, "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": sweep_bytes * steps / el / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "whole-sweep effective rate over the aggregate HBM peak of the ranks"}})
     return None
 
@@ -587,6 +753,8 @@ def main():
     ap.add_argument("--burnin", type=int, default=None,
                     help="sweeps run as part of chain set-up, before the W warm-up steps: the chain starts from a prior draw "
                          "and relabels thousands of nodes in its first few sweeps; the metric is the sampler's steady state")
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="timed blocks of `--steps` sweeps per chain; the median block is the chain's time (min / max reported)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs of the default run (mixing chains, configs[2], configs[3] on one GPU, one AIS chain)")
@@ -688,24 +856,32 @@ def main():
     forms = dict(sweeps_fused=0, sweeps_two_launch=0, sweeps_serial=0)
     chg = 0
     r = None
+    # a chain's `steps` timed sweeps are run as R blocks of exactly `steps` sweeps (after one untimed block), each
+    # bracketed by barrier + synchronisation with the MAX over ranks taken per block; the chain's time is the MEDIAN block.
+    # `value` = (chains x steps) / (sum of the chains' median block times); min / max blocks are reported beside it.
+    R = max(1, args.repeats)
+    total_min = total_max = total_timed = 0.0
     for seed in seeds:
         del r
         r = run_chain(abi, data, N, K, seed, device, args.burnin, args.warmup, args.steps, every, barrier,
-                      stepwise=bool(os.environ.get("GG_BENCH_STEPWISE")))
-        el_s = max_over_ranks(r["elapsed"])
+                      stepwise=bool(os.environ.get("GG_BENCH_STEPWISE")), repeats=R, max_over_ranks=max_over_ranks)
+        el_s = r["elapsed"]
         total_el += el_s
+        total_min += min(r["blocks"]); total_max += max(r["blocks"]); total_timed += r["total_timed_s"]
         chg += r["changes"]
         for k in bulk:
             bulk[k] += r["bulk"][k]
         for k in forms:
             forms[k] += r["forms"][k]
         chains.append({"chain_seed": seed, "value": world * args.steps / el_s, "ms_per_step": el_s / args.steps * 1e3,
+                       "ms_per_step_min_max_over_blocks": [min(r["blocks"]) / args.steps * 1e3, max(r["blocks"]) / args.steps * 1e3],
                        "label_changes_per_sweep": r["changes"] / float(args.steps),
                        "scan_rounds_per_sweep": r["rounds"] / float(args.steps), "weight_model_sweep_forms": r["forms"],
                        "bulk_launch_ms": r["bulk"]["w_ms"] / max(r["bulk"]["w_n"], 1),
                        "bulk_launch_GBs": r["bulk"]["w_bytes"] / (r["bulk"]["w_ms"] * 1e-3) / 1e9 if r["bulk"]["w_ms"] > 0 else None})
         if rank == 0:
-            _progress("chain seed %d: %d sweeps in %.4f s (%.1f label changes per sweep)" % (seed, args.steps, el_s, r["changes"] / float(args.steps)))
+            _progress("chain seed %d: %d sweeps in %.4f s (median of %d blocks, %.4f .. %.4f; %.1f label changes per sweep)" % (
+                seed, args.steps, el_s, R, min(r["blocks"]), max(r["blocks"]), r["changes"] / float(args.steps)))
     adj, w = r["adj"], r["w"]
     el, nsw = total_el, len(seeds) * args.steps
 
@@ -743,9 +919,15 @@ def main():
                     ("BASELINE.json configs[3], one replica of the chain per GPU" if (N, K) == (65536, 64) else "same recipe, other size")),
                 "parallelism": "one replica of the chain per GPU, no collective" if world > 1 else "single GPU",
                 "chain_seeds": seeds, "timed_sweeps": nsw, "steps_per_chain": args.steps,
-                "value_is": "timed sweeps of all chains / their timed seconds (each chain: burn-in, warm-up, then `steps` timed sweeps)",
+                "value_is": "timed sweeps of all chains / their timed seconds; each chain: burn-in, warm-up, one untimed block, then R "
+                            "timed blocks of exactly `steps` sweeps (barrier + synchronisation on both sides, max over ranks per block) "
+                            "of which the MEDIAN is the chain's time: value = chains x steps / sum of the medians",
+                "timed_blocks_per_chain": R, "timed_sweeps_run": nsw * R, "total_timed_seconds": total_timed,
+                "value_min_max_over_blocks": [world * nsw / total_max, world * nsw / total_min],
                 "burn_in_sweeps": args.burnin,
                 "label_changes_in_timed_region": int(chg), "label_changes_per_sweep": chg / float(nsw),
+                "labels_digest": int(np.bitwise_xor.reduce(adj.get(abi.ST_C, (N,), np.int32) * np.arange(1, N + 1, dtype=np.int32))),
+                "labels_digest_of": "adjacency labels of chain seed %d after its last timed block" % seeds[-1],
                 "chains": chains,
                 "sweep_algorithmic_bytes": sweep_bytes,
                 "sweep_effective_GBs": sweep_bytes * nsw / el / 1e9,
@@ -856,7 +1038,9 @@ def main():
             # (extra keys; `value` stays the configs[1] headline).  Each leg is bounded and must never cost the line.
             del adj, w, r, data
             legs = {}
-            for name, fn in (("eigen_n4096_d8", extra_eigen), ("ais_sbm_n8192", extra_ais), ("sbm_n65536_k64_one_gpu", extra_big)):
+            for name, fn in (("reference_call_pattern_host_classes", extra_host_classes), ("eigen_n4096_d8", extra_eigen),
+                             ("ais_sbm_n8192", extra_ais), ("ais_eigen_n8192", extra_ais_eigen), ("ais_latent_n8192", extra_ais_latent),
+                             ("sbm_n65536_k64_one_gpu", extra_big)):
                 _progress("extra config: %s" % name)
                 try:
                     legs[name] = fn(abi, device)
@@ -864,16 +1048,47 @@ def main():
                     legs[name] = {"error": str(exc)}
             out["other_configs"] = legs
     if world > 1 and not os.environ.get("GG_BENCH_NO_SHARD_LEG"):
-        # BASELINE.json configs[3] as written: ONE chain of the same network sharded over the G GPUs (every rank takes part)
+        # BASELINE.json configs[3] as written: ONE chain of the same network sharded over the G GPUs (every rank takes part).
+        # A failing leg must not cost the replica line: (i) whether the leg runs is decided by ALL ranks - each
+        # reports how its set-up went, one failure skips the leg everywhere; (ii) a rank that fails or hangs INSIDE the
+        # chain leaves the others in the library's collectives, so the leg runs under a deadline: when it passes, rank 0
+        # prints the line it has (the replica result, `sharded_chain` = the timeout) and every rank leaves the process.
+        # GG_BENCH_NO_SHARD_LEG=1 switches the leg off, GG_BENCH_SHARD_LEG_SECONDS sets the deadline (default 240).
         adj = w = r = data = None
         import gc
+        import threading
         gc.collect()
         if rank == 0:
             _progress("sharded chain over %d ranks" % world)
+
+        def all_ok(flag):
+            import torch
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        deadline = float(os.environ.get("GG_BENCH_SHARD_LEG_SECONDS", "240"))
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(deadline):
+                return
+            if rank == 0:
+                out["sharded_chain"] = {"error": "the sharded chain did not finish within %.0f s (a rank failed or hung inside it); "
+                                                 "the replica line above is complete" % deadline}
+                _emit(json.dumps(out))
+            sys.stderr.write("[bench] rank %d: sharded leg timed out, leaving\n" % rank)
+            sys.stderr.flush()
+            os._exit(0)
+
+        wd = threading.Thread(target=watchdog, daemon=True)
+        wd.start()
         try:
-            line = run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K)
-        except Exception as exc:      # (a failing leg must not cost the replica line)
+            line = run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K, all_ok=all_ok,
+                               steps=min(args.steps, 20), warmup=min(args.warmup, 3))
+        except Exception as exc:
             line = {"error": str(exc)}
+        done.set()
         if rank == 0:
             out["sharded_chain"] = line
     if rank == 0:

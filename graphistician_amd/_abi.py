@@ -42,11 +42,13 @@ class Config(C.Structure):
                 ("device", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64), ("tau1", C.c_double), ("tau0", C.c_double), ("sigma_mu0", C.c_double),
                 ("sigma_F", C.c_double), ("sigma_lmbda", C.c_double), ("mu_mu_0", C.c_double),
                 ("lmbda_given", C.c_int32), ("reserved", C.c_int32), ("shard_begin", C.c_int32),
-                ("shard_end", C.c_int32)]
+                ("shard_end", C.c_int32), ("shard_block", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+                ("reserved1", C.c_int32)]
 
 
 class Stats(C.Structure):
-    _fields_ = [("sweeps", C.c_uint64), ("label_changes", C.c_uint64), ("resolve_rounds", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("sweeps", C.c_uint64), ("label_changes", C.c_uint64), ("resolve_rounds", C.c_uint64),
                 ("bulk_bytes", C.c_double), ("bulk_ms", C.c_double), ("bulk_launches", C.c_uint64),
                 ("total_ms", C.c_double), ("sweeps_fused", C.c_uint64), ("sweeps_two_launch", C.c_uint64),
                 ("sweeps_serial", C.c_uint64)]
@@ -56,7 +58,8 @@ EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "
            "gg_data_create_sbm", "gg_data_download", "gg_model_create", "gg_model_destroy", "gg_set_state",
            "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_part_many", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_predictive_ll", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
            "gg_comm_create_host", "gg_comm_destroy", "gg_comm_info", "gg_shard_sweep", "gg_shard_log_likelihood",
-           "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws"]
+           "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws", "gg_hash64", "gg_data_create_shard_blocks",
+           "gg_data_create_sbm_shard_blocks"]
 
 
 def build(force=False):
@@ -112,11 +115,16 @@ def lib():
         L.gg_data_create_shard.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
         L.gg_data_create_sbm_shard.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp, C.c_double,
                                                C.c_double, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
+        L.gg_data_create_shard_blocks.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.gg_data_create_sbm_shard_blocks.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp, C.c_double,
+                                                      C.c_double, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.gg_hash64.argtypes = [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_uint64)]
         L.gg_comm_unique_id.argtypes = [vp]
         L.gg_comm_create_rccl.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, C.c_int32]
         L.gg_comm_create_host.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, HOST_ALLREDUCE, HOST_ALLGATHER, vp, C.c_int32]
         L.gg_comm_destroy.argtypes = [vp]
-        L.gg_comm_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.gg_comm_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64)]
         L.gg_shard_sweep.argtypes = [vp, vp, vp, C.c_int32]
         L.gg_shard_log_likelihood.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
         L.gg_selftest_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, C.c_int64]
@@ -128,6 +136,14 @@ def lib():
 def check(rc):
     if rc != 0:
         raise EngineError(rc, lib().gg_last_error().decode("utf-8", "replace"))
+
+
+def hash64(a, threads=0):
+    """64-bit content hash of a C-contiguous ndarray's buffer, computed on all host threads inside the library (gg_hash64; the
+    GIL is released for the call).  134 MB of float64 W: 2-4 ms against 17 ms for a single-threaded hash."""
+    out = C.c_uint64(0)
+    check(lib().gg_hash64(a.ctypes.data_as(C.c_void_p), a.nbytes, int(threads), C.byref(out)))
+    return out.value
 
 
 def device_count():
@@ -205,8 +221,9 @@ class DeviceData(object):
                           RuntimeWarning, stacklevel=3)
 
     @classmethod
-    def shard(cls, A, W, n0, n1, device=0):
-        """Column shard [n0, n1) of the network for a chain sharded over several GPUs."""
+    def shard(cls, A, W, n0=None, n1=None, device=0, blocks=None):
+        """Column shard of the network for a chain sharded over several GPUs: the contiguous node range [n0, n1), or with
+        blocks=(block, rank, world) the blocks rank, rank + world, ... of `block` consecutive nodes (sharded.Ownership)."""
         A = _adjacency_u8(A)
         N = A.shape[0]
         h = C.c_void_p()
@@ -214,25 +231,31 @@ class DeviceData(object):
             W = np.ascontiguousarray(W, dtype=np.float64)
             if W.ndim == 2:
                 W = W[:, :, None].copy()
-            B = W.shape[2]
-            check(lib().gg_data_create_shard(C.byref(h), N, B, _ptr(A), _ptr(W), n0, n1, device))
+        B = W.shape[2] if W is not None else 1
+        pW = _ptr(W) if W is not None else None
+        if blocks is not None:
+            check(lib().gg_data_create_shard_blocks(C.byref(h), N, B, _ptr(A), pW, int(blocks[0]), int(blocks[1]), int(blocks[2]), device))
         else:
-            B = 1
-            check(lib().gg_data_create_shard(C.byref(h), N, 1, _ptr(A), None, n0, n1, device))
+            check(lib().gg_data_create_shard(C.byref(h), N, B, _ptr(A), pW, n0, n1, device))
         obj = cls(handle=h, N=N, B=B, device=device)
         obj.has_w = W is not None
         return obj
 
     @classmethod
-    def synthetic_sbm(cls, N, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device=0, shard=None):
-        """Planted Gaussian SBM (B = 1) generated on the device; shard=(n0, n1) generates that column shard only."""
+    def synthetic_sbm(cls, N, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device=0, shard=None, blocks=None):
+        """Planted Gaussian SBM (B = 1) generated on the device; shard=(n0, n1) generates that column shard only, blocks=(block,
+        rank, world) the block-interleaved shard of that rank."""
         c = np.ascontiguousarray(c, dtype=np.int32)
         p = np.ascontiguousarray(p, dtype=np.float64)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         sigma = np.ascontiguousarray(sigma, dtype=np.float64)
         K = p.shape[0]
         h = C.c_void_p()
-        if shard is None:
+        if blocks is not None:
+            check(lib().gg_data_create_sbm_shard_blocks(C.byref(h), N, K, _ptr(c), _ptr(p), float(p_self), _ptr(mu), _ptr(sigma),
+                                                        float(mu_self), float(sigma_self), C.c_uint64(seed), int(blocks[0]),
+                                                        int(blocks[1]), int(blocks[2]), device))
+        elif shard is None:
             check(lib().gg_data_create_sbm(C.byref(h), N, K, _ptr(c), _ptr(p), float(p_self), _ptr(mu), _ptr(sigma),
                                            float(mu_self), float(sigma_self), C.c_uint64(seed), device))
         else:
@@ -351,8 +374,9 @@ class Model(object):
 
     def stats(self):
         s = Stats()
+        s.struct_size = C.sizeof(Stats)
         check(lib().gg_last_stats(self._h, C.byref(s)))
-        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_ if f[0] not in ("struct_size", "reserved")}
 
     def bench_bulk(self, data, reps=20):
         ms, nb = C.c_double(0), C.c_double(0)
@@ -433,9 +457,9 @@ class Comm(object):
         return self._h
 
     def info(self):
-        r, w, k, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
-        check(lib().gg_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k), C.byref(n)))
-        return dict(rank=r.value, world=w.value, rccl=bool(k.value), collectives=n.value)
+        r, w, k, n, nr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        check(lib().gg_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k), C.byref(n), C.byref(nr)))
+        return dict(rank=r.value, world=w.value, rccl=bool(k.value), collectives=n.value, rounds=nr.value)
 
     def close(self):
         if self._h:

@@ -1047,8 +1047,7 @@ __global__ __launch_bounds__(256) void k_params_w(gg_params_args g, gg_ride_args
 #define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index) - for the host; the device
                              //                reads gg_shard_state
 #define GG_RS_ROUNDS 14      //                rounds of the sharded scan that did something
-#define GG_SHARD_M 32        // surprises a rank reports per round
-#define GG_SHARD_WINDOW 4096
+#define GG_SHARD_M 64        // surprises a rank reports per round (k_shard_eval)
 #define GG_SHARD_NONE 0x7fffffff
 
 // ------------------------------------------------------------------ per-node conditional
@@ -1742,18 +1741,27 @@ __global__ __launch_bounds__(256) void k_shared_cov(gg_params_args g) {
 // ---- the sharded scan's round (gg_shard_sweep), with hypotheses exactly as in k_scan (gg_scan_kernels.h): every rank keeps
 // the same hypothesis H per node of the band, its own nodes' statistics hold every accepted or hypothesised change at a
 // position before theirs, and what a rank reports are the first GG_SHARD_M SURPRISES among its own nodes - decisions that
-// differ from what H says.  Ranks own contiguous node ranges, so the gathered reports are in position order; everything of
-// H before the earliest one, and that one itself, is the sequential chain.  One all-gather per ROUND, not per change.
+// differ from what H says.  Everything of H before the earliest reported surprise, and that one itself, is the sequential
+// chain (a rank's unreported surprises lie behind its reported ones, so behind the earliest report).  One all-gather per ROUND.
 //
-// A round is TWO launches around the all-gather (round 3; four before):
+// Round 4: ownership is block-interleaved (gg_own: blocks of 2^lb nodes dealt out round-robin), so a band's nodes - and the
+// evaluation of a round - spread over ALL ranks instead of sitting on the one rank that owns that stretch of the node range; and
+// the band is as wide as the hypotheses can carry (W nodes, chosen per scan by the host from the previous scan's change count,
+// up to GG_SHARD_WMAX): a round costs one collective whatever its width, and a band needs 1 + (depth of mutually dependent
+// decisions) rounds, not one per 4096 nodes.  H lives in global memory, ONE copy: the evaluation only reads it, and in the
+// apply launch every workgroup amends, accepts and resets its own slice of the band (a report carries the label its node
+// was hypothesised to have, so nobody needs H to price a move).
+//
+// A round is TWO launches around the all-gather:
 //   k_shard_eval   the rank's own nodes of the band behind the scan position evaluated under the hypotheses; the workgroup
 //                  that finishes last compacts the first GG_SHARD_M surprises, in position order, into `trip`
+//                  (2 ints each: node, old << 16 | hypothesised << 8 | drawn)
 //   [all-gather of trip]
-//   k_shard_apply  every workgroup derives the round's moves from the gathered reports and applies them to the statistics of
-//                  the rank's nodes behind each moved node; workgroup 0 also folds the reports into the hypotheses, accepts
-//                  everything up to the earliest surprise into labels and block sizes and moves the scan on.
-// The scan state (position, band start) and the hypotheses are kept TWICE and used alternately (round r reads copy r & 1,
-// workgroup 0 of k_shard_apply writes copy (r + 1) & 1), so that no workgroup of a launch reads a word another one writes.
+//   k_shard_apply  every workgroup: the earliest report; its slice of the band amended / accepted (labels, block sizes) / reset;
+//                  the round's moves applied to the statistics of the rank's nodes behind each moved node.
+// The scan state (position, band start) is kept TWICE and used alternately (round r reads copy r & 1, workgroup 0 of
+// k_shard_apply writes copy (r + 1) & 1), so that no workgroup of a launch reads a word another one writes.
+#define GG_SHARD_WMAX 65536      // widest band (nodes): H holds one hypothesis per node of the band
 struct gg_shard_state {
   int32_t st[2][2];   // [copy][spos, wbase]
   int32_t ticket;     // workgroups of the running k_shard_eval that are done
@@ -1761,45 +1769,50 @@ struct gg_shard_state {
 };
 
 template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, uint64_t seed, uint32_t site, uint32_t sweep,
+__global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, gg_own own, int W, uint64_t seed, uint32_t site, uint32_t sweep,
                                                     int32_t* __restrict__ cand, const int32_t* __restrict__ c,
-                                                    const int32_t* __restrict__ Hb, gg_shard_state* __restrict__ S, int round,
+                                                    const int32_t* __restrict__ H, gg_shard_state* __restrict__ S, int round,
                                                     int ntot, int stage_tables, int32_t* __restrict__ trip) {
-  __shared__ int s_scan[256];
-  __shared__ int s_last;
-  const int t = (int)threadIdx.x, per = 256 / x.Kp;
+  __shared__ int s_scan[64];
+  __shared__ int s_last, s_found;
+  const int t = (int)threadIdx.x;
   const int spos = S->st[round & 1][0], wbase = S->st[round & 1][1];
-  const int32_t* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;   // -1 none, else (old << 8 | new): 8-bit labels, up to 256 blocks
   int lo = 0, hi = 0;
   if (spos < ntot) {
-    const int wend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;   // the band the scan stands in
-    lo = spos - x.n0; hi = wend - x.n0;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > x.N ? x.N : hi;
+    const int wend = wbase + W < ntot ? wbase + W : ntot;   // the band the scan stands in
+    lo = gg_own_below(own, spos); hi = gg_own_below(own, wend);
   }
+  // Workgroups start at multiples of their node count in the LOCAL numbering: the nodes of one workgroup then lie in one
+  // ownership block (2^lb >= 8 nodes), where local and global index differ by a constant - which is all the evaluation needs
+  // to know about ownership (its x.n0).  Nodes in front of lo are evaluated and dropped.
+  const int per = (x.Kp == 64 && NT <= 3) ? 8 : 256 / x.Kp;
+  const int lo_al = lo & ~(per - 1);
+  const int first = lo_al + (int)blockIdx.x * per;
   // (an atomic exchange at agent scope publishes a decision: performed at the memory side, and its return value holds the wave
   // until it has been - the decision is out before the workgroup's ticket is drawn.  No fence: a release fence per workgroup
   // writes back every dirty line of the XCD's L2, megabytes of statistics - measured at +115 us per round)
-  if (x.Kp == 64 && NT <= 3) {
-    if (hi > lo && lo + (int)blockIdx.x * 8 < hi) {        // eight nodes per workgroup, two passes of four
+  if (hi > lo && first < hi) {                                     // (uniform over the workgroup)
+    gg_node_ctx xl = x;
+    xl.n0 = gg_own_glob(own, first) - first;
+    if (x.Kp == 64 && NT <= 3) {                                   // eight nodes per workgroup, two passes of four
       int labs[2], nodes[2];
       bool lives[2];
-      gg_spec_eval_split8<NT, ADJ>(x, lo, seed, site, sweep, labs, nodes, lives);
+      gg_spec_eval_split8<NT, ADJ>(xl, lo_al, seed, site, sweep, labs, nodes, lives);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        if (lives[p] && nodes[p] < hi && (t & 63) == 0) {
+        if (lives[p] && nodes[p] >= lo && nodes[p] < hi && (t & 63) == 0) {
           const int old = atomicExch(&cand[nodes[p]], labs[p]);
           asm volatile("" ::"v"(old) : "memory");
         }
-    }
-  } else if (hi > lo && lo + (int)blockIdx.x * per < hi) {        // (uniform over the workgroup)
-    int n;
-    bool live;
-    const int lab = x.Kp > 64 ? gg_spec_eval<NT, ADJ, 0, 2>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live)
-                              : gg_spec_eval<NT, ADJ>(x, lo, seed, site, sweep, -1, nullptr, stage_tables, &n, &live);
-    if (live && n < hi && t % x.Kp == 0) {
-      const int old = atomicExch(&cand[n], lab);
-      asm volatile("" ::"v"(old) : "memory");
+    } else {
+      int n;
+      bool live;
+      const int lab = x.Kp > 64 ? gg_spec_eval<NT, ADJ, 0, 2>(xl, lo_al, seed, site, sweep, -1, nullptr, stage_tables, &n, &live)
+                                : gg_spec_eval<NT, ADJ>(xl, lo_al, seed, site, sweep, -1, nullptr, stage_tables, &n, &live);
+      if (live && n >= lo && n < hi && t % x.Kp == 0) {
+        const int old = atomicExch(&cand[n], lab);
+        asm volatile("" ::"v"(old) : "memory");
+      }
     }
   }
   // last workgroup out: it sees every decision (read with agent-scope loads, not through a stale cache line)
@@ -1808,109 +1821,120 @@ __global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, uint64_t seed
     const int tk = atomicAdd(&S->ticket, 1);
     s_last = tk == (int)gridDim.x - 1 ? 1 : 0;
     if (s_last) __hip_atomic_store(&S->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_found = 0;
   }
   __syncthreads();
   if (!s_last) return;
-  if (t < GG_SHARD_M) { trip[3 * t] = GG_SHARD_NONE; trip[3 * t + 1] = 0; trip[3 * t + 2] = 0; }
+  if (t < GG_SHARD_M) { trip[2 * t] = GG_SHARD_NONE; trip[2 * t + 1] = 0; }
   __syncthreads();
-  // The first GG_SHARD_M deviations in position order.  Thread t looks at the nodes lo + 256 i + t (i < 16: the band has at
-  // most 4096 nodes), all of its loads in flight together - the decisions are read with agent-scope loads, a memory-side
-  // round trip each, and sixteen of them one after the other were most of this launch; a node's rank is the number of
-  // deviations in the stripes before its own plus those of the lanes before it in its stripe.
-  constexpr int NS = GG_SHARD_WINDOW / 256;
-  int cv[NS], hv[NS], ov[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const int nl = lo + i * 256 + t;
-    const bool in = nl < hi;
-    cv[i] = in ? __hip_atomic_load(&cand[nl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    hv[i] = in ? (int)H[x.n0 + nl - wbase] : 0;
-    ov[i] = in ? c[x.n0 + nl] : 0;
-  }
-  unsigned dev = 0;
+  // The first GG_SHARD_M deviations in position order, 4096 own nodes at a time.  Thread t looks at the nodes base + 256 i + t
+  // (i < 16), all of its loads in flight together - the decisions are read with agent-scope loads, a memory-side round trip
+  // each; a node's rank is the number of deviations found before its chunk, in the stripes before its own and in the lanes
+  // before it in its stripe.
+  constexpr int NS = 16;
   const int wv = t >> 6, ln = t & 63;
+  for (int base = lo; base < hi; base += NS * 256) {
+    int cv[NS], fv[NS], ov[NS], gv[NS];
 #pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const bool d = lo + i * 256 + t < hi && cv[i] != (hv[i] >= 0 ? (hv[i] & 0xff) : ov[i]);
-    dev |= d ? (1u << i) : 0u;
-    const unsigned long long bal = __ballot(d);
-    if (ln == 0) s_scan[i * 4 + wv] = __popcll(bal);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const bool d = (dev >> i) & 1u;
-    const unsigned long long bal = __ballot(d);
-    if (d) {
-      int rk = __popcll(bal & ((1ull << ln) - 1ull));
-      for (int q = 0; q < i * 4 + wv; ++q) rk += s_scan[q];
-      if (rk < GG_SHARD_M) { trip[3 * rk] = x.n0 + lo + i * 256 + t; trip[3 * rk + 1] = ov[i]; trip[3 * rk + 2] = cv[i]; }
+    for (int i = 0; i < NS; ++i) {
+      const int nl = base + i * 256 + t;
+      const bool in = nl < hi;
+      cv[i] = in ? __hip_atomic_load(&cand[nl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      gv[i] = in ? gg_own_glob(own, nl) : 0;
+      const int hv = in ? (int)H[gv[i] - wbase] : -1;
+      ov[i] = in ? c[gv[i]] : 0;
+      fv[i] = hv >= 0 ? (hv & 0xff) : ov[i];        // the label the node has for everybody behind it
     }
+    unsigned dev = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const bool d = base + i * 256 + t < hi && cv[i] != fv[i];
+      dev |= d ? (1u << i) : 0u;
+      const unsigned long long bal = __ballot(d);
+      if (ln == 0) s_scan[i * 4 + wv] = __popcll(bal);
+    }
+    __syncthreads();
+    const int found0 = s_found;
+    int tot = 0;
+#pragma unroll
+    for (int q = 0; q < NS * 4; ++q) tot += s_scan[q];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const bool d = (dev >> i) & 1u;
+      const unsigned long long bal = __ballot(d);
+      if (d) {
+        int rk = found0 + __popcll(bal & ((1ull << ln) - 1ull));
+        for (int q = 0; q < i * 4 + wv; ++q) rk += s_scan[q];
+        if (rk < GG_SHARD_M) { trip[2 * rk] = gv[i]; trip[2 * rk + 1] = (ov[i] << 16) | (fv[i] << 8) | cv[i]; }
+      }
+    }
+    __syncthreads();
+    if (t == 0) s_found = found0 + tot;
+    __syncthreads();
+    if (found0 + tot >= GG_SHARD_M) break;          // (uniform)
   }
 }
 
-// all: the gathered reports [world][GG_SHARD_M][3] (node, label it has, label it draws), in position order.
+// all: the gathered reports [world][GG_SHARD_M][2] (node, old << 16 | hypothesised << 8 | drawn).
 template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, int32_t* cnt, int32_t* Hb, int32_t* rs,
-                                                     gg_shard_state* S, int round, int ntot, const int32_t* __restrict__ all,
-                                                     int world, int32_t* __restrict__ cntn, int32_t* Gc0, int32_t* Gc1,
-                                                     long long* Gs0, long long* Gs1, const uint32_t* XA, const uint32_t* XAT,
-                                                     const int32_t* XW, const int32_t* XWT) {
+__global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, gg_own own, int W, int32_t* c, int32_t* cnt, int32_t* H,
+                                                     int32_t* rs, gg_shard_state* S, int round, int ntot,
+                                                     const int32_t* __restrict__ all, int world, int32_t* __restrict__ cntn,
+                                                     int32_t* Gc0, int32_t* Gc1, long long* Gs0, long long* Gs1,
+                                                     const uint32_t* XA, const uint32_t* XAT, const int32_t* XW, const int32_t* XWT) {
   constexpr int B = gg_tB(NT);
   constexpr int NSI = gg_tNSI(NT);
-  extern __shared__ int s_mv[];                // [world][GG_SHARD_M][3]
-  __shared__ int32_t s_H[GG_SHARD_WINDOW];
-  __shared__ int s_pstar, s_acc;
+  extern __shared__ int s_mv[];                // [world][GG_SHARD_M][4]: node, from, to, old
+  __shared__ int s_pstar;
   const int t = (int)threadIdx.x;
   const int spos = S->st[round & 1][0], wbase = S->st[round & 1][1];
-  const int32_t* H = Hb + (size_t)(round & 1) * GG_SHARD_WINDOW;   // -1 none, else (old << 8 | new): 8-bit labels, up to 256 blocks
   const bool first = blockIdx.x == 0 && blockIdx.y == 0;
   if (spos >= ntot) {          // the scan is over: the state is handed on as it is
     if (first && t == 0) { S->st[(round + 1) & 1][0] = spos; S->st[(round + 1) & 1][1] = wbase; }
     return;
   }
   const int nrep = world * GG_SHARD_M;
+  if (t == 0) s_pstar = GG_SHARD_NONE;
+  __syncthreads();
   // the moves the reports imply: node f leaves the block its hypothesis put it in (or its old one) for the one it draws
   for (int e = t; e < nrep; e += 256) {
-    const int f = all[3 * e];
-    int from = 0;
-    if (f != GG_SHARD_NONE) { const int h = H[f - wbase]; from = h >= 0 ? (h & 0xff) : all[3 * e + 1]; }
-    s_mv[3 * e] = f; s_mv[3 * e + 1] = from; s_mv[3 * e + 2] = all[3 * e + 2];
-  }
-  if (first) {
-    if (t == 0) { s_pstar = GG_SHARD_NONE; s_acc = 0; }
-    for (int i = t; i < GG_SHARD_WINDOW; i += 256) s_H[i] = H[i];
+    const int f = all[2 * e], pk = all[2 * e + 1];
+    s_mv[4 * e] = f; s_mv[4 * e + 1] = (pk >> 8) & 0xff; s_mv[4 * e + 2] = pk & 0xff; s_mv[4 * e + 3] = (pk >> 16) & 0xff;
+    if (f != GG_SHARD_NONE) atomicMin(&s_pstar, f);
   }
   __syncthreads();
-  if (first) {
-    // ---- fold, accept, move the scan on (one workgroup; everything it writes is read by LATER launches only)
-    const int bend = wbase + GG_SHARD_WINDOW < ntot ? wbase + GG_SHARD_WINDOW : ntot;
-    for (int e = t; e < nrep; e += 256) {
-      const int f = all[3 * e];
-      if (f == GG_SHARD_NONE) continue;
-      const int old = all[3 * e + 1], nw = all[3 * e + 2];
-      s_H[f - wbase] = (nw == old) ? -1 : ((old << 8) | nw);
-      atomicMin(&s_pstar, f);
+  const int bend = wbase + W < ntot ? wbase + W : ntot;
+  const bool quiet = s_pstar == GG_SHARD_NONE;
+  const int hi = quiet ? bend : s_pstar + 1;
+  {
+    // ---- fold, accept, reset: this workgroup's slice of the band (what it writes here is read by LATER launches only,
+    // or by itself behind its own barrier)
+    const int nwg = (int)(gridDim.x * gridDim.y), wg = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int slice = ((W + nwg - 1) / nwg + 63) & ~63;
+    const int b0 = wbase + wg * slice, b1 = b0 + slice < bend ? b0 + slice : bend;
+    if (b0 < b1) {                             // (uniform over the workgroup)
+      for (int e = t; e < nrep; e += 256) {
+        const int f = s_mv[4 * e];
+        if (f == GG_SHARD_NONE || f < b0 || f >= b1) continue;
+        const int old = s_mv[4 * e + 3], nw = s_mv[4 * e + 2];
+        H[f - wbase] = (nw == old) ? -1 : ((old << 8) | nw);
+      }
+      __syncthreads();
+      int mine = 0;
+      const int a0 = b0 > spos ? b0 : spos, a1 = b1 < hi ? b1 : hi;
+      for (int n = a0 + t; n < a1; n += 256) {
+        const int h = H[n - wbase];
+        if (h < 0) continue;
+        c[n] = h & 0xff;
+        atomicSub(&cnt[h >> 8], 1);
+        atomicAdd(&cnt[h & 0xff], 1);
+        ++mine;
+      }
+      // (a final band starts the next one without hypotheses)
+      if (quiet) for (int n = b0 + t; n < b1; n += 256) H[n - wbase] = -1;
+      if (mine) atomicAdd(&rs[2], mine);
     }
-    __syncthreads();
-    const bool quiet = s_pstar == GG_SHARD_NONE;
-    const int hi = quiet ? bend : s_pstar + 1;
-    int mine = 0;
-    for (int n = spos + t; n < hi; n += 256) {
-      const int h = s_H[n - wbase];
-      if (h < 0) continue;
-      c[n] = h & 0xff;
-      atomicSub(&cnt[h >> 8], 1);
-      atomicAdd(&cnt[h & 0xff], 1);
-      ++mine;
-    }
-    if (mine) atomicAdd(&s_acc, mine);
-    int32_t* Hn = Hb + (size_t)((round + 1) & 1) * GG_SHARD_WINDOW;
-    // (a final band starts the next one without hypotheses)
-    for (int i = t; i < GG_SHARD_WINDOW; i += 256) Hn[i] = quiet ? -1 : s_H[i];
-    __syncthreads();
-    if (t == 0) {
-      rs[2] += s_acc;
+    if (first && t == 0) {
       rs[GG_RS_ROUNDS] += 1;
       rs[GG_RS_SPOS] = hi;        // (for the host: the device reads the state copies)
       S->st[(round + 1) & 1][0] = hi;
@@ -1920,10 +1944,11 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, int32_t* c, 
   // ---- the moves applied to the statistics (and the block sizes) of this rank's nodes BEHIND the moved node
   const int n = blockIdx.x * blockDim.x + t;
   if (n >= x.N) return;
+  const int gn = gg_own_glob(own, n);
   const int Np = x.Np, K = x.K;
   for (int e = blockIdx.y; e < nrep; e += gridDim.y) {
-    const int f = s_mv[3 * e], a = s_mv[3 * e + 1], b = s_mv[3 * e + 2];
-    if (f == GG_SHARD_NONE || x.n0 + n <= f) continue;
+    const int f = s_mv[4 * e], a = s_mv[4 * e + 1], b = s_mv[4 * e + 2];
+    if (f == GG_SHARD_NONE || gn <= f) continue;
     atomicSub(&cntn[(size_t)n * K + a], 1);
     atomicAdd(&cntn[(size_t)n * K + b], 1);
     const size_t at = (size_t)f * Np + n;
@@ -1967,7 +1992,14 @@ __global__ void k_shard_init(const int32_t* __restrict__ cnt, int32_t* __restric
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { rs[GG_RS_ROUNDS] = 0; rs[GG_RS_SPOS] = 0; S->st[0][0] = 0; S->st[0][1] = 0; S->ticket = 0; }
   if (i < (size_t)Nl * K) cntn[i] = cnt[i % K];
-  if (i < GG_SHARD_WINDOW) H[i] = -1;
+  if (i < GG_SHARD_WMAX) H[i] = -1;
+}
+// sharded chain: the label sort with LOCAL node indices (-1 for a node another rank owns), what the pair tables' reduction walks
+__global__ void k_perm_local(const int32_t* __restrict__ perm, int32_t* __restrict__ perm_loc, int N, gg_own own) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  const int n = perm[r];
+  perm_loc[r] = gg_own_has(own, n) ? gg_own_below(own, n) : -1;
 }
 #endif
 

@@ -75,6 +75,50 @@ static inline int gg_qbits(int N) { int b = (62 - gg_ceil_log2(N)) / 2; return b
 // Number of integer weight statistics per (node, block): B first moments + B(B+1)/2 second moments.
 static inline int gg_nsi(int B) { return B + B * (B + 1) / 2; }
 
+// Which nodes a rank of a sharded chain owns.  lb < 0: the contiguous range [n0, n0 + Nl).  lb >= 0:
+// blocks of 2^lb consecutive nodes dealt out round-robin - node n belongs to rank (n >> lb) % world - so that every band of the
+// sequential scan spreads over all ranks; a rank's nodes keep their global order in its local numbering, local block i being
+// global block i * world + rank.  An unsharded model owns everything: {0, N, -1, 0, 1}.
+struct gg_own {
+  int n0, Nl, lb, rank, world;
+};
+// global index of local node nl
+GG_HD int gg_own_glob(const gg_own& o, int nl) {
+  if (o.lb < 0) return o.n0 + nl;
+  return ((((nl >> o.lb) * o.world) + o.rank) << o.lb) | (nl & ((1 << o.lb) - 1));
+}
+// number of owned nodes with a global index below n (= the local index of n when n is owned)
+GG_HD int gg_own_below(const gg_own& o, int n) {
+  int v;
+  if (o.lb < 0) {
+    v = n - o.n0;
+    v = v < 0 ? 0 : v;
+  } else {
+    const int nb = n >> o.lb, q = nb / o.world, r = nb - q * o.world;
+    v = (q << o.lb) + (r > o.rank ? (1 << o.lb) : (r == o.rank ? (n & ((1 << o.lb) - 1)) : 0));
+  }
+  return v > o.Nl ? o.Nl : v;
+}
+GG_HD bool gg_own_has(const gg_own& o, int n) {
+  if (o.lb < 0) return n >= o.n0 && n < o.n0 + o.Nl;
+  const int nb = n >> o.lb;
+  return nb % o.world == o.rank;
+}
+// (the same ownership on both sides of a call?)
+static inline bool gg_own_same(const gg_own& a, const gg_own& b) {
+  if (a.Nl != b.Nl || (a.lb < 0) != (b.lb < 0)) return false;
+  return a.lb < 0 ? a.n0 == b.n0 : (a.lb == b.lb && a.rank == b.rank && a.world == b.world);
+}
+// block-interleaved ownership of N nodes; returns false for arguments that describe none
+static inline bool gg_own_blocks(int N, int block, int rank, int world, gg_own* o) {
+  if (block < 8 || (block & (block - 1)) || world < 1 || rank < 0 || rank >= world) return false;
+  o->n0 = 0; o->lb = 0; o->rank = rank; o->world = world;
+  while ((1 << o->lb) < block) o->lb += 1;
+  o->Nl = 0x7fffffff;
+  o->Nl = gg_own_below(*o, N);
+  return true;
+}
+
 // Device-resident network.  Layout:
 //   A, AT   : uint8  [N][Np]      off-diagonal adjacency and its transpose (diag = 0, pad = 0)
 //   Ab, AbT : uint32 [N][Np/32]   the same, bit-packed (block adjacency models: 1/8 of the bytes per pass)
@@ -85,7 +129,8 @@ static inline int gg_nsi(int B) { return B + B * (B + 1) / 2; }
 struct gg_data {
   int device;
   int N, B, Np;      // N rows (all nodes); Np = padded number of stored columns
-  int n0, n1;        // stored columns = nodes [n0, n1) (0, N unless this is a shard)
+  int n0, n1;        // stored columns = nodes [n0, n1) (0, N unless this is a shard; -1, -1 for a block-interleaved shard)
+  gg_own own;        // the stored columns, in general: local column nl holds node gg_own_glob(own, nl)
   int has_w;
   int shift;
   long long n_edges;

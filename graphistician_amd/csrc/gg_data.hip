@@ -131,14 +131,14 @@ __device__ __forceinline__ int32_t gg_gen_edge(int i, int j, int K, const int32_
 }
 
 __global__ void k_generate_sbm_shard(uint8_t* A, uint8_t* AT, int32_t* Wq, int32_t* WqT, uint8_t* dA, int32_t* dWq, int N,
-                                     int Np, int n0, int Nl, int K, const int32_t* __restrict__ c,
+                                     int Np, gg_own own, int Nl, int K, const int32_t* __restrict__ c,
                                      const double* __restrict__ p, double p_self, const double* __restrict__ mu,
                                      const double* __restrict__ sd, double mu_self, double sd_self, uint64_t seed,
                                      double scale, int qmax) {
   const int nl = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;
   if (nl >= Nl) return;
-  const int n = n0 + nl;
+  const int n = gg_own_glob(own, nl);
   int a_in, a_out;
   const int32_t q_in = gg_gen_edge(i, n, K, c, p, p_self, mu, sd, mu_self, sd_self, seed, scale, qmax, &a_in);
   if (i == n) {
@@ -337,7 +337,7 @@ int gg_device_count(int* count) {
 }
 
 const char* gg_last_error(void) { return gg_err_text.c_str(); }
-const char* gg_version(void) { return "graphgibbs-mi355x 0.1 (gfx950)"; }
+const char* gg_version(void) { return "graphgibbs-mi355x 0.4 (gfx950)"; }
 
 int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t device) {
   if (!out || !A || N <= 0) return gg_fail(GG_ERR_INVALID, "gg_data_create: bad arguments");
@@ -350,6 +350,7 @@ int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const 
   d->device = device;
   d->N = N;
   d->n0 = 0; d->n1 = N;
+  d->own = gg_own{0, N, -1, 0, 1};
   d->B = W ? B : 1;
   d->Np = gg_round_up(N, 64);
   d->has_w = W ? 1 : 0;
@@ -377,33 +378,45 @@ int gg_data_update(gg_data* d, const uint8_t* A, const double* W) {
 
 static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
                            const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
-                           int32_t device, int32_t n0, int32_t n1);
+                           int32_t device, gg_own own);
 
 int gg_data_create_sbm(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
                        const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
                        int32_t device) {
-  return create_sbm_impl(out, N, K, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device, 0, N);
+  return create_sbm_impl(out, N, K, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device, gg_own{0, N, -1, 0, 1});
 }
 
 int gg_data_create_sbm_shard(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
                              const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
                              int32_t n0, int32_t n1, int32_t device) {
   if (n0 < 0 || n1 > N || n0 >= n1) return gg_fail(GG_ERR_INVALID, "gg_data_create_sbm_shard: bad node range");
-  return create_sbm_impl(out, N, K, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device, n0, n1);
+  return create_sbm_impl(out, N, K, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device, gg_own{n0, n1 - n0, -1, 0, 1});
+}
+
+int gg_data_create_sbm_shard_blocks(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                                    const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                                    int32_t block, int32_t rank, int32_t world, int32_t device) {
+  gg_own own;
+  if (N <= 0 || !gg_own_blocks(N, block, rank, world, &own))
+    return gg_fail(GG_ERR_INVALID, "gg_data_create_sbm_shard_blocks: block %d (a power of two >= 8), rank %d of %d", block, rank, world);
+  if (own.Nl < 1) return gg_fail(GG_ERR_INVALID, "gg_data_create_sbm_shard_blocks: rank %d of %d owns no node of %d in blocks of %d", rank, world, N, block);
+  return create_sbm_impl(out, N, K, c, p, p_self, mu, sigma, mu_self, sigma_self, seed, device, own);
 }
 
 static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
                            const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
-                           int32_t device, int32_t n0, int32_t n1) {
+                           int32_t device, gg_own own) {
   if (!out || N <= 0 || K <= 0 || !c || !p || !mu || !sigma) return gg_fail(GG_ERR_INVALID, "gg_data_create_sbm: bad arguments");
   int rc = gg_ensure_device(device);
   if (rc) return rc;
-  const bool shard = !(n0 == 0 && n1 == N);
-  const int Nl = n1 - n0;
+  const bool shard = !(own.lb < 0 && own.n0 == 0 && own.Nl == N);
+  const int Nl = own.Nl;
   gg_data* d = new gg_data();
   memset(d, 0, sizeof(*d));
   d->uid = gg_next_data_uid();
-  d->device = device; d->N = N; d->n0 = n0; d->n1 = n1; d->B = 1; d->Np = gg_round_up(Nl, 64); d->has_w = 1;
+  d->device = device; d->N = N; d->B = 1; d->Np = gg_round_up(Nl, 64); d->has_w = 1;
+  d->own = own;
+  if (own.lb < 0) { d->n0 = own.n0; d->n1 = own.n0 + Nl; } else { d->n0 = d->n1 = -1; }
   if ((rc = data_open(d))) return rc;
   // fixed-point scale from a bound on |w|: max |mu| + 8 sd (values beyond are clamped; probability < 1e-15 per edge)
   double wb = fabs(mu_self) + 8.0 * sqrt(sigma_self);
@@ -435,7 +448,7 @@ static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c
     if (rc) return rc;
   } else {
     dim3 grd((Nl + 255) / 256, N);
-    k_generate_sbm_shard<<<grd, 256, 0, d->stream>>>(d->A, d->AT, d->Wq, d->WqT, d->dA, d->dWq, N, d->Np, n0, Nl, K, dc, dp,
+    k_generate_sbm_shard<<<grd, 256, 0, d->stream>>>(d->A, d->AT, d->Wq, d->WqT, d->dA, d->dWq, N, d->Np, own, Nl, K, dc, dp,
                                                      p_self, dmu, dsd, mu_self, sqrt(sigma_self), seed,
                                                      ldexp(1.0, d->shift), 1 << qb);
     GG_HIP(hipGetLastError());
@@ -458,9 +471,24 @@ static int create_sbm_impl(gg_data** out, int32_t N, int32_t K, const int32_t* c
   return GG_OK;
 }
 
+static int create_shard_impl(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, gg_own own, int32_t device);
+
 int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t n0, int32_t n1,
                          int32_t device) {
   if (!out || !A || N <= 0 || n0 < 0 || n1 > N || n0 >= n1) return gg_fail(GG_ERR_INVALID, "gg_data_create_shard: bad arguments");
+  return create_shard_impl(out, N, B, A, W, gg_own{n0, n1 - n0, -1, 0, 1}, device);
+}
+
+int gg_data_create_shard_blocks(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t block, int32_t rank,
+                                int32_t world, int32_t device) {
+  gg_own own;
+  if (!out || !A || N <= 0 || !gg_own_blocks(N, block, rank, world, &own))
+    return gg_fail(GG_ERR_INVALID, "gg_data_create_shard_blocks: block %d (a power of two >= 8), rank %d of %d", block, rank, world);
+  if (own.Nl < 1) return gg_fail(GG_ERR_INVALID, "gg_data_create_shard_blocks: rank %d of %d owns no node of %d in blocks of %d", rank, world, N, block);
+  return create_shard_impl(out, N, B, A, W, own, device);
+}
+
+static int create_shard_impl(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, gg_own own, int32_t device) {
   if (W && (B < 1 || B > GG_MAXB)) return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d not in 1..%d", B, GG_MAXB);
   int rc = gg_ensure_device(device);
   if (rc) return rc;
@@ -468,9 +496,11 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
   memset(d, 0, sizeof(*d));
   d->uid = gg_next_data_uid();
   d->device = device;
-  d->N = N; d->n0 = n0; d->n1 = n1;
+  d->N = N;
+  d->own = own;
+  if (own.lb < 0) { d->n0 = own.n0; d->n1 = own.n0 + own.Nl; } else { d->n0 = d->n1 = -1; }
   d->B = W ? B : 1;
-  const int Nl = n1 - n0;
+  const int Nl = own.Nl;
   d->Np = gg_round_up(Nl, 64);
   d->has_w = W ? 1 : 0;
   if ((rc = data_open(d))) return rc;
@@ -480,7 +510,7 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
   long long nedges = 0;
   for (int i = 0; i < N; ++i)
     for (int nl = 0; nl < Nl; ++nl) {
-      const int n = n0 + nl;
+      const int n = gg_own_glob(own, nl);
       const uint8_t a_in = A[(size_t)i * N + n] ? 1 : 0;    // i -> n
       const uint8_t a_out = A[(size_t)n * N + i] ? 1 : 0;   // n -> i
       if (i == n) { hdA[nl] = a_in; nedges += a_in; continue; }
@@ -537,7 +567,7 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
     for (int nl = 0; nl < Nl; ++nl) hdW[(size_t)nl * B] = GG_NO_EDGE;
     for (int i = 0; i < N; ++i)
       for (int nl = 0; nl < Nl; ++nl) {
-        const int n = n0 + nl;
+        const int n = gg_own_glob(own, nl);
         const size_t in = (size_t)i * N + n, on = (size_t)n * N + i;
         if (i == n) {
           if (A[in]) for (int b = 0; b < B; ++b) hdW[(size_t)nl * B + b] = (int32_t)llrint(ldexp(W[in * B + b], d->shift));
@@ -630,6 +660,7 @@ int gg_data_quantisation(const gg_data* d, double* w_max, double* w_low, int32_t
 
 int gg_data_download(const gg_data* d, uint8_t* A, double* W) {
   if (!d || !A) return gg_fail(GG_ERR_INVALID, "gg_data_download: bad arguments");
+  if (d->n0 != 0 || d->n1 != d->N) return gg_fail(GG_ERR_INVALID, "gg_data_download: not for column shards");
   GG_HIP(hipSetDevice(d->device));
   int N = d->N, Np = d->Np, B = d->B;
   std::vector<uint8_t> hA((size_t)N * Np), hdA(N);

@@ -45,7 +45,8 @@ struct gg_model {
   bool is_adj, is_block, sbm;
   bool joint;                           // GG_SBM_JOINT: a weight model that also carries p and the adjacency terms of the conditional
   int N, K, Kp, B, NT, NSI, Np, NTAB;   // N = all nodes (labels, rows); Np = padded number of OWNED nodes
-  int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded)
+  int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded; n0 = 0 when block-interleaved)
+  gg_own own;                           // the owned nodes, in general (gg_common.h)
   bool sharded;
   int ngraphs = 1;                      // graphs whose tables the parameter step is drawing from (gg_resample_part_many)
   long long* tab_sum = nullptr;         // their summed K x K tables
@@ -120,7 +121,9 @@ struct gg_model {
   long long chg_seen;           // label changes (control word 2) at the last decision
   long long clean_run;          // consecutive sweeps without a label change while in k_scan mode
   int32_t* sh_cntn;             // sharded scan: [Nl][K] block sizes as own node n sees them
-  int32_t* sh_H;                //               [2][GG_SHARD_WINDOW] hypothesis per node of the band, two copies used alternately
+  int32_t* sh_H;                //               [GG_SHARD_WMAX] hypothesis per node of the band
+  int32_t* perm_loc;            //               the label sort with local node indices (k_perm_local)
+  int sh_band;                  //               width of the scan's band chosen for the next scan (0: not yet)
   gg_shard_state* sh_state;     //               scan position / band start (two copies) + the evaluation launch's ticket
   int sh_hint;                  //               rounds the last scan of this model needed (+ margin): the first batch of the next
   bool wide;                    // 65..256 blocks: a node's lanes span two or four wavefronts - the resident scan's wide instantiation is the
@@ -313,10 +316,21 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   m->NSI = m->is_adj ? 0 : gg_nsi(m->B);
   m->NTAB = m->is_adj ? 1 : 1 + 2 * m->NSI;
   m->n0 = 0; m->Nl = m->N; m->sharded = false;
-  if (cfg->shard_end > cfg->shard_begin) {
+  m->own = gg_own{0, m->N, -1, 0, 1};
+  if (cfg->shard_block > 0) {
+    if (!gg_own_blocks(m->N, cfg->shard_block, cfg->shard_rank, cfg->shard_world, &m->own) || m->own.Nl < 1) {
+      const int bl = cfg->shard_block, rk = cfg->shard_rank, wd = cfg->shard_world, NN = m->N;
+      delete m;
+      return gg_fail(GG_ERR_INVALID, "shard_block %d (a power of two >= 8), rank %d of %d: no such share of %d nodes", bl, rk, wd, NN);
+    }
+    m->Nl = m->own.Nl;
+    m->sharded = m->own.world > 1;
+    if (!m->sharded) m->own = gg_own{0, m->N, -1, 0, 1};      // one rank owns everything, in order
+  } else if (cfg->shard_end > cfg->shard_begin) {
     if (cfg->shard_begin < 0 || cfg->shard_end > m->N) { delete m; return gg_fail(GG_ERR_INVALID, "shard [%d,%d) outside [0,%d)", cfg->shard_begin, cfg->shard_end, m->N); }
     m->n0 = cfg->shard_begin; m->Nl = cfg->shard_end - cfg->shard_begin;
     m->sharded = !(m->n0 == 0 && m->Nl == m->N);
+    m->own = gg_own{m->n0, m->Nl, -1, 0, 1};
   }
   m->Np = gg_round_up(m->Nl, 64);
   // NIW / non-SBM weight kinds always keep a separate self Gaussian (weights.py:91-94)
@@ -474,7 +488,7 @@ int gg_model_destroy(gg_model* m) {
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
                   m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all,
-                  m->sh_cntn, m->sh_H, m->sh_state, m->pred_buf, m->tab_sum};
+                  m->sh_cntn, m->sh_H, m->sh_state, m->pred_buf, m->tab_sum, m->perm_loc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (m->h_rs) hipHostFree(m->h_rs);
   if (m->h_tab) hipHostFree(m->h_tab);
@@ -616,8 +630,14 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes) {
 static int check_data(const gg_model* m, const gg_data* d) {
   if (!d) return gg_fail(GG_ERR_INVALID, "null data handle");
   if (d->N != m->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", d->N, m->N);
-  if (d->n0 != m->n0 || d->n1 != m->n0 + m->Nl)
-    return gg_fail(GG_ERR_INVALID, "data holds nodes [%d,%d), model owns [%d,%d)", d->n0, d->n1, m->n0, m->n0 + m->Nl);
+  if (!gg_own_same(d->own, m->own)) {
+    if (d->own.lb < 0 && m->own.lb < 0)
+      return gg_fail(GG_ERR_INVALID, "data holds nodes [%d,%d), model owns [%d,%d)", d->n0, d->n1, m->n0, m->n0 + m->Nl);
+    return gg_fail(GG_ERR_INVALID, "data and model do not describe the same share of the nodes (data: %d nodes, blocks of %d, rank %d of %d; "
+                                   "model: %d nodes, blocks of %d, rank %d of %d; block 0 = a contiguous range)", d->own.Nl,
+                   d->own.lb < 0 ? 0 : 1 << d->own.lb, d->own.rank, d->own.world, m->own.Nl, m->own.lb < 0 ? 0 : 1 << m->own.lb,
+                   m->own.rank, m->own.world);
+  }
   if (d->device != m->cfg.device) return gg_fail(GG_ERR_INVALID, "data on device %d, model on device %d", d->device, m->cfg.device);
   if (d->n_missing) return gg_fail(GG_ERR_UNSUPPORTED, "the network has %lld unobserved entries: missing data is defined for the eigenmodels only (eigenmodel.py:121-127)", d->n_missing);
   if (!m->is_adj) {
@@ -649,7 +669,7 @@ static long long* gs(const gg_model* m, int buf, int dir) {
 static gg_node_ctx node_ctx(const gg_model* m, const gg_data* d, int buf) {
   gg_node_ctx x;
   x.beta = m->beta;
-  x.n0 = m->n0;
+  x.n0 = m->own.lb < 0 ? m->n0 : 0;      // (block-interleaved shards: the sharded kernels set it per workgroup)
   x.N = m->Nl; x.Np = m->Np; x.K = m->K; x.Kp = m->Kp; x.B = m->B; x.shift = m->is_adj ? 0 : d->shift;
   x.special = m->cfg.special_case_self_conns;
   x.c = m->c; x.cnt = m->cnt; x.cntn = nullptr; x.logm = m->logm; x.T = m->T; x.Tout = m->Tout; x.Tin = m->Tin;
@@ -813,10 +833,11 @@ static gg_params_args fill_params_args(gg_model* m, const gg_data* d, int buf, b
   memset(&g, 0, sizeof(g));
   g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.Kp = m->Kp; g.B = m->B; g.NSI = m->NSI; g.Np = m->Np; g.N = m->N;
   g.n0 = m->n0; g.Nl = m->Nl;
+  if (m->sharded) g.n0 = 0;      // (the pair tables walk perm_loc: local indices, -1 for another rank's node)
   g.do_tables = tables; g.do_draw = draw; g.do_prep = prep;
   g.add_diag = m->cfg.special_case_self_conns ? 0 : 1;
   g.Gcnt0 = gcnt(m, buf, 0); g.GS0 = gs(m, buf, 0);
-  g.perm = m->permb[pidx]; g.lab_start = m->labb[pidx]; g.cnt = m->cnt;
+  g.perm = m->sharded ? m->perm_loc : m->permb[pidx]; g.lab_start = m->labb[pidx]; g.cnt = m->cnt;
   g.dA = d ? d->dA : nullptr; g.dWq = d ? d->dWq : nullptr;
   g.tab = m->tab;
   g.ah.tau1 = m->cfg.tau1; g.ah.tau0 = m->cfg.tau0;
@@ -866,6 +887,11 @@ static int enqueue_params(gg_model* m, const gg_data* d, int buf, bool tables, b
                                                           m->is_adj ? GG_SITE_ADJ_M : GG_SITE_W_M, m->m_sweep, m->m, m->rs);
     GG_HIP(hipGetLastError());
     m->m_pending = false;
+  }
+  if (m->sharded && tables) {
+    if (!m->perm_loc) { int rcp = dmalloc(&m->perm_loc, (size_t)m->N); if (rcp) return rcp; }
+    k_perm_local<<<(m->N + 255) / 256, 256, 0, m->stream>>>(m->permb[pidx], m->perm_loc, m->N, m->own);
+    GG_HIP(hipGetLastError());
   }
   gg_params_args g = fill_params_args(m, d, buf, tables, draw, prep, zero_buf, sweep, pidx);
   // more than 64 blocks (plain SBM kinds): a wave per block pair, four pairs per workgroup, log m in the same launch
@@ -2353,12 +2379,13 @@ struct gg_comm {
   void* user;
   std::vector<long long> h64;
   std::vector<int32_t> h32s, h32r;
-  unsigned long long collectives;   // collectives issued through this communicator
+  unsigned long long collectives;   // collectives issued through this communicator (none with one rank: nothing travels)
+  unsigned long long rounds;        // rounds of the sharded scans driven through it (each is one all-gather when world > 1)
 };
 
 static int comm_allreduce_i64(gg_comm* c, long long* dbuf, size_t n, hipStream_t st) {
+  if (c->world == 1) return GG_OK;      // (one rank: nothing travels, nothing is counted - ADVICE r3)
   c->collectives += 1;
-  if (c->world == 1) return GG_OK;
   if (c->nccl) {
     const ncclResult_t r = ncclAllReduce(dbuf, dbuf, n, ncclInt64, ncclSum, c->nccl, st);
     if (r != ncclSuccess) return gg_fail(GG_ERR_HIP, "ncclAllReduce failed: %s", ncclGetErrorString(r));
@@ -2374,7 +2401,7 @@ static int comm_allreduce_i64(gg_comm* c, long long* dbuf, size_t n, hipStream_t
 }
 
 static int comm_allgather_i32(gg_comm* c, const int32_t* dsend, int32_t* drecv, size_t n, hipStream_t st) {
-  c->collectives += 1;
+  if (c->world > 1) c->collectives += 1;
   if (c->world == 1) {
     GG_HIP(hipMemcpyAsync(drecv, dsend, n * 4, hipMemcpyDeviceToDevice, st));
     return GG_OK;
@@ -2409,7 +2436,7 @@ int gg_comm_create_rccl(gg_comm** out, int32_t rank, int32_t world, const uint8_
   if (rc) return rc;
   gg_comm* c = new gg_comm();
   c->rank = rank; c->world = world; c->device = device; c->nccl = nullptr; c->ar = nullptr; c->ag = nullptr; c->user = nullptr;
-  c->collectives = 0;
+  c->collectives = 0; c->rounds = 0;
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   const ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
@@ -2426,7 +2453,7 @@ int gg_comm_create_host(gg_comm** out, int32_t rank, int32_t world, gg_host_allr
   if (rc) return rc;
   gg_comm* c = new gg_comm();
   c->rank = rank; c->world = world; c->device = device; c->nccl = nullptr; c->ar = ar; c->ag = ag; c->user = user;
-  c->collectives = 0;
+  c->collectives = 0; c->rounds = 0;
   *out = c;
   return GG_OK;
 }
@@ -2438,12 +2465,13 @@ int gg_comm_destroy(gg_comm* c) {
   return GG_OK;
 }
 
-int gg_comm_info(const gg_comm* c, int32_t* rank, int32_t* world, int32_t* is_rccl, uint64_t* collectives) {
+int gg_comm_info(const gg_comm* c, int32_t* rank, int32_t* world, int32_t* is_rccl, uint64_t* collectives, uint64_t* rounds) {
   if (!c) return gg_fail(GG_ERR_INVALID, "null communicator");
   if (rank) *rank = c->rank;
   if (world) *world = c->world;
   if (is_rccl) *is_rccl = c->nccl ? 1 : 0;
   if (collectives) *collectives = c->collectives;
+  if (rounds) *rounds = c->rounds;
   return GG_OK;
 }
 
@@ -2481,15 +2509,21 @@ static int shard_global_tables(gg_model* m, const gg_data* d, gg_comm* c, int di
   return comm_allreduce_i64(c, m->tab, (size_t)m->K * m->K * m->NTAB, m->stream);
 }
 
-// One round of the sharded scan = these two launches around the all-gather (gg_block_kernels.h).
-static int launch_shard_eval(gg_model* m, const gg_data* d, int buf, int round) {
+// One round of the sharded scan = these two launches around the all-gather (gg_block_kernels.h).  W: width of the band.
+static int launch_shard_eval(gg_model* m, const gg_data* d, int buf, int round, int W) {
   gg_node_ctx x = node_ctx(m, d, buf);
   x.cntn = m->sh_cntn;   // block sizes as each own node sees them (hypotheses at earlier positions included)
   // (33..64 blocks, NT <= 3: eight nodes per workgroup in two passes of four - gg_spec_eval_split8)
   const int K = m->K, per = (m->Kp == 64 && m->NT <= 3) ? 8 : 256 / m->Kp;
-  const int count = m->Nl < GG_SHARD_WINDOW ? m->Nl : GG_SHARD_WINDOW;
-  int nb = (count + per - 1) / per;
-  if (nb < 1) nb = 1;                    // (a rank without nodes still reports "no surprise")
+  // own nodes of a band: at most ceil(W / (block * world)) own blocks (+1 for a band that starts inside one)
+  int count = m->Nl;
+  if (m->own.lb >= 0) {
+    const long long span = (long long)m->own.world << m->own.lb;
+    const long long c2 = ((long long)W / span + 2) << m->own.lb;
+    if (c2 < count) count = (int)c2;
+  } else if (W < count) count = W;
+  int nb = (count + per - 1) / per + 1;       // (+1: workgroups start at a multiple of `per` at or before the first node)
+  if (nb < 1) nb = 1;                         // (a rank without nodes in the band still reports "no surprise")
   const uint32_t site = m->is_adj ? GG_SITE_ADJ_C : GG_SITE_W_C;
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double);
   const int stage = (lds + table_bytes(m) <= 64 * 1024) ? 1 : 0;
@@ -2503,8 +2537,8 @@ static int launch_shard_eval(gg_model* m, const gg_data* d, int buf, int round) 
       GG_HIP(hipFuncSetAttribute((const void*)k_shard_eval<NTV, ADJV>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    k_shard_eval<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, m->cfg.seed, site, m->sweep, m->cand, m->c, m->sh_H, m->sh_state, \
-                                                         round, m->N, stage, m->sh_trip);                                  \
+    k_shard_eval<NTV, ADJV><<<nb, 256, lds, m->stream>>>(x, m->own, W, m->cfg.seed, site, m->sweep, m->cand, m->c, m->sh_H,  \
+                                                         m->sh_state, round, m->N, stage, m->sh_trip);                     \
   } while (0)
   if (m->is_adj) SHE(2, true);
   else if (m->B == 1) SHE(3, false);
@@ -2516,13 +2550,13 @@ static int launch_shard_eval(gg_model* m, const gg_data* d, int buf, int round) 
   return GG_OK;
 }
 
-static int launch_shard_apply(gg_model* m, const gg_data* d, int buf, int round, const int32_t* all, int world) {
+static int launch_shard_apply(gg_model* m, const gg_data* d, int buf, int round, int W, const int32_t* all, int world) {
   gg_node_ctx x = node_ctx(m, d, buf);
   dim3 grd((m->Nl + 255) / 256 > 0 ? (m->Nl + 255) / 256 : 1, 8);
-  const size_t lds = (size_t)3 * GG_SHARD_M * world * sizeof(int);
+  const size_t lds = (size_t)4 * GG_SHARD_M * world * sizeof(int);
 #define SHA(NTV, ADJV)                                                                                                 \
-  k_shard_apply<NTV, ADJV><<<grd, 256, lds, m->stream>>>(x, m->c, m->cnt, m->sh_H, m->rs, m->sh_state, round, m->N, all, world, \
-                                                         m->sh_cntn, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0),  \
+  k_shard_apply<NTV, ADJV><<<grd, 256, lds, m->stream>>>(x, m->own, W, m->c, m->cnt, m->sh_H, m->rs, m->sh_state, round, m->N, all, \
+                                                         world, m->sh_cntn, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0), \
                                                          gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT)
   if (m->is_adj) SHA(2, true);
   else if (m->B == 1) SHA(3, false);
@@ -2534,9 +2568,41 @@ static int launch_shard_apply(gg_model* m, const gg_data* d, int buf, int round,
   return GG_OK;
 }
 
+static int shard_alloc(gg_model* m, const gg_comm* c) {
+  int rc;
+  if (!m->sh_buf) {
+    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, (size_t)2 * GG_SHARD_M + 4)) ||
+        (rc = dmalloc(&m->sh_all, (size_t)2 * GG_SHARD_M * c->world + 4)))
+      return rc;
+    m->sh_world = c->world;
+  }
+  return GG_OK;
+}
+
+// Width of the band of the next scan.  A round costs one collective and two launches whatever the band's width, and a band is
+// closed after 1 + (depth of mutually dependent decisions) rounds, so the band should be as wide as the reports can describe:
+// a rank reports GG_SHARD_M surprises per round, and the first round of a band meets every node that changes its label - the
+// previous scan's count (replicated: the same on every rank) sizes the band so that a round's reports hold about half of
+// what they can.  A burn-in scan (most labels change) runs 4096-node bands, a converged chain one band for the whole scan.
+// GG_SHARD_BAND fixes it (tests cross several widths: the chain does not depend on it).
+static int shard_band(const gg_model* m, int world, long long last_changes) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("GG_SHARD_BAND"); forced = e ? atoi(e) : 0; }
+  long long W;
+  if (forced > 0) W = forced;
+  else {
+    const long long room = (long long)GG_SHARD_M * world / 2;
+    W = last_changes <= 0 ? GG_SHARD_WMAX : (long long)m->N * room / last_changes;
+  }
+  long long p = 256;                       // (a power of two: band boundaries fall on ownership-block boundaries)
+  while (p * 2 <= W && p * 2 <= GG_SHARD_WMAX) p *= 2;
+  if (forced <= 0 && p < 4096) p = 4096;
+  return (int)p;
+}
+
 // n half-sweeps (adjacency.py:615-618 / weights.py:394-397) of a chain whose nodes are sharded over the communicator's
 // ranks.  Per half-sweep: one all-reduce of the integer tables; the scan in rounds of
-//   speculate (own nodes of the band, under the hypotheses) -> first surprises -> ALL-GATHER of (node, old, new) x GG_SHARD_M
+//   speculate (own nodes of the band, under the hypotheses) -> first surprises -> ALL-GATHER of (node, labels) x GG_SHARD_M
 //   -> fold / accept up to the earliest surprise -> moves of the own nodes' statistics         (k_shard_* kernels),
 // all enqueued on the engine stream in batches, the host reading the scan position once per batch.  Every rank issues the
 // same collectives (the position it reads is the same everywhere), and rounds beyond the scan's end are no-ops.
@@ -2545,14 +2611,11 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
   int rc = shard_check(m, d, c);
   if (rc) return rc;
   if (!m->sharded && c->world > 1) return gg_fail(GG_ERR_INVALID, "gg_shard_sweep: the model was not created with a node shard");
-  if (!m->sh_buf) {
-    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, (size_t)3 * GG_SHARD_M + 4)) ||
-        (rc = dmalloc(&m->sh_all, (size_t)3 * GG_SHARD_M * c->world + 4)))
-      return rc;
-    m->sh_world = c->world;
-  }
+  if (m->own.lb >= 0 && m->own.world != c->world)
+    return gg_fail(GG_ERR_INVALID, "gg_shard_sweep: the model's nodes are dealt out to %d ranks, the communicator has %d", m->own.world, c->world);
+  if ((rc = shard_alloc(m, c))) return rc;
   if (!m->sh_cntn) {
-    if ((rc = dmalloc(&m->sh_cntn, (size_t)(m->Nl > 0 ? m->Nl : 1) * m->K)) || (rc = dmalloc(&m->sh_H, (size_t)2 * GG_SHARD_WINDOW)) ||
+    if ((rc = dmalloc(&m->sh_cntn, (size_t)(m->Nl > 0 ? m->Nl : 1) * m->K)) || (rc = dmalloc(&m->sh_H, (size_t)GG_SHARD_WMAX)) ||
         (rc = dmalloc(&m->sh_state, 1)))
       return rc;
   }
@@ -2572,10 +2635,13 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
     if (rc) return rc;
     if (m->K > 1) {
       {
-        const size_t cells = (size_t)m->Nl * m->K > (size_t)GG_SHARD_WINDOW ? (size_t)m->Nl * m->K : (size_t)GG_SHARD_WINDOW;
+        const size_t cells = (size_t)m->Nl * m->K > (size_t)GG_SHARD_WMAX ? (size_t)m->Nl * m->K : (size_t)GG_SHARD_WMAX;
         k_shard_init<<<(unsigned)((cells + 255) / 256), 256, 0, m->stream>>>(m->cnt, m->sh_cntn, m->sh_H, m->Nl, m->K, m->rs, m->sh_state);
         GG_HIP(hipGetLastError());
       }
+      if (m->sh_band <= 0) m->sh_band = shard_band(m, c->world, (long long)m->N);   // (first scan: nothing known - burn-in width)
+      const int W = m->sh_band;
+      const long long chg0 = (long long)(uint32_t)m->h_rs[2];      // (the running count the previous scan left: replicated)
       // Rounds are enqueued in batches without host synchronisation; a round beyond the scan's end is a no-op on the device
       // but still a collective on the wire, so the first batch is what the previous scan needed plus a margin (the same
       // number on every rank: it comes from the replicated control block), later ones a quarter of that.
@@ -2586,12 +2652,12 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
       for (;;) {
         for (int r = 0; r < batch; ++r, ++round) {
           // one round: own nodes of the band behind the scan position evaluated under the hypotheses, the first GG_SHARD_M
-          // surprises compacted by the launch's last workgroup -> ALL-GATHER -> fold into the hypotheses, accept up to the
-          // earliest surprise, moves of the owned nodes' statistics
-          if ((rc = launch_shard_eval(m, d, buf, round))) return rc;
-          if (c->world > 1) { if ((rc = comm_allgather_i32(c, m->sh_trip, m->sh_all, 3 * GG_SHARD_M, m->stream))) return rc; }
-          else c->collectives += 1;
-          if ((rc = launch_shard_apply(m, d, buf, round, all, c->world))) return rc;
+          // surprises compacted by the launch's last workgroup -> ALL-GATHER -> every workgroup amends / accepts / resets its
+          // slice of the band up to the earliest surprise, moves of the owned nodes' statistics
+          if ((rc = launch_shard_eval(m, d, buf, round, W))) return rc;
+          if (c->world > 1) { if ((rc = comm_allgather_i32(c, m->sh_trip, m->sh_all, 2 * GG_SHARD_M, m->stream))) return rc; }
+          c->rounds += 1;
+          if ((rc = launch_shard_apply(m, d, buf, round, W, all, c->world))) return rc;
         }
         GG_HIP(hipMemcpyAsync(m->h_rs, m->rs, 24 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
         GG_HIP(hipStreamSynchronize(m->stream));
@@ -2606,6 +2672,7 @@ int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n) {
         const int hint = used + (used / 8 > 1 ? used / 8 : 1);
         m->sh_hint = hint < 2 ? 2 : (hint > 4096 ? 4096 : hint);
       }
+      m->sh_band = shard_band(m, c->world, (long long)(uint32_t)m->h_rs[2] - chg0);
       m->perm_valid = false;
     }
     k_draw_m<<<1, m->K > 64 ? 256 : 64, (m->K > 64 ? 256 : 64) * sizeof(double), m->stream>>>(m->cnt, m->pi, m->K, m->cfg.seed,
@@ -2624,12 +2691,7 @@ int gg_shard_log_likelihood(gg_model* m, const gg_data* d, gg_comm* c, double* o
   int rc = shard_check(m, d, c);
   if (rc) return rc;
   if (!out) return gg_fail(GG_ERR_INVALID, "gg_shard_log_likelihood: null output");
-  if (!m->sh_buf) {
-    if ((rc = dmalloc(&m->sh_buf, 64)) || (rc = dmalloc(&m->sh_trip, (size_t)3 * GG_SHARD_M + 4)) ||
-        (rc = dmalloc(&m->sh_all, (size_t)3 * GG_SHARD_M * c->world + 4)))
-      return rc;
-    m->sh_world = c->world;
-  }
+  if ((rc = shard_alloc(m, c))) return rc;
   drop_ahead(m);
   if ((rc = shard_global_diag(m, d, c))) return rc;
   if ((rc = shard_global_tables(m, d, c, 1))) return rc;
@@ -2757,8 +2819,7 @@ int gg_resample_part_many(gg_model* m, const gg_data* const* ds, int32_t nd, int
   return GG_OK;
 }
 
-int gg_last_stats(gg_model* m, gg_stats* out) {
-  if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_last_stats: null argument");
+static int last_stats_full(gg_model* m, gg_stats* out) {
   if (m->eig) return gg_eigen_stats(m->eig, out);
   if (m->ld) return gg_latent_stats(m->ld, out);
   int rc = model_sync(m);
@@ -2770,6 +2831,23 @@ int gg_last_stats(gg_model* m, gg_stats* out) {
     if ((rc = read_ctl(m))) return rc;
     out->resolve_rounds += (uint64_t)(uint32_t)m->h_rs[GG_RS_ROUNDS];
   }
+  return GG_OK;
+}
+
+// The caller states the size of ITS gg_stats (the struct grew, and a binding built against the shorter one was
+// written past its end): no more than that is written; fields beyond what the library knows stay untouched.
+int gg_last_stats(gg_model* m, gg_stats* out) {
+  if (!m || !out) return gg_fail(GG_ERR_INVALID, "gg_last_stats: null argument");
+  const uint32_t want = out->struct_size;
+  if (want < 2 * sizeof(uint32_t) || want > 4096)
+    return gg_fail(GG_ERR_INVALID, "gg_last_stats: gg_stats.struct_size = %u: set it to sizeof(gg_stats) before the call", want);
+  gg_stats full;
+  memset(&full, 0, sizeof(full));
+  int rc = last_stats_full(m, &full);
+  if (rc) return rc;
+  full.struct_size = want < sizeof(gg_stats) ? want : (uint32_t)sizeof(gg_stats);
+  full.reserved = 0;
+  memcpy(out, &full, full.struct_size);
   return GG_OK;
 }
 

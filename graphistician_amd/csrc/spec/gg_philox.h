@@ -40,7 +40,8 @@ enum gg_site {
   GG_SITE_W_SHCOV = 19,    // shared covariance of SBMGaussianWeightSharedCov            weights.py:548
   GG_SITE_LDW_HMC = 20,    // latent-distance weights: HMC momenta and acceptance uniform  weights.py:777-792
   GG_SITE_LDW = 21,        // latent-distance weights: b, sigma, self Gaussian, eta draws  weights.py:833-886
-  GG_SITE_EIG_FN = 22      // eigenmodels: per-pair normals of the perturbation draw of F[n] (spec/gg_eig.h)   eigenmodel.py:908, :329
+  GG_SITE_EIG_FN = 22,     // eigenmodels: per-pair normals of the perturbation draw of F[n] (spec/gg_eig.h)   eigenmodel.py:908, :329
+  GG_SITE_EIG_F_REF = 23   // oracle only: the D normals of F[n] drawn the reference's way (mean + chol(Sigma_post) z)   eigenmodel.py:903-908
 };
 
 struct gg_u32x4 { uint32_t v[4]; };

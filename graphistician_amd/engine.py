@@ -22,30 +22,60 @@ _DATA_CACHE_SIZE = 4
 _IMMUTABLE = {}        # id(array) -> weakref: arrays the caller has declared read-only (identity is then the whole key)
 
 
+_HASH_WARN_S = 2e-3
+_hash_warned = [False]
+
+
 def _content_hash(a):
-    """64-bit hash of the WHOLE buffer (xxh3: ~10 GB/s, 1.7 ms for a 4096 x 4096 byte adjacency).  The reference reads
-    its arrays on every call (networks.py:28,69); the engine keeps a device copy, so a copy is only reused when every
-    byte of the host array is what it was when the copy was made - one flipped entry is new data."""
+    """64-bit hash of the WHOLE buffer.  The reference reads its arrays on every call (networks.py:28,69); the engine keeps a
+    device copy, so a copy is only reused when every byte of the host array is what it was when the copy was made - one flipped
+    entry is new data.  Computed inside the library on all host threads (gg_hash64: the ctypes call releases the GIL; a
+    single-threaded Python-side hash of a 134 MB float64 W costs 17 ms per call), and still milliseconds for a large network:
+    the first time it takes more than a millisecond a warning names the ways around it."""
+    import time
     buf = a if a.flags.c_contiguous else np.ascontiguousarray(a)
-    view = memoryview(buf.reshape(-1).view(np.uint8))
+    t0 = time.perf_counter()
+    h = _abi.hash64(buf)
+    dt = time.perf_counter() - t0
+    if dt > _HASH_WARN_S and not _hash_warned[0]:
+        _hash_warned[0] = True
+        import warnings
+        warnings.warn("graphistician_amd: hashing a %.0f MB data array took %.1f ms, and a writeable array is hashed on every "
+                      "resample / log_likelihood call (it may have been edited in place since the last one). For a fixed network "
+                      "make the arrays read-only (`A.setflags(write=False)`), call graphistician_amd.engine.declare_immutable(A, W) "
+                      "or pass a DeviceData handle: the device copy is then found by identity alone."
+                      % (buf.nbytes / 1e6, dt * 1e3), RuntimeWarning, stacklevel=4)
+    return h
+
+
+def _is_frozen(a):
+    """Nobody can write this buffer through numpy: the array and every ndarray it is a view of are read-only (`setflags(write=
+    False)`; a read-only view of a writeable base does not count), and a foreign exporter underneath is read-only too.  Such an
+    array is keyed by identity alone - for as long as it stays read-only (switching the flag back on, editing, and switching it
+    off again between two calls is not seen)."""
+    x = a
+    while isinstance(x, np.ndarray):
+        if x.flags.writeable:
+            return False
+        x = x.base
+    if x is None:
+        return True
     try:
-        import xxhash
-        return xxhash.xxh3_64_intdigest(view)
-    except ImportError:       # pragma: no cover
-        import zlib
-        return zlib.crc32(view)
+        return bool(memoryview(x).readonly)
+    except TypeError:
+        return False
 
 
 def _fingerprint(a):
     """Cache key of one host array: identity (id, buffer address, shape, dtype) plus a hash of its full content, so that
     any in-place edit - `A[:] = model.rvs()`, masking a held-out row and column, one flipped entry - is seen as new data
-    and uploaded again.  Arrays registered with `declare_immutable` skip the hash (identity only): that, or passing a
-    `DeviceData` handle, is what a loop over a large fixed network should do."""
+    and uploaded again.  Arrays that cannot be written (`_is_frozen`) and arrays registered with `declare_immutable` skip the
+    hash (identity only): that, or passing a `DeviceData` handle, is what a loop over a large fixed network should do."""
     if a is None:
         return None
     ident = (id(a), a.shape, a.dtype.str, a.__array_interface__["data"][0])
     ref = _IMMUTABLE.get(id(a))
-    if ref is not None and ref() is a:
+    if (ref is not None and ref() is a) or _is_frozen(a):
         return ident + ("immutable",)
     return ident + (_content_hash(a),)
 

@@ -89,6 +89,11 @@ typedef struct gg_config {
   int32_t lmbda_given;            /* eigenmodel.py:65-67 */
   int32_t reserved;
   int32_t shard_begin, shard_end; /* sharded single chain: this rank owns nodes [shard_begin, shard_end); 0,0 = all */
+  /* sharded single chain, block-interleaved ownership (shard_block > 0; shard_begin / shard_end are then ignored): the nodes are
+   * dealt out in blocks of shard_block consecutive nodes (a power of two >= 8), block b to rank b % shard_world - every band of
+   * the sequential scan then spreads over all ranks */
+  int32_t shard_block, shard_rank, shard_world;
+  int32_t reserved1;              /* set to 0 */
 } gg_config;
 
 /* State ids for gg_get_state / gg_set_state.  Shapes in comments, C order. */
@@ -126,13 +131,16 @@ enum gg_part {
 };
 
 typedef struct gg_stats {
+  uint32_t struct_size;         /* IN: sizeof(gg_stats) as the CALLER compiled / declared it - gg_last_stats writes no more than
+                                   that many bytes and refuses 0 (a binding built against an older, shorter struct is not overrun) */
+  uint32_t reserved;
   uint64_t sweeps;              /* sweeps run on this handle */
   uint64_t label_changes;       /* labels changed by resample_c since creation */
   uint64_t resolve_rounds;      /* rounds of the node scans: 1 per quiet scan, 1 per grid-wide exchange of a resident scan */
   double bulk_bytes;            /* algorithmic bytes streamed by the bulk statistics kernels, last call */
   double bulk_ms;               /* HIP-event time of those kernels, last call */
   uint64_t bulk_launches;       /* number of bulk kernel launches, last call */
-  double total_ms;              /* HIP-event time of the whole last call */
+  double total_ms;              /* HIP-event time of the whole last call - measured only while timing is on (gg_set_timing > 0), 0 otherwise */
   /* sweeps ENQUEUED since creation, by execution form (block models; a sweep voided by a stalled scan and run again is
    * counted again).  fused: one launch per sweep (scan | gated parameter step | riders); two_launch: parameter step +
    * riders, scan + riders (the first / last sweep of a run, K > 32 without staged tables); serial: pass, parameter step,
@@ -185,6 +193,17 @@ int gg_data_create_shard(gg_data** out, int32_t N, int32_t B, const uint8_t* A, 
 int gg_data_create_sbm_shard(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
                              const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
                              int32_t n0, int32_t n1, int32_t device);
+/* Block-interleaved column shards (gg_config.shard_block): rank `rank` of `world` owns the blocks b = rank, rank + world, ... of
+ * `block` consecutive nodes (a power of two >= 8) and stores their columns of A / A^T (W / W^T) side by side in block order. */
+int gg_data_create_shard_blocks(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t block, int32_t rank,
+                                int32_t world, int32_t device);
+int gg_data_create_sbm_shard_blocks(gg_data** out, int32_t N, int32_t K, const int32_t* c, const double* p, double p_self,
+                                    const double* mu, const double* sigma, double mu_self, double sigma_self, uint64_t seed,
+                                    int32_t block, int32_t rank, int32_t world, int32_t device);
+/* 64-bit content hash of a host buffer on `threads` host threads (0 = all): what the Python binding keys its device copies of
+ * the caller's (A, W) arrays with (networks.py:28,69: the reference reads its arrays on every call, so an in-place edit must be
+ * seen).  The digest does not depend on the number of threads; a change confined to one 8-byte word always changes it. */
+int gg_hash64(const void* buf, size_t nbytes, int32_t threads, uint64_t* out);
 /* Copy the stored network back (de-quantised weights); W may be NULL. */
 int gg_data_download(const gg_data* d, uint8_t* A, double* W);
 
@@ -243,6 +262,7 @@ int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, co
  * weights.py:488) — for parity tests. */
 int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp);
 
+/* out->struct_size must be set by the caller (see gg_stats). */
 int gg_last_stats(gg_model* m, gg_stats* out);
 /* Device time of the bulk statistics kernel alone (HIP events on the engine stream), for the roofline line. */
 int gg_bench_bulk(gg_model* m, const gg_data* d, int32_t reps, double* ms_per_launch, double* bytes_per_launch);
@@ -263,10 +283,12 @@ int gg_set_timing(gg_model* m, int32_t on);
  *   gg_comm_create_host   a pair of host callbacks (in-place SUM of int64; all-gather of int32) - the protocol's test
  *                         harness (gloo through ctypes), buffers staged through the host.
  * gg_shard_sweep runs n half-sweeps: per half-sweep one all-reduce of the K x K integer tables, then the sequential scan
- * (adjacency.py:650-695, weights.py:415-488) in rounds - every rank evaluates its own nodes of the current 4096-node band
- * under the changes hypothesised so far and reports its first 32 surprises (node, old, new); one all-gather per round; every
- * rank accepts the hypotheses up to the earliest surprise and amends the rest - enqueued in batches on
- * the engine stream; the host reads the scan position once per batch, never once per change. */
+ * (adjacency.py:650-695, weights.py:415-488) in rounds - every rank evaluates its own nodes of the current band (as wide as the
+ * previous scan's change count lets the reports describe, 4096 .. 65536 nodes) under the changes hypothesised so far and reports
+ * its first 64 surprises (node, labels); one all-gather per round; every rank accepts the hypotheses up to the earliest surprise
+ * and amends the rest - enqueued in batches on the engine stream; the host reads the scan position once
+ * per batch, never once per change.  Ownership: a contiguous range (shard_begin / shard_end) or, so that every band spreads over
+ * all ranks, blocks dealt out round-robin (shard_block / shard_rank / shard_world, gg_data_create_shard_blocks). */
 typedef struct gg_comm gg_comm;
 typedef int (*gg_host_allreduce_fn)(void* user, int64_t* buf, int64_t n);                          /* in place, SUM over ranks */
 typedef int (*gg_host_allgather_fn)(void* user, const int32_t* send, int32_t* recv, int64_t n);    /* recv[world][n] */
@@ -275,7 +297,9 @@ int gg_comm_create_rccl(gg_comm** out, int32_t rank, int32_t world, const uint8_
 int gg_comm_create_host(gg_comm** out, int32_t rank, int32_t world, gg_host_allreduce_fn ar, gg_host_allgather_fn ag, void* user,
                         int32_t device);
 int gg_comm_destroy(gg_comm* c);
-int gg_comm_info(const gg_comm* c, int32_t* rank, int32_t* world, int32_t* is_rccl, uint64_t* collectives);
+/* collectives: all-reduces and all-gathers that went over the wire (none with one rank); rounds: rounds of the sharded scans
+ * driven through the communicator (each is one all-gather when world > 1).  Any output pointer may be NULL. */
+int gg_comm_info(const gg_comm* c, int32_t* rank, int32_t* world, int32_t* is_rccl, uint64_t* collectives, uint64_t* rounds);
 int gg_shard_sweep(gg_model* m, const gg_data* d, gg_comm* c, int32_t n_half_sweeps);
 /* log-likelihood from the all-reduced tables (abstractions.py:111-115, weights.py:316-331) */
 int gg_shard_log_likelihood(gg_model* m, const gg_data* d, gg_comm* c, double* out);

@@ -298,12 +298,24 @@ PART_EIG_ALL = 120
 
 
 def eig_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given, seed, sweep,
-              parts=PART_EIG_ALL, Omega=None, beta=1.0):
-    """In-place sweep of (F, lmbda); returns (mu_0, Omega).  beta < 1: tempered likelihood (build-defined, PG(beta, psi))."""
+              parts=PART_EIG_ALL, Omega=None, beta=1.0, f_draw="perturbation"):
+    """In-place sweep of (F, lmbda); returns (mu_0, Omega).  beta < 1: tempered likelihood (build-defined, PG(beta, psi)).
+    f_draw="reference": F[n] is drawn the reference's way - Sigma_post = inv(prec), Sigma_post h + chol(Sigma_post) z
+    (eigenmodel.py:903-908) - instead of by perturbation (spec/gg_eig.h); the same conditional law, another stream."""
     N, D = F.shape
     A8, pA = _u8(A != 0)
     if Omega is None:
         Omega = np.zeros((N, N))
+    if f_draw == "reference" and (parts & PART_F):
+        args = (mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lmbda, lmbda_given, seed, sweep)
+        if parts & PART_OMEGA:
+            eig_sweep(A, F, lmbda, mu_0, *args, parts=PART_OMEGA, Omega=Omega, beta=beta)
+        eig_F_window(A, Omega, F, lmbda, mu_0, sigma_F, seed, sweep, 0, N, beta=beta, ref_draw=True)
+        rest = parts & (PART_MU0 | PART_LMBDA)
+        if rest:
+            mu_0, _ = eig_sweep(A, F, lmbda, mu_0, *args, parts=rest, Omega=Omega, beta=beta)
+        return mu_0, Omega
+    assert f_draw in ("perturbation", "reference")
     mu = C.c_double(float(mu_0))
     rc = lib().orc_eig_sweep(N, D, pA, _f64(F), _f64(lmbda), C.byref(mu), _f64(Omega),
                              _f64(np.ascontiguousarray(mu_lmbda, dtype=np.float64)), C.c_double(mu_mu_0),
@@ -312,6 +324,30 @@ def eig_sweep(A, F, lmbda, mu_0, mu_lmbda, mu_mu_0, sigma_mu0, sigma_F, sigma_lm
     if rc:
         raise RuntimeError("oracle eig_sweep failed rc=%d" % rc)
     return mu.value, Omega
+
+
+def eig_F_window(A, Omega, F, lmbda, mu_0, sigma_F, seed, sweep, n_begin, n_end, beta=1.0, ref_draw=False):
+    """The nodes [n_begin, n_end) of _resample_F's sequential scan (eigenmodel.py:876-908), F updated in place: F must hold the
+    new features of the nodes before n_begin and the old ones from there on.  Omega: dense (N, N) auxiliaries; only the sums
+    Omega[n, nn] + Omega[nn, n] of the window's rows and columns are read.  ref_draw: the reference's form of the draw
+    (inverse, mean, Cholesky factor of the covariance; eigenmodel.py:903-908) instead of the perturbation draw."""
+    N, D = F.shape
+    A8, pA = _u8(A != 0)
+    rc = lib().orc_eig_resample_F_window(N, D, pA, _f64(Omega), _f64(F), _f64(lmbda), C.c_double(float(mu_0)), C.c_double(sigma_F),
+                                         C.c_uint64(seed), C.c_uint32(sweep), C.c_double(beta), int(n_begin), int(n_end), 1 if ref_draw else 0)
+    if rc:
+        raise RuntimeError("oracle eig_F_window failed rc=%d" % rc)
+
+
+def eig_omega_block(A, F, lmbda, mu_0, seed, sweep, idx, beta=1.0):
+    """omega_{ij} of _resample_Omega (eigenmodel.py:859-874) for i, j in idx only -> (len(idx), len(idx))."""
+    N, D = F.shape
+    A8, pA = _u8(A != 0)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.zeros((idx.size, idx.size))
+    lib().orc_eig_omega_block(N, D, pA, _f64(F), _f64(lmbda), C.c_double(float(mu_0)), C.c_uint64(seed), C.c_uint32(sweep),
+                              C.c_double(beta), _i32(idx), int(idx.size), _f64(out))
+    return out
 
 
 def _adj_missing(A):
@@ -474,6 +510,12 @@ class FastSweeper(object):
 
 # ---------------------------------------------------------------- latent-distance adjacency model (oracle_latent.cpp)
 LD_PART_L, LD_PART_MU0, LD_PART_MUSELF, LD_PART_ALL = 1, 2, 4, 7
+
+
+def ld_set_threads(n):
+    """n > 1: the latent-distance oracle evaluates node-parallel on n threads (same terms, per-node partial sums added in node
+    order: agrees with the plain loop to rounding); 1: the plain double loop of adjacency.py:244-275."""
+    lib().orc_ld_set_threads(int(n))
 
 
 def ld_logprob(A, L, mu0, mu_self, sigma, beta=1.0, grad=False):

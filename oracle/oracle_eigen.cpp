@@ -69,10 +69,21 @@ void orc_eig_resample_omega_multi(int nG, int N, int D, const uint8_t* As, const
 // reference's loops (over the graphs, then over nn); the draw F[n] ~ N(prec^{-1} h, prec^{-1}) (:908,
 // np.random.multivariate_normal) is made by perturbation (spec/gg_eig.h): b = h + z / sqrt(sigma_F) +
 // sum_nn sqrt(sum of the pair's omegas) eps[n,nn] f_nn * lambda, x = prec^{-1} b - the same law, no matrix square root.
-int orc_eig_resample_F_multi(int nG, int N, int D, const uint8_t* As, const double* Omegas, double* F, const double* lmbda,
-                             double mu_0, double sigma_F, uint64_t seed, uint32_t sweep, double beta) {
+// The scan over the nodes [n_begin, n_end) only (the whole scan: [0, N)).  F must hold what the scan has left behind when it
+// reaches n_begin - the NEW features of the nodes before it, the old ones from there on -, so that a window of a long scan can be
+// checked on its own (tests at N = 8192, where 8192 dependent steps of O(N D^2) take minutes on one core).
+//
+// ref_draw: the draw is made THE REFERENCE'S WAY instead (eigenmodel.py:903-908: `post_cov = inv(post_prec)`, `post_mu =
+// post_cov.dot(h)`, `np.random.multivariate_normal(post_mu, post_cov)`): Sigma_post by inversion, x = Sigma_post h + L z with
+// L the Cholesky factor of Sigma_post and z the node's D standard normals from their own Philox site (numpy factorises the
+// covariance by SVD; any square root gives the same law).  The engine never draws this way; the form exists so that the
+// perturbation draw is pinned to the reference's statement and not only to itself (tests/test_spec_and_oracle.py compares
+// the two chains in law).
+static int eig_resample_F_window(int nG, int N, int D, const uint8_t* As, const double* Omegas, double* F, const double* lmbda,
+                                 double mu_0, double sigma_F, uint64_t seed, uint32_t sweep, double beta, int n_begin, int n_end,
+                                 int ref_draw = 0) {
   std::vector<double> prec((size_t)D * D), h(D), b(D), x(D), wsum(N);
-  for (int n = 0; n < N; ++n) {
+  for (int n = n_begin; n < n_end; ++n) {
     for (int a = 0; a < D * D; ++a) prec[a] = 0.0;
     for (int a = 0; a < D; ++a) {
       prec[a * D + a] = 1.0 / sigma_F; h[a] = 0.0;
@@ -96,6 +107,25 @@ int orc_eig_resample_F_multi(int nG, int N, int D, const uint8_t* As, const doub
         }
       }
     }
+    if (ref_draw) {
+      // post_cov = inv(post_prec): column by column through the Cholesky factor of the precision
+      double cov[GG_MAXD * GG_MAXD], col[GG_MAXD], e[GG_MAXD], mean[GG_MAXD];
+      for (int cidx = 0; cidx < D; ++cidx) {
+        for (int a = 0; a < D; ++a) e[a] = a == cidx ? 1.0 : 0.0;
+        if (gg_solve_spd(prec.data(), e, D, col)) return -5;
+        for (int a = 0; a < D; ++a) cov[a * D + cidx] = col[a];
+      }
+      for (int a = 0; a < D; ++a)
+        for (int c = a + 1; c < D; ++c) { const double s = 0.5 * (cov[a * D + c] + cov[c * D + a]); cov[a * D + c] = cov[c * D + a] = s; }
+      for (int a = 0; a < D; ++a) { double v = 0.0; for (int c = 0; c < D; ++c) v += cov[a * D + c] * h[c]; mean[a] = v; }   // post_mu
+      if (gg_chol_d(cov, D)) return -5;                                                                                      // cov = L L^T
+      for (int a = 0; a < D; ++a) {
+        double v = mean[a];
+        for (int c = 0; c <= a; ++c) v += cov[a * D + c] * gg_normal_at(seed, GG_SITE_EIG_F_REF, sweep, (uint32_t)(n * D + c));
+        F[(size_t)n * D + a] = v;
+      }
+      continue;
+    }
     for (int nn = 0; nn < N; ++nn) {
       if (nn == n) continue;
       const double w = gg_sqrt(wsum[nn]) * gg_eig_noise_at(seed, sweep, (uint32_t)N, (uint32_t)n, (uint32_t)nn);
@@ -107,6 +137,36 @@ int orc_eig_resample_F_multi(int nG, int N, int D, const uint8_t* As, const doub
     for (int a = 0; a < D; ++a) F[(size_t)n * D + a] = x[a];
   }
   return 0;
+}
+
+int orc_eig_resample_F_multi(int nG, int N, int D, const uint8_t* As, const double* Omegas, double* F, const double* lmbda,
+                             double mu_0, double sigma_F, uint64_t seed, uint32_t sweep, double beta) {
+  return eig_resample_F_window(nG, N, D, As, Omegas, F, lmbda, mu_0, sigma_F, seed, sweep, beta, 0, N);
+}
+
+// One graph, the nodes [n_begin, n_end) of the scan; ref_draw != 0: the reference's own form of the draw (see above).
+int orc_eig_resample_F_window(int N, int D, const uint8_t* A, const double* Omega, double* F, const double* lmbda, double mu_0,
+                              double sigma_F, uint64_t seed, uint32_t sweep, double beta, int n_begin, int n_end, int ref_draw) {
+  if (D > GG_MAXD || n_begin < 0 || n_end > N || n_begin > n_end) return -1;
+  return eig_resample_F_window(1, N, D, A, Omega, F, lmbda, mu_0, sigma_F, seed, sweep, beta, n_begin, n_end, ref_draw);
+}
+
+// The auxiliaries of _resample_Omega (eigenmodel.py:859-874) for the node subset idx only: out[a][b] = omega_{idx[a], idx[b]},
+// each from the very stream the full draw gives that entry (one graph, plain site).
+void orc_eig_omega_block(int N, int D, const uint8_t* A, const double* F, const double* lmbda, double mu_0, uint64_t seed,
+                         uint32_t sweep, double beta, const int32_t* idx, int n_idx, double* out) {
+  for (int a = 0; a < n_idx; ++a)
+    for (int b = 0; b < n_idx; ++b) {
+      const int i = idx[a], j = idx[b];
+      const double psi = eig_psi(N, D, F, lmbda, mu_0, i, j);
+      double o = 0.0;
+      if (A[(size_t)i * N + j] != ORC_A_MISSING && beta != 0.0) {
+        gg_stream s;
+        gg_stream_init(&s, seed, (uint32_t)GG_SITE_EIG_OMEGA, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j);
+        o = beta == 1.0 ? gg_pg1(&s, psi) : gg_pg_frac(&s, beta, psi);
+      }
+      out[(size_t)a * n_idx + b] = o;
+    }
 }
 
 // eigenmodel.py:910-932 _resample_mu_0.

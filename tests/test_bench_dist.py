@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,3 +32,27 @@ def test_bench_single_process_dry_run():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 1 and r["steps"] == 3
+
+
+@pytest.mark.gpu
+def test_combined_replica_and_sharded_line_with_two_ranks():
+    """The form the driver's scaling run executes, `bench.py --gpus G` with G > 1: every rank runs a replica of
+    the chain AND, in the same invocation, all ranks run ONE chain of that network sharded over them; rank 0 prints ONE JSON
+    line that carries both.  Two ranks sharing this box's one GPU (gloo for the rendezvous and for the library's collectives -
+    RCCL refuses two ranks on one device), at N=4096 so that the box holds both."""
+    import json
+    env = dict(os.environ, GG_BENCH_BACKEND="gloo", GG_BENCH_SAME_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nodes", "4096", "--steps", "6", "--warmup", "2",
+           "--repeats", "2", "--no-cpu", "--no-extras"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0 and "labels_digest" in r["config"]
+    assert r["config"]["timed_blocks_per_chain"] == 2 and len(r["config"]["chains"]) == 6
+    sh = r["sharded_chain"]
+    assert "error" not in sh, sh
+    assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["value"] > 0
+    assert sh["config"]["ranks"] == 2 and "labels_digest" in sh["config"] and sh["config"]["collectives_on_the_wire_in_run"] > 0

@@ -586,3 +586,67 @@ def test_missing_entries_are_refused_by_the_block_models():
         m.resample(d, 1)
     with pytest.raises(abi.EngineError):
         abi.DeviceData(A, np.zeros((40, 40, 1)), missing_ok=True)
+
+
+# ================================================================ oracle helpers of the at-size tests, the reference's form of the F draw
+def test_oracle_window_and_block_forms_are_the_full_sweep():
+    """The pieces tests/test_gpu_at_size.py checks N = 8192 with are the full oracle sweep restricted: the scan over consecutive
+    windows leaves the features of the one full scan bit for bit, and the block of auxiliaries for a node subset is that block
+    of the full draw (same Philox stream per entry), tempered or not."""
+    N, D = 57, 3
+    A, F0, l0, m0 = make_case(N, D, 5)
+    for beta in (1.0, 0.4):
+        F_full = F0.copy()
+        _, Om = O.eig_sweep(A, F_full, l0.copy(), m0, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 77, 2, parts=O.PART_OMEGA | O.PART_F, beta=beta)
+        idx = np.array([0, 3, 56, 17, 18], dtype=np.int32)
+        assert np.array_equal(O.eig_omega_block(A, F0, l0, m0, 77, 2, idx, beta=beta), Om[np.ix_(idx, idx)])
+        Fw = F0.copy()
+        for a, b in ((0, 10), (10, 11), (11, 40), (40, N)):
+            O.eig_F_window(A, Om, Fw, l0, m0, 1.0, 77, 2, a, b, beta=beta)
+        assert np.array_equal(Fw, F_full)
+        # only Omega + Omega^T enters: the symmetrised halves give the same scan to rounding
+        S = Om + Om.T
+        Fh = F0.copy()
+        O.eig_F_window(A, 0.5 * S, Fh, l0, m0, 1.0, 77, 2, 0, N, beta=beta)
+        assert np.allclose(Fh, F_full, rtol=1e-10, atol=1e-12)
+
+
+def test_reference_form_of_the_feature_draw_has_the_law_of_the_perturbation_draw():
+    """VERDICT r3 #10.  The engine and the oracle draw F[n] by perturbation (spec/gg_eig.h); the reference inverts the precision
+    and calls np.random.multivariate_normal(Sigma_post h, Sigma_post) (eigenmodel.py:903-908).  `f_draw="reference"` restates
+    that form (inverse, mean, Cholesky factor of the covariance, the node's own D normals).  (i) One conditional: over many
+    seeds both forms have the mean Sigma_post h and covariance Sigma_post of the literal numpy transliteration, and the whitened
+    draws are standard normal.  (ii) Whole chains: 200 sweeps from the same start under either form, many independent seeds -
+    F, mu_0 and lambda after the last sweep agree in law (two-sample KS)."""
+    N, D = 14, 2
+    A, F0, l0, m0 = make_case(N, D, 11)
+    # (i) node 5's conditional given fixed auxiliaries
+    _, Om = O.eig_sweep(A, F0.copy(), l0.copy(), m0, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 5, 0, parts=O.PART_OMEGA)
+    n = 5
+    prec, h = R.eigen_F_conditional(A, Om, F0, l0, m0, 1.0, n)
+    cov = np.linalg.inv(prec)
+    mean = cov.dot(h)
+    for ref in (True, False):
+        x = []
+        for seed in range(3000):
+            F = F0.copy()
+            O.eig_F_window(A, Om, F, l0, m0, 1.0, seed, 0, n, n + 1, ref_draw=ref)
+            x.append(F[n].copy())
+        x = np.array(x)
+        assert np.all(np.abs(x.mean(0) - mean) < 5 * np.sqrt(np.diag(cov) / x.shape[0]))
+        assert np.allclose(np.cov(x.T), cov, rtol=0.15, atol=0.02 * np.abs(cov).max())
+        wht = np.linalg.solve(np.linalg.cholesky(cov), (x - mean).T).ravel()
+        assert stats.kstest(wht, "norm").pvalue > 1e-3
+    # (ii) whole chains, many independent seeds
+    ends = {"reference": [], "perturbation": []}
+    nchains, nsweeps = 160, 200
+    for form in ends:
+        for ch in range(nchains):
+            F, l, mu = F0.copy(), l0.copy(), m0
+            for s in range(nsweeps):
+                mu, _ = O.eig_sweep(A, F, l, mu, np.zeros(D), -0.3, 1.0, 1.0, 1.0, 0, 1000 + ch, s, f_draw=form)
+            ends[form].append(np.concatenate([F[0], F[N - 1], [mu], l, [np.abs(F).mean()]]))
+    a, b = np.array(ends["reference"]), np.array(ends["perturbation"])
+    pv = [stats.ks_2samp(a[:, k], b[:, k]).pvalue for k in range(a.shape[1])]
+    assert min(pv) > 1e-3, pv
+

@@ -253,3 +253,169 @@ def test_cfg3_n65536_k64_full_size_properties(abi, monkeypatch):
         got = chain(env)
         for k in ref:
             assert np.array_equal(ref[k], got[k]), "N=65536, K=64: %s differs under %s" % (k, env or "a second run")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] names three model families at N = 8192.  The SBM family is above; the other two - the logistic
+# eigenmodel's tempered sweep and the latent-distance model's tempered HMC resample - ran at N = 24 / 14 only.
+def eigen_truth(N, D, seed, mm=-1.2815515655446004):
+    rng = np.random.RandomState(seed)
+    Ft, lt = rng.randn(N, D) * 0.6, rng.randn(D)
+    mu_t = mm + 0.3 * rng.randn()
+    A = np.empty((N, N), dtype=np.uint8)
+    for i0 in range(0, N, 1024):          # (row blocks: no N x N float temporaries)
+        Mu = mu_t + (Ft[i0:i0 + 1024] * lt).dot(Ft.T)
+        Mu[np.arange(Mu.shape[0]), i0 + np.arange(Mu.shape[0])] = mu_t
+        A[i0:i0 + 1024] = rng.rand(*Mu.shape) < 1.0 / (1.0 + np.exp(-Mu))
+    return A, np.ascontiguousarray(rng.randn(N, D)), np.ascontiguousarray(rng.randn(D)), mm + 0.5 * rng.randn(), mm
+
+
+@pytest.mark.parametrize("beta", [0.37, 1.0])
+def test_cfg4_eigenmodel_n8192_d8_tempered_sweep(abi, beta):
+    """One sweep of GG_LOGISTIC_EIG (D = 8) at N = 8192 at an inverse temperature AIS visits and at beta = 1
+    (examples/demo_ais.py:10-62, graph_models.py:50-64; eigenmodel.py:836-965).  The oracle's plain loops need minutes for a whole
+    sweep of this size (67 M Polya-gamma draws, 8192 dependent O(N D^2) steps), so it is asked for exactly the pieces it restates,
+    at the float tolerances of DESIGN.md section 7:
+      * Omega: the auxiliaries of a node subset that straddles tile and workgroup boundaries (first / middle / last nodes), each
+        from its own Philox stream (PG(beta, psi) for the tempered sweep) - against the engine's S = Omega + Omega^T;
+      * F: windows of the sequential scan (its first nodes, a stretch across the tile boundary at 4096, its last nodes), the
+        oracle continuing from the engine's own features in front of the window and given the engine's S;
+      * mu_0, lambda, log-likelihood: the oracle's full double loops on the engine's S and F;
+      * the whole sweep run a second time from the same state gives the same bits (no order-dependent float atomics)."""
+    N, D, seed = 8192, 8, 23
+    A, F0, l0, m0, mm = eigen_truth(N, D, 4321)
+    d = abi.DeviceData(A, None)
+
+    def model():
+        m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=seed, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=mm)
+        m.set(abi.ST_F, F0); m.set(abi.ST_LMBDA, l0); m.set(abi.ST_MU0, np.array([m0])); m.set(abi.ST_MU_LMBDA, np.zeros(D))
+        return m
+
+    m = model()
+    m.resample_part(d, abi.PART_OMEGA, beta)
+    S = m.get(abi.ST_OMEGA_S, (N, N))
+    idx = np.concatenate([np.arange(0, 70), np.arange(4064, 4130), np.arange(N - 70, N)]).astype(np.int32)
+    blk = O.eig_omega_block(A, F0, l0, m0, seed, 0, idx, beta=beta)
+    ref = blk + blk.T
+    ref[np.arange(idx.size), np.arange(idx.size)] = np.diag(blk)
+    assert np.allclose(S[np.ix_(idx, idx)], ref, rtol=1e-9, atol=1e-13), np.abs(S[np.ix_(idx, idx)] - ref).max()
+    assert np.all(np.isfinite(S)) and S.min() >= 0.0 and np.array_equal(S, S.T)
+    m.resample_part(d, abi.PART_F, beta)
+    F1 = m.get(abi.ST_F, (N, D))
+    dg = np.diag(S).copy()
+    S *= 0.5                                     # the two halves of S: Omega[n, nn] + Omega[nn, n] = S[n, nn] exactly
+    S[np.arange(N), np.arange(N)] = dg           # (the diagonal of S is omega_nn itself)
+    for a, b in ((0, 300), (3990, 4200), (N - 300, N)):
+        Fw = np.ascontiguousarray(np.concatenate([F1[:a], F0[a:]]))
+        O.eig_F_window(A, S, Fw, l0, m0, 1.0, seed, 0, a, b, beta=beta)
+        assert np.allclose(Fw[a:b], F1[a:b], rtol=1e-6, atol=1e-8), (a, b, np.abs(Fw[a:b] - F1[a:b]).max())
+    m.resample_part(d, abi.PART_MU0, beta)
+    m.resample_part(d, abi.PART_LMBDA, beta)
+    lo = l0.copy()
+    mu_o, _ = O.eig_sweep(A, F1.copy(), lo, m0, np.zeros(D), mm, 1.0, 1.0, 1.0, 0, seed, 0, parts=O.PART_MU0 | O.PART_LMBDA, Omega=S,
+                          beta=beta)
+    mu_e, l_e = m.get(abi.ST_MU0, (1,))[0], m.get(abi.ST_LMBDA, (D,))
+    assert abs(mu_e - mu_o) < 1e-7, (mu_e, mu_o)
+    assert np.allclose(l_e, lo, rtol=1e-6, atol=1e-8), (l_e, lo)
+    del S
+    ll, ref_ll = m.log_likelihood(d), O.eig_loglik(A, F1, l_e, mu_e)
+    assert abs(ll - ref_ll) <= 1e-9 * abs(ref_ll), (ll, ref_ll)
+    # the whole sweep in one call: the same state as the parts, and the same bits when it is run again
+    outs = []
+    for _ in range(2):
+        m2 = model()
+        m2.resample(d, 1, beta)
+        outs.append((m2.get(abi.ST_F, (N, D)), m2.get(abi.ST_LMBDA, (D,)), m2.get(abi.ST_MU0, (1,))))
+        m2.close()
+    assert all(np.array_equal(x, y) for x, y in zip(outs[0], outs[1])), "the eigenmodel sweep is not a function of (seed, state)"
+    assert np.allclose(outs[0][0], F1, rtol=1e-9, atol=1e-11) and np.allclose(outs[0][1], l_e, rtol=1e-9)
+
+
+@pytest.mark.parametrize("beta", [0.37, 1.0])
+def test_cfg4_latent_distance_n8192_tempered_hmc_resample(abi, beta):
+    """One HMC resample of GG_LATENT_DIST (dim = 2) at N = 8192 (adjacency.py:360-421; tempered: graph_models.py:50-64): 10 leapfrog
+    steps on L, on mu_0 and on mu_self - 33 passes over the 67 M pairs - against the oracle's restatement (its node-parallel
+    flavour, checked against the plain double loop in tests/test_latent_distance.py), from a start near the generating geometry
+    with a step the sampler accepts: positions at 1e-8, the scalar parameters, the adapted step size and every accept / reject
+    decision.  Then the proposal must have been accepted (a rejected one would compare the untouched start with itself)."""
+    N, dim, sigma, seed = 8192, 2, 2.0, 88
+    rng = np.random.RandomState(7)
+    Lt = rng.randn(N, dim) * 1.3
+    A = np.empty((N, N), dtype=np.uint8)
+    for i0 in range(0, N, 1024):
+        X = -((Lt[i0:i0 + 1024, None, :] - Lt[None, :, :]) ** 2).sum(2) + 1.0
+        A[i0:i0 + 1024] = rng.rand(*X.shape) < 1.0 / (1.0 + np.exp(-X))
+    L0 = np.ascontiguousarray(Lt + 0.05 * rng.randn(N, dim))
+    mu0, ms, st, ar = 0.8, 0.1, 2e-4, 0.9
+    d = abi.DeviceData(A, None)
+    m = abi.Model(kind=abi.LATENT_DIST, N=N, D=dim, K=1, B=1, seed=seed, sigma_F=sigma)
+    m.set(abi.ST_F, L0); m.set(abi.ST_MU0, np.array([mu0])); m.set(abi.ST_LD_AUX, np.array([ms, st, ar]))
+    O.ld_set_threads(min(16, os.cpu_count() or 1))
+    try:
+        ll, ref = m.log_likelihood(d), O.ld_loglik(A, L0, mu0, ms)
+        assert abs(ll - ref) <= 1e-10 * abs(ref)
+        m.resample(d, 1, beta)
+        Lo = L0.copy()
+        mu0o, mso, sto, aro, acc = O.ld_resample(A, Lo, mu0, ms, sigma, st, ar, seed, 0, beta=beta)
+    finally:
+        O.ld_set_threads(1)
+    assert acc & 1, "the L proposal was rejected by the oracle: the test would compare the start with itself"
+    L1 = m.get(abi.ST_F, (N, dim))
+    assert not np.array_equal(L1, L0)
+    assert np.allclose(L1, Lo, rtol=1e-8, atol=1e-10), np.abs(L1 - Lo).max()
+    aux = m.get(abi.ST_LD_AUX, (3,))
+    assert abs(m.get(abi.ST_MU0, (1,))[0] - mu0o) < 1e-9 and abs(aux[0] - mso) < 1e-9
+    assert abs(aux[1] - sto) < 1e-15 and abs(aux[2] - aro) < 1e-15
+
+
+def test_cfg3_sharded_n65536_k64_equals_the_unsharded_chain(abi):
+    """BASELINE.json configs[3] AT ITS OWN SIZE through the sharded entry points: gg_shard_sweep over the library's
+    RCCL communicator (one rank: this box has one GPU) against the plain gg_resample chain of the same seeds, from a prior draw -
+    labels, block probabilities and Gaussians BIT FOR BIT after every one of three sweeps (log-likelihoods: 1e-12).  Both are the
+    sequential chain of adjacency.py:650-695 / weights.py:415-488 by construction (integer statistics), so
+    they must agree without an oracle in between; the unsharded side is checked against the oracle at N = 16384 above."""
+    from graphistician_amd import sharded as S
+    N, K, nsweeps = 65536, 64, 3
+    t = planted_truth(N, K, 1234)
+    data = abi.DeviceData.synthetic_sbm(N, t["c"], t["p"], t["p_self"], t["mu"], t["sigma"], 0.0, 1.0, seed=1234)
+
+    def models():
+        rng = np.random.RandomState(5)
+        adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=11, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
+        adj.set(abi.ST_C, rng.choice(K, size=N).astype(np.int32), np.int32); adj.set(abi.ST_M, rng.dirichlet(np.ones(K)))
+        adj.set(abi.ST_PI, np.ones(K)); adj.set(abi.ST_P, np.ascontiguousarray(rng.beta(1.0, 1.0, size=(K, K)))); adj.set(abi.ST_P_SELF, np.array([0.5]))
+        w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=12, special_case_self_conns=1)
+        niw = O.pack_niw([0.0], [[1.0]], 3.0, 1.0)
+        w.set(abi.ST_C, rng.choice(K, size=N).astype(np.int32), np.int32); w.set(abi.ST_M, rng.dirichlet(np.ones(K) * 10.0))
+        w.set(abi.ST_PI, np.ones(K) * 10.0); w.set(abi.ST_MU, np.ascontiguousarray(rng.randn(K, K, 1))); w.set(abi.ST_SIGMA, np.ones((K, K, 1, 1)))
+        w.set(abi.ST_NIW, niw); w.set(abi.ST_NIW_SELF, niw)
+        return adj, w
+
+    def state(adj, w):
+        return dict(ca=adj.get(abi.ST_C, (N,), np.int32), p=adj.get(abi.ST_P, (K, K)), ps=adj.get(abi.ST_P_SELF, (1,)), ma=adj.get(abi.ST_M, (K,)),
+                    cw=w.get(abi.ST_C, (N,), np.int32), mu=w.get(abi.ST_MU, (K, K, 1)), sig=w.get(abi.ST_SIGMA, (K, K, 1, 1)),
+                    mus=w.get(abi.ST_MU_SELF, (1,)), mw=w.get(abi.ST_M, (K,)))
+
+    adj, w = models()
+    plain = []
+    for s in range(nsweeps):
+        abi.resample_many([adj, w], data, 1)
+        st = state(adj, w)
+        st["ll"] = np.array(abi.log_likelihood_many([adj, w], data))
+        plain.append(st)
+    changes = adj.stats()["label_changes"] + w.stats()["label_changes"]
+    assert changes > 50000
+    adj.close(); w.close()
+    adj, w = models()
+    comm = S.local_comm()
+    assert comm.info()["rccl"] and comm.info()["world"] == 1
+    for s in range(nsweeps):
+        S.half_sweep(adj, data, comm)
+        S.half_sweep(w, data, comm)
+        st = state(adj, w)
+        for k, v in st.items():
+            assert np.array_equal(v, plain[s][k]), "N=65536, K=64, sweep %d: %s of the sharded chain differs from the plain chain" % (s, k)
+        ll = np.array([S.log_likelihood(adj, data, comm), S.log_likelihood(w, data, comm)])
+        # (the plain call reduces the pair terms on the device in a fixed tree, the sharded one on the host from the all-reduced tables)
+        assert np.allclose(ll, plain[s]["ll"], rtol=1e-12, atol=0.0), (ll, plain[s]["ll"])
+    assert adj.stats()["label_changes"] + w.stats()["label_changes"] == changes

@@ -45,6 +45,29 @@ def test_oracle_logprob_and_gradient():
     assert np.isfinite(O.ld_logprob(A, far, mu0, ms, sigma))
 
 
+def test_node_parallel_oracle_flavour_is_the_plain_loop():
+    """oracle_latent.cpp::ld_eval_mt (the flavour tests/test_gpu_at_size.py uses at N = 8192) against the plain double loop:
+    log probability and every gradient to rounding, and an HMC transition built on it takes the same decisions."""
+    N, dim, sigma = 70, 3, 2.0
+    A, L, mu0, ms = make_case(N, dim, 3)
+    try:
+        for beta in (1.0, 0.37):
+            O.ld_set_threads(1)
+            lp, gL, g0, gs = O.ld_logprob(A, L, mu0, ms, sigma, beta, grad=True)
+            L1 = L.copy()
+            r1 = O.ld_resample(A, L1, mu0, ms, sigma, 0.01, 0.9, 9, 0, beta=beta)
+            O.ld_set_threads(4)
+            lp2, gL2, g02, gs2 = O.ld_logprob(A, L, mu0, ms, sigma, beta, grad=True)
+            assert abs(lp2 - lp) <= 1e-12 * abs(lp) and np.allclose(gL2, gL, rtol=1e-11, atol=1e-11)
+            assert abs(g02 - g0) <= 1e-11 * max(1.0, abs(g0)) and abs(gs2 - gs) <= 1e-11 * max(1.0, abs(gs))
+            assert abs(O.ld_logprob(A, L, mu0, ms, sigma, beta) - lp) <= 1e-12 * abs(lp)      # (no gradient: no transpose)
+            L2 = L.copy()
+            r2 = O.ld_resample(A, L2, mu0, ms, sigma, 0.01, 0.9, 9, 0, beta=beta)
+            assert r1[4] == r2[4] and np.allclose(L2, L1, rtol=1e-10, atol=1e-12) and np.allclose(r1[:4], r2[:4], rtol=1e-10)
+    finally:
+        O.ld_set_threads(1)
+
+
 def test_oracle_hmc_leaves_the_prior_invariant():
     """With beta = 0 the target is the prior: mu_0, mu_self ~ N(0, 1), L ~ N(0, sigma I), whatever the data; the
     adaptive step size settles where the running acceptance rate is near the 0.9 target."""
