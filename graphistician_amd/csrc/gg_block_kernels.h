@@ -1881,11 +1881,12 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, gg_own own, 
                                                      int32_t* rs, gg_shard_state* S, int round, int ntot,
                                                      const int32_t* __restrict__ all, int world, int32_t* __restrict__ cntn,
                                                      int32_t* Gc0, int32_t* Gc1, long long* Gs0, long long* Gs1,
-                                                     const uint32_t* XA, const uint32_t* XAT, const int32_t* XW, const int32_t* XWT) {
+                                                     const uint32_t* XA, const uint32_t* XAT, const int32_t* XW, const int32_t* XWT,
+                                                     int fold1) {
   constexpr int B = gg_tB(NT);
   constexpr int NSI = gg_tNSI(NT);
   extern __shared__ int s_mv[];                // [world][GG_SHARD_M][4]: node, from, to, old
-  __shared__ int s_pstar;
+  __shared__ int s_pstar, s_pe;
   const int t = (int)threadIdx.x;
   const int spos = S->st[round & 1][0], wbase = S->st[round & 1][1];
   const bool first = blockIdx.x == 0 && blockIdx.y == 0;
@@ -1903,32 +1904,45 @@ __global__ __launch_bounds__(256) void k_shard_apply(gg_node_ctx x, gg_own own, 
     if (f != GG_SHARD_NONE) atomicMin(&s_pstar, f);
   }
   __syncthreads();
+  for (int e = t; e < nrep; e += 256)
+    if (s_mv[4 * e] != GG_SHARD_NONE && s_mv[4 * e] == s_pstar) s_pe = e;      // (a node is reported by its one owner)
+  __syncthreads();
   const int bend = wbase + W < ntot ? wbase + W : ntot;
   const bool quiet = s_pstar == GG_SHARD_NONE;
   const int hi = quiet ? bend : s_pstar + 1;
   {
     // ---- fold, accept, reset: this workgroup's slice of the band (what it writes here is read by LATER launches only,
     // or by itself behind its own barrier)
-    const int nwg = (int)(gridDim.x * gridDim.y), wg = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int nwg = fold1 ? 1 : (int)(gridDim.x * gridDim.y), wg = fold1 ? (first ? 0 : 1) : (int)(blockIdx.y * gridDim.x + blockIdx.x);
     const int slice = ((W + nwg - 1) / nwg + 63) & ~63;
     const int b0 = wbase + wg * slice, b1 = b0 + slice < bend ? b0 + slice : bend;
     if (b0 < b1) {                             // (uniform over the workgroup)
-      for (int e = t; e < nrep; e += 256) {
-        const int f = s_mv[4 * e];
-        if (f == GG_SHARD_NONE || f < b0 || f >= b1) continue;
-        const int old = s_mv[4 * e + 3], nw = s_mv[4 * e + 2];
-        H[f - wbase] = (nw == old) ? -1 : ((old << 8) | nw);
-      }
-      __syncthreads();
+      // No word of H is read in the launch that writes it: every report lies at or behind the earliest one, p*, so the
+      // accepted stretch [spos, p*) holds hypotheses of EARLIER rounds only (read from H), p* itself is accepted from its
+      // report, and the reports behind it amend H for later rounds.
       int mine = 0;
       const int a0 = b0 > spos ? b0 : spos, a1 = b1 < hi ? b1 : hi;
       for (int n = a0 + t; n < a1; n += 256) {
-        const int h = H[n - wbase];
+        int h = H[n - wbase];
+        if (!quiet && n == hi - 1) {           // p*: what its report says
+          const int e = s_pe, old = s_mv[4 * e + 3], nw = s_mv[4 * e + 2];
+          h = (nw == old) ? -1 : ((old << 8) | nw);
+        }
         if (h < 0) continue;
         c[n] = h & 0xff;
         atomicSub(&cnt[h >> 8], 1);
         atomicAdd(&cnt[h & 0xff], 1);
         ++mine;
+      }
+      // (the writes below touch words OTHER threads of this workgroup have just read - the two loops deal the band's nodes out
+      // differently: without this barrier a reset could overtake the read of the very hypothesis it clears, and the node's
+      // accepted change was lost on that rank only: found as an intermittent mismatch with three ranks and one wide band)
+      __syncthreads();
+      for (int e = t; e < nrep; e += 256) {
+        const int f = s_mv[4 * e];
+        if (f == GG_SHARD_NONE || f < b0 || f >= b1) continue;
+        const int old = s_mv[4 * e + 3], nw = s_mv[4 * e + 2];
+        H[f - wbase] = (nw == old) ? -1 : ((old << 8) | nw);
       }
       // (a final band starts the next one without hypotheses)
       if (quiet) for (int n = b0 + t; n < b1; n += 256) H[n - wbase] = -1;

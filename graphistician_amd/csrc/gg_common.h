@@ -116,6 +116,7 @@ static inline bool gg_own_blocks(int N, int block, int rank, int world, gg_own* 
   while ((1 << o->lb) < block) o->lb += 1;
   o->Nl = 0x7fffffff;
   o->Nl = gg_own_below(*o, N);
+  if (world == 1) *o = gg_own{0, N, -1, 0, 1};     // (one rank owns everything, in order: the plain range)
   return true;
 }
 

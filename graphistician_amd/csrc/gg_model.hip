@@ -324,8 +324,7 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
       return gg_fail(GG_ERR_INVALID, "shard_block %d (a power of two >= 8), rank %d of %d: no such share of %d nodes", bl, rk, wd, NN);
     }
     m->Nl = m->own.Nl;
-    m->sharded = m->own.world > 1;
-    if (!m->sharded) m->own = gg_own{0, m->N, -1, 0, 1};      // one rank owns everything, in order
+    m->sharded = m->own.lb >= 0;      // (gg_own_blocks turns one rank's share into the plain range [0, N))
   } else if (cfg->shard_end > cfg->shard_begin) {
     if (cfg->shard_begin < 0 || cfg->shard_end > m->N) { delete m; return gg_fail(GG_ERR_INVALID, "shard [%d,%d) outside [0,%d)", cfg->shard_begin, cfg->shard_end, m->N); }
     m->n0 = cfg->shard_begin; m->Nl = cfg->shard_end - cfg->shard_begin;
@@ -2557,7 +2556,9 @@ static int launch_shard_apply(gg_model* m, const gg_data* d, int buf, int round,
 #define SHA(NTV, ADJV)                                                                                                 \
   k_shard_apply<NTV, ADJV><<<grd, 256, lds, m->stream>>>(x, m->own, W, m->c, m->cnt, m->sh_H, m->rs, m->sh_state, round, m->N, all, \
                                                          world, m->sh_cntn, gcnt(m, buf, 0), gcnt(m, buf, 1), gs(m, buf, 0), \
-                                                         gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT)
+                                                         gs(m, buf, 1), d->Ab, d->AbT, d->Wq, d->WqT, fold1)
+  static int fold1 = -1;      // GG_SHARD_FOLD1=1 (diagnosis): the whole band folded / accepted by ONE workgroup
+  if (fold1 < 0) { const char* e = getenv("GG_SHARD_FOLD1"); fold1 = e ? atoi(e) : 0; }
   if (m->is_adj) SHA(2, true);
   else if (m->B == 1) SHA(3, false);
   else if (m->B == 2) SHA(6, false);

@@ -46,6 +46,25 @@ def main():
                        (abi.ST_MU_SELF, w.mu_self, np.float64), (abi.ST_SIGMA_SELF, w.sigma_self, np.float64),
                        (abi.ST_NIW, w.niw, np.float64), (abi.ST_NIW_SELF, w.niw_self, np.float64)):
         wm.set(sid, v, dt)
+    if os.environ.get("GG_SHARD_DIAG"):
+        # diagnosis: the oracle's chain sweep by sweep beside the engine's, the first difference printed (rank 0)
+        q, shift = O.quantise(A, W)
+        ps = a.p_self
+        for s in range(nsweeps):
+            S.half_sweep(adj, data, comm)
+            S.half_sweep(wm, data, comm)
+            ps = O.sbm_adj_sweep(A, a.c, a.m, a.p, ps, a.pi, 1.0, 1.0, special, 901, s)
+            O.sbm_w_sweep(A, q, shift, w.c, w.m, w.mu, w.sigma, w.mu_self, w.sigma_self, w.pi, w.niw, w.niw_self, special, 902, s)
+            ca, cw = adj.get(abi.ST_C, (N,), np.int32), wm.get(abi.ST_C, (N,), np.int32)
+            if rank == 0:
+                da, dw = np.nonzero(ca != a.c)[0], np.nonzero(cw != w.c)[0]
+                print("DIAG sweep %d: adj labels differ at %s, p %s, m %s | w labels differ at %s, mu %s, m %s | changes %d %d" % (
+                    s, da[:8].tolist(), np.array_equal(adj.get(abi.ST_P, (K, K)), a.p), np.array_equal(adj.get(abi.ST_M, (K,)), a.m),
+                    dw[:8].tolist(), np.array_equal(wm.get(abi.ST_MU, (K, K, B)), w.mu), np.array_equal(wm.get(abi.ST_M, (K,)), w.m),
+                    adj.stats()["label_changes"], wm.stats()["label_changes"]), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for s in range(nsweeps - 1):
         S.half_sweep(adj, data, comm)
         S.half_sweep(wm, data, comm)
@@ -53,6 +72,15 @@ def main():
         S.half_sweep(adj, data, comm, 1)
         S.half_sweep(wm, data, comm, 1)
     ll = S.log_likelihood(adj, data, comm) + S.log_likelihood(wm, data, comm)
+    # every rank holds every label and draws every parameter: the replicas must agree to the bit (rank 0 alone is compared with
+    # the oracle below; a rank that lost an accepted change shows up here even while rank 0 is still right)
+    import hashlib
+    mine = hashlib.sha1(b"".join(np.ascontiguousarray(x).tobytes() for x in (
+        adj.get(abi.ST_C, (N,), np.int32), adj.get(abi.ST_P, (K, K)), adj.get(abi.ST_M, (K,)), wm.get(abi.ST_C, (N,), np.int32),
+        wm.get(abi.ST_MU, (K, K, B)), wm.get(abi.ST_SIGMA, (K, K, B, B)), wm.get(abi.ST_M, (K,))))).hexdigest()
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    assert len(set(everyone)) == 1, "the ranks' replicas of the chain differ: %s" % everyone
     if rank == 0:
         q, shift = O.quantise(A, W)
         ps = a.p_self

@@ -32,12 +32,16 @@ def test_sharded_chain_equals_single_chain(world, N, K, B, special, form, band):
     divide N and ranks that own one block more than others), contiguous ranges remain, and the band of the scan is as wide as
     the change count allows or as GG_SHARD_BAND forces (256 .. 65536 nodes) - the chain is the same whatever the width."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(29600 + world + 4 * B + 16 * special), os.path.join(ROOT, "tests", "shard_worker.py"),
-           str(N), str(K), "3", str(B), str(special), form]
+           "127.0.0.1", "--master-port", str(29600 + CASES.index((world, N, K, B, special, form, band))),      # (a port per case)
+           os.path.join(ROOT, "tests", "shard_worker.py"), str(N), str(K), "3", str(B), str(special), form]
     env = dict(os.environ)
     if band:
         env["GG_SHARD_BAND"] = str(band)
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:      # keep the workers' whole output where a GPU-box run leaves its files
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "shard_case_%d_%d_%d_%s_%d.log" % (world, N, K, form, band)), "w") as f:
+            f.write(out.stdout + "\n==== stderr ====\n" + out.stderr)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "SHARD-OK world=%d" % world in out.stdout, out.stdout[-1500:]
 
