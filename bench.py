@@ -461,10 +461,6 @@ def extra_host_classes(abi, device, N=4096, K=16, iters=40):
     Ar.setflags(write=False); Wr.setflags(write=False)
     loop((Ar, Wr), 5)
     t_r, lps = loop((Ar, Wr), iters)
-    E.clear_data_cache()
-    E.declare_immutable(A, W)
-    loop((A, W), 5)
-    t_i, _ = loop((A, W), iters)
     t0 = time.perf_counter()
     for _ in range(iters):
         model.resample((Ar, Wr))
@@ -473,15 +469,24 @@ def extra_host_classes(abi, device, N=4096, K=16, iters=40):
     for _ in range(iters):
         model.log_prior()
     t_prior = (time.perf_counter() - t0) / iters
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        model.adjacency._log_prior_host() + model.weights._log_prior_host()
+    t_prior_host = (time.perf_counter() - t0) / iters
+    E.clear_data_cache()
+    E.declare_immutable(A, W)
+    loop((A, W), 5)
+    t_i, _ = loop((A, W), iters)
     E.clear_data_cache()
     return {"workload": "FactorizedNetworkDistribution(SBMAdjacencyDistribution, SBMGaussianWeightDistribution).resample((A, W)); "
                         "log_probability((A, W)) on numpy arrays, N=%d, K=%d (examples/demo_model_comparison.py:69-72)" % (N, K),
             "us_per_iteration_read_only_arrays": t_r * 1e6, "us_per_iteration_declare_immutable": t_i * 1e6,
             "us_per_iteration_writeable_arrays": t_w * 1e6,
             "us_per_resample_read_only_arrays": t_res * 1e6, "us_per_log_prior": t_prior * 1e6,
+            "us_per_log_prior_host_formula": t_prior_host * 1e6,
             "last_log_probability": float(lps[-1]),
-            "note": "writeable arrays: the buffers of A (uint8, %.0f MB) and W (float64, %.0f MB) are hashed on every call (xxh3, in "
-                    "parallel chunks) so that an in-place edit is new data; read-only / declared arrays: identity only"
+            "note": "writeable arrays: the buffers of A (uint8, %.0f MB) and W (float64, %.0f MB) are hashed on every call (gg_hash64, "
+                    "all host threads) so that an in-place edit is new data; read-only / declared arrays: identity only"
                     % (A.nbytes / 1e6, W.nbytes / 1e6)}
 
 

@@ -21,6 +21,9 @@ def demo(N=30, N_samples=1000, seed=1234):
     true_model.L = np.hstack(((s * (np.arange(N) % w))[:, None], (s * (np.arange(N) // w))[:, None]))
     true_model.mu_0 = 1.0
     A = true_model.rvs().astype(np.uint8)
+    # the network is fixed for the whole run: read-only arrays are found on the device by identity alone (a writeable array is
+    # hashed on every call - it may have been edited in place since the last one; graphistician_amd/engine.py)
+    A.setflags(write=False)
     test_model = LatentDistanceAdjacencyDistribution(N=N, dim=D)
     lps = [test_model.log_probability(A)]
     for smpl in range(N_samples):

@@ -18,6 +18,9 @@ def demo(link="probit", N=30, D=2, N_samples=1000, seed=1234):
     p, sigma_F = 0.01, 9.0            # sparse base rate, wide features: the reference demo's setting
     true_model = cls(N=N, D=D, p=p, sigma_F=sigma_F, lmbda=np.ones(D))
     A = true_model.rvs().astype(np.uint8)
+    # the network is fixed for the whole run: read-only arrays are found on the device by identity alone (a writeable array is
+    # hashed on every call - it may have been edited in place since the last one; graphistician_amd/engine.py)
+    A.setflags(write=False)
     test_model = cls(N=N, D=D, p=p, sigma_F=sigma_F, lmbda=np.ones(D))
     lps = [test_model.log_probability(A)]
     for smpl in range(N_samples):

@@ -30,6 +30,10 @@ def demo(N=30, N_samples=1000, seed=1234):
     th = np.linspace(0, 4 * np.pi, N, endpoint=False)
     true_model.weights.L = np.hstack(((r * np.cos(th))[:, None], (r * np.sin(th))[:, None]))
     A, W = true_model.rvs()
+    # the network is fixed for the whole run: read-only arrays are found on the device by identity alone (a writeable array is
+    # hashed on every call - it may have been edited in place since the last one; graphistician_amd/engine.py)
+    A, W = np.ascontiguousarray(A), np.ascontiguousarray(W)
+    A.setflags(write=False); W.setflags(write=False)
     test_model = FactorizedNetworkDistribution(N, CompleteAdjacencyDistribution, {},
                                                LatentDistanceGaussianWeightDistribution, dict(dim=D, b=-12.0))
     lps = [test_model.log_probability((A, W))]

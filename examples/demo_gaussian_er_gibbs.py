@@ -21,6 +21,10 @@ def demo(seed=1234, N=50, B=2, N_samples=100):
     true_model = FactorizedNetworkDistribution(N, BetaBernoulliAdjacencyDistribution, {},
                                                NIWGaussianWeightDistribution, {"B": B})
     A, W = true_model.rvs()
+    # the network is fixed for the whole run: read-only arrays are found on the device by identity alone (a writeable array is
+    # hashed on every call - it may have been edited in place since the last one; graphistician_amd/engine.py)
+    A, W = np.ascontiguousarray(A), np.ascontiguousarray(W)
+    A.setflags(write=False); W.setflags(write=False)
     test_model = FactorizedNetworkDistribution(N, BetaBernoulliAdjacencyDistribution, {},
                                                NIWGaussianWeightDistribution, {"B": B})
     lps = [test_model.log_probability((A, W))]

@@ -20,6 +20,10 @@ def demo(N=512, C=4, N_samples=50, seed=1234):
     true_model = FactorizedNetworkDistribution(N, SBMAdjacencyDistribution, {"C": C},
                                                SBMGaussianWeightDistribution, {"C": C})
     A, W = true_model.rvs()
+    # the network is fixed for the whole run: read-only arrays are found on the device by identity alone (a writeable array is
+    # hashed on every call - it may have been edited in place since the last one; graphistician_amd/engine.py)
+    A, W = np.ascontiguousarray(A), np.ascontiguousarray(W)
+    A.setflags(write=False); W.setflags(write=False)
     test_model = FactorizedNetworkDistribution(N, SBMAdjacencyDistribution, {"C": C},
                                                SBMGaussianWeightDistribution, {"C": C})
     lps = [test_model.log_probability((A, W))]

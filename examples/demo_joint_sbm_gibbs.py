@@ -17,6 +17,10 @@ def demo(N=400, C=4, N_samples=40, seed=1234):
     np.random.seed(seed)
     true_model = GaussianStochasticBlockModel(N, 1, C=C, pi=5.0)
     A, W = true_model.rvs()
+    # the network is fixed for the whole run: read-only arrays are found on the device by identity alone (a writeable array is
+    # hashed on every call - it may have been edited in place since the last one; graphistician_amd/engine.py)
+    A, W = np.ascontiguousarray(A), np.ascontiguousarray(W)
+    A.setflags(write=False); W.setflags(write=False)
     test_model = GaussianStochasticBlockModel(N, 1, C=C, pi=5.0)
     lls = [test_model.log_likelihood((A, W))]
     t0 = time.time()

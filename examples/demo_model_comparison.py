@@ -25,6 +25,9 @@ def demo(N=30, N_samples=200, seed=1234):
     Afull, Wfull = true_model.rvs()
     Afull = Afull.astype(np.uint8)
     Atrain, Wtrain = np.ascontiguousarray(Afull[:N, :N]), np.ascontiguousarray(Wfull[:N, :N, :])
+    # the training network is fixed for the whole comparison: read-only arrays are found on the device by identity alone (a
+    # writeable array is hashed on every call - it may have been edited in place since the last one; graphistician_amd/engine.py)
+    Atrain.setflags(write=False); Wtrain.setflags(write=False)
     Atest_row, Wtest_row = Afull[N:, :].ravel(), Wfull[N:, :, :].reshape((N + N_test, 1))
     Atest_col, Wtest_col = Afull[:, N:].ravel(), Wfull[:, N:, :].reshape((N + N_test, 1))
     results = []

@@ -59,7 +59,7 @@ EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "
            "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_part_many", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_predictive_ll", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
            "gg_comm_create_host", "gg_comm_destroy", "gg_comm_info", "gg_shard_sweep", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws", "gg_hash64", "gg_data_create_shard_blocks",
-           "gg_data_create_sbm_shard_blocks"]
+           "gg_data_create_sbm_shard_blocks", "gg_log_prior_many"]
 
 
 def build(force=False):
@@ -107,6 +107,7 @@ def lib():
         L.gg_resample_many.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int32, C.c_int32, C.c_double]
         L.gg_log_likelihood_many.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int32, C.POINTER(C.c_double)]
         L.gg_log_likelihood.argtypes = [vp, vp, C.POINTER(C.c_double)]
+        L.gg_log_prior_many.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(C.c_double)]
         L.gg_node_lp.argtypes = [vp, vp, C.c_int32, vp]
         L.gg_predictive_ll.argtypes = [vp, vp, vp, vp, vp, vp]
         L.gg_last_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -512,6 +513,22 @@ def log_likelihood_many(models, datas):
     marr, darr, out = _handles(models, datas)
     check(lib().gg_log_likelihood_many(marr, darr, len(models), out))
     return [float(v) for v in out]
+
+
+_prior_args = {}
+
+
+def log_prior_many(models):
+    """log_prior of several SBM adjacency / weight models from their device-resident state (gg_log_prior_many): list of values."""
+    key = tuple(m._h.value for m in models)
+    hit = _prior_args.get(key)
+    if hit is None:
+        if len(_prior_args) > 64:
+            _prior_args.clear()
+        hit = ((C.c_void_p * len(models))(*[m._h for m in models]), (C.c_double * len(models))())
+        _prior_args[key] = hit
+    check(lib().gg_log_prior_many(hit[0], len(models), hit[1]))
+    return [float(v) for v in hit[1]]
 
 
 def resample_many(models, datas, n_sweeps=1, beta=1.0):

@@ -420,7 +420,17 @@ class SBMAdjacencyDistribution(AdjacencyDistribution, GibbsSampling, EngineBacke
     def initialize_hypers(self, A):
         pass
 
+    _device_prior = True      # gg_log_prior_many evaluates this class's log_prior from the engine's state
+
     def log_prior(self):
+        """adjacency.py:538-555.  Once the model lives on the engine the value comes from there (one small launch instead of
+        four state reads and three scipy calls: the reference's loops ask for log_probability once per sweep); a model that has
+        not touched the engine yet uses the host formula below - the two agree to rounding (tests/test_gpu_edge_cases.py)."""
+        if self._model is not None:
+            return _abi.log_prior_many([self._engine()])[0]
+        return self._log_prior_host()
+
+    def _log_prior_host(self):
         # adjacency.py:538-555
         lp = 0
         lp += _dirichlet(self.pi).logpdf(self.m)

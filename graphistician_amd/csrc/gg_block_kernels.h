@@ -1047,7 +1047,9 @@ __global__ __launch_bounds__(256) void k_params_w(gg_params_args g, gg_ride_args
 #define GG_RS_SPOS 22        // control block: scan position of the sharded chain (global node index) - for the host; the device
                              //                reads gg_shard_state
 #define GG_RS_ROUNDS 14      //                rounds of the sharded scan that did something
-#define GG_SHARD_M 64        // surprises a rank reports per round (k_shard_eval)
+#ifndef GG_SHARD_M
+#define GG_SHARD_M 64        // surprises a rank reports per round (k_shard_eval); (-DGG_SHARD_M=512 on ONE rank emulates what 8 ranks report per round: tools/scripts/shard_model.sh)
+#endif
 #define GG_SHARD_NONE 0x7fffffff
 
 // ------------------------------------------------------------------ per-node conditional
@@ -1825,7 +1827,7 @@ __global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, gg_own own, i
   }
   __syncthreads();
   if (!s_last) return;
-  if (t < GG_SHARD_M) { trip[2 * t] = GG_SHARD_NONE; trip[2 * t + 1] = 0; }
+  for (int i = t; i < GG_SHARD_M; i += 256) { trip[2 * i] = GG_SHARD_NONE; trip[2 * i + 1] = 0; }
   __syncthreads();
   // The first GG_SHARD_M deviations in position order, 4096 own nodes at a time.  Thread t looks at the nodes base + 256 i + t
   // (i < 16), all of its loads in flight together - the decisions are read with agent-scope loads, a memory-side round trip

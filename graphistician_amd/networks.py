@@ -52,7 +52,11 @@ class FactorizedNetworkDistribution(NetworkDistribution, GibbsSampling):
         return adj.log_likelihood(self._adjacency_arg(d, data)) + wts.log_likelihood(d)
 
     def log_prior(self):
-        return sum(half.log_prior() for half in self._halves)
+        halves = self._halves
+        if all(getattr(h, "_device_prior", False) and getattr(h, "_model", None) is not None for h in halves):
+            # both priors in one call: the two small launches are enqueued before either is waited for (gg_log_prior_many)
+            return sum(_abi.log_prior_many([h._engine() for h in halves]))
+        return sum(half.log_prior() for half in halves)
 
     # -- sampling (networks.py:39-58) ------------------------------------------------------------------------------
     def rvs(self, *args, **kwargs):

@@ -408,7 +408,15 @@ class SBMGaussianWeightDistribution(_WeightsBase):
         km.fit(features)
         self.c = km.labels_.astype(np.int32)
 
+    _device_prior = True      # gg_log_prior_many evaluates this class's log_prior from the engine's state
+
     def log_prior(self):
+        """weights.py:333-357; from the engine's state once the model lives there (see SBMAdjacencyDistribution.log_prior)."""
+        if self._model is not None:
+            return _abi.log_prior_many([self._engine()])[0]
+        return self._log_prior_host()
+
+    def _log_prior_host(self):
         # weights.py:333-357
         lp = 0
         lp += _dirichlet(self.pi).logpdf(self.m)
@@ -514,7 +522,7 @@ class SBMGaussianWeightSharedCov(SBMGaussianWeightDistribution):
         self._hset("_sigma", sig)
         self._cov_model = _SharedCovView(self)
 
-    def log_prior(self):
+    def _log_prior_host(self):
         # weights.py:554-577 (the Gaussian terms are commented out in the reference too)
         lp = _dirichlet(self.pi).logpdf(self.m)
         lp += (np.log(self.m)[self.c]).sum()

@@ -251,6 +251,12 @@ int gg_log_likelihood(gg_model* m, const gg_data* d, double* out);
  * run concurrently. */
 int gg_log_likelihood_many(gg_model** models, const gg_data* const* data, int32_t n, double* out);
 
+/* log_prior of n models at once (models[i] -> out[i]): SBMAdjacencyDistribution.log_prior (adjacency.py:538-555),
+ * SBMGaussianWeightDistribution.log_prior (weights.py:333-357), SBMGaussianWeightSharedCov.log_prior (weights.py:554-577) from
+ * the state where it lives - what `log_probability` (abstractions.py:39-40) adds to the log-likelihood once per sweep in the
+ * reference's loops.  Other kinds: GG_ERR_UNSUPPORTED (their priors are O(1) host formulas in the Python classes). */
+int gg_log_prior_many(gg_model** models, int32_t n, double* out);
+
 /* approx_predictive_ll (abstractions.py:157-182, 313-357; networks.py:60-67), the held-out evaluation of
  * examples/demo_model_comparison.py:61-74: log-likelihood of an (N+1)-th node's row and column, a_row / a_col uint8 [N+1]
  * (entry N = the self connection), w_row / w_col double [N+1][B] (weight kinds; NULL otherwise), for each block k the new

@@ -779,3 +779,40 @@ def test_call_epilogue_is_the_plain_chain_and_the_plain_log_likelihood(abi, N, K
     assert abs(ll2 - ref2) <= 1e-9 * abs(ref2) + 1e-7 and ll2 != plain[0]
     st = adj.stats()
     assert st["sweeps_two_launch"] > 0     # the quiet phase was reached: calls ended in the epilogue form
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,B,special,shared", [(120, 3, 1, True, False), (90, 5, 2, False, False), (200, 16, 1, True, False),
+                                                  (150, 70, 1, True, False), (100, 4, 2, True, True), (80, 1, 3, True, False)])
+def test_log_prior_on_the_device_is_the_host_formula(abi, N, K, B, special, shared):
+    """log_prior of the SBM classes (adjacency.py:538-555, weights.py:333-357, :554-577) evaluated by the engine from the state
+    where it lives (gg_log_prior_many: what `log_probability` adds once per sweep in the reference's loops) against the scipy /
+    numpy formula of the host classes, after a few sweeps, for both halves at once and one at a time; also with a label that
+    no node carries (its log m enters the Dirichlet term only) and after host-side edits of the state."""
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution, SBMGaussianWeightSharedCov
+    A, W, _ = planted_sbm(N, max(K, 2) if K < 64 else 8, B=B, seed=N)
+    np.random.seed(N + 1)
+    wcls = SBMGaussianWeightSharedCov if shared else SBMGaussianWeightDistribution
+    model = FactorizedNetworkDistribution(N, SBMAdjacencyDistribution, dict(C=K, tau1=1.3, tau0=0.8, pi=2.0, special_case_self_conns=special, seed=3),
+                                          wcls, dict(B=B, C=K, special_case_self_conns=special, seed=4))
+    host0 = model.adjacency._log_prior_host() + model.weights._log_prior_host()
+    assert abs(model.log_prior() - host0) <= 1e-12 * abs(host0)          # (nothing on the engine yet: the host formula itself)
+    for it in range(4):
+        model.resample((A, W))
+        dev = model.log_prior()
+        host = model.adjacency._log_prior_host() + model.weights._log_prior_host()
+        assert np.isfinite(dev) and abs(dev - host) <= 1e-10 * abs(host), (it, dev, host)
+        assert abs(model.adjacency.log_prior() - model.adjacency._log_prior_host()) <= 1e-10 * abs(host)
+        assert abs(model.weights.log_prior() - model.weights._log_prior_host()) <= 1e-10 * abs(host)
+        lp = model.log_probability((A, W))
+        assert abs(lp - (model.log_likelihood((A, W)) + host)) <= 1e-9 * abs(lp)
+    if K > 1:
+        c = model.adjacency.c.copy()
+        c[c == 0] = 1                                   # block 0 is empty now
+        model.adjacency.c = c
+        m = np.random.dirichlet(np.ones(K) * 3.0)
+        model.weights.m = m
+        dev, host = model.log_prior(), model.adjacency._log_prior_host() + model.weights._log_prior_host()
+        assert abs(dev - host) <= 1e-10 * abs(host), (dev, host)
