@@ -53,6 +53,12 @@ struct gg_eigen {
   int* status;
   long long* dbgbuf;   // GG_EIG_DBG: cycle counters of the chain's solver wave
   hipStream_t stream;
+  // round 4: the auxiliary draws of a full sweep run on a second stream, in the order the feature scan consumes them (DESIGN.md
+  // section 7): that stream's queue is kept off a few compute units (CU mask), so that the scan's one workgroup per tile - which
+  // needs most of a compute unit's LDS - always finds one free instead of waiting for the draws' workgroups to drain
+  hipStream_t stream2;
+  hipEvent_t ev_fork, ev_chunk[16];
+  int overlap;             // 1: the overlapped form is available (second stream created)
   uint32_t sweep;
   int parts_done;          // parts already drawn under the current sweep index (step-wise calls, see gg_resample_part)
   bool have_omega;
@@ -151,13 +157,13 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
                                                    uint64_t seed, uint32_t sweep, double* __restrict__ S,
                                                    double* __restrict__ dO, double beta, const uint8_t* __restrict__ A,
                                                    const uint8_t* __restrict__ AT, const uint8_t* __restrict__ dA, int gen,
-                                                   int accumulate, uint32_t site) {
+                                                   int accumulate, uint32_t site, int pair_base) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
   __shared__ double s_t[32][33];
   __shared__ double s_psi[32][33];
   const int nt = (N + 31) / 32;
   int I, J;
-  eig_tile_pair(blockIdx.x, nt, &I, &J);
+  eig_tile_pair((int)blockIdx.x + pair_base, nt, &I, &J);
   const int tid = threadIdx.x;
   const double mu0 = *mu0p;
   for (int e = tid; e < 32 * DM; e += 256) {
@@ -230,13 +236,14 @@ template <int DM>
 __global__ __launch_bounds__(256, 4) void k_eig_z(int N, int Np, int D, const double* __restrict__ F,
                                                const double* __restrict__ lmbda, const double* __restrict__ mu0p,
                                                const uint8_t* __restrict__ A, const uint8_t* __restrict__ AT,
-                                               uint64_t seed, uint32_t sweep, double* __restrict__ S, int accumulate, uint32_t site) {
+                                               uint64_t seed, uint32_t sweep, double* __restrict__ S, int accumulate, uint32_t site,
+                                               int pair_base) {
   __shared__ double s_fi[32][DM], s_fj[32][DM];
   __shared__ double s_t[32][33];
   __shared__ double s_psi[32][33];
   const int nt = (N + 31) / 32;
   int I, J;
-  eig_tile_pair(blockIdx.x, nt, &I, &J);
+  eig_tile_pair((int)blockIdx.x + pair_base, nt, &I, &J);
   const int tid = threadIdx.x;
   const double mu0 = *mu0p;
   for (int e = tid; e < 32 * DM; e += 256) {
@@ -315,8 +322,8 @@ __global__ __launch_bounds__(256, 4) void k_eig_z(int N, int Np, int D, const do
 __global__ __launch_bounds__(64) void k_eig_vblocks(int N, int Np, const double* __restrict__ S, eig_obs ob,
                                                     const double* __restrict__ mu0p,
                                                     double* __restrict__ Sb, double* __restrict__ Vb, int probit, double ka,
-                                                    uint64_t seed, uint32_t sweep) {
-  const int n = blockIdx.x;
+                                                    uint64_t seed, uint32_t sweep, int n_base) {
+  const int n = (int)blockIdx.x + n_base;
   const int m0 = (n / EIG_T) * EIG_T - EIG_T + 2 * (int)threadIdx.x;   // this thread's pair of columns (m0 even)
   const double mu0 = *mu0p;
   double sv[2] = {0.0, 0.0}, vv[2] = {0.0, 0.0};
@@ -943,6 +950,36 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   GG_HIP(hipStreamCreate(&e->stream));
   GG_HIP(hipEventCreate(&e->e0));
   GG_HIP(hipEventCreate(&e->e1));
+  {
+    // second stream for the auxiliary draws of a full sweep, kept off every 32nd compute unit (8 of 256): the feature scan's
+    // workgroup asks for ~130 KB of LDS and would otherwise wait until the draws' four-workgroups-per-CU stream happens to
+    // drain one (a stream of small workgroups backfills every hole: DESIGN.md section 5).  GG_EIG_OVERLAP=0: the serial form.
+    e->overlap = 0;
+    // Measured on MI355X (round 4, profiles/r04_eigen_overlap_timeline.txt): exact, and SLOWER - 5.8 against 5.0 ms per sweep at
+    // N=4096, D=8 - so it is off unless GG_EIG_OVERLAP=1: the draws' workgroups live ~200 us each, the scan's launches carry a
+    // thousand rider workgroups that need slots within their 43 us, and neither a CU mask nor the eight chunk boundaries (each
+    // with its own tail) leave the riders room.
+    const char* eo = getenv("GG_EIG_OVERLAP");
+    if (eo && atoi(eo) == 1) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
+        const int ncu = prop.multiProcessorCount;
+        const int nw = (ncu + 31) / 32;
+        std::vector<uint32_t> mask(nw, 0xffffffffu);
+        const char* er = getenv("GG_EIG_RESERVE");          // every r-th compute unit stays free of the draws (default 32)
+        const int every = er && atoi(er) > 1 ? atoi(er) : 32;
+        for (int cu = 0; cu < ncu; cu += every) mask[cu / 32] &= ~(1u << (cu % 32));
+        if (ncu % 32) mask[nw - 1] &= (1u << (ncu % 32)) - 1u;
+        if (hipExtStreamCreateWithCUMask(&e->stream2, (uint32_t)nw, mask.data()) == hipSuccess) e->overlap = 1;
+        else (void)hipGetLastError();
+      }
+      if (e->overlap) {
+        bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); e->overlap = 0; }
+      }
+    }
+  }
   const size_t N = e->N, D = e->D;
   if ((rc = emalloc(&e->F, N * D)) || (rc = emalloc(&e->lmbda, D)) || (rc = emalloc(&e->mu0, 1)) ||
       (rc = emalloc(&e->mu_lmbda, D)) || (rc = emalloc(&e->S, N * e->Np)) || (rc = emalloc(&e->dO, N)) ||
@@ -963,6 +1000,9 @@ int gg_eigen_destroy(gg_eigen* e) {
   if (e->e0) (void)hipEventDestroy(e->e0);
   if (e->e1) (void)hipEventDestroy(e->e1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  for (int i = 0; i < 16; ++i) if (e->ev_chunk[i]) (void)hipEventDestroy(e->ev_chunk[i]);
   delete e;
   return GG_OK;
 }
@@ -1061,7 +1101,50 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
     int rc;
     if ((rc = emalloc(&e->a2, (size_t)N * Np)) || (rc = emalloc(&e->nob, (size_t)N * Np)) || (rc = emalloc(&e->da2, (size_t)N))) return rc;
   }
-  if (parts & GG_PART_OMEGA) {
+  // Overlapped form (round 4; one fully observed graph, a whole sweep): the auxiliaries are drawn on the second stream in
+  // chunks of tile rows, top to bottom - row t of S is complete once the tile rows 0..t of the upper triangle are done -,
+  // each chunk followed by its nodes' tile-local blocks and an event; the feature scan on the main stream waits, tile by
+  // tile, only for the chunk that holds the rows its riders read next.  The draws (the whole chip, divergence-bound) and the
+  // scan (one workgroup's latency chain) were 2.0 + 2.7 ms in series; the scan now starts after the first chunk.
+  const int nt32 = (N + 31) / 32;
+  int nchunk = 0, rows_per_chunk = 0;
+  const bool ovl = e->overlap && full && !general && nd == 1 && N >= 1024;
+  if (ovl) {
+    nchunk = 8;
+    rows_per_chunk = ((nt32 + nchunk - 1) / nchunk + 1) & ~1;          // (even: a 64-node tile is two rows)
+    nchunk = (nt32 + rows_per_chunk - 1) / rows_per_chunk;
+    GG_HIP(hipEventRecord(e->ev_fork, st));
+    GG_HIP(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    hipStream_t sb = e->stream2;
+    const gg_data* dg = ds[0];
+    const uint32_t site = (uint32_t)(e->probit ? GG_SITE_EIG_Z : GG_SITE_EIG_OMEGA);
+    eig_obs obv;
+    obv.A = dg->A; obv.AT = dg->AT; obv.a2 = e->a2; obv.nob = e->nob; obv.gen = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      const int I0 = c * rows_per_chunk, I1 = (I0 + rows_per_chunk < nt32) ? I0 + rows_per_chunk : nt32;
+      const long long p0 = (long long)I0 * nt32 - (long long)I0 * (I0 - 1) / 2, p1 = (long long)I1 * nt32 - (long long)I1 * (I1 - 1) / 2;
+      const int np = (int)(p1 - p0), pb = (int)p0;
+      if (e->probit) {
+#define CALL(DMV) k_eig_z<DMV><<<np, 256, 0, sb>>>(N, Np, D, e->F, e->lmbda, e->mu0, dg->A, dg->AT, e->cfg.seed, e->sweep, e->S, 0, site, pb)
+        EIG_DISPATCH(CALL);
+#undef CALL
+      } else {
+#define CALL(DMV)                                                                                                                  \
+  if (e->beta != 1.0) k_eig_omega<DMV, true><<<np, 256, 0, sb>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, 0, 0, site, pb); \
+  else k_eig_omega<DMV, false><<<np, 256, 0, sb>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, 0, 0, site, pb)
+        EIG_DISPATCH(CALL);
+#undef CALL
+      }
+      const int n0c = I0 * 32, n1c = I1 * 32 < N ? I1 * 32 : N;
+      k_eig_vblocks<<<n1c - n0c, 64, 0, sb>>>(N, Np, e->S, obv, e->mu0, e->Sb, e->Vb, e->probit, e->beta, e->cfg.seed, e->sweep, n0c);
+      GG_HIP(hipGetLastError());
+      GG_HIP(hipEventRecord(e->ev_chunk[c], sb));
+    }
+    e->have_omega = true;
+    e->gen = 0;
+    e->omega_uid = d->uid;
+  }
+  if ((parts & GG_PART_OMEGA) && !ovl) {
     const int nt = (N + 31) / 32;
     const int npairs = nt * (nt + 1) / 2;
     for (int g = 0; g < nd; ++g) {
@@ -1070,13 +1153,13 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
       // graph g draws from its own Philox site (the plain site for the first: one graph is the plain sweep)
       const uint32_t site = (uint32_t)(e->probit ? GG_SITE_EIG_Z : GG_SITE_EIG_OMEGA) + ((uint32_t)g << 8);
       if (e->probit) {
-#define CALL(DMV) k_eig_z<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, dg->A, dg->AT, e->cfg.seed, e->sweep, e->S, acc, site)
+#define CALL(DMV) k_eig_z<DMV><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, dg->A, dg->AT, e->cfg.seed, e->sweep, e->S, acc, site, 0)
         EIG_DISPATCH(CALL);
 #undef CALL
       } else {
 #define CALL(DMV)                                                                                                                  \
-  if (e->beta != 1.0) k_eig_omega<DMV, true><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site); \
-  else k_eig_omega<DMV, false><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site)
+  if (e->beta != 1.0) k_eig_omega<DMV, true><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site, 0); \
+  else k_eig_omega<DMV, false><<<npairs, 256, 0, st>>>(N, Np, D, e->F, e->lmbda, e->mu0, e->cfg.seed, e->sweep, e->S, e->dO, e->beta, dg->A, dg->AT, dg->dA, general ? 1 : 0, acc, site, 0)
         EIG_DISPATCH(CALL);
 #undef CALL
       }
@@ -1114,7 +1197,21 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
       attr8 = true;
     }
     // the tile-local blocks of pair weights and mean coefficients (previous tile | own tile) for every node
-    k_eig_vblocks<<<N, 64, 0, st>>>(N, Np, e->S, ob, e->mu0, e->Sb, e->Vb, e->probit, e->beta, e->cfg.seed, e->sweep);
+    // (overlapped form: made chunk by chunk on the second stream, behind the draws they read)
+    if (!ovl) k_eig_vblocks<<<N, 64, 0, st>>>(N, Np, e->S, ob, e->mu0, e->Sb, e->Vb, e->probit, e->beta, e->cfg.seed, e->sweep, 0);
+    int waited = -1;        // chunks of the second stream the main stream has waited for
+    auto need_rows = [&](int row) -> int {      // the main stream may read the rows 0..row of S (32-row units) from here on
+      if (!ovl) return GG_OK;
+      int c = (row < nt32 ? row : nt32 - 1) / rows_per_chunk;
+      if (c > waited) { GG_HIP(hipStreamWaitEvent(st, e->ev_chunk[c], 0)); waited = c; }
+      return GG_OK;
+    };
+    {
+      static int serial_b = -1;      // GG_EIG_SERIAL_B=1 (measurement): the draws on the second stream, the scan only behind ALL of them
+      if (serial_b < 0) { const char* ev = getenv("GG_EIG_SERIAL_B"); serial_b = ev ? atoi(ev) : 0; }
+      int rcw = need_rows(serial_b ? nt32 - 1 : 1);
+      if (rcw) return rcw;
+    }
     // Tile 0's statistics in a launch of their own; every chain launch then carries, as extra workgroups, the
     // statistics of the tile after it (all nodes outside both tiles), and adds the previous tile's nodes itself.
     const size_t part_stride = (size_t)EIG_T * e->NCH * e->NEm;
@@ -1130,6 +1227,7 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
       double* partn = e->part + (size_t)((ti + 1) & 1) * part_stride;
       const int Tn = (t0 + EIG_T < N) ? ((N - t0 - EIG_T < EIG_T) ? (N - t0 - EIG_T) : EIG_T) : 0;
       const int grid = 1 + Tn * e->NCH;
+      { int rcw = need_rows((t0 + 2 * EIG_T) / 32 - 1); if (rcw) return rcw; }     // (the riders read the rows of the NEXT tile)
 #define CALL(DMV)                                                                                                      \
   k_eig_chain<DMV><<<grid, 64 * DMV, chain_lds, st>>>(N, Np, D, t0, e->S, ob, e->F, e->lmbda, e->mu0,                   \
                                                       e->cfg.sigma_F, e->NCH, partb, e->Z, e->Sb, e->Vb, e->status, dbg, \
@@ -1140,6 +1238,7 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
   }
   const int do_mu0 = (parts & GG_PART_MU0) ? 1 : 0;
   const int do_lm = ((parts & GG_PART_LMBDA) && !e->cfg.lmbda_given) ? 1 : 0;
+  if (ovl) GG_HIP(hipStreamWaitEvent(st, e->ev_chunk[nchunk - 1], 0));       // (everything the second stream did)
   if (do_mu0 || do_lm) {
 #define CALL(DMV)                                                                                                   \
   k_eig_global<DMV><<<(N < 512 ? N : 512), 256, 0, st>>>(N, Np, D, e->S, ob, e->F, e->gpart, e->probit, e->beta);             \

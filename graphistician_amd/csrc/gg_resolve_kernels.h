@@ -755,6 +755,56 @@ __global__ __launch_bounds__(256) void k_apply_L(gg_node_ctx x, const int32_t* _
   if (mode != 3) ap[n] = 0;
 }
 
+// k_apply_L's mode 3 as a kernel of its own (round 4): the changes a completed k_scan made (rs[GG_RS_CARRY] entries of L) moved
+// in the buffer the NEXT sweep's statistics were counted into under the labels the scan started with.  k_apply_L walks the list
+// once per node with plain read-modify-writes - a chain of dependent memory round trips: 125 us for 52 changes at N=4096.  Here the
+// entries are dealt out over blockIdx.y and applied with integer atomics (no return value, nothing to wait for): any order gives
+// the same integers.  Nothing behind a stalled scan (the slow path drops what was counted ahead).
+template <int NT, bool ADJ>
+__global__ __launch_bounds__(256) void k_apply_moves(gg_node_ctx x, const int32_t* __restrict__ L, const int32_t* __restrict__ rs,
+                                                     int32_t* Gc0, int32_t* Gc1, long long* Gs0, long long* Gs1,
+                                                     const uint32_t* XA, const uint32_t* XAT, const int32_t* XW, const int32_t* XWT) {
+  constexpr int B = gg_tB(NT);
+  constexpr int NSI = gg_tNSI(NT);
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= x.N || rs[4] != 0) return;
+  const int nL = rs[25 /* GG_RS_CARRY, gg_scan_kernels.h */], Np = x.Np;
+  for (int e = blockIdx.y; e < nL; e += gridDim.y) {
+    const int n2 = L[e * 3], a = L[e * 3 + 1], b = L[e * 3 + 2];
+    const size_t at = (size_t)n2 * Np + n;
+    if (ADJ) {
+      if (gg_abit(XAT, at)) { atomicSub(&Gc0[(size_t)a * Np + n], 1); atomicAdd(&Gc0[(size_t)b * Np + n], 1); }
+      if (gg_abit(XA, at)) { atomicSub(&Gc1[(size_t)a * Np + n], 1); atomicAdd(&Gc1[(size_t)b * Np + n], 1); }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int32_t* q = (d == 0 ? XWT : XW) + at * B;
+        int32_t qq[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) qq[r] = q[r];
+        if (qq[0] == GG_NO_EDGE) continue;
+        int32_t* Gc = d == 0 ? Gc0 : Gc1;
+        long long* Gs = d == 0 ? Gs0 : Gs1;
+        atomicSub(&Gc[(size_t)a * Np + n], 1);
+        atomicAdd(&Gc[(size_t)b * Np + n], 1);
+        long long v[NSI > 0 ? NSI : 1];
+        int tt = 0;
+#pragma unroll
+        for (int r = 0; r < B; ++r) v[tt++] = qq[r];
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+          for (int s = r; s < B; ++s) v[tt++] = (long long)qq[r] * (long long)qq[s];
+#pragma unroll
+        for (int s = 0; s < NSI; ++s) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&Gs[((size_t)a * Np + n) * NSI + s]), (unsigned long long)(-v[s]));
+          atomicAdd(reinterpret_cast<unsigned long long*>(&Gs[((size_t)b * Np + n) * NSI + s]), (unsigned long long)v[s]);
+        }
+      }
+    }
+  }
+}
+
 #ifndef GG_ONLY_SWEEPQ   // (non-template kernels: defined once, in gg_model.hip)
 __global__ void k_reset_L(int32_t* rs, int mode) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && !(mode == 0 ? rs[7] != 0 : (mode == 1 ? rs[4] != 0 : false))) {
