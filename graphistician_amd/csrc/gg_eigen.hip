@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
         double dv = 0.0;
         if (!gen || dA[gi] != GG_A_MISSING) {
           gg_stream s0;
-          gg_stream_init(&s0, seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gi);
+          gg_stream_init64(&s0, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gi);
           // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
           dv = TEMP ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
         }
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
         const size_t at = (size_t)gi * Np + gj;
         const bool o1 = !gen || A[at] != GG_A_MISSING, o2 = !gen || AT[at] != GG_A_MISSING;   // i -> j, j -> i observed
         gg_stream s1, s2;
-        gg_stream_init(&s1, seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj);
-        gg_stream_init(&s2, seed, site, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi);
+        gg_stream_init64(&s1, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gj);
+        gg_stream_init64(&s2, seed, site, sweep, (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
         if (TEMP) {
           if (beta > 0.0) val = (o1 ? gg_pg_frac(&s1, beta, psi) : 0.0) + (o2 ? gg_pg_frac(&s2, beta, psi) : 0.0);
         } else {
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256, 4) void k_eig_z(int N, int Np, int D, const do
       const size_t at = (size_t)gi * Np + gj;
       // (an unobserved entry has no auxiliary variable: it is absent from every conditional)
       const int a1 = A[at], a2v = AT[at];
-      const double z1 = a1 == GG_A_MISSING ? 0.0 : gg_truncnorm(gg_uniform_at(seed, site, sweep, (uint32_t)gi * (uint32_t)N + (uint32_t)gj), psi, a1 ? 1 : 0);
-      const double z2 = a2v == GG_A_MISSING ? 0.0 : gg_truncnorm(gg_uniform_at(seed, site, sweep, (uint32_t)gj * (uint32_t)N + (uint32_t)gi), psi, a2v ? 1 : 0);
+      const double z1 = a1 == GG_A_MISSING ? 0.0 : gg_truncnorm(gg_uniform_at64(seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gj), psi, a1 ? 1 : 0);
+      const double z2 = a2v == GG_A_MISSING ? 0.0 : gg_truncnorm(gg_uniform_at64(seed, site, sweep, (uint64_t)gj * (uint64_t)N + (uint64_t)gi), psi, a2v ? 1 : 0);
       val = z1 + z2;
     }
     if (I < J || li <= lj) s_t[li][lj] = val;
@@ -929,8 +929,8 @@ static int emalloc(T** p, size_t n) {
 int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
   if (cfg->N <= 0 || cfg->D < 1 || cfg->D > 8)
     return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: need N > 0 and 1 <= D <= 8 (got N=%d D=%d)", cfg->N, cfg->D);
-  if ((long long)cfg->N * cfg->N >= (1LL << 32) + 1)
-    return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: N*N must fit the 32-bit Philox index");
+  if (cfg->N >= (1 << 20))
+    return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: N < 2^20 (the 40-bit Philox index of a pair of nodes, spec/gg_philox.h)");
   {
     const double v[4] = {cfg->sigma_mu0, cfg->sigma_F, cfg->sigma_lmbda, cfg->mu_mu_0};
     if (gg_first_nonfinite(v, 4) >= 0 || !(v[0] > 0.0 && v[1] > 0.0 && v[2] > 0.0))

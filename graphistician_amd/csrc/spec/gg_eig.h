@@ -31,7 +31,8 @@ GG_HD double gg_u52_open(uint32_t a, uint32_t b) {
 
 GG_HD void gg_eig_noise_pair(uint64_t seed, uint32_t sweep, uint32_t N, uint32_t n, uint32_t pp, double* e0, double* e1) {
   const uint32_t Nh = (N + 1u) >> 1;
-  const gg_u32x4 r = gg_philox4x32_10(0u, n * Nh + pp, sweep, (uint32_t)GG_SITE_EIG_FN, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint64_t idx = (uint64_t)n * Nh + pp;      // (passes 2^32 at N = 92 682: the high word takes the counter word that was 0)
+  const gg_u32x4 r = gg_philox4x32_10((uint32_t)(idx >> 32), (uint32_t)idx, sweep, (uint32_t)GG_SITE_EIG_FN, (uint32_t)seed, (uint32_t)(seed >> 32));
   *e0 = gg_ndtri(gg_u52_open(r.v[0], r.v[1]));
   *e1 = gg_ndtri(gg_u52_open(r.v[2], r.v[3]));
 }

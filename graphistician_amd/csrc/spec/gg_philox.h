@@ -101,6 +101,19 @@ GG_HD void gg_stream_init(gg_stream* s, uint64_t seed, uint32_t site, uint32_t s
   s->w2 = s->w3 = 0u;
 }
 
+// The same addressing for a 64-bit index - a PAIR of nodes, i N + j, which passes 2^32 at N = 65536 (the eigenmodels' auxiliary
+// variables): the low word goes where the 32-bit index goes, the high word into the top byte of the word that counts the
+// stream's blocks (no stream draws 2^24 blocks), so an index below 2^32 addresses exactly the stream it always did and
+// indices up to 2^40 (N < 2^20) never collide.
+GG_HD void gg_stream_init64(gg_stream* s, uint64_t seed, uint32_t site, uint32_t sweep, uint64_t index) {
+  gg_stream_init(s, seed, site, sweep, (uint32_t)index);
+  s->c0 = (uint32_t)(index >> 32) << 24;
+}
+GG_HD double gg_uniform_at64(uint64_t seed, uint32_t site, uint32_t sweep, uint64_t index) {
+  gg_u32x4 r = gg_philox4x32_10((uint32_t)(index >> 32) << 24, (uint32_t)index, sweep, site, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return gg_u53(r.v[0], r.v[1]);
+}
+
 // Words are consumed in pairs: block b yields uniforms (w0,w1) then (w2,w3).
 GG_HD double gg_stream_uniform(gg_stream* s) {
   if (s->have) {

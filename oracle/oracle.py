@@ -228,6 +228,14 @@ def uniform_at(seed, site, sweep, index):
     return lib().orc_uniform_at(C.c_uint64(seed), C.c_uint32(site), C.c_uint32(sweep), C.c_uint32(index))
 
 
+def uniform_at64(seed, site, sweep, index, stream=False):
+    """The uniform addressed by a 64-bit index (spec/gg_philox.h: gg_uniform_at64; stream=True: the first uniform of
+    gg_stream_init64's stream)."""
+    f = lib().orc_stream_first64 if stream else lib().orc_uniform_at64
+    f.restype = C.c_double
+    return f(C.c_uint64(seed), C.c_uint32(site), C.c_uint32(sweep), C.c_uint64(index))
+
+
 def normal_at(seed, site, sweep, index):
     return lib().orc_normal_at(C.c_uint64(seed), C.c_uint32(site), C.c_uint32(sweep), C.c_uint32(index))
 

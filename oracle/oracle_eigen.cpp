@@ -57,7 +57,7 @@ void orc_eig_resample_omega_multi(int nG, int N, int D, const uint8_t* As, const
         double o = 0.0;
         if (A[(size_t)i * N + j] != ORC_A_MISSING && beta != 0.0) {
           gg_stream s;
-          gg_stream_init(&s, seed, site, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j);
+          gg_stream_init64(&s, seed, site, sweep, (uint64_t)i * (uint64_t)N + (uint64_t)j);
           o = beta == 1.0 ? gg_pg1(&s, psi) : gg_pg_frac(&s, beta, psi);
         }
         Omega[(size_t)i * N + j] = o;
@@ -162,7 +162,7 @@ void orc_eig_omega_block(int N, int D, const uint8_t* A, const double* F, const 
       double o = 0.0;
       if (A[(size_t)i * N + j] != ORC_A_MISSING && beta != 0.0) {
         gg_stream s;
-        gg_stream_init(&s, seed, (uint32_t)GG_SITE_EIG_OMEGA, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j);
+        gg_stream_init64(&s, seed, (uint32_t)GG_SITE_EIG_OMEGA, sweep, (uint64_t)i * (uint64_t)N + (uint64_t)j);
         o = beta == 1.0 ? gg_pg1(&s, psi) : gg_pg_frac(&s, beta, psi);
       }
       out[(size_t)a * n_idx + b] = o;
@@ -303,7 +303,7 @@ void orc_probit_resample_Z_multi(int nG, int N, int D, const uint8_t* As, const 
       for (int j = 0; j < N; ++j) {
         const uint8_t a = A[(size_t)i * N + j];
         Z[(size_t)i * N + j] = a == ORC_A_MISSING ? 0.0
-            : gg_truncnorm(gg_uniform_at(seed, site, sweep, (uint32_t)i * (uint32_t)N + (uint32_t)j), eig_psi(N, D, F, lmbda, mu_0, i, j), a ? 1 : 0);
+            : gg_truncnorm(gg_uniform_at64(seed, site, sweep, (uint64_t)i * (uint64_t)N + (uint64_t)j), eig_psi(N, D, F, lmbda, mu_0, i, j), a ? 1 : 0);
       }
   }
 }

@@ -692,6 +692,14 @@ double orc_normal_at(uint64_t seed, uint32_t site, uint32_t sweep, uint32_t inde
   gg_stream_init(&s, seed, site, sweep, index);
   return gg_normal(&s);
 }
+// 64-bit index (a pair of nodes beyond 2^32): the uniform, and the first uniform of the stream, addressed that way
+double orc_uniform_at64(uint64_t seed, uint32_t site, uint32_t sweep, uint64_t index) { return gg_uniform_at64(seed, site, sweep, index); }
+double orc_stream_first64(uint64_t seed, uint32_t site, uint32_t sweep, uint64_t index) {
+  gg_stream s;
+  gg_stream_init64(&s, seed, site, sweep, index);
+  return gg_stream_uniform(&s);
+}
+
 double orc_uniform_at(uint64_t seed, uint32_t site, uint32_t sweep, uint32_t index) {
   return gg_uniform_at(seed, site, sweep, index);
 }

@@ -419,3 +419,51 @@ def test_cfg3_sharded_n65536_k64_equals_the_unsharded_chain(abi):
         # (the plain call reduces the pair terms on the device in a fixed tree, the sharded one on the host from the all-reduced tables)
         assert np.allclose(ll, plain[s]["ll"], rtol=1e-12, atol=0.0), (ll, plain[s]["ll"])
     assert adj.stats()["label_changes"] + w.stats()["label_changes"] == changes
+
+
+def test_eigenmodel_beyond_65535_nodes(abi):
+    """the eigenmodels addressed a pair's Philox stream with the 32-bit index i N + j and refused N >= 65536 - so
+    the model family could not run at configs[3]'s N at all.  The index is 64-bit now (spec/gg_philox.h: gg_stream_init64).
+    N = 66 000 (35 GB of auxiliary variables): the draws of a node subset that holds pairs on both sides of 2^32 against the
+    oracle's same streams - among them pairs whose 32-bit indices would collide -, then the rest of the sweep: finite features,
+    a log-likelihood that improves on the start, the same bits when run again."""
+    N, D, seed = 66000, 4, 29
+    rng = np.random.RandomState(3)
+    A = np.empty((N, N), dtype=np.uint8)
+    for i0 in range(0, N, 4000):
+        A[i0:i0 + 4000] = rng.randint(0, 256, size=(min(4000, N - i0), N), dtype=np.uint8) < 20
+    F0 = np.ascontiguousarray(rng.randn(N, D) * 0.5); l0 = np.ascontiguousarray(rng.randn(D)); m0, mm = -2.0, -1.2815515655446004
+    d = abi.DeviceData(A, None)
+
+    def model():
+        m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=seed, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=mm)
+        m.set(abi.ST_F, F0); m.set(abi.ST_LMBDA, l0); m.set(abi.ST_MU0, np.array([m0])); m.set(abi.ST_MU_LMBDA, np.zeros(D))
+        return m
+
+    m = model()
+    ll0 = m.log_likelihood(d)
+    m.resample(d, 1)
+    F1, l1, mu1 = m.get(abi.ST_F, (N, D)), m.get(abi.ST_LMBDA, (D,)), m.get(abi.ST_MU0, (1,))[0]
+    assert np.all(np.isfinite(F1)) and np.all(np.isfinite(l1)) and np.isfinite(mu1) and not np.array_equal(F1, F0)
+    assert m.log_likelihood(d) > ll0
+    m.close()
+    # the auxiliaries alone, on a fresh model (the same Philox sweep index 0): a block of S against the oracle
+    m = model()
+    m.resample_part(d, abi.PART_OMEGA)
+    idx = np.concatenate([np.arange(0, 40), np.arange(65500, 65580), np.arange(N - 40, N)]).astype(np.int32)
+    # (i N + j passes 2^32 from i = 65075 on: the block holds pairs below, across and above it, and pairs such as
+    # (65536 + a, b) whose 32-bit index equals that of a pair in the first rows)
+    assert (int(idx[-1]) * N + int(idx[-1])) > 2 ** 32 > int(idx[39]) * N
+    # gg_get_state(GG_ST_OMEGA_S) hands out all of S (35 GB): read the block through the rows it lies in instead
+    S = m.get(abi.ST_OMEGA_S, (N, N))
+    blk = O.eig_omega_block(A, F0, l0, m0, seed, 0, idx)
+    ref = blk + blk.T
+    ref[np.arange(idx.size), np.arange(idx.size)] = np.diag(blk)
+    got = S[np.ix_(idx, idx)]
+    del S
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-13), np.abs(got - ref).max()
+    assert len(np.unique(got[np.triu_indices(idx.size, 1)])) > 0.99 * idx.size * (idx.size - 1) / 2      # (no two pairs share a stream)
+    m.close()
+    m = model()
+    m.resample(d, 1)
+    assert np.array_equal(m.get(abi.ST_F, (N, D)), F1) and np.array_equal(m.get(abi.ST_LMBDA, (D,)), l1)

@@ -414,3 +414,16 @@ def test_joint_sbm_sweep_is_the_two_halves_with_one_label_vector():
     p_a = np.full((K, K), 0.5)
     O.sbm_adj_sweep(A, c0.copy(), st.m.copy(), p_a, 0.5, np.ones(K), 1.0, 1.0, 0, 31, 0, parts=O.PART_PARAMS)
     assert np.array_equal(p, p_a)
+
+
+def test_64_bit_pair_index_extends_the_32_bit_streams():
+    """spec/gg_philox.h: the eigenmodels address one auxiliary variable per ordered PAIR of nodes, index i N + j, which passes
+    2^32 at N = 65536.  The 64-bit addressing gives every index below 2^32 the stream it always had, and
+    indices that differ only above bit 32 - which the 32-bit form folded onto each other - streams of their own."""
+    for idx in (0, 1, 12345, 2 ** 31 + 7, 2 ** 32 - 1):
+        assert O.uniform_at64(5, 11, 3, idx) == O.uniform_at(5, 11, 3, idx)
+    lo = [O.uniform_at64(5, 11, 3, 77 + (h << 32)) for h in range(6)]
+    st = [O.uniform_at64(5, 11, 3, 77 + (h << 32), stream=True) for h in range(6)]
+    assert len(set(lo)) == 6 and len(set(st)) == 6 and st[0] == lo[0]      # (a stream's first uniform is the plain uniform)
+    u = np.array([O.uniform_at64(9, 17, 0, (1 << 32) + k) for k in range(4000)])
+    assert abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12.0) < 0.01
