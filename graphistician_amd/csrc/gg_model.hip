@@ -338,10 +338,8 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
   if (m->joint) m->cfg.special_case_self_conns = 0;   // stochastic_block_model.py:291-296: the diagonal belongs to pair (c_n, c_n)
   if (m->joint && m->sharded) { delete m; return gg_fail(GG_ERR_UNSUPPORTED, "GG_SBM_JOINT: not for node shards"); }
   m->wide = m->K > 64;
-  if (m->wide && m->joint) {
-    delete m;
-    return gg_fail(GG_ERR_UNSUPPORTED, "C=%d: more than 64 blocks are supported for the SBM adjacency / weight kinds (not for the joint model)", m->K);
-  }
+  // (more than 64 blocks: the joint model runs the same wide forms - its one extra statistic per block, the partner count, is
+  // carried by every evaluation the plain kinds have; round 4)
   if (m->kind == GG_SBM_GAUSS_SHCOV_W && !m->cfg.special_case_self_conns && m->sharded) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "SBMGaussianWeightSharedCov without special_case_self_conns: the node-sharded chain does not carry the diagonal's share of the pair tables");

@@ -76,7 +76,7 @@ typedef struct gg_config {
                                      mismatch (a stale binding would otherwise be read past its end) */
   int32_t kind;                   /* gg_kind */
   int32_t N;                      /* nodes */
-  int32_t K;                      /* blocks C, 1..256 (1 for non-SBM kinds; 65..256: one GPU, no joint model, no gg_node_lp) */
+  int32_t K;                      /* blocks C, 1..256 (1 for non-SBM kinds) */
   int32_t B;                      /* weight dimension (weights kinds), 1..4 */
   int32_t D;                      /* latent dimension (eigenmodel) */
   int32_t allow_self_connections; /* adjacency.py:461 */

@@ -208,7 +208,8 @@ def test_bb_and_niw_config1(abi):
 
 
 # ------------------------------------------------------------------ joint SBM (stochastic_block_model.py:202-309)
-@pytest.mark.parametrize("N,K,B", [(60, 3, 1), (200, 8, 1), (260, 16, 2), (300, 40, 1), (150, 33, 2)])
+@pytest.mark.parametrize("N,K,B", [(60, 3, 1), (200, 8, 1), (260, 16, 2), (300, 40, 1), (150, 33, 2), (400, 70, 1), (520, 100, 2),
+                                   (700, 200, 1)])
 def test_joint_sbm_chain_bitexact(abi, N, K, B):
     """GG_SBM_JOINT: one label vector for adjacency and weights.  Conditionals, labels, p, (mu, Sigma), m bit-exact against
     the oracle's restatement over several sweeps from a random start; step-wise parts; log-likelihood vs the per-pair sum."""
