@@ -490,6 +490,49 @@ def extra_host_classes(abi, device, N=4096, K=16, iters=40):
                     % (A.nbytes / 1e6, W.nbytes / 1e6)}
 
 
+def extra_wide(abi, device, N=4096, K=16, burnin=30, warmup=5, steps=20, repeats=5):
+    """the configs[1] network with REFERENCE-PRECISION weight storage (two 24-bit limbs, sW = 8 bytes per stored
+    weight): the weight model with wide_weights = 1 on gg_data_create_wide data, the adjacency model on the same handle.  The
+    same planted network as the headline (downloaded and uploaded again in the wide form), chain seed 1."""
+    truth = planted_truth(N, K, seed=1234)
+    dd = abi.DeviceData.synthetic_sbm(N, truth["c"], truth["p"], truth["p_self"], truth["mu"], truth["sigma"],
+                                      truth["mu_self"], truth["sigma_self"], seed=1234, device=device)
+    A, W = dd.download()
+    del dd
+    data = abi.DeviceData(A, W, device=device, wide=True)
+    del A, W
+    adj, _w = build_models(abi, N, K, chain_seed=1, device=device)
+    del _w
+    rng = np.random.RandomState(1)
+    rng.dirichlet(np.ones(K)); rng.choice(K, size=N); rng.beta(1.0, 1.0, size=(K, K)); rng.beta(1.0, 1.0)      # (build_models' stream up to the weight model)
+    w = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=4, special_case_self_conns=1, device=device, wide_weights=1)
+    pi_w = np.ones(K) * 10.0
+    m_w = rng.dirichlet(pi_w)
+    w.set(abi.ST_PI, pi_w); w.set(abi.ST_M, m_w); w.set(abi.ST_C, rng.choice(K, p=m_w, size=N).astype(np.int32), np.int32)
+    w.set(abi.ST_MU, rng.randn(K, K, 1)); w.set(abi.ST_SIGMA, np.ones((K, K, 1, 1)))
+    niw = np.array([0.0, 1.0, 3.0, 1.0])
+    w.set(abi.ST_NIW, niw); w.set(abi.ST_NIW_SELF, niw)
+    abi.resample_many([adj, w], data, burnin)
+    abi.resample_many([adj, w], data, warmup)
+    chg0 = adj.stats()["label_changes"] + w.stats()["label_changes"]
+    blocks = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        abi.resample_many([adj, w], data, steps)
+        blocks.append(time.perf_counter() - t0)
+    el = float(np.median(blocks))
+    chg = adj.stats()["label_changes"] + w.stats()["label_changes"] - chg0
+    ms, nb = w.bench_bulk(data, 20)
+    sweep_bytes = 2.0 * N * N * (0.125 + 8.0)
+    return {"workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1, WIDE weight storage (two 24-bit limbs per weight, 48 bits under the one scale)" % (N, K),
+            "value": steps / el, "unit": "sweeps/s", "ms_per_step": el / steps * 1e3, "steps": steps, "timed_blocks": repeats,
+            "label_changes_per_sweep": chg / float(steps * repeats),
+            "sweep_algorithmic_bytes": sweep_bytes, "sweep_effective_GBs": sweep_bytes * steps / el / 1e9,
+            "weight_pass_standalone_GBs": nb / ms / 1e6,
+            "note": "the integer statistics of the two limbs are those of a B = 2 weight (k_bulk_w<2>, the B = 2 scans); the parameter step "
+                    "collapses them to (n, sum w, sum w^2), the coefficient tables spread (g, h, Q) over them (spec/gg_lp.h)"}
+
+
 def bench_eigen(args, abi, device, rank, world, barrier, max_over_ranks):
     """BASELINE.json configs[2]: logistic eigenmodel Gibbs, N=4096, D=8 (eigenmodel.py:836-857)."""
     N, D = args.nodes, args.latent
@@ -1045,7 +1088,7 @@ def main():
             legs = {}
             for name, fn in (("reference_call_pattern_host_classes", extra_host_classes), ("eigen_n4096_d8", extra_eigen),
                              ("ais_sbm_n8192", extra_ais), ("ais_eigen_n8192", extra_ais_eigen), ("ais_latent_n8192", extra_ais_latent),
-                             ("sbm_n65536_k64_one_gpu", extra_big)):
+                             ("sbm_n4096_k16_wide", extra_wide), ("sbm_n65536_k64_one_gpu", extra_big)):
                 _progress("extra config: %s" % name)
                 try:
                     legs[name] = fn(abi, device)

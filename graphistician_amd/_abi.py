@@ -41,7 +41,7 @@ class Config(C.Structure):
                 ("D", C.c_int32), ("allow_self_connections", C.c_int32), ("special_case_self_conns", C.c_int32),
                 ("device", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64), ("tau1", C.c_double), ("tau0", C.c_double), ("sigma_mu0", C.c_double),
                 ("sigma_F", C.c_double), ("sigma_lmbda", C.c_double), ("mu_mu_0", C.c_double),
-                ("lmbda_given", C.c_int32), ("reserved", C.c_int32), ("shard_begin", C.c_int32),
+                ("lmbda_given", C.c_int32), ("wide_weights", C.c_int32), ("shard_begin", C.c_int32),
                 ("shard_end", C.c_int32), ("shard_block", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
                 ("reserved1", C.c_int32)]
 
@@ -59,7 +59,7 @@ EXPORTS = ["gg_device_count", "gg_last_error", "gg_version", "gg_data_create", "
            "gg_get_state", "gg_resample", "gg_resample_part", "gg_resample_part_many", "gg_resample_async", "gg_sync", "gg_sync_many", "gg_resample_many", "gg_log_likelihood", "gg_log_likelihood_many", "gg_node_lp", "gg_predictive_ll", "gg_last_stats", "gg_bench_bulk", "gg_data_create_shard", "gg_data_create_sbm_shard", "gg_comm_unique_id", "gg_comm_create_rccl",
            "gg_comm_create_host", "gg_comm_destroy", "gg_comm_info", "gg_shard_sweep", "gg_shard_log_likelihood",
            "gg_set_timing", "gg_bench_stream", "gg_selftest_math", "gg_selftest_draws", "gg_hash64", "gg_data_create_shard_blocks",
-           "gg_data_create_sbm_shard_blocks", "gg_log_prior_many"]
+           "gg_data_create_sbm_shard_blocks", "gg_log_prior_many", "gg_data_create_wide"]
 
 
 def build(force=False):
@@ -85,6 +85,7 @@ def lib():
         L.gg_version.restype = C.c_char_p
         vp = C.c_void_p
         L.gg_data_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, vp, vp, C.c_int32]
+        L.gg_data_create_wide.argtypes = [C.POINTER(vp), C.c_int32, vp, vp, C.c_int32]
         L.gg_data_destroy.argtypes = [vp]
         L.gg_data_update.argtypes = [vp, vp, vp]
         L.gg_data_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -180,8 +181,11 @@ def _adjacency_u8(A, missing_ok=False):
 class DeviceData(object):
     """Device-resident (A, W): replaces the ndarray pair of networks.py:28,69."""
 
-    def __init__(self, A=None, W=None, device=0, handle=None, N=None, B=None, missing_ok=False):
+    def __init__(self, A=None, W=None, device=0, handle=None, N=None, B=None, missing_ok=False, wide=False):
+        """wide=True (B = 1): reference-precision weights, 48 bits in two limbs instead of 24 (gg_data_create_wide) - for a model
+        created with wide_weights=1."""
         self._h = C.c_void_p()
+        self.wide = bool(wide)
         if handle is not None:
             self._h = handle
         else:
@@ -194,8 +198,15 @@ class DeviceData(object):
                     W = W[:, :, None].copy()
                 assert W.shape[:2] == (N, N)
                 B = W.shape[2]
-                check(lib().gg_data_create(C.byref(self._h), N, B, _ptr(A), _ptr(W), device))
+                if wide:
+                    if B != 1:
+                        raise ValueError("wide weights are built for one-dimensional weights (B = 1)")
+                    check(lib().gg_data_create_wide(C.byref(self._h), N, _ptr(A), _ptr(W), device))
+                else:
+                    check(lib().gg_data_create(C.byref(self._h), N, B, _ptr(A), _ptr(W), device))
             else:
+                if wide:
+                    raise ValueError("wide=True needs weights")
                 B = 1
                 check(lib().gg_data_create(C.byref(self._h), N, 1, _ptr(A), None, device))
         self.N, self.B, self.device = N, B, device

@@ -752,6 +752,9 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
         if (gate_tag) commit = gg_poll_verdict(g.ctl, g.verdict, gate_tag, 0);
         if (commit && g.do_draw) g.p[t] = pv;
       } else {
+        // wide weights (spec/gg_lp.h): the data are the two limbs of a ONE-dimensional weight (template B = 2, g.B = 1) - the
+        // statistics collapse to (n, sum w, sum w^2) for the draw, the parameters are scalars, the table spreads them again
+        const bool wide1 = (B == 2) && g.B == 1;
         double mo[GG_MAXB], so[GG_MAXB * GG_MAXB];
         if (g.do_draw && g.shared) {
           // weights.py:529-535: mean of the pair given the shared covariance; its centred scatter for :545-548
@@ -780,16 +783,20 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
           gg_unpack_wstats(s_tab + 1, B, g.wh.shift, s1, s2);
           gg_stream s;
           gg_stream_init(&s, g.seed, GG_SITE_W_NIW, g.sweep, (uint32_t)t);
+          if (wide1) { double w1, w2; gg_wide_collapse(s1, s2, &w1, &w2); s1[0] = w1; s2[0] = w2; }
+          const int Bd = wide1 ? 1 : B;
           // tempered posterior (build-defined for the weights: Gaussian likelihood to the power beta scales the
           // sufficient statistics, as graph_models.py:366-367 does for the adjacency counts); beta = 1: x * 1.0 == x
-          for (int i = 0; i < B; ++i) s1[i] *= g.beta;
-          for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
-          gg_niw_posterior_draw(&s, &g.wh.niw, B, g.beta * (double)s_tab[0], s1, s2, mo, so);
+          for (int i = 0; i < Bd; ++i) s1[i] *= g.beta;
+          for (int i = 0; i < Bd * Bd; ++i) s2[i] *= g.beta;
+          gg_niw_posterior_draw(&s, &g.wh.niw, Bd, g.beta * (double)s_tab[0], s1, s2, mo, so);
+        } else if (wide1) {
+          mo[0] = g.mu[t]; so[0] = g.sigma[t];
         } else {
           for (int i = 0; i < B; ++i) mo[i] = g.mu[(size_t)t * B + i];
           for (int i = 0; i < B * B; ++i) so[i] = g.sigma[(size_t)t * B * B + i];
         }
-        if (g.do_prep && !(g.shared && g.do_draw) && gg_gauss_table(mo, so, B, e)) {
+        if (g.do_prep && !(g.shared && g.do_draw) && (wide1 ? gg_gauss_table_wide(mo, so, e) : gg_gauss_table(mo, so, B, e))) {
           bad = true;
           for (int i = 0; i < NT; ++i) e[i] = gg_nan();
         }
@@ -812,8 +819,11 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
           if (bad) atomicOr(&g.ctl[3], 1);
           if (JOINT && g.do_draw) g.p[t] = pj;
           if (g.do_draw && !g.shared) {
-            for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
-            for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
+            if (wide1) { g.mu[t] = mo[0]; g.sigma[t] = so[0]; }
+            else {
+              for (int i = 0; i < B; ++i) g.mu[(size_t)t * B + i] = mo[i];
+              for (int i = 0; i < B * B; ++i) g.sigma[(size_t)t * B * B + i] = so[i];
+            }
           }
         }
       }
@@ -850,11 +860,14 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
         gg_unpack_wstats(hl, B, g.wh.shift, s1, s2);
         gg_stream s;
         gg_stream_init(&s, g.seed, GG_SITE_W_NIW_SELF, g.sweep, 0u);
-        for (int i = 0; i < B; ++i) s1[i] *= g.beta;
-        for (int i = 0; i < B * B; ++i) s2[i] *= g.beta;
-        gg_niw_posterior_draw(&s, &g.wh.niw_self, B, g.beta * (double)g.wh.d1, s1, s2, mo, so);
-        for (int i = 0; i < B; ++i) g.mu_self[i] = mo[i];
-        for (int i = 0; i < B * B; ++i) g.sigma_self[i] = so[i];
+        const bool wide1 = (B == 2) && g.B == 1;          // (wide weights: see the pair branch above)
+        if (wide1) { double w1, w2; gg_wide_collapse(s1, s2, &w1, &w2); s1[0] = w1; s2[0] = w2; }
+        const int Bd = wide1 ? 1 : B;
+        for (int i = 0; i < Bd; ++i) s1[i] *= g.beta;
+        for (int i = 0; i < Bd * Bd; ++i) s2[i] *= g.beta;
+        gg_niw_posterior_draw(&s, &g.wh.niw_self, Bd, g.beta * (double)g.wh.d1, s1, s2, mo, so);
+        for (int i = 0; i < Bd; ++i) g.mu_self[i] = mo[i];
+        for (int i = 0; i < Bd * Bd; ++i) g.sigma_self[i] = so[i];
       }
     }
     __shared__ double s_gam[64];
@@ -2033,6 +2046,7 @@ struct gg_ll_args {
   long long d1, d0;
   long long dS[GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2];
   int joint;            // GG_SBM_JOINT: Bernoulli terms of every block pair (diagonal included) on top of the Gaussian ones
+  int wide;             // wide weights: B = 2 statistics (the limbs), scalar parameters (spec/gg_lp.h)
   int diag_zero;        // adjacency.py:525-526 with the special case: the diagonal has probability 0
   double* out;          // out[0] = log-likelihood, out[1] = 1.0 if a covariance was not positive definite
 };
@@ -2045,11 +2059,13 @@ __device__ __forceinline__ double gg_ll_bern(double P, long long n1, long long n
   return v;
 }
 
+// (B: dimension of the STATISTICS; wide weights - the limbs of a one-dimensional weight, spec/gg_lp.h - have B = 2 statistics and
+// scalar parameters: wide != 0)
 __device__ __forceinline__ double gg_ll_gauss(const double* mu, const double* sig, int B, int NSI, double n, const long long* hl,
-                                              double sc1, double sc2, bool* bad) {
+                                              double sc1, double sc2, bool* bad, int wide = 0) {
   if (n == 0) return 0.0;
   double e[GG_MAXNT];
-  if (gg_gauss_table(mu, sig, B, e)) { *bad = true; return 0.0; }
+  if (wide ? gg_gauss_table_wide(mu, sig, e) : gg_gauss_table(mu, sig, B, e)) { *bad = true; return 0.0; }
   double v = n * e[0];
   for (int s = 0; s < NSI; ++s) v += e[1 + s] * (gg_hilo_to_double(hl[2 * s], hl[2 * s + 1]) * (s < B ? sc1 : sc2));
   return v;
@@ -2073,7 +2089,8 @@ __global__ __launch_bounds__(256) void k_loglik(gg_ll_args g) {
       acc += gg_ll_bern(g.p[ab], n1, pairs - n1);
     } else {
       const long long* e = g.tab + (size_t)ab * g.NTAB;
-      acc += gg_ll_gauss(g.mu + (size_t)ab * g.B, g.sigma + (size_t)ab * g.B * g.B, g.B, g.NSI, (double)e[0], e + 1, sc1, sc2, &bad);
+      const int Bx = g.wide ? 1 : g.B;      // (stride of the parameters)
+      acc += gg_ll_gauss(g.mu + (size_t)ab * Bx, g.sigma + (size_t)ab * Bx * Bx, g.B, g.NSI, (double)e[0], e + 1, sc1, sc2, &bad, g.wide);
       if (g.joint) acc += gg_ll_bern(g.p[ab], e[0], (long long)g.cnt[a] * g.cnt[b] - e[0]);
     }
   }
@@ -2093,7 +2110,7 @@ __global__ __launch_bounds__(256) void k_loglik(gg_ll_args g) {
       long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
       for (int s = 0; s < g.NSI; ++s) { hl[2 * s] = g.dS[s] >> 32; hl[2 * s + 1] = g.dS[s] & 0xffffffffll; }
       bool b2 = false;
-      ll += gg_ll_gauss(g.mu_self, g.sigma_self, g.B, g.NSI, (double)g.d1, hl, sc1, sc2, &b2);
+      ll += gg_ll_gauss(g.mu_self, g.sigma_self, g.B, g.NSI, (double)g.d1, hl, sc1, sc2, &b2, g.wide);
       if (b2) s_bad = 1;
     }
     g.out[0] = ll;

@@ -133,6 +133,7 @@ struct gg_data {
   int n0, n1;        // stored columns = nodes [n0, n1) (0, N unless this is a shard; -1, -1 for a block-interleaved shard)
   gg_own own;        // the stored columns, in general: local column nl holds node gg_own_glob(own, nl)
   int has_w;
+  int wide;          // 1: W is one-dimensional, stored as two 24-bit limbs in the B = 2 layout (gg_data_create_wide; spec/gg_lp.h)
   int shift;
   long long n_edges;
   // dynamic range of the stored weights (gg_data_quantisation): the largest |w| on an edge fixes ONE shift for the whole

@@ -246,6 +246,7 @@ static void diag_stats_host(gg_data* d, const uint8_t* dA, const int32_t* dWq) {
 // Host staging of a whole (A, W) into an allocated handle (gg_data_create, gg_data_update).
 static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
   const int N = d->N, B = d->B;
+  const int Bin = d->wide ? 1 : B;      // dimension of W as the caller hands it (wide: one weight, stored as two limbs)
   // host staging: off-diagonal copy, diagonal, quantisation (same arithmetic as the
   // oracle's orc_quantise: shift = qbits - frexp-exponent of max |w| over edges).
   size_t nA = (size_t)N * d->Np;
@@ -269,8 +270,8 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
     double wmax = 0.0;
     for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
       if (!A[ij]) continue;
-      for (int b = 0; b < B; ++b) {
-        double a = fabs(W[ij * B + b]);
+      for (int b = 0; b < Bin; ++b) {
+        double a = fabs(W[ij * Bin + b]);
         if (!(a <= 1.7e308)) return gg_fail(GG_ERR_NUMERIC, "non-finite weight on an edge");
         if (a > wmax) wmax = a;
       }
@@ -285,13 +286,13 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
       // is the data's scale that has to stand clear of the step, not its smallest entries (all of them up to 2^22 values, a strided sample beyond).
       std::vector<float> mags;
       size_t nval = 0;
-      for (size_t ij = 0; ij < (size_t)N * N; ++ij) if (A[ij] == 1 || (A[ij] && A[ij] != GG_A_MISSING)) nval += B;
+      for (size_t ij = 0; ij < (size_t)N * N; ++ij) if (A[ij] == 1 || (A[ij] && A[ij] != GG_A_MISSING)) nval += Bin;
       const size_t stride = nval > ((size_t)1 << 22) ? nval / ((size_t)1 << 22) : 1;
       size_t seen = 0;
       for (size_t ij = 0; ij < (size_t)N * N; ++ij) {
         if (!A[ij] || A[ij] == GG_A_MISSING) continue;
-        for (int b = 0; b < B; ++b, ++seen)
-          if (seen % stride == 0) { const double a = fabs(W[ij * B + b]); if (a > 0.0) mags.push_back((float)a); }
+        for (int b = 0; b < Bin; ++b, ++seen)
+          if (seen % stride == 0) { const double a = fabs(W[ij * Bin + b]); if (a > 0.0) mags.push_back((float)a); }
       }
       d->w_max = wmax; d->w_low = 0.0; d->low_bits = -1;
       if (!mags.empty()) {
@@ -301,6 +302,7 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
         int el;
         frexp(ldexp(d->w_low, d->shift), &el);      // w_low 2^shift in [2^(el-1), 2^el)
         d->low_bits = el - 1 < 0 ? 0 : el - 1;
+        if (d->wide) d->low_bits += GG_WIDE_LIMB;    // (the second limb carries 24 bits more)
       }
     }
     hW.assign(nA * B, 0);
@@ -312,7 +314,15 @@ static int fill_full(gg_data* d, const uint8_t* A, const double* W) {
         size_t ij = (size_t)i * N + j;
         if (!A[ij]) continue;
         int32_t* dst = (i == j) ? &hdW[(size_t)i * B] : &hW[((size_t)i * d->Np + j) * B];
-        for (int b = 0; b < B; ++b) dst[b] = (int32_t)llrint(ldexp(W[ij * B + b], d->shift));
+        if (d->wide) {
+          // two limbs: q0 = rint(w 2^s), q1 = rint((w - q0 2^-s) 2^(s+24)) - the remainder is exact in double, |q1| <= 2^23
+          const double w = W[ij];
+          const long long q0 = llrint(ldexp(w, d->shift));
+          const double rem = w - ldexp((double)q0, -d->shift);
+          dst[0] = (int32_t)q0;
+          dst[1] = (int32_t)llrint(ldexp(rem, d->shift + GG_WIDE_LIMB));
+        } else
+          for (int b = 0; b < B; ++b) dst[b] = (int32_t)llrint(ldexp(W[ij * B + b], d->shift));
       }
     }
     GG_HIP(hipMemcpyAsync(d->Wq, hW.data(), hW.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
@@ -595,6 +605,23 @@ static int create_shard_impl(gg_data** out, int32_t N, int32_t B, const uint8_t*
 // lock-free rendezvous let the loser read a handle the winner had deleted): destroy with references outstanding only marks
 // it, and the release that takes the count to zero frees it.  These are per-call operations, not per sweep.
 
+int gg_data_create_wide(gg_data** out, int32_t N, const uint8_t* A, const double* W, int32_t device) {
+  if (!out || !A || !W || N <= 0) return gg_fail(GG_ERR_INVALID, "gg_data_create_wide: bad arguments (W is required)");
+  int rc = gg_ensure_device(device);
+  if (rc) return rc;
+  gg_data* d = new gg_data();
+  memset(d, 0, sizeof(*d));
+  d->uid = gg_next_data_uid();
+  d->device = device; d->N = N; d->B = 2; d->Np = gg_round_up(N, 64); d->has_w = 1; d->wide = 1;
+  d->n0 = 0; d->n1 = N;
+  d->own = gg_own{0, N, -1, 0, 1};
+  if ((rc = data_open(d))) return rc;
+  rc = fill_full(d, A, W);
+  if (rc) { gg_data_destroy(d); return rc; }
+  *out = d;
+  return GG_OK;
+}
+
 int gg_data_destroy(gg_data* d) {
   if (!d) return GG_OK;
   {
@@ -643,7 +670,7 @@ extern "C" {
 int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64_t* n_edges) {
   if (!d) return gg_fail(GG_ERR_INVALID, "null data");
   if (N) *N = d->N;
-  if (B) *B = d->B;
+  if (B) *B = d->wide ? 1 : d->B;      // (the weights' dimension as the caller knows it)
   if (shift) *shift = d->shift;
   if (n_edges) *n_edges = d->n_edges;
   return GG_OK;
@@ -675,8 +702,11 @@ int gg_data_download(const gg_data* d, uint8_t* A, double* W) {
     for (int i = 0; i < N; ++i)
       for (int j = 0; j < N; ++j) {
         const int32_t* q = (i == j) ? &hdW[(size_t)i * B] : &hW[((size_t)i * Np + j) * B];
-        for (int b = 0; b < B; ++b)
-          W[((size_t)i * N + j) * B + b] = (q[0] == GG_NO_EDGE) ? 0.0 : ldexp((double)q[b], -d->shift);
+        if (d->wide)      // (N, N, 1): the two limbs put together again - exact, 48 bits fit a double
+          W[(size_t)i * N + j] = (q[0] == GG_NO_EDGE) ? 0.0 : ldexp((double)q[0], -d->shift) + ldexp((double)q[1], -d->shift - GG_WIDE_LIMB);
+        else
+          for (int b = 0; b < B; ++b)
+            W[((size_t)i * N + j) * B + b] = (q[0] == GG_NO_EDGE) ? 0.0 : ldexp((double)q[b], -d->shift);
       }
   }
   return GG_OK;

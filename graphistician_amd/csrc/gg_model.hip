@@ -44,6 +44,9 @@ struct gg_model {
   int kind;
   bool is_adj, is_block, sbm;
   bool joint;                           // GG_SBM_JOINT: a weight model that also carries p and the adjacency terms of the conditional
+  bool wide1;                           // wide weights (gg_config.wide_weights): the data are the two 24-bit limbs of a one-dimensional
+                                        // weight - B = 2 through every statistics kernel, Bx = 1 for the parameters (spec/gg_lp.h)
+  int Bx;                               // dimension of the Gaussian PARAMETERS (= B unless wide1)
   int N, K, Kp, B, NT, NSI, Np, NTAB;   // N = all nodes (labels, rows); Np = padded number of OWNED nodes
   int Nl, n0;                           // owned nodes [n0, n0 + Nl) (all of them unless the chain is sharded; n0 = 0 when block-interleaved)
   gg_own own;                           // the owned nodes, in general (gg_common.h)
@@ -303,6 +306,17 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "weight dimension B=%d: the HIP engine supports B in 1..%d", cfg->B, GG_MAXB);
   }
+  m->Bx = m->B;
+  m->wide1 = false;
+  if (cfg->wide_weights) {
+    // reference-precision weights: 48 bits in two limbs (spec/gg_lp.h)
+    if (!(cfg->kind == GG_SBM_GAUSS_W || cfg->kind == GG_NIW_W) || cfg->B != 1 || m->K > 64) {
+      const int kd = cfg->kind, bb = cfg->B, kk = m->K;
+      delete m;
+      return gg_fail(GG_ERR_UNSUPPORTED, "wide_weights: for GG_SBM_GAUSS_W / GG_NIW_W with B = 1 and at most 64 blocks (kind %d, B = %d, C = %d)", kd, bb, kk);
+    }
+    m->wide1 = true; m->B = 2; m->Bx = 1;
+  }
   if (m->joint && m->B > 2) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "GG_SBM_JOINT: weight dimension B=%d (the joint model's scan kernels are built for B <= 2)", cfg->B);
@@ -462,14 +476,15 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     GG_HIP(hipMemcpy(m->p_self, &h, 8, hipMemcpyHostToDevice));
   }
   if (!m->is_adj) {
+    const int Bx = m->Bx;      // (the parameters' dimension: 1 for wide weights, whose buffers are sized for B = 2)
     memset(&m->niw, 0, sizeof(gg_niw));
-    for (int i = 0; i < B; ++i) m->niw.sigma_0[i * B + i] = 1.0;
-    m->niw.nu_0 = B + 2; m->niw.kappa_0 = 1.0;
+    for (int i = 0; i < Bx; ++i) m->niw.sigma_0[i * Bx + i] = 1.0;
+    m->niw.nu_0 = Bx + 2; m->niw.kappa_0 = 1.0;
     m->niw_self = m->niw;
-    std::vector<double> sig(KK * B * B, 0.0), sself((size_t)B * B, 0.0);
+    std::vector<double> sig(KK * Bx * Bx, 0.0), sself((size_t)Bx * Bx, 0.0);
     for (size_t ab = 0; ab < KK; ++ab)
-      for (int i = 0; i < B; ++i) sig[ab * B * B + i * B + i] = 1.0;
-    for (int i = 0; i < B; ++i) sself[i * B + i] = 1.0;
+      for (int i = 0; i < Bx; ++i) sig[ab * Bx * Bx + i * Bx + i] = 1.0;
+    for (int i = 0; i < Bx; ++i) sself[i * Bx + i] = 1.0;
     GG_HIP(hipMemcpy(m->sigma, sig.data(), sig.size() * 8, hipMemcpyHostToDevice));
     GG_HIP(hipMemcpy(m->sigma_self, sself.data(), sself.size() * 8, hipMemcpyHostToDevice));
   }
@@ -503,7 +518,7 @@ int gg_model_destroy(gg_model* m) {
 }
 
 static int state_ptr(gg_model* m, int id, void** p, size_t* nbytes) {
-  const size_t K = m->K, KK = K * K, B = m->B;
+  const size_t K = m->K, KK = K * K, B = m->Bx;
   *p = nullptr;
   switch (id) {
     case GG_ST_C: *p = m->c; *nbytes = (size_t)m->N * 4; break;
@@ -534,7 +549,7 @@ int gg_set_state(gg_model* m, int32_t id, const void* buf, size_t nbytes) {
   if (m->eig) return gg_eigen_set_state(m->eig, id, buf, nbytes);
   if (m->ld) return gg_latent_set_state(m->ld, id, buf, nbytes);
   { int rc0 = model_sync(m); if (rc0) return rc0; }
-  const size_t B = m->B;
+  const size_t B = m->Bx;
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
     m->sweep = *(const uint32_t*)buf;
@@ -595,7 +610,7 @@ int gg_get_state(gg_model* m, int32_t id, void* buf, size_t nbytes) {
   if (m->eig) return gg_eigen_get_state(m->eig, id, buf, nbytes);
   if (m->ld) return gg_latent_get_state(m->ld, id, buf, nbytes);
   { int rc0 = model_sync(m); if (rc0) return rc0; }
-  const size_t B = m->B;
+  const size_t B = m->Bx;
   if (id == GG_ST_SWEEP) {
     if (nbytes != 4) return gg_fail(GG_ERR_INVALID, "GG_ST_SWEEP expects 4 bytes");
     *(uint32_t*)buf = m->sweep;
@@ -642,6 +657,9 @@ static int check_data(const gg_model* m, const gg_data* d) {
   if (!m->is_adj) {
     if (!d->has_w) return gg_fail(GG_ERR_INVALID, "weight model needs data created with W");
     if (d->B != m->B) return gg_fail(GG_ERR_INVALID, "data has B=%d, model has B=%d", d->B, m->B);
+    if ((d->wide != 0) != m->wide1)
+      return gg_fail(GG_ERR_INVALID, m->wide1 ? "the model was created with wide_weights: it needs data created with gg_data_create_wide"
+                                              : "the data hold wide (two-limb) weights: the model must be created with wide_weights");
   }
   return GG_OK;
 }
@@ -830,7 +848,7 @@ static gg_params_args fill_params_args(gg_model* m, const gg_data* d, int buf, b
                                        uint32_t sweep, int pidx) {
   gg_params_args g;
   memset(&g, 0, sizeof(g));
-  g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.Kp = m->Kp; g.B = m->B; g.NSI = m->NSI; g.Np = m->Np; g.N = m->N;
+  g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.Kp = m->Kp; g.B = m->Bx; g.NSI = m->NSI; g.Np = m->Np; g.N = m->N;   // (g.B: the parameters' dimension - the kernels' template argument is the statistics')
   g.n0 = m->n0; g.Nl = m->Nl;
   if (m->sharded) g.n0 = 0;      // (the pair tables walk perm_loc: local indices, -1 for another rank's node)
   g.do_tables = tables; g.do_draw = draw; g.do_prep = prep;
@@ -1132,6 +1150,7 @@ static gg_ll_args fill_ll_args(const gg_model* m, const gg_data* d, double* out)
   for (int i = 0; i < gg_nsi(GG_MAXB); ++i) g.dS[i] = d->dS[i];
   g.diag_zero = (m->is_adj && !m->cfg.allow_self_connections && m->kind == GG_SBM_ADJ) ? 1 : 0;
   g.joint = m->joint ? 1 : 0;
+  g.wide = m->wide1 ? 1 : 0;
   g.out = out;
   return g;
 }
@@ -2229,7 +2248,7 @@ int gg_node_lp(gg_model* m, const gg_data* d, int32_t n, double* lp) {
 
 // Closed forms from the K x K tables (shared by the single-GPU and the sharded path).
 static int loglik_from_tables(gg_model* m, const gg_data* d, const long long* tabp, const int32_t* cntp, double* out) {
-  const int K = m->K, B = m->B;
+  const int K = m->K, B = m->B, Bx = m->Bx;
   const size_t KK = (size_t)K * K;
   const long long* tab = tabp;
   const int32_t* cnt = cntp;
@@ -2270,7 +2289,7 @@ static int loglik_from_tables(gg_model* m, const gg_data* d, const long long* ta
     }
   } else {
     const int NSI = m->NSI;
-    std::vector<double> mu(KK * B), sigma(KK * B * B), mus(B), sigs((size_t)B * B);
+    std::vector<double> mu(KK * Bx), sigma(KK * Bx * Bx), mus(Bx), sigs((size_t)Bx * Bx);
     GG_HIP(hipMemcpy(mu.data(), m->mu, mu.size() * 8, hipMemcpyDeviceToHost));
     GG_HIP(hipMemcpy(sigma.data(), m->sigma, sigma.size() * 8, hipMemcpyDeviceToHost));
     GG_HIP(hipMemcpy(mus.data(), m->mu_self, mus.size() * 8, hipMemcpyDeviceToHost));
@@ -2279,7 +2298,7 @@ static int loglik_from_tables(gg_model* m, const gg_data* d, const long long* ta
     auto ll_of = [&](const double* mu_, const double* sig_, double n, const long long* hl) -> double {
       if (n == 0) return 0.0;
       double e[GG_MAXNT];
-      if (gg_gauss_table(mu_, sig_, B, e)) return NAN;
+      if (m->wide1 ? gg_gauss_table_wide(mu_, sig_, e) : gg_gauss_table(mu_, sig_, B, e)) return NAN;
       double v = n * e[0];
       for (int s = 0; s < NSI; ++s) {
         double x = gg_hilo_to_double(hl[2 * s], hl[2 * s + 1]) * (s < B ? sc1 : sc2);
@@ -2289,7 +2308,7 @@ static int loglik_from_tables(gg_model* m, const gg_data* d, const long long* ta
     };
     for (size_t ab = 0; ab < KK; ++ab) {
       const long long* e = &tab[ab * m->NTAB];
-      ll += ll_of(&mu[ab * B], &sigma[ab * B * B], (double)e[0], e + 1);
+      ll += ll_of(&mu[ab * Bx], &sigma[ab * Bx * Bx], (double)e[0], e + 1);
     }
     if (special) {
       long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
@@ -2460,7 +2479,7 @@ static int lprior_enqueue(gg_model* m) {
   if (!m->h_lp) GG_HIP(hipHostMalloc((void**)&m->h_lp, 2 * sizeof(double), hipHostMallocDefault));
   gg_lprior_args g;
   memset(&g, 0, sizeof(g));
-  g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.B = m->B; g.special = m->cfg.special_case_self_conns; g.shcov = m->kind == GG_SBM_GAUSS_SHCOV_W;
+  g.is_adj = m->is_adj ? 1 : 0; g.K = m->K; g.B = m->Bx; g.special = m->cfg.special_case_self_conns; g.shcov = m->kind == GG_SBM_GAUSS_SHCOV_W;
   g.tau1 = m->cfg.tau1; g.tau0 = m->cfg.tau0;
   g.m = m->m; g.pi = m->pi; g.p = m->p; g.p_self = m->p_self; g.mu = m->mu; g.sigma = m->sigma; g.mu_self = m->mu_self;
   g.sigma_self = m->sigma_self; g.niw = m->niw; g.niw_self = m->niw_self; g.cnt = m->cnt; g.out = m->h_lp;
@@ -2864,7 +2883,7 @@ int gg_predictive_ll(gg_model* m, const uint8_t* a_row, const uint8_t* a_col, co
   if (!m->is_adj && (!w_row || !w_col)) return gg_fail(GG_ERR_INVALID, "gg_predictive_ll: weight kinds need the weight row and column");
   int rc = model_sync(m);
   if (rc) return rc;
-  const int N = m->N, K = m->K, B = m->B;
+  const int N = m->N, K = m->K, B = m->Bx;      // (the weights as the caller hands them: doubles, the parameters' dimension)
   const size_t na = (size_t)N + 1, nw = ((size_t)N + 1) * B;
   const size_t bytes = 2 * na + (m->is_adj ? 0 : 2 * nw * 8) + 16;
   const size_t need = bytes + (size_t)(K + 1) * 8 + 64;

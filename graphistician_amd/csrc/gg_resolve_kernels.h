@@ -628,7 +628,8 @@ __device__ __forceinline__ void gg_epilogue_body(const gg_params_args& g, const 
         term = gg_ll_bern(la.p[t], n1, pairs - n1);
       } else {
         const double sc1 = gg_pow2i(-la.shift), sc2 = gg_pow2i(-2 * la.shift);
-        term = gg_ll_gauss(la.mu + (size_t)t * B, la.sigma + (size_t)t * B * B, B, NSI, (double)s_tab[0], s_tab + 1, sc1, sc2, &bad);
+        const int Bx = la.wide ? 1 : B;      // (wide weights: B = 2 statistics, scalar parameters)
+        term = gg_ll_gauss(la.mu + (size_t)t * Bx, la.sigma + (size_t)t * Bx * Bx, B, NSI, (double)s_tab[0], s_tab + 1, sc1, sc2, &bad, la.wide);
       }
     }
   }
@@ -681,7 +682,7 @@ __device__ __forceinline__ void gg_epilogue_body(const gg_params_args& g, const 
         long long hl[2 * (GG_MAXB + GG_MAXB * (GG_MAXB + 1) / 2)];
         for (int s2 = 0; s2 < la.NSI; ++s2) { hl[2 * s2] = la.dS[s2] >> 32; hl[2 * s2 + 1] = la.dS[s2] & 0xffffffffll; }
         bool b2 = false;
-        ll += gg_ll_gauss(la.mu_self, la.sigma_self, la.B, la.NSI, (double)la.d1, hl, sc1, sc2, &b2);
+        ll += gg_ll_gauss(la.mu_self, la.sigma_self, la.B, la.NSI, (double)la.d1, hl, sc1, sc2, &b2, la.wide);
         if (b2) isbad = 1;
       }
     }

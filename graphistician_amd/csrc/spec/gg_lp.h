@@ -76,6 +76,40 @@ GG_HD int gg_gauss_table(const double* mu, const double* sigma, int B, double* o
   return 0;
 }
 
+// ---- reference-precision weights (opt-in "wide" storage, B = 1): two 24-bit limbs per weight -----------------------------
+// The reference computes on float64 W (abstractions.py:257-274, weights.py:316-331).  The default storage keeps 24 bits
+// absolute under ONE scale (q = rint(w 2^s)); the wide mode keeps 48: w = (q0 + q1 2^-24) 2^-s with |q0|, |q1| <= 2^23, stored
+// as the two components of a B = 2 integer weight.  Every exact integer statistic the engine forms for B = 2 -
+// n, sum q0, sum q1, sum q0^2, sum q0 q1, sum q1^2 - is then exactly what the one-dimensional Gaussian needs:
+//     sum w   = 2^-s  (sum q0 + 2^-24 sum q1),
+//     sum w^2 = 2^-2s (sum q0^2 + 2^-23 sum q0 q1 + 2^-48 sum q1^2),
+// so the bulk passes, the scans and their integer corrections run UNCHANGED on the (q0, q1) data (the B = 2 instantiations),
+// and only two places know about the limbs: the parameter step collapses the pair tables to (n, sum w, sum w^2) before its
+// one-dimensional NIW draw, and the coefficient table of a pair spreads the one-dimensional (g, h, Q) over the five
+// statistics - multiplications by powers of two, exact.
+#define GG_WIDE_LIMB 24
+#define GG_2M24 (1.0 / 16777216.0)                          /* 2^-24, 2^-23, 2^-48: exact */
+#define GG_2M23 (1.0 / 8388608.0)
+#define GG_2M48 ((1.0 / 16777216.0) * (1.0 / 16777216.0))
+// s1[2], s2[2 x 2] (statistics of the limbs, real units of the FIRST limb) -> sum w, sum w^2
+GG_HD void gg_wide_collapse(const double* s1, const double* s2, double* w1, double* w2) {
+  *w1 = gg_fma(s1[1], GG_2M24, s1[0]);
+  *w2 = gg_fma(s2[3], GG_2M48, gg_fma(s2[1], GG_2M23, s2[0]));
+}
+// Coefficient table entry of the one-dimensional Gaussian (mu, sigma) against the limbs' statistics: out[6] = {g, h, h 2^-24,
+// Q, 2 Q 2^-24, Q 2^-48} (the order of gg_gauss_table for B = 2: n, s1_0, s1_1, s2_00, s2_01, s2_11).
+GG_HD int gg_gauss_table_wide(const double* mu, const double* sigma, double* out) {
+  double e[3];
+  if (gg_gauss_table(mu, sigma, 1, e)) return 1;
+  out[0] = e[0];
+  out[1] = e[1];
+  out[2] = e[1] * GG_2M24;
+  out[3] = e[2];
+  out[4] = e[2] * GG_2M23;
+  out[5] = e[2] * GG_2M48;
+  return 0;
+}
+
 // Joint SBM (one label vector for adjacency and weights, stochastic_block_model.py:252-302): per ordered pair of nodes
 // the conditional adds Bernoulli(p).log_probability(A) = A log p + (1 - A) log(1 - p) to A * log N(W) (:280-296).  Summed
 // over a node's potential partners in block j: (g + log p - log(1 - p)) * #edges + h.s1 + Q.s2 + log(1 - p) * #partners,

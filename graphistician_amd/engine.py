@@ -91,9 +91,10 @@ def declare_immutable(*arrays):
         _IMMUTABLE[id(a)] = weakref.ref(a, lambda _r, k=id(a): _IMMUTABLE.pop(k, None))
 
 
-def as_device_data(A, W=None, device=0, immutable=False, missing_ok=False):
+def as_device_data(A, W=None, device=0, immutable=False, missing_ok=False, wide=False):
     """Device-resident network for (A, W); accepts an existing DeviceData.  immutable=True: see `declare_immutable`;
-    missing_ok: NaN entries of A are unobserved (eigenmodels only, eigenmodel.py:121-127)."""
+    missing_ok: NaN entries of A are unobserved (eigenmodels only, eigenmodel.py:121-127); wide: reference-precision weight
+    storage (two limbs, `DeviceData(..., wide=True)`) for a weight model built with wide_weights=True."""
     if isinstance(A, _abi.DeviceData):
         return A
     if isinstance(A, tuple) and W is None:
@@ -102,7 +103,7 @@ def as_device_data(A, W=None, device=0, immutable=False, missing_ok=False):
     Wn = None if W is None else np.asarray(W)
     if immutable:
         declare_immutable(A, Wn)
-    key = (_fingerprint(A), _fingerprint(Wn), device, bool(missing_ok))
+    key = (_fingerprint(A), _fingerprint(Wn), device, bool(missing_ok), bool(wide))
     hit = _DATA_CACHE.get(key)
     if hit is not None:
         _DATA_CACHE.move_to_end(key)
@@ -118,7 +119,8 @@ def as_device_data(A, W=None, device=0, immutable=False, missing_ok=False):
         old, oldW = entry[0], entry[2]
         B = 1 if Wn is None else (1 if Wn.ndim == 2 else Wn.shape[2])
         sole_owner = sys.getrefcount(old) <= 3      # the cache entry, `old`, getrefcount's argument
-        if sole_owner and old.N == A.shape[0] and old.device == device and (oldW is None) == (Wn is None) and old.B == B:
+        if sole_owner and old.N == A.shape[0] and old.device == device and (oldW is None) == (Wn is None) and old.B == B and \
+                bool(getattr(old, "wide", False)) == bool(wide):
             try:
                 old.update(A, Wn, missing_ok=missing_ok)
                 d = old
@@ -127,7 +129,7 @@ def as_device_data(A, W=None, device=0, immutable=False, missing_ok=False):
                 d = None
         del old, entry
     if d is None:
-        d = _abi.DeviceData(A, Wn, device=device, missing_ok=missing_ok)
+        d = _abi.DeviceData(A, Wn, device=device, missing_ok=missing_ok, wide=wide)
     _DATA_CACHE[key] = (d, A, Wn)  # keep the arrays alive so ids are not reused
     while len(_DATA_CACHE) > _DATA_CACHE_SIZE:
         _DATA_CACHE.popitem(last=False)
@@ -201,7 +203,7 @@ class EngineBacked(object):
         if isinstance(data, _abi.DeviceData):
             return data
         if isinstance(data, (tuple, list)):
-            return as_device_data(data[0], data[1], device=self._device, missing_ok=missing_ok)
+            return as_device_data(data[0], data[1], device=self._device, missing_ok=missing_ok, wide=getattr(self, "_wide", False))
         return as_device_data(data, None, device=self._device, missing_ok=missing_ok)
 
     @property

@@ -35,7 +35,7 @@ class FactorizedNetworkDistribution(NetworkDistribution, GibbsSampling):
             return data
         A, W = data
         adj, wts = self._halves
-        return as_device_data(A, W, device=getattr(wts, "_device", getattr(adj, "_device", 0)))
+        return as_device_data(A, W, device=getattr(wts, "_device", getattr(adj, "_device", 0)), wide=getattr(wts, "_wide", False))
 
     def _adjacency_arg(self, d, data):
         # host-only adjacency classes (Fixed / Complete / Empty) take the matrix itself

@@ -212,9 +212,13 @@ class NIWGaussianWeightDistribution(_WeightsBase):
 
     _fields = FixedGaussianWeightDistribution._fields
 
-    def __init__(self, N, B=1, mu_0=None, Sigma_0=None, nu_0=None, kappa_0=None, device=0, seed=None):
+    def __init__(self, N, B=1, mu_0=None, Sigma_0=None, nu_0=None, kappa_0=None, device=0, seed=None, wide_weights=False):
+        """wide_weights=True (B = 1): reference-precision weight storage - 48 bits in two limbs under the one scale instead of
+        24 (the reference computes on float64 W: abstractions.py:257-274) - for data with a wide dynamic range; the (A, W)
+        arrays handed to the model are then uploaded in that form."""
         super(NIWGaussianWeightDistribution, self).__init__(N)
         self.B = B
+        self._wide = bool(wide_weights)
         if mu_0 is None:
             mu_0 = np.zeros(B)
         if Sigma_0 is None:
@@ -223,7 +227,8 @@ class NIWGaussianWeightDistribution(_WeightsBase):
             nu_0 = B + 2
         if kappa_0 is None:
             kappa_0 = 1.0
-        self._init_engine(device=device, seed=seed, kind=_abi.NIW_W, N=N, K=1, B=B, special_case_self_conns=1)
+        self._init_engine(device=device, seed=seed, kind=_abi.NIW_W, N=N, K=1, B=B, special_case_self_conns=1,
+                          wide_weights=1 if wide_weights else 0)
         hyp = _pack_niw(mu_0, Sigma_0, nu_0, kappa_0)
         self._hset("_niw", hyp)
         self._hset("_niw_self", hyp)
@@ -309,9 +314,11 @@ class SBMGaussianWeightDistribution(_WeightsBase):
                "_niw_self": (_abi.ST_NIW_SELF, np.float64, lambda s: (s.B + s.B * s.B + 2,))}
 
     def __init__(self, N, B=1, C=2, pi=10.0, mu_0=None, Sigma_0=None, nu_0=None, kappa_0=None,
-                 special_case_self_conns=True, device=0, seed=None):
+                 special_case_self_conns=True, device=0, seed=None, wide_weights=False):
+        """wide_weights=True (B = 1, C <= 64): reference-precision weight storage, see NIWGaussianWeightDistribution."""
         super(SBMGaussianWeightDistribution, self).__init__(N)
         self.B = B
+        self._wide = bool(wide_weights)
         assert isinstance(C, (int, np.integer)) and C >= 1, "C must be a positive integer number of blocks"
         self.C = int(C)
         if isinstance(pi, (int, float)):
@@ -320,7 +327,7 @@ class SBMGaussianWeightDistribution(_WeightsBase):
             assert isinstance(pi, np.ndarray) and pi.shape == (C,), "pi must be a sclar or a C-vector"
         self.special_case_self_conns = special_case_self_conns
         self._init_engine(device=device, seed=seed, kind=self._kind, N=N, K=self.C, B=B,
-                          special_case_self_conns=1 if special_case_self_conns else 0)
+                          special_case_self_conns=1 if special_case_self_conns else 0, wide_weights=1 if wide_weights else 0)
         self.pi = pi
         self.m = np.random.dirichlet(self.pi)
         self.c = np.random.choice(self.C, p=self.m, size=(self.N))

@@ -87,7 +87,8 @@ typedef struct gg_config {
   double tau1, tau0;              /* Beta prior (adjacency.py:460) */
   double sigma_mu0, sigma_F, sigma_lmbda, mu_mu_0; /* eigenmodel.py:41-56 */
   int32_t lmbda_given;            /* eigenmodel.py:65-67 */
-  int32_t reserved;
+  int32_t wide_weights;           /* 1: reference-precision weights for GG_SBM_GAUSS_W / GG_NIW_W with B = 1 (at most 64 blocks): the
+                                     network must come from gg_data_create_wide - 48 bits per weight in two limbs instead of 24 */
   int32_t shard_begin, shard_end; /* sharded single chain: this rank owns nodes [shard_begin, shard_end); 0,0 = all */
   /* sharded single chain, block-interleaved ownership (shard_block > 0; shard_begin / shard_end are then ignored): the nodes are
    * dealt out in blocks of shard_block consecutive nodes (a power of two >= 8), block b to rank b % shard_world - every band of
@@ -163,6 +164,12 @@ const char* gg_version(void);
 int gg_data_create(gg_data** out, int32_t N, int32_t B, const uint8_t* A, const double* W, int32_t device);
 /* A model that has sweeps enqueued on a network (gg_resample_async) holds a reference to it until it is synchronised:
  * destroying the handle earlier only marks it, the last reference frees it. */
+/* The same with REFERENCE-PRECISION weights (B = 1): W is kept as two 24-bit limbs, w = (q0 + q1 2^-24) 2^-shift - 48 bits
+ * under the one scale instead of 24 - for data whose dynamic range the default storage cannot carry (a few large weights
+ * among many small ones: gg_data_quantisation).  The engine's statistics of the two limbs are exact integers as before, and
+ * they determine sum w and sum w^2 exactly; a model uses such data iff it was created with
+ * gg_config.wide_weights = 1.  Twice the weight bytes per pass. */
+int gg_data_create_wide(gg_data** out, int32_t N, const uint8_t* A, const double* W, int32_t device);
 int gg_data_destroy(gg_data* d);
 /* Replace the network held by an existing handle with another (A, W) of the same N, B (W NULL iff it was created without
  * weights): one staging copy instead of freeing and allocating every device buffer - for callers that draw fresh data
@@ -175,8 +182,8 @@ int gg_data_info(const gg_data* d, int32_t* N, int32_t* B, int32_t* shift, int64
  * reference's float64 (abstractions.py:261) keeps 53 relative.  w_max: that largest |w|; w_low: the median of |w| over
  * the edges' components; low_bits: the significant bits a weight of size w_low keeps, floor(log2(w_low 2^shift)) (-1: not
  * measured - no weights, or data generated on the device).  low_bits < 12: a few outliers have set the scale and the bulk of
- * the data is stored coarsely - the Python binding warns; rescale, clip or transform the weights (a wider storage mode is not
- * built). */
+ * the data is stored coarsely - the Python binding warns; rescale, clip or transform the weights or the wide storage
+ * (gg_data_create_wide). */
 int gg_data_quantisation(const gg_data* d, double* w_max, double* w_low, int32_t* low_bits, int32_t* shift);
 /* Synthetic planted-SBM network generated on the device (bench / large N):
  * mirrors SBMAdjacencyDistribution.rvs (adjacency.py:558-560) and

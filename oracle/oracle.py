@@ -82,6 +82,34 @@ def quantise(A, W):
     return q, shift.value
 
 
+def quantise_wide(A, W):
+    """Wide weight storage (spec/gg_lp.h): W (N, N[, 1]) as two 24-bit limbs, w = (q0 + q1 2^-24) 2^-shift -> (q int32 (N,N,2), shift)."""
+    N = A.shape[0]
+    W = np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(N, N))
+    A8, pA = _u8(A != 0)
+    q = np.empty((N, N, 2), dtype=np.int32)
+    shift = C.c_int(0)
+    rc = lib().orc_quantise_wide(N, pA, _f64(W), _i32(q), C.byref(shift))
+    if rc:
+        raise ValueError("non-finite weight on an edge")
+    return q, shift.value
+
+
+class _wide_mode(object):
+    """with _wide_mode(flag): the Gaussian-weight oracle functions treat q as the two limbs of a one-dimensional weight."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            lib().orc_set_wide(1)
+
+    def __exit__(self, *exc):
+        if self.on:
+            lib().orc_set_wide(0)
+
+
 def dequantise(q, shift):
     return np.ldexp(q.astype(np.float64), -shift)
 
@@ -135,13 +163,15 @@ def const_adj_loglik(A, p, p_self):
 
 # ---------------------------------------------------------------- Gaussian weights
 def sbm_w_sweep(A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, niw, niw_self, special, seed, sweep,
-                parts=PART_ALL, beta=1.0):
+                parts=PART_ALL, beta=1.0, wide=False):
+    """wide: q holds the two limbs of a one-dimensional weight (quantise_wide); mu (K,K,1), sigma (K,K,1,1), one-dimensional priors."""
     N, K, B = A.shape[0], m.shape[0], q.shape[2]
     A8, pA = _u8(A != 0)
-    rc = lib().orc_sbm_w_sweep_beta(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma),
-                                    _f64(mu_self), _f64(sigma_self), _f64(np.ascontiguousarray(pi, dtype=np.float64)),
-                                    _f64(niw), _f64(niw_self), int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts),
-                                    C.c_double(beta))
+    with _wide_mode(wide):
+        rc = lib().orc_sbm_w_sweep_beta(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma),
+                                        _f64(mu_self), _f64(sigma_self), _f64(np.ascontiguousarray(pi, dtype=np.float64)),
+                                        _f64(niw), _f64(niw_self), int(special), C.c_uint64(seed), C.c_uint32(sweep), int(parts),
+                                        C.c_double(beta))
     if rc:
         raise RuntimeError("oracle sbm_w_sweep failed rc=%d" % rc)
 
@@ -159,23 +189,26 @@ def sbm_wsh_sweep(A, q, shift, c, m, mu, sigma, mu_self, sigma_self, pi, prior, 
         raise RuntimeError("oracle sbm_wsh_sweep failed rc=%d" % rc)
 
 
-def sbm_w_node_lp(A, q, shift, c, m, mu, sigma, special, n1, literal=False):
+def sbm_w_node_lp(A, q, shift, c, m, mu, sigma, special, n1, literal=False, wide=False):
     N, K, B = A.shape[0], m.shape[0], q.shape[2]
     A8, pA = _u8(A != 0)
     lp = np.zeros(K)
+    assert not (wide and literal)
     f = lib().orc_sbm_w_node_lp_literal if literal else lib().orc_sbm_w_node_lp
-    rc = f(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma), int(special), int(n1), _f64(lp))
+    with _wide_mode(wide):
+        rc = f(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(m), _f64(mu), _f64(sigma), int(special), int(n1), _f64(lp))
     if rc:
         raise RuntimeError("oracle sbm_w_node_lp failed rc=%d" % rc)
     return lp
 
 
-def sbm_w_loglik(A, q, shift, c, mu, sigma, mu_self, sigma_self, special=True):
+def sbm_w_loglik(A, q, shift, c, mu, sigma, mu_self, sigma_self, special=True, wide=False):
     N, B = A.shape[0], q.shape[2]
     K = mu.shape[0]
     A8, pA = _u8(A != 0)
-    return lib().orc_sbm_w_loglik(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(mu), _f64(sigma), _f64(mu_self),
-                                  _f64(sigma_self), int(special))
+    with _wide_mode(wide):
+        return lib().orc_sbm_w_loglik(N, K, B, pA, _i32(q), int(shift), _i32(c), _f64(mu), _f64(sigma), _f64(mu_self),
+                                      _f64(sigma_self), int(special))
 
 
 # ---------------------------------------------------------------- joint SBM (stochastic_block_model.py:202-309)

@@ -55,6 +55,37 @@ int orc_qbits(int N) {
   return b > 23 ? 23 : b;
 }
 
+// Wide weights (spec/gg_lp.h): a ONE-dimensional weight kept as two 24-bit limbs, w = (q0 + q1 2^-24) 2^-shift,
+// in the layout of a B = 2 integer weight.  orc_set_wide(1): the Gaussian-weight functions below then take q with two
+// components and B = 2 for every statistic, while the parameters (mu, sigma, the NIW priors) are those of one dimension - the
+// statistics collapse to (n, sum w, sum w^2) for the draws, the coefficient table spreads (g, h, Q) over the limbs' statistics.
+static int g_wide = 0;
+void orc_set_wide(int on) { g_wide = on ? 1 : 0; }
+
+int orc_quantise_wide(int N, const uint8_t* A, const double* W, int32_t* q, int* shift_out) {
+  double wmax = 0.0;
+  for (long long ij = 0; ij < (long long)N * N; ++ij) {
+    if (!A[ij]) continue;
+    const double a = fabs(W[ij]);
+    if (!(a <= 1.7e308)) return -1;
+    if (a > wmax) wmax = a;
+  }
+  if (wmax == 0.0) wmax = 1.0;
+  int e;
+  frexp(wmax, &e);
+  const int shift = orc_qbits(N) - e;
+  for (long long ij = 0; ij < (long long)N * N; ++ij) {
+    if (!A[ij]) { q[ij * 2] = ORC_NO_EDGE; q[ij * 2 + 1] = 0; continue; }
+    const double w = W[ij];
+    const long long q0 = llrint(ldexp(w, shift));
+    const double rem = w - ldexp((double)q0, -shift);            // exact
+    q[ij * 2] = (int32_t)q0;
+    q[ij * 2 + 1] = (int32_t)llrint(ldexp(rem, shift + GG_WIDE_LIMB));
+  }
+  *shift_out = shift;
+  return 0;
+}
+
 int orc_quantise(int N, int B, const uint8_t* A, const double* W, int32_t* q, int* shift_out) {
   double wmax = 0.0;
   for (long long ij = 0; ij < (long long)N * N; ++ij) {
@@ -383,26 +414,29 @@ static void sbm_w_resample_mu_sig(int N, int K, int B, const uint8_t* A, const i
       wstat_add(&st[(size_t)c[i] * K + c[j]], qq, B);
     }
   double n, s1[GG_MAXB], s2[GG_MAXB * GG_MAXB];
+  const int Bd = g_wide ? 1 : B;      // dimension of the parameters (wide: the limbs' statistics collapse to one weight's)
   for (int c1 = 0; c1 < K; ++c1)
     for (int c2 = 0; c2 < K; ++c2) {
       wstat_to_double(&st[(size_t)c1 * K + c2], B, shift, &n, s1, s2);
+      if (g_wide) { double w1, w2; gg_wide_collapse(s1, s2, &w1, &w2); s1[0] = w1; s2[0] = w2; }
       // tempered posterior (build-defined, mirrors graph_models.py:366-367): statistics weighted by beta
       n *= beta;
-      for (int r = 0; r < B; ++r) s1[r] *= beta;
-      for (int r = 0; r < B * B; ++r) s2[r] *= beta;
+      for (int r = 0; r < Bd; ++r) s1[r] *= beta;
+      for (int r = 0; r < Bd * Bd; ++r) s2[r] *= beta;
       gg_stream s;
       gg_stream_init(&s, seed, GG_SITE_W_NIW, sweep, (uint32_t)(c1 * K + c2));
-      gg_niw_posterior_draw(&s, h, B, n, s1, s2, mu + (size_t)(c1 * K + c2) * B,
-                            sigma + (size_t)(c1 * K + c2) * B * B);
+      gg_niw_posterior_draw(&s, h, Bd, n, s1, s2, mu + (size_t)(c1 * K + c2) * Bd,
+                            sigma + (size_t)(c1 * K + c2) * Bd * Bd);
     }
   if (special) {
     wstat_to_double(&sd, B, shift, &n, s1, s2);
+    if (g_wide) { double w1, w2; gg_wide_collapse(s1, s2, &w1, &w2); s1[0] = w1; s2[0] = w2; }
     n *= beta;
-    for (int r = 0; r < B; ++r) s1[r] *= beta;
-    for (int r = 0; r < B * B; ++r) s2[r] *= beta;
+    for (int r = 0; r < Bd; ++r) s1[r] *= beta;
+    for (int r = 0; r < Bd * Bd; ++r) s2[r] *= beta;
     gg_stream s;
     gg_stream_init(&s, seed, GG_SITE_W_NIW_SELF, sweep, 0u);
-    gg_niw_posterior_draw(&s, hs, B, n, s1, s2, mu_self, sigma_self);
+    gg_niw_posterior_draw(&s, hs, Bd, n, s1, s2, mu_self, sigma_self);
   }
 }
 
@@ -421,7 +455,8 @@ static int sbm_w_tables(int K, int B, const double* m, const double* mu, const d
   int NT = gg_nt_gauss(B);
   for (int k = 0; k < K; ++k) logm[k] = gg_log(m[k]);
   for (int ab = 0; ab < K * K; ++ab)
-    if (gg_gauss_table(mu + (size_t)ab * B, sigma + (size_t)ab * B * B, B, T + (size_t)ab * NT)) return 1;
+    if (g_wide ? gg_gauss_table_wide(mu + ab, sigma + ab, T + (size_t)ab * NT)
+               : gg_gauss_table(mu + (size_t)ab * B, sigma + (size_t)ab * B * B, B, T + (size_t)ab * NT)) return 1;
   return 0;
 }
 
@@ -476,10 +511,10 @@ int orc_sbm_w_sweep_beta(int N, int K, int B, const uint8_t* A, const int32_t* q
                          double* m, double* mu, double* sigma, double* mu_self, double* sigma_self,
                          const double* pi, const double* niw, const double* niw_self, int special,
                          uint64_t seed, uint32_t sweep, int parts, double beta) {
-  if (B > GG_MAXB) return -1;
+  if (B > GG_MAXB || (g_wide && B != 2)) return -1;
   gg_niw h, hs;
-  unpack_niw(niw, B, &h);
-  unpack_niw(niw_self, B, &hs);
+  unpack_niw(niw, g_wide ? 1 : B, &h);
+  unpack_niw(niw_self, g_wide ? 1 : B, &hs);
   if (parts & ORC_PART_PARAMS)
     sbm_w_resample_mu_sig(N, K, B, A, q, shift, c, mu, sigma, mu_self, sigma_self, &h, &hs, special, seed, sweep, beta);
   if (parts & ORC_PART_C) {
@@ -568,6 +603,13 @@ double orc_sbm_w_loglik(int N, int K, int B, const uint8_t* A, const int32_t* q,
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
       if (!A[(size_t)i * N + j]) continue;
+      if (g_wide) {      // the weight itself, put together from its limbs (exact in double), under the one-dimensional Gaussian
+        const int32_t* qq = q + ((size_t)i * N + j) * 2;
+        x[0] = ldexp((double)qq[0], -shift) + ldexp((double)qq[1], -shift - GG_WIDE_LIMB);
+        if (i == j && special) ll += mvn_logpdf(x, mu_self, sigma_self, 1);
+        else ll += mvn_logpdf(x, mu + (size_t)(c[i] * K + c[j]), sigma + (size_t)(c[i] * K + c[j]), 1);
+        continue;
+      }
       for (int b = 0; b < B; ++b) x[b] = ldexp((double)q[((size_t)i * N + j) * B + b], -shift);
       if (i == j && special) ll += mvn_logpdf(x, mu_self, sigma_self, B);
       else ll += mvn_logpdf(x, mu + (size_t)(c[i] * K + c[j]) * B, sigma + (size_t)(c[i] * K + c[j]) * B * B, B);

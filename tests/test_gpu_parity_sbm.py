@@ -414,3 +414,97 @@ def test_more_than_64_blocks_quiet_form_is_the_same_chain(abi, N, K, B, special)
     # (which forms a chain went through depends on when it went quiet: at least one of the two must have used the new one)
     assert sta["sweeps_two_launch"] + stw["sweeps_two_launch"] > 0, (sta, stw)
     assert sta["sweeps_serial"] + stw["sweeps_serial"] > 0
+
+
+# ------------------------------------------------------------------ wide weights: two 24-bit limbs
+def heavy_tailed_network(N, K, seed, outlier=1e3):
+    rng = np.random.RandomState(seed)
+    c = rng.choice(K, size=N).astype(np.int32)
+    A = (rng.rand(N, N) < 0.6).astype(np.uint8)
+    mu = rng.randn(K, K) * 0.05
+    W = (mu[np.ix_(c, c)] + 0.01 * rng.randn(N, N))[:, :, None]
+    i, j = np.argwhere(A)[7]
+    W[i, j, 0] = outlier
+    return A, np.ascontiguousarray(W), c
+
+
+@pytest.mark.parametrize("N,K,special", [(70, 3, 1), (200, 8, 0), (300, 16, 1), (260, 40, 1), (150, 64, 0)])
+def test_wide_weights_chain_bitexact(abi, N, K, special):
+    """GG_SBM_GAUSS_W with wide_weights = 1 on data from gg_data_create_wide - reference-precision storage, 48 bits in two limbs
+    (the reference computes on float64 W: abstractions.py:257-274, weights.py:316-331): labels, means, covariances and m bit for
+    bit against the oracle fed the same two-limb data, over sweeps that change labels; the conditionals (gg_node_lp) to the bit;
+    the log-likelihood against the oracle's per-edge sum on the recombined weights at 1e-9 and against scipy on the FLOAT64
+    weights at 1e-10 - on a heavy-tailed network (weights ~ 0.01, one of 1e3) whose default storage keeps 6 bits and warns."""
+    import warnings
+    from oracle import literal as R
+    A, W, _ = heavy_tailed_network(N, K, 11 * N)
+    q2, sh = O.quantise_wide(A, W)
+    st = WState(N, K, 1, seed=K + 5)
+    st.sigma[:] = 1e-3
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                 # (the wide upload keeps 30 bits of a typical weight: no warning)
+        d = abi.DeviceData(A, W, wide=True)
+    assert d.info()["B"] == 1 and d.info()["shift"] == sh and d.quantisation()[2] >= 24
+    Aback, Wback = d.download()
+    assert np.array_equal(Aback, A) and np.all(np.abs(Wback - W)[A != 0] <= 2.0 ** (-sh - 25) * (1 + 1e-12))
+    with pytest.warns(RuntimeWarning):
+        abi.DeviceData(A, W)                           # the default storage reports its coarse scale
+    m = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=4321, special_case_self_conns=special, wide_weights=1)
+    for sid, v, dt in ((abi.ST_C, st.c, np.int32), (abi.ST_M, st.m, np.float64), (abi.ST_PI, st.pi, np.float64), (abi.ST_MU, st.mu, np.float64),
+                       (abi.ST_SIGMA, st.sigma, np.float64), (abi.ST_MU_SELF, st.mu_self, np.float64), (abi.ST_SIGMA_SELF, st.sigma_self, np.float64),
+                       (abi.ST_NIW, st.niw, np.float64), (abi.ST_NIW_SELF, st.niw_self, np.float64)):
+        m.set(sid, v, dt)
+    for n1 in (0, N // 2, N - 1):
+        assert np.array_equal(m.node_lp(d, n1, K), O.sbm_w_node_lp(A, q2, sh, st.c, st.m, st.mu, st.sigma, special, n1, wide=True)), n1
+    nsweeps = 5
+    m.resample(d, 2)
+    m.resample(d, nsweeps - 2)
+    for s in range(nsweeps):
+        O.sbm_w_sweep(A, q2, sh, st.c, st.m, st.mu, st.sigma, st.mu_self, st.sigma_self, st.pi, st.niw, st.niw_self, special, 4321, s, wide=True)
+    assert np.array_equal(m.get(abi.ST_C, (N,), np.int32), st.c)
+    assert np.array_equal(m.get(abi.ST_MU, (K, K, 1)), st.mu) and np.array_equal(m.get(abi.ST_SIGMA, (K, K, 1, 1)), st.sigma)
+    assert np.array_equal(m.get(abi.ST_M, (K,)), st.m)
+    if special:
+        assert np.array_equal(m.get(abi.ST_MU_SELF, (1,)), st.mu_self) and np.array_equal(m.get(abi.ST_SIGMA_SELF, (1, 1)), st.sigma_self)
+    assert m.stats()["label_changes"] > 0
+    ll = m.log_likelihood(d)
+    ll_o = O.sbm_w_loglik(A, q2, sh, st.c, st.mu, st.sigma, st.mu_self, st.sigma_self, special, wide=True)
+    assert abs(ll - ll_o) <= 1e-9 * abs(ll_o)
+    Mu, Sig = st.mu[np.ix_(st.c, st.c)], st.sigma[np.ix_(st.c, st.c)]
+    if special:
+        Mu[np.arange(N), np.arange(N)] = st.mu_self
+        Sig[np.arange(N), np.arange(N)] = st.sigma_self
+    ref = R.w_loglik(A, W, Mu, Sig)                    # scipy, per edge, on the float64 weights themselves
+    assert abs(ll - ref) <= 1e-10 * abs(ref), (ll, ref)
+    # mismatched pairs are refused, and the shapes the wide mode is not built for
+    with pytest.raises(abi.EngineError):
+        m.resample(abi.DeviceData(A, W[:, :, :1] * 0 + 0.5), 1)
+    plain = abi.Model(kind=abi.SBM_GAUSS_W, N=N, K=K, B=1, seed=1)
+    with pytest.raises(abi.EngineError):
+        plain.resample(d, 1)
+    for bad in (dict(kind=abi.SBM_GAUSS_W, B=2, K=K), dict(kind=abi.SBM_GAUSS_W, B=1, K=70), dict(kind=abi.SBM_JOINT, B=1, K=K)):
+        with pytest.raises(abi.EngineError):
+            abi.Model(N=N, seed=1, wide_weights=1, **bad)
+
+
+def test_wide_weights_through_the_host_classes(abi):
+    """FactorizedNetworkDistribution with SBMGaussianWeightDistribution(wide_weights=True): the (A, W) arrays are uploaded in the
+    wide form, the adjacency half shares the handle, resample / log_probability / log_prior run, the NIW kind too."""
+    from graphistician_amd.networks import FactorizedNetworkDistribution
+    from graphistician_amd.adjacency import SBMAdjacencyDistribution
+    from graphistician_amd.weights import SBMGaussianWeightDistribution, NIWGaussianWeightDistribution
+    N, K = 120, 4
+    A, W, _ = heavy_tailed_network(N, K, 9)
+    A.setflags(write=False); W.setflags(write=False)
+    np.random.seed(2)
+    for wcls, kw in ((SBMGaussianWeightDistribution, dict(B=1, C=K, seed=5, wide_weights=True)),
+                     (NIWGaussianWeightDistribution, dict(B=1, seed=6, wide_weights=True))):
+        model = FactorizedNetworkDistribution(N, SBMAdjacencyDistribution, dict(C=K, seed=4), wcls, kw)
+        lps = []
+        for _ in range(6):
+            model.resample((A, W))
+            lps.append(model.log_probability((A, W)))
+        assert np.all(np.isfinite(lps)) and lps[-1] > lps[0] - 1e-6 * abs(lps[0])
+        assert model._device_data((A, W)).wide
+        host = model.weights.log_prior() if not hasattr(model.weights, "_log_prior_host") else model.weights._log_prior_host()
+        assert abs(model.weights.log_prior() - host) <= 1e-10 * abs(host)
