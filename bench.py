@@ -216,14 +216,14 @@ def pmc_traffic(N, K, forms):
     try:
         fused = forms.get("sweeps_fused", 0)
         if (N, K) == (4096, 16) and fused > forms.get("sweeps_serial", 0) + forms.get("sweeps_two_launch", 0):
-            e = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_n4096.json")))["k_sweep_q<3"]
-            return {"traffic": e["traffic_bytes"], "traffic_source": "from_profile: profiles/r03_pmc_traffic_n4096.json (round 3, commit 4e3fc9f: tools/scripts/pmc_traffic_r03.sh)",
+            e = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_n4096.json")))["k_sweep_q<3"]
+            return {"traffic": e["traffic_bytes"], "traffic_source": "from_profile: profiles/r04_pmc_traffic_n4096.json (round 4: tools/scripts/pmc_traffic_r04.sh, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes)",
                     "note": "k_sweep_q<3,false,0,0> at N=4096: %.1f MB read (FETCH_SIZE x 2) + %.1f MB written per launch against %.1f MB "
-                            "algorithmic (ratio %.3f); the 138 MB working set stays in the 256 MiB Infinity Cache, whose hits the "
-                            "memory-side counters include" % (e["hbm_read_bytes_corrected"] / 1e6, e["hbm_write_bytes"] / 1e6,
+                            "algorithmic (ratio %.3f); the 138 MB working set stays in the 256 MiB Infinity Cache, so these memory-side "
+                            "counters move with what else is resident (0.82 in round 3's passes)" % (e["hbm_read_bytes_corrected"] / 1e6, e["hbm_write_bytes"] / 1e6,
                                                               e["algorithmic_bytes_per_launch"] / 1e6, e["traffic_over_algorithmic"])}
         return {"traffic": None, "traffic_source": None,
-                "note": "no PMC profile of this launch shape on file (N=%d, K=%d, forms %s); profiles/r03_pmc_traffic_n32768.json holds "
+                "note": "no PMC profile of this launch shape on file (N=%d, K=%d, forms %s); profiles/r04_pmc_traffic_n32768.json holds "
                         "k_bulk_w<1,4,true> at N=32768: 8.74 GB per launch against 8.59 GB algorithmic" % (N, K, forms)}
     except Exception as exc:
         return {"traffic": None, "traffic_source": None, "note": "no PMC summary on file (%s)" % exc}

@@ -34,10 +34,11 @@ def _content_hash(a):
     the first time it takes more than a millisecond a warning names the ways around it."""
     import time
     buf = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+    _abi.lib()                                   # (loaded outside the timed call)
     t0 = time.perf_counter()
     h = _abi.hash64(buf)
     dt = time.perf_counter() - t0
-    if dt > _HASH_WARN_S and not _hash_warned[0]:
+    if dt > _HASH_WARN_S and buf.nbytes >= (8 << 20) and not _hash_warned[0]:
         _hash_warned[0] = True
         import warnings
         warnings.warn("graphistician_amd: hashing a %.0f MB data array took %.1f ms, and a writeable array is hashed on every "
