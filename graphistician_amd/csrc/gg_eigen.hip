@@ -49,6 +49,7 @@ struct gg_eigen {
   uint8_t *nob;
   int gen;                // the auxiliary variables in S were drawn in the general form
   unsigned long long omega_uid;   // the network they were drawn for (one graph), 0: a list
+  std::vector<unsigned long long> omega_uids;   // ... every network of the list, in order (parts drawn later must name the same list)
   double *part, *gpart, *llpart;
   int* status;
   long long* dbgbuf;   // GG_EIG_DBG: cycle counters of the chain's solver wave
@@ -1087,6 +1088,7 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
     if (!ds[g]) return gg_fail(GG_ERR_INVALID, "null data handle");
     if (ds[g]->N != e->N) return gg_fail(GG_ERR_INVALID, "data has N=%d, model has N=%d", ds[g]->N, e->N);
     if (ds[g]->n0 != 0 || ds[g]->n1 != e->N) return gg_fail(GG_ERR_INVALID, "eigenmodel: whole networks only, not column shards");
+    if (ds[g]->device != e->cfg.device) return gg_fail(GG_ERR_INVALID, "data on device %d, model on device %d", ds[g]->device, e->cfg.device);
     if (ds[g]->n_missing) general = true;
   }
   const gg_data* d = ds[0];
@@ -1143,6 +1145,7 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
     e->have_omega = true;
     e->gen = 0;
     e->omega_uid = d->uid;
+    e->omega_uids.assign(1, d->uid);
   }
   if ((parts & GG_PART_OMEGA) && !ovl) {
     const int nt = (N + 31) / 32;
@@ -1171,11 +1174,18 @@ int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int pa
     e->have_omega = true;
     e->gen = general ? 1 : 0;
     e->omega_uid = nd == 1 ? d->uid : 0;
+    e->omega_uids.resize(nd);
+    for (int g = 0; g < nd; ++g) e->omega_uids[g] = ds[g]->uid;
   }
   if ((parts & (GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) && !e->have_omega)
     return gg_fail(GG_ERR_INVALID, "eigenmodel: resample F / mu_0 / lambda needs the auxiliary variables (GG_PART_OMEGA) first");
-  if ((parts & (GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) && !(parts & GG_PART_OMEGA) && (general ? 1 : 0) != e->gen)
-    return gg_fail(GG_ERR_INVALID, "eigenmodel: the auxiliary variables were drawn for a different list of networks");
+  if ((parts & (GG_PART_F | GG_PART_MU0 | GG_PART_LMBDA)) && !(parts & GG_PART_OMEGA)) {
+    //  the kappa terms of F / mu_0 / lambda come from THESE networks, the auxiliaries from the ones GG_PART_OMEGA was
+    // called with: they must be the same list, network for network
+    bool same = (general ? 1 : 0) == e->gen && (int)e->omega_uids.size() == nd;
+    for (int g = 0; same && g < nd; ++g) same = e->omega_uids[g] == ds[g]->uid;
+    if (!same) return gg_fail(GG_ERR_INVALID, "eigenmodel: the auxiliary variables were drawn for a different list of networks");
+  }
   eig_obs ob;
   ob.A = d->A; ob.AT = d->AT; ob.a2 = e->a2; ob.nob = e->nob; ob.gen = e->gen;
   const int8_t* da2 = e->gen ? e->da2 : nullptr;

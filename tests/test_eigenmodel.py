@@ -650,3 +650,28 @@ def test_reference_form_of_the_feature_draw_has_the_law_of_the_perturbation_draw
     pv = [stats.ks_2samp(a[:, k], b[:, k]).pvalue for k in range(a.shape[1])]
     assert min(pv) > 1e-3, pv
 
+
+
+@pytest.mark.gpu
+def test_parts_on_another_network_than_the_auxiliaries_are_refused():
+    """_resample_F(A2) after _resample_Omega(A1) would mix A1's auxiliary variables with A2's kappa terms - the
+    engine remembers which networks GG_PART_OMEGA was called with and refuses the later parts on any other list."""
+    from graphistician_amd import _abi as abi
+    N, D = 60, 3
+    A, F, lmbda, mu_0 = make_case(N, D, 2)
+    A2 = A.copy(); A2[3, 4] ^= 1
+    d1, d2 = abi.DeviceData(A, None), abi.DeviceData(A2, None)
+    m = abi.Model(kind=abi.LOGISTIC_EIG, N=N, D=D, K=1, B=1, seed=5, sigma_mu0=1.0, sigma_F=1.0, sigma_lmbda=1.0, mu_mu_0=-0.3)
+    m.set(abi.ST_F, F); m.set(abi.ST_LMBDA, lmbda); m.set(abi.ST_MU0, np.array([mu_0])); m.set(abi.ST_MU_LMBDA, np.zeros(D))
+    m.resample_part(d1, abi.PART_OMEGA)
+    m.resample_part(d1, abi.PART_F)                                  # the same network: fine
+    for part in (abi.PART_F, abi.PART_MU0, abi.PART_LMBDA):
+        with pytest.raises(abi.EngineError) as e:
+            m.resample_part(d2, part)
+        assert "different list of networks" in str(e.value)
+    with pytest.raises(abi.EngineError):
+        m.resample_part_many([d1, d2], abi.PART_MU0)                 # another length of the list
+    m.resample_part_many([d1, d2], abi.PART_OMEGA)
+    m.resample_part_many([d1, d2], abi.PART_MU0)
+    with pytest.raises(abi.EngineError):
+        m.resample_part_many([d2, d1], abi.PART_LMBDA)               # the same networks in another order
