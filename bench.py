@@ -258,11 +258,15 @@ def run_chain(abi, data, N, K, chain_seed, device, burnin, warmup, steps, every,
     st0a, st0w = adj.stats(), w.stats()
     chg0 = st0a["label_changes"] + st0w["label_changes"]
     rnd0 = st0a["resolve_rounds"] + st0w["resolve_rounds"]
-    adj.set_timing(every)
-    w.set_timing(every)
     blocks = []
     bulk = dict(adj_ms=0.0, adj_n=0, adj_bytes=0.0, w_ms=0.0, w_n=0, w_bytes=0.0)
-    for _ in range(repeats):
+    for b in range(repeats):
+        # HIP events around the sampled launches (each record drains the engine's queue: the instrumentation costs the quiet
+        # chains a few microseconds per sweep) in every third block only - the roofline is still measured live, inside timed
+        # blocks of this very run, and the median block is one the instrumentation did not touch
+        on = every if (repeats < 3 or b % 3 == 0) else 0
+        adj.set_timing(on)
+        w.set_timing(on)
         barrier()
         t0 = time.perf_counter()
         block()
@@ -971,6 +975,7 @@ def main():
                             "timed blocks of exactly `steps` sweeps (barrier + synchronisation on both sides, max over ranks per block) "
                             "of which the MEDIAN is the chain's time: value = chains x steps / sum of the medians",
                 "timed_blocks_per_chain": R, "timed_sweeps_run": nsw * R, "total_timed_seconds": total_timed,
+                "event_sampled_blocks": "every third block of a chain (blocks 0, 3, 6): HIP events around %d launches each" % per_chain,
                 "value_min_max_over_blocks": [world * nsw / total_max, world * nsw / total_min],
                 "burn_in_sweeps": args.burnin,
                 "label_changes_in_timed_region": int(chg), "label_changes_per_sweep": chg / float(nsw),
