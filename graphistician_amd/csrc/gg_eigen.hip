@@ -956,10 +956,10 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
     // workgroup asks for ~130 KB of LDS and would otherwise wait until the draws' four-workgroups-per-CU stream happens to
     // drain one (a stream of small workgroups backfills every hole: DESIGN.md section 5).  GG_EIG_OVERLAP=0: the serial form.
     e->overlap = 0;
-    // Measured on MI355X (round 4, profiles/r04_eigen_overlap_timeline.txt): exact, and SLOWER - 5.8 against 5.0 ms per sweep at
-    // N=4096, D=8 - so it is off unless GG_EIG_OVERLAP=1: the draws' workgroups live ~200 us each, the scan's launches carry a
-    // thousand rider workgroups that need slots within their 43 us, and neither a CU mask nor the eight chunk boundaries (each
-    // with its own tail) leave the riders room.
+    // Measured on MI355X (round 4, profiles/r04_eigen_overlap_timeline.txt): exact, and NO FASTER - 4.95 ms per sweep at N=4096,
+    // D=8 with 8 compute units per XCD kept free, 5.1-5.2 with 4, 5.4 with 2, against 5.0 ms serial - so it is off unless
+    // GG_EIG_OVERLAP=1: while the draws run, a scan launch takes ~100 us instead of 42 (its latency chain is clock-bound and the
+    // chip is busy), and the draws, chunked and on fewer compute units, take 3.4 instead of 2.0 ms.
     const char* eo = getenv("GG_EIG_OVERLAP");
     if (eo && atoi(eo) == 1) {
       hipDeviceProp_t prop;
@@ -967,9 +967,13 @@ int gg_eigen_create(gg_eigen** out, const gg_config* cfg) {
         const int ncu = prop.multiProcessorCount;
         const int nw = (ncu + 31) / 32;
         std::vector<uint32_t> mask(nw, 0xffffffffu);
-        const char* er = getenv("GG_EIG_RESERVE");          // every r-th compute unit stays free of the draws (default 32)
-        const int every = er && atoi(er) > 1 ? atoi(er) : 32;
-        for (int cu = 0; cu < ncu; cu += every) mask[cu / 32] &= ~(1u << (cu % 32));
+        // Bit i of the mask is compute unit i / 8 of XCD i % 8 (tools/probe/cu_mask.hip, measured: bits 0..7 = one CU in each
+        // of the 8 XCDs; an XCD whose bits are ALL clear is not masked at all).  GG_EIG_RESERVE = r: the first r compute units
+        // of every XCD stay free of the draws (default 4: 32 of 256).
+        const char* er = getenv("GG_EIG_RESERVE");
+        int r = er && atoi(er) > 0 ? atoi(er) : 4;
+        if (r > 24) r = 24;
+        for (int b = 0; b < 8 * r && b < ncu; ++b) mask[b / 32] &= ~(1u << (b % 32));
         if (ncu % 32) mask[nw - 1] &= (1u << (ncu % 32)) - 1u;
         if (hipExtStreamCreateWithCUMask(&e->stream2, (uint32_t)nw, mask.data()) == hipSuccess) e->overlap = 1;
         else (void)hipGetLastError();
