@@ -311,10 +311,33 @@ def extra_eigen(abi, device, N=4096, D=8, warmup=5, steps=20):
     m.get(abi.ST_MU0, (1,))
     el = time.perf_counter() - t0
     sweep_bytes = float(N) * N * (3 * 8 + 2 * 2)
-    return {"workload": "Logistic eigenmodel Gibbs (Polya-gamma), N=%d, D=%d (BASELINE.json configs[2])" % (N, D),
-            "value": steps / el, "unit": "sweeps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-            "sweep_algorithmic_bytes": sweep_bytes, "effective_GBs": sweep_bytes * steps / el / 1e9,
-            "bound": "latency of the sequential latent-feature scan (N dependent D x D solves) + PG(1,z) draws, not HBM (DESIGN.md 7)"}
+    out = {"workload": "Logistic eigenmodel Gibbs (Polya-gamma), N=%d, D=%d (BASELINE.json configs[2])" % (N, D),
+           "value": steps / el, "unit": "sweeps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+           "sweep_algorithmic_bytes": sweep_bytes, "effective_GBs": sweep_bytes * steps / el / 1e9,
+           "bound": "latency of the sequential latent-feature scan (N dependent D x D solves) + PG(1,z) draws, not HBM (DESIGN.md 7)"}
+    out.update(eigen_phases(abi, m, data, N))
+    return out
+
+
+def eigen_phases(abi, m, data, N, reps=5):
+    """the eigenmodel's sweep against the bound it is ON - a latency chain, not HBM.  The sweep's parts timed one
+    at a time (gg_resample_part, host clock, a synchronisation each): the auxiliary draws use the whole chip; the feature scan is
+    ONE workgroup's chain of dependent steps, node after node - its time over N nodes, in shader clocks per node, is the
+    number to read (1 155 clocks per scanned node inside the kernel + the tiles' prologues and launch boundaries)."""
+    t = {"omega": 0.0, "F": 0.0, "mu0_lambda": 0.0}
+    for _ in range(reps):
+        for key, parts in (("omega", abi.PART_OMEGA), ("F", abi.PART_F), ("mu0_lambda", abi.PART_MU0 | abi.PART_LMBDA)):
+            t0 = time.perf_counter()
+            m.resample_part(data, parts)
+            t[key] += time.perf_counter() - t0
+    ms = {k: v / reps * 1e3 for k, v in t.items()}
+    clock_ghz = 2.4          # MI355X_MICROARCH.md: peak engine clock (tools/probe/clock_rate.hip: clock64 ticks at 2.4 GHz)
+    return {"phases_ms": ms,
+            "latency_bound": {"what": "the feature scan: one workgroup, N dependent steps (perturbation draw + Sherman-Morrison fold per node)",
+                              "f_scan_us_per_node": ms["F"] * 1e3 / N, "f_scan_clocks_per_node_at_2p4GHz": ms["F"] * 1e-3 * clock_ghz * 1e9 / N,
+                              "share_of_sweep": ms["F"] / max(sum(ms.values()), 1e-9),
+                              "note": "in-kernel step 1 155 clocks per scanned node (GG_EIG_DBG); the rest of the per-node figure is the 64 tile "
+                                      "prologues and launch boundaries; the auxiliary draws (phases_ms.omega) are divergence-bound on the whole chip"}}
 
 
 def extra_big(abi, device, N=65536, K=64, burnin=12, warmup=2, steps=20):
