@@ -1155,6 +1155,36 @@ __device__ __forceinline__ int gg_group_categorical_wide(double lp, int k, int K
   return idx > K - 1 ? K - 1 : idx;
 }
 
+// The self connection's chain of node n under label k (gg_block_lp's last term; models that do not special-case the diagonal):
+// depends on the node's diagonal entry and the coefficients of pair (k, k) only - the same in every round of a scan.
+template <int NT, bool ADJ>
+__device__ __forceinline__ double gg_node_self_acc(const gg_node_ctx& x, int n, int k) {
+  constexpr int B = gg_tB(NT);
+  const int K = x.K;
+  const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  double self[NT];
+  if (ADJ) {
+    double a = x.dA[n] ? 1.0 : 0.0;
+    self[0] = a; self[1] = 1.0 - a;
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) self[t] = 0.0;
+    if (x.dA[n]) {
+      const int32_t* q = x.dWq + (size_t)n * B;
+      self[0] = 1.0;
+      int t = 1;
+      for (int r = 0; r < B; ++r) self[t++] = (double)q[r] * sc1;
+      for (int r = 0; r < B; ++r)
+        for (int s = r; s < B; ++s) self[t++] = (double)((long long)q[r] * (long long)q[s]) * sc2;
+    }
+    if (gg_tJ(NT)) self[NT - 1] = 1.0;   // the node is its own one potential partner (stochastic_block_model.py:291-296)
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc = gg_fma(x.T[((size_t)k * K + k) * NT + t], self[t], acc);
+  return acc;
+}
+
 // Combination of the finished chains of node n, label k (the tail of gg_lp.h::gg_block_lp).
 template <int NT, bool ADJ>
 __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n, int k, const double* acc_o,
@@ -1166,31 +1196,7 @@ __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n,
   for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_o[t], lp);
 #pragma unroll
   for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_i[t], lp);
-  if (!x.special) {
-    constexpr int B = gg_tB(NT);
-    const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
-    double self[NT];
-    if (ADJ) {
-      double a = x.dA[n] ? 1.0 : 0.0;
-      self[0] = a; self[1] = 1.0 - a;
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) self[t] = 0.0;
-      if (x.dA[n]) {
-        const int32_t* q = x.dWq + (size_t)n * B;
-        self[0] = 1.0;
-        int t = 1;
-        for (int r = 0; r < B; ++r) self[t++] = (double)q[r] * sc1;
-        for (int r = 0; r < B; ++r)
-          for (int s = r; s < B; ++s) self[t++] = (double)((long long)q[r] * (long long)q[s]) * sc2;
-      }
-      if (gg_tJ(NT)) self[NT - 1] = 1.0;   // the node is its own one potential partner (stochastic_block_model.py:291-296)
-    }
-    double acc = 0.0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc = gg_fma(x.T[((size_t)k * K + k) * NT + t], self[t], acc);
-    lp = gg_fma(x.beta, acc, lp);
-  }
+  if (!x.special) lp = gg_fma(x.beta, gg_node_self_acc<NT, ADJ>(x, n, k), lp);
   return lp;
 }
 
@@ -1410,6 +1416,136 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
   return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, &logm_k);
 }
 
+// The same conditional on the matrix cores (33 <= K <= 64, a workgroup of 4 waves, PER = 8 or 16 nodes at once).
+// Chain c = (direction, statistic) of gg_block_lp is a matrix product: Acc_c[node][k] = sum_j stat_c[node][j] * T_c[j][k], and
+// v_mfma_f64_16x16x4_f64 IS a chain of four fused multiply-adds in ascending order of its inner index, bit for bit
+// (tools/probe/mfma_f64_exact.hip: 4.7 M outputs at inner lengths 4, 16, 64, all identical to fma chains, none of the other
+// candidate orders), so instruction after instruction over j = 0, 4, 8, ... produces the spec's chain - same order, same bits.
+// Wave w owns the 16 blocks k = 16 w .. 16 w + 15 for all nodes and all 2 NT chains: per step of four j a lane supplies one
+// statistic (node l % 16, block j = 4 s + l / 16: one LDS read per chain from the split layout [dir][j][t][PER]) and one
+// coefficient (block j, label k: Tout / Tin as they lie in global memory, 128-byte segments) and the matrix pipe does the 16 x 16
+// x 4 products - against gg_lp_split4, where every fma needed its coefficient loaded per lane AND a broadcast LDS read of the
+// statistic, a coefficient now serves 16 nodes and a statistic 16 labels.  The coefficients of the next batch of steps are in
+// flight while the current batch multiplies.  Results: lane l, element r = (node 4 r + l / 16, label 16 w + l % 16); each lane
+// finishes its (node, label) entries (gg_node_lp_finish) and leaves lp in s_lp[node][64], where the caller's waves pick a node
+// each for the categorical draw.  Padding (j >= K in the last step, nodes >= PER) multiplies zeros: fma(0, 0, acc) = acc.
+typedef double gg_d4 __attribute__((ext_vector_type(4)));
+#ifndef GG_MFMA_UB
+#define GG_MFMA_UB 2
+#endif
+// The coefficients of steps s0 .. s0 + UB - 1 as this lane supplies them (gg_lp_mfma_b0: the first batch, which the caller may
+// fetch ahead of the evaluation - the tables do not change during a scan).
+template <int NT>
+__device__ __forceinline__ void gg_lp_mfma_b(const gg_node_ctx& x, int s0, double (&bn)[GG_MFMA_UB][2 * NT]) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, K = x.K;
+  const int jr = l >> 4, kk = 16 * w + (l & 15);
+#pragma unroll
+  for (int u = 0; u < GG_MFMA_UB; ++u) {
+    const int j = 4 * (s0 + u) + jr;
+    const bool in = j < K;
+    const size_t at = ((size_t)(in ? j : K - 1) * NT) * 64 + kk;
+#pragma unroll
+    for (int c = 0; c < 2 * NT; ++c) {
+      const double v = (c < NT ? x.Tout : x.Tin)[at + (size_t)(c % NT) * 64];
+      bn[u][c] = in ? v : 0.0;
+    }
+  }
+}
+// selfacc[r]: gg_node_self_acc of (node 4 r + l / 16, label kk) - constant over a band's rounds, so the caller computes it once
+// per band instead of behind every round's chains (unused when the model special-cases the diagonal).
+template <int NT, bool ADJ, int PER>
+__device__ __forceinline__ void gg_lp_mfma(const gg_node_ctx& x, const double* s_st, double* s_lp, double logm_kk,
+                                           const double (&b0)[GG_MFMA_UB][2 * NT], const double (&selfacc)[4]) {
+  static_assert(PER == 8 || PER == 16, "one 16-row tile of nodes");
+  constexpr int NCH = 2 * NT;
+  constexpr int UB = GG_MFMA_UB;              // steps (of four j) per batch
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, K = x.K;
+  const int jr = l >> 4, c16 = l & 15;
+  const int kk = 16 * w + c16;                // the label this lane's results belong to
+  const bool node_in = c16 < PER;
+  const int S = (K + 3) >> 2;
+  gg_d4 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = gg_d4{0.0, 0.0, 0.0, 0.0};
+  double bn[UB][NCH];
+#pragma unroll
+  for (int u = 0; u < UB; ++u)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) bn[u][c] = b0[u][c];
+  auto load_b = [&](int s0) { gg_lp_mfma_b<NT>(x, s0, bn); };
+  for (int s0 = 0; s0 < S; s0 += UB) {
+    double bc[UB][NCH], av[UB][NCH];
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) bc[u][c] = bn[u][c];
+    if (s0 + UB < S) load_b(s0 + UB);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int j = 4 * (s0 + u) + jr;
+      const bool in = node_in && j < K;
+      const double* sp = s_st + ((size_t)(in ? j : 0) * NT) * PER + (node_in ? c16 : 0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const double v = sp[((size_t)(c / NT) * K * NT + (c % NT)) * PER];
+        av[u][c] = in ? v : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][c], bc[u][c], acc[c], 0, 0, 0);
+  }
+  // the tail of gg_block_lp (gg_node_lp_finish, with the self chain handed in)
+  const bool special = x.special != 0;
+  const double beta = x.beta;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + jr;
+    double lp = logm_kk;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) lp = gg_fma(beta, acc[t][r], lp);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) lp = gg_fma(beta, acc[NT + t][r], lp);
+    if (!special) lp = gg_fma(beta, selfacc[r], lp);
+    if (kk >= K) lp = -gg_inf();
+    if (i < PER) s_lp[i * 64 + kk] = lp;
+  }
+}
+
+// gg_group_categorical for P nodes held by one wave (Kp = 64: lane k holds lp[p][k]), the P draws' reductions and scans
+// interleaved - each is a chain of a dozen dependent cross-lane steps, and P chains in flight cost little more than one.
+template <int P>
+__device__ __forceinline__ void gg_group_categorical64(const double (&lp)[P], int k, int K, const double (&u)[P], int (&lab)[P]) {
+  double mx[P], xs[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) mx[p] = lp[p];
+  for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const double o = __shfl_xor(mx[p], s, 64);
+      mx[p] = o > mx[p] ? o : mx[p];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) xs[p] = (k < K) ? gg_exp(lp[p] - mx[p]) : 0.0;
+  for (int s = 1; s < 64; s <<= 1) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const double o = __shfl_up(xs[p], s, 64);
+      if (k >= s) xs[p] = xs[p] + o;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const double tot = __shfl(xs[p], K - 1, 64);
+    const double thr = u[p] * tot;
+    const bool flag = (k < K) && (thr > xs[p]);
+    const int idx = __popcll(__ballot(flag));
+    lab[p] = idx > K - 1 ? K - 1 : idx;
+  }
+}
+
 // Integer statistics -> spec-order doubles.
 template <int NT, bool ADJ>
 __device__ __forceinline__ void gg_stats_to_double(int cnt_o, int cnt_i, const long long* so_i, const long long* si_i,
@@ -1592,7 +1728,14 @@ __device__ __forceinline__ void gg_spec_eval_split8(const gg_node_ctx& x, int n_
 #endif
 #define GG_WIDE_P(NT) ((NT) <= 3 ? GG_WIDE_P3 : ((NT) <= 6 ? 2 : 1))
 #define GG_SCAN_WIDE_P(NT) ((NT) <= 3 ? 2 : 1)   // the resident scan's (k_scan, MODE 2): both models' grids share a CU's LDS
-#define GG_SCAN_SPLIT_P(NT) ((NT) <= 3 ? 2 : 1)  // ... and for 33..64 blocks (MODE 1): two passes of four nodes per group
+// ... and for 33..64 blocks (MODE 1): 4 P nodes per group, evaluated together by gg_lp_mfma - 8 for the adjacency model, 16 for
+// one-dimensional weights (whose evaluation is the longer one; the two grids' LDS still fit one CU together: gg_model.hip)
+#ifndef GG_SCAN_SPLIT_P3
+#define GG_SCAN_SPLIT_P3 4
+#endif
+#define GG_SCAN_SPLIT_P(NT) ((NT) == 3 ? GG_SCAN_SPLIT_P3 : ((NT) < 3 ? 2 : 1))
+// LDS where the evaluation's partial results meet (k_scan, MODE 1): lp[4 P][64] of gg_lp_mfma, or the split chains of gg_lp_split4
+#define GG_SCAN_MEET_BYTES(NT) ((size_t)(GG_SCAN_SPLIT_P(NT) > 1 ? 4 * GG_SCAN_SPLIT_P(NT) * 64 : 4 * 2 * (NT) * 64) * sizeof(double))
 template <int NT, bool ADJ, int P>
 __device__ __forceinline__ void gg_spec_eval_wide(const gg_node_ctx& x, uint64_t seed, uint32_t site, uint32_t sweep, int* labs,
                                                   int* nodes, bool* lives) {

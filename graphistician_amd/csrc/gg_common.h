@@ -157,6 +157,11 @@ struct gg_data {
   // created network (a new allocation at a recycled address is never mistaken for the old one).
   int refs, dead;
   unsigned long long uid;
+  // Pair scheduling (gg_model.hip, launch_scan): the weight model on this network records an event behind each of its resident
+  // scans; the adjacency model's scan waits for the latest one - it then assembles on the empty chip just before the weight
+  // model's next pass instead of meeting the weight model's scan.  A scheduling hint only: no result depends on it.
+  mutable hipEvent_t ev_wscan = nullptr, ev_wpass = nullptr;
+  mutable int ev_wscan_set = 0, ev_wpass_set = 0;
 };
 
 int gg_ensure_device(int device);

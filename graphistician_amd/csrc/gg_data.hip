@@ -662,6 +662,8 @@ static void data_free(gg_data* d) {
   if (d->WqT) hipFree(d->WqT);
   if (d->dWq) hipFree(d->dWq);
   if (d->stream) hipStreamDestroy(d->stream);
+  if (d->ev_wscan) hipEventDestroy(d->ev_wscan);
+  if (d->ev_wpass) hipEventDestroy(d->ev_wpass);
   delete d;
 }
 

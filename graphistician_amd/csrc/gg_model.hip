@@ -249,7 +249,7 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
   // that stays below 72 KB (2: K up to 32 at B = 1); else from global memory (0).  (At K = 64 the one copy fits the 150 KB
   // but gains 10 % of a round's evaluation and leaves no room for anything else on the CU: not taken.)  Kp = 64 without layout 1 evaluates with
   // gg_lp_split4, which needs its meeting place.
-  const size_t split_acc = m->Kp == 64 ? (size_t)4 * 2 * m->NT * 64 * sizeof(double) : 0;
+  const size_t split_acc = m->Kp == 64 ? GG_SCAN_MEET_BYTES(m->NT) : 0;
   const size_t one_copy = (size_t)K * ((K * m->NT) | 1) * sizeof(double);
   int stage = 0;
   if (lds + table_bytes(m) <= 64 * 1024) { stage = 1; lds += table_bytes(m); }
@@ -358,7 +358,18 @@ int gg_model_create(gg_model** out, const gg_config* cfg) {
     delete m;
     return gg_fail(GG_ERR_UNSUPPORTED, "SBMGaussianWeightSharedCov without special_case_self_conns: the node-sharded chain does not carry the diagonal's share of the pair tables");
   }
-  GG_HIP(hipStreamCreate(&m->stream));
+  {
+    // GG_ADJ_PRIO=1: the adjacency model (the short half of a network's sweep) on a queue of higher priority.  Measured at
+    // N=65536, K=64 and N=4096, K=16: no difference either way (a queue's priority does not let a large workgroup into a compute
+    // unit that small ones keep backfilling; what does is the order of the launches - pair scheduling, launch_scan) - off.
+    int lo = 0, hi = 0;
+    const char* e = getenv("GG_ADJ_PRIO");
+    const bool want = m->is_adj && e && atoi(e) != 0;
+    if (want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+      GG_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamDefault, hi));
+    else
+      GG_HIP(hipStreamCreate(&m->stream));
+  }
   const int N = m->N, K = m->K, B = m->B, NT = m->NT;
   const size_t KK = (size_t)K * K;
   if ((rc = dmalloc(&m->c, N)) || (rc = dmalloc(&m->cand, N)) || (rc = dmalloc(&m->cnt, K)) ||
@@ -750,6 +761,34 @@ static bulk_shape bulk_shape_of(const gg_model* m, int ndirs) {
 }
 
 // BULK statistics under the current labels into buffer `buf`.  dirs: bit 0 = out (reads X^T), bit 1 = in (reads X).
+static int pair_sched_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GG_PAIR_SCHED"); on = e ? atoi(e) : 1; }
+  return on;
+}
+// the adjacency model's pass behind the weight model's pass as well (GG_PAIR_PASS, default 1): it then streams while the weight
+// model's scan - latency-bound, the memory system idle - runs, instead of sharing the pass's bandwidth
+static int pair_pass_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GG_PAIR_PASS"); on = e ? atoi(e) : 1; }
+  return on;
+}
+static int pair_min_n() {
+  static int n = -1;
+  if (n < 0) { const char* e = getenv("GG_PAIR_MIN_N"); n = e ? atoi(e) : 16384; }
+  return n;
+}
+// how long the weight model's stream idles behind its scan, in ticks of the 100 MHz wall clock (GG_PAIR_DELAY_US, default 12)
+static long long pair_delay_ticks() {
+  static long long t = -1;
+  if (t < 0) { const char* e = getenv("GG_PAIR_DELAY_US"); t = (long long)((e ? atof(e) : 12.0) * 100.0); }
+  return t;
+}
+__global__ void k_delay(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool pipelined, uint32_t sweep = 0) {
   const int N = m->N, K = m->K, Np = m->Np;
   int rc;
@@ -766,6 +805,8 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   const bulk_shape bs = bulk_shape_of(m, ndirs);
   dim3 grd(bs.strips, bs.nslots, ndirs);
   const int RW = bs.RW;
+  const bool pair = pair_sched_on() && pair_pass_on() && m->N >= pair_min_n() && m->use_scan && !m->sharded && pipelined;   // (pipelined: a sweep's pass)
+  if (pair && m->is_adj && d->ev_wpass_set) GG_HIP(hipStreamWaitEvent(st, d->ev_wpass, 0));
   if (m->is_adj) {
     if (bs.ntl)
       k_bulk_adj<true><<<grd, 256, 0, st>>>(d->AbT, d->Ab, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
@@ -1416,6 +1457,11 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   // (with riders every workgroup of the launch is given the scan's LDS: a shorter list - flushed more often in a burn-in
   // sweep, never in a steady one - lets a third workgroup onto the CU)
   if (ride_buf >= 0 && riders_here && a.Lcap > 256) a.Lcap = 256;
+  // 33..64 blocks: the weight model's group holds 16 nodes (gg_lp_mfma) - 116 KB of statistics and hypotheses; with a list of 256
+  // entries its workgroup (116 KB at K = 64, B = 1) and the adjacency model's (38 KB) still fit one CU's 160 KB TOGETHER, which
+  // is what keeps two resident grids launched at the same moment from starving each other (each CU can take one of each,
+  // whatever the order the dispatcher places them in)
+  if (m->Kp == 64 && a.Lcap > 256) a.Lcap = 256;
   { const char* el = getenv("GG_SCAN_LCAP"); if (el && atoi(el) >= 2 && atoi(el) < a.Lcap) a.Lcap = atoi(el); }   // (tests: flush the list often)
   const int per = scan_nodes_per_wg(m);
   const int ngroups = (m->Nl + per - 1) / per;
@@ -1437,6 +1483,15 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     timed = riders_here && m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
     if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, m->stream)); }
   }
+  // Pair scheduling at sizes where the weight model's pass fills the chip for milliseconds (N >= GG_PAIR_MIN_N, default 16384;
+  // GG_PAIR_SCHED=0 turns it off).  A resident grid cannot assemble while a pass keeps backfilling the compute units, so the
+  // adjacency model's scan used to wait out the weight model's pass and then share the chip with the weight model's scan -
+  // each grid's rounds then wait for workgroups that share a CU with the other's (N=65536, K=64: the weight model's scan 2.6 ms
+  // instead of 0.8).  Now the adjacency model's scan waits for the weight model's latest scan instead, and the weight model's
+  // stream idles for a few microseconds behind its scan (k_delay): the adjacency model's grid assembles on the empty chip, the
+  // pass then fills the room around it, and the weight model's next scan has the chip to itself.
+  const bool pair = pair_sched_on() && m->N >= pair_min_n() && !resume && ride_buf < 0 && !m->sharded;
+  if (pair && m->is_adj && d->ev_wscan_set) GG_HIP(hipStreamWaitEvent(m->stream, d->ev_wscan, 0));
 #define SCN1(NTV, ADJV, SPV)                                                                                       \
   do {                                                                                                            \
     static bool attr_set = false;                                                                                 \
@@ -1478,6 +1533,13 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   if (ride_buf >= 0) {
     if (timed) { m->ev_bytes.push_back(ride_bytes); m->ev_sweep.push_back(sweep); GG_HIP(hipEventRecord(e1, m->stream)); }
     m->zeroed[ride_buf] = false;
+  }
+  if (pair && !m->is_adj) {
+    if (!d->ev_wscan) GG_HIP(hipEventCreateWithFlags(&d->ev_wscan, hipEventDisableTiming));
+    GG_HIP(hipEventRecord(d->ev_wscan, m->stream));
+    d->ev_wscan_set = 1;
+    k_delay<<<1, 64, 0, m->stream>>>(pair_delay_ticks());
+    GG_HIP(hipGetLastError());
   }
   return GG_OK;
 }
@@ -1627,6 +1689,13 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep, b
     if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, nxt))) return rc;
     if ((rc = enqueue_params(m, d, buf, true, true, true, c3, sweep, P, nxt, 2))) return rc;
   } else if ((rc = enqueue_params(m, d, buf, true, true, scan, nxt, sweep, P))) return rc;
+  if (scan && m->use_scan && !m->is_adj && !m->sharded && pair_sched_on() && pair_pass_on() && m->N >= pair_min_n()) {
+    // (pair scheduling: the adjacency model's next pass waits for this point - it streams under the weight model's scan,
+    // which leaves the memory system idle, not under its pass or its parameter step, which read at the memory system's rate)
+    if (!d->ev_wpass) GG_HIP(hipEventCreateWithFlags(&d->ev_wpass, hipEventDisableTiming));
+    GG_HIP(hipEventRecord(d->ev_wpass, m->stream));
+    d->ev_wpass_set = 1;
+  }
   if (scan) {
     if (pride) {
       static int rec_on = -1;

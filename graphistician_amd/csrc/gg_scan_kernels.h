@@ -181,8 +181,9 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   // nodes per group: one pass of 256 / Kp nodes; more than 64 blocks with NT <= 3: TWO passes' worth (GG_SCAN_WIDE_P) - a lane
   // keeps the chains of two nodes and a coefficient-table entry fetched from L2 serves both (the quiet scan's
   // gg_spec_eval_wide takes four; here both models' grids must fit a CU's LDS together).  Half the bands, half the rounds.
-  // 33..64 blocks (MODE 1), NT <= 3: two passes of four nodes (gg_lp_split4 per pass; the evaluation doubles, the exchanges
-  // and the band starts do not: N=65536, K=64: 128 rounds of 9.5 + 7.2 us became 64 of 19 + 7.2).
+  // 33..64 blocks (MODE 1), NT <= 3: 8 nodes per group (adjacency) or 16 (one-dimensional weights), evaluated together on the
+  // matrix cores (gg_lp_mfma, round 4; before: two passes of gg_lp_split4 over four nodes each - N=65536, K=64: 67 rounds of
+  // 15.9 us of evaluation).
   constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : (MODE == 1 ? GG_SCAN_SPLIT_P(NT) : 1);
   const int per = (256 / Kp) * PW;
   const int tid = threadIdx.x, b = blockIdx.x, G = a.G;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   else if (stage_tables == 2) off += (size_t)K * RS * sizeof(double);
   double* s_acc = reinterpret_cast<double*>(s_raw + off);     // gg_lp_split4: where the chains of the four waves meet
   constexpr bool split = MODE == 1;   // (the host: stage_tables != 1 && Kp == 64)
-  if (split) off += (size_t)4 * 2 * NT * 64 * sizeof(double);
+  if (split) off += GG_SCAN_MEET_BYTES(NT);                   // (4 PW nodes at once: gg_lp_mfma leaves lp[node][64] here)
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
   int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);
@@ -257,6 +258,8 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     if (tid < per && grp * per + tid < N) a.ap[grp * per + tid] = 0;
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
   const double logm_k = x.logm[(tid % Kp) < K ? tid % Kp : 0];   // (the same in every round: not behind each round's chains)
+  const int kk_mf = 16 * (tid >> 6) + (tid & 15);                // (the label of this lane's results in gg_lp_mfma)
+  const double logm_mf = x.logm[kk_mf < K ? kk_mf : 0];
 
   int pos = a.resume ? g.rs[0] : 0, nL = 0, nchg = 0;   // (resume: uniform, written by an earlier launch)
   const long long t_init0 = g.dbg ? wall_clock64() : 0;
@@ -383,6 +386,15 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
       u_bandp[p] = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + ((has && nb < N) ? nb : N - 1)));
     }
     const double u_band = u_bandp[0];
+    // gg_lp_mfma's lane layout: the self chains of this lane's (node, label) entries, once per band
+    double self_mf[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MODE == 1 && PW > 1 && !x.special) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nb = n0 + 4 * r + ((tid >> 4) & 3);
+        self_mf[r] = gg_node_self_acc<NT, ADJ>(x, (has && 4 * r + ((tid >> 4) & 3) < per && nb < N) ? nb : N - 1, kk_mf < K ? kk_mf : 0);
+      }
+    }
     // ---- iterate until the band holds no further surprise
     // Spec-order doubles of the statistics: all of them when the band starts and after a round with several surprises;
     // after a single one (f: ca -> cb) only the entries of blocks ca and cb can differ - edges to / from f moved between
@@ -407,6 +419,9 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     const int wv = tid >> 6, ln = tid & 63;
     for (;;) {
       const long long c0 = g.dbg ? wall_clock64() : 0;
+      // (the evaluation's first batch of coefficients is on its way while the statistics are converted)
+      double b0_mf[GG_MFMA_UB][2 * NT];
+      if (MODE == 1 && PW > 1) gg_lp_mfma_b<NT>(x, 0, b0_mf);
       __syncthreads();
       if (tid == 0) *s_min = GG_NO_CHANGE;
       if (has) {
@@ -491,18 +506,23 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           }
         }
       } else if (MODE == 1 && PW > 1) {
-        // two passes of four nodes: wave w evaluates node 4 p + w in pass p (the split chains of a pass meet in s_acc)
+        // the group's 4 PW nodes at once on the matrix cores (gg_lp_mfma: the chains of gg_block_lp as f64 MFMA steps, bit for
+        // bit); wave w then draws for node 4 p + w, p = 0 .. PW - 1
         const int w4 = tid >> 6, k = tid & 63;
+        gg_lp_mfma<NT, ADJ, (PW > 1 ? 4 * PW : 8)>(x, s_st, s_acc, logm_mf, b0_mf, self_mf);   // (PW == 1: this branch is not taken)
+        __syncthreads();
+        if (g.dbg) cb = wall_clock64();
+        double lpp[PW];
+        int labp[PW];
+#pragma unroll
+        for (int p = 0; p < PW; ++p) lpp[p] = s_acc[(4 * p + w4) * 64 + k];
+        gg_group_categorical64<PW>(lpp, k, K, u_bandp, labp);
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
-          if (p) __syncthreads();      // (the previous pass's meeting place has been read)
           const int i = 4 * p + w4;
           const int n = n0 + i;
           const bool live = has && n < N && n >= pos;
-          const int nn = (has && n < N) ? n : N - 1;
-          const double lp = gg_lp_split4<NT, ADJ, 4 * PW>(x, s_st + 4 * p, s_acc, nn, stage_tables == 2 ? s_T : nullptr, RS);
-          if (g.dbg && p == PW - 1) cb = wall_clock64();
-          const int lab = gg_group_categorical(lp, k, K, Kp, u_bandp[p]);
+          const int lab = labp[p];
           if (k == 0) {
             unsigned long long dv = GG_SLOT_NONE;
             if (live) {
