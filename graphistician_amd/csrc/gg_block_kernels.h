@@ -354,8 +354,11 @@ __device__ __forceinline__ void gg_bulk_w_body(const int32_t* __restrict__ XT, c
   }
 }
 
+#ifndef GG_BULK_W_WAVES
+#define GG_BULK_W_WAVES 1
+#endif
 template <int B, int U, bool NTL>
-__global__ __launch_bounds__(256) void k_bulk_w(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
+__global__ __launch_bounds__(256, GG_BULK_W_WAVES) void k_bulk_w(const int32_t* __restrict__ XT, const int32_t* __restrict__ X1,
                                                 int Np, const int32_t* __restrict__ perm,
                                                 const int32_t* __restrict__ lab_start, int K, int RW,
                                                 int32_t* __restrict__ Gc0, int32_t* __restrict__ Gc1,
@@ -1430,35 +1433,35 @@ __device__ __forceinline__ double gg_lp_split4(const gg_node_ctx& x, const doubl
 // finishes its (node, label) entries (gg_node_lp_finish) and leaves lp in s_lp[node][64], where the caller's waves pick a node
 // each for the categorical draw.  Padding (j >= K in the last step, nodes >= PER) multiplies zeros: fma(0, 0, acc) = acc.
 typedef double gg_d4 __attribute__((ext_vector_type(4)));
-#ifndef GG_MFMA_UB
-#define GG_MFMA_UB 2
-#endif
-// The coefficients of steps s0 .. s0 + UB - 1 as this lane supplies them (gg_lp_mfma_b0: the first batch, which the caller may
-// fetch ahead of the evaluation - the tables do not change during a scan).
+#define GG_MFMA_RING 4     /* steps (of four j) whose coefficients are in flight ahead of the matrix pipe */
+// The coefficients of step s as this lane supplies them (the caller fetches the first GG_MFMA_RING steps ahead of the evaluation -
+// the tables do not change during a scan).
 template <int NT>
-__device__ __forceinline__ void gg_lp_mfma_b(const gg_node_ctx& x, int s0, double (&bn)[GG_MFMA_UB][2 * NT]) {
+__device__ __forceinline__ void gg_lp_mfma_b1(const gg_node_ctx& x, int step, double (&b)[2 * NT]) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, K = x.K;
-  const int jr = l >> 4, kk = 16 * w + (l & 15);
+  const int j = 4 * step + (l >> 4), kk = 16 * w + (l & 15);
+  // (a step beyond K reads block K - 1's coefficients again: its statistics are supplied as zeros, and 0 * finite adds nothing -
+  // no select on the loaded value, which would make the wave wait for the load where it is issued)
+  const size_t at = ((size_t)(j < K ? j : K - 1) * NT) * 64 + kk;
 #pragma unroll
-  for (int u = 0; u < GG_MFMA_UB; ++u) {
-    const int j = 4 * (s0 + u) + jr;
-    const bool in = j < K;
-    const size_t at = ((size_t)(in ? j : K - 1) * NT) * 64 + kk;
-#pragma unroll
-    for (int c = 0; c < 2 * NT; ++c) {
-      const double v = (c < NT ? x.Tout : x.Tin)[at + (size_t)(c % NT) * 64];
-      bn[u][c] = in ? v : 0.0;
-    }
-  }
+  for (int c = 0; c < 2 * NT; ++c) b[c] = (c < NT ? x.Tout : x.Tin)[at + (size_t)(c % NT) * 64];
 }
 // selfacc[r]: gg_node_self_acc of (node 4 r + l / 16, label kk) - constant over a band's rounds, so the caller computes it once
 // per band instead of behind every round's chains (unused when the model special-cases the diagonal).
+// s_st[zoff]: an LDS double that holds 0.0 - what a lane reads for a statistic that does not exist (j >= K, node >= PER): an
+// address select instead of a select on the loaded value, so that a step's reads are all in flight before the first is waited
+// for.  (An OFFSET from s_st, not a pointer: a select between two pointers loses the LDS address space, the reads become flat
+// loads, and a flat load is waited for together with every global load in flight - the coming steps' coefficients.)
+// Schedule (fixed with scheduling barriers - left to itself the scheduler sinks the loads below the matrix instructions to save
+// registers and then waits for them at once): step i multiplies while the statistics of step i + 1 are being read and the
+// coefficients of steps i + 1 .. i + 4 are in flight (a ring of four: an L2 round trip is longer than two steps' 12 matrix
+// instructions, measured).
 template <int NT, bool ADJ, int PER>
 __device__ __forceinline__ void gg_lp_mfma(const gg_node_ctx& x, const double* s_st, double* s_lp, double logm_kk,
-                                           const double (&b0)[GG_MFMA_UB][2 * NT], const double (&selfacc)[4]) {
+                                           const double (&b0)[GG_MFMA_RING][2 * NT], const double (&selfacc)[4], int zoff) {
   static_assert(PER == 8 || PER == 16, "one 16-row tile of nodes");
   constexpr int NCH = 2 * NT;
-  constexpr int UB = GG_MFMA_UB;              // steps (of four j) per batch
+  constexpr int R = GG_MFMA_RING;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, K = x.K;
   const int jr = l >> 4, c16 = l & 15;
   const int kk = 16 * w + c16;                // the label this lane's results belong to
@@ -1467,34 +1470,32 @@ __device__ __forceinline__ void gg_lp_mfma(const gg_node_ctx& x, const double* s
   gg_d4 acc[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) acc[c] = gg_d4{0.0, 0.0, 0.0, 0.0};
-  double bn[UB][NCH];
+  double bq[R][NCH], av[2][NCH];
 #pragma unroll
-  for (int u = 0; u < UB; ++u)
+  for (int u = 0; u < R; ++u)
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) bn[u][c] = b0[u][c];
-  auto load_b = [&](int s0) { gg_lp_mfma_b<NT>(x, s0, bn); };
-  for (int s0 = 0; s0 < S; s0 += UB) {
-    double bc[UB][NCH], av[UB][NCH];
+    for (int c = 0; c < NCH; ++c) bq[u][c] = b0[u][c];
+  auto load_a = [&](int step, double (&a)[NCH]) {
+    const int j = 4 * step + jr;
+    const bool in = node_in && j < K;
+    const int base = in ? j * NT * PER + c16 : zoff;
+    const int d1 = in ? K * NT * PER : 0, t1 = in ? PER : 0;
 #pragma unroll
-    for (int u = 0; u < UB; ++u)
+    for (int c = 0; c < NCH; ++c) a[c] = s_st[base + (c / NT) * d1 + (c % NT) * t1];
+  };
+  load_a(0, av[0]);
+  for (int s0 = 0; s0 < S; s0 += R) {
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) bc[u][c] = bn[u][c];
-    if (s0 + UB < S) load_b(s0 + UB);
+    for (int i = 0; i < R; ++i) {
+      const int step = s0 + i;
+      load_a(step + 1, av[(i + 1) & 1]);      // (beyond the last step: zeros)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int j = 4 * (s0 + u) + jr;
-      const bool in = node_in && j < K;
-      const double* sp = s_st + ((size_t)(in ? j : 0) * NT) * PER + (node_in ? c16 : 0);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const double v = sp[((size_t)(c / NT) * K * NT + (c % NT)) * PER];
-        av[u][c] = in ? v : 0.0;
-      }
+      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i & 1][c], bq[i][c], acc[c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (step + R < S) gg_lp_mfma_b1<NT>(x, step + R, bq[i]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int u = 0; u < UB; ++u)
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][c], bc[u][c], acc[c], 0, 0, 0);
   }
   // the tail of gg_block_lp (gg_node_lp_finish, with the self chain handed in)
   const bool special = x.special != 0;
@@ -1680,6 +1681,20 @@ __device__ __forceinline__ void gg_spec_eval_split8(const gg_node_ctx& x, int n_
   const int n0 = n_begin + (int)blockIdx.x * 8;
   const int tid = threadIdx.x;
   const double sc1 = gg_pow2i(-x.shift), sc2 = gg_pow2i(-2 * x.shift);
+  // gg_lp_mfma's inputs that do not depend on the statistics, requested first: the first steps' coefficients, log m and the self
+  // chains of this lane's (node, label) entries
+  double b0[GG_MFMA_RING][2 * NT], selfacc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < GG_MFMA_RING; ++u) gg_lp_mfma_b1<NT>(x, u, b0[u]);
+  const int kk = 16 * (tid >> 6) + (tid & 15);
+  const double logm_kk = x.logm[kk < K ? kk : 0];
+  if (!x.special) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {       // (rows 8..15 of the tile are padding)
+      const int nb = n0 + 4 * r + ((tid >> 4) & 3);
+      selfacc[r] = gg_node_self_acc<NT, ADJ>(x, nb < x.N ? nb : x.N - 1, kk < K ? kk : 0);
+    }
+  }
   for (int idx = tid; idx < 2 * K * 8; idx += 256) {
     const int i = idx % 8, j = (idx / 8) % K, d = idx / (8 * K);
     const int n = (n0 + i < x.N) ? n0 + i : x.N - 1;
@@ -1699,20 +1714,25 @@ __device__ __forceinline__ void gg_spec_eval_split8(const gg_node_ctx& x, int n_
       if (gg_tJ(NT)) dst[(NT - 1) * ts] = (double)((x.cntn ? x.cntn[(size_t)n * K + j] : x.cnt[j]) - (x.c[x.n0 + n] == j ? 1 : 0));
     }
   }
+  // (round 4) the eight nodes' chains on the matrix cores: gg_lp_mfma leaves lp[node][64] in the meeting place; s_acc[8 * 64] is
+  // the zero it reads for statistics that do not exist
+  if (tid == 0) s_acc[8 * 64] = 0.0;
+  __syncthreads();
+  gg_lp_mfma<NT, ADJ, 8>(x, s_st, s_acc, logm_kk, b0, selfacc, (int)(s_acc + 8 * 64 - s_st));
   __syncthreads();
   const int w = tid >> 6, k = tid & 63;
+  double lpp[2], up[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    if (p) __syncthreads();       // (the previous pass's meeting place has been read)
     const int n = n0 + 4 * p + w;
     const bool live = n < x.N;
     const int nn = live ? n : x.N - 1;
-    const double lp = gg_lp_split4<NT, ADJ, 8>(x, s_st + 4 * p, s_acc, nn);
-    const double u = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
-    labs[p] = gg_group_categorical(lp, k, K, 64, u);
+    lpp[p] = s_acc[(4 * p + w) * 64 + k];
+    up[p] = gg_uniform_at(seed, site, sweep, (uint32_t)(x.n0 + nn));
     nodes[p] = n;
     lives[p] = live;
   }
+  gg_group_categorical64<2>(lpp, k, K, up, *reinterpret_cast<int(*)[2]>(labs));
 }
 
 // More than 64 blocks, the quiet scan's evaluation (k_spec_resolve / k_spec_resolve_epi, SPLIT == 2): a node's lanes span two or
@@ -1926,8 +1946,9 @@ struct gg_shard_state {
   int32_t pad[3];
 };
 
+// (two workgroups per CU where the statistics allow it: one stages its nodes while the other multiplies)
 template <int NT, bool ADJ>
-__global__ __launch_bounds__(256) void k_shard_eval(gg_node_ctx x, gg_own own, int W, uint64_t seed, uint32_t site, uint32_t sweep,
+__global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void k_shard_eval(gg_node_ctx x, gg_own own, int W, uint64_t seed, uint32_t site, uint32_t sweep,
                                                     int32_t* __restrict__ cand, const int32_t* __restrict__ c,
                                                     const int32_t* __restrict__ H, gg_shard_state* __restrict__ S, int round,
                                                     int ntot, int stage_tables, int32_t* __restrict__ trip) {

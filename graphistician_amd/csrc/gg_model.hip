@@ -236,8 +236,8 @@ static int scan_nodes_per_wg(const gg_model* m) {
   return (256 / m->Kp) * (m->Kp > 64 ? GG_SCAN_WIDE_P(m->NT) : (m->Kp == 64 ? GG_SCAN_SPLIT_P(m->NT) : 1));
 }
 
-static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
-  const int K = m->K, per = scan_nodes_per_wg(m);
+static size_t lds_scan(const gg_model* m, int lcap, int* stage_out, int per_override = 0) {
+  const int K = m->K, per = per_override ? per_override : scan_nodes_per_wg(m);
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
                (size_t)(per + K + 8) * sizeof(int) + 64 + (size_t)lcap * 3 * sizeof(int);
   // deviations, the round's surprises, per-node block sizes, scratch, one hypothesis per node of a band
@@ -249,7 +249,7 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out) {
   // that stays below 72 KB (2: K up to 32 at B = 1); else from global memory (0).  (At K = 64 the one copy fits the 150 KB
   // but gains 10 % of a round's evaluation and leaves no room for anything else on the CU: not taken.)  Kp = 64 without layout 1 evaluates with
   // gg_lp_split4, which needs its meeting place.
-  const size_t split_acc = m->Kp == 64 ? GG_SCAN_MEET_BYTES(m->NT) : 0;
+  const size_t split_acc = m->Kp == 64 ? (per_override ? (size_t)per_override * 64 * sizeof(double) : GG_SCAN_MEET_BYTES(m->NT)) : 0;
   const size_t one_copy = (size_t)K * ((K * m->NT) | 1) * sizeof(double);
   int stage = 0;
   if (lds + table_bytes(m) <= 64 * 1024) { stage = 1; lds += table_bytes(m); }
@@ -771,6 +771,11 @@ static int pair_sched_on() {
 static int pair_pass_on() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("GG_PAIR_PASS"); on = e ? atoi(e) : 1; }
+  return on;
+}
+static int pair_adj16_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GG_PAIR_ADJ16"); on = e ? atoi(e) : 1; }
   return on;
 }
 static int pair_min_n() {
@@ -1463,11 +1468,14 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   // whatever the order the dispatcher places them in)
   if (m->Kp == 64 && a.Lcap > 256) a.Lcap = 256;
   { const char* el = getenv("GG_SCAN_LCAP"); if (el && atoi(el) >= 2 && atoi(el) < a.Lcap) a.Lcap = atoi(el); }   // (tests: flush the list often)
-  const int per = scan_nodes_per_wg(m);
+  // (pair scheduling, below: the adjacency model's grid is never resident next to the weight model's - 16 nodes per group, MODE 3)
+  const bool pair = pair_sched_on() && m->N >= pair_min_n() && !resume && ride_buf < 0 && !m->sharded;
+  const bool adj16 = pair && m->is_adj && m->Kp == 64 && pair_adj16_on();
+  const int per = adj16 ? 16 : scan_nodes_per_wg(m);
   const int ngroups = (m->Nl + per - 1) / per;
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
   int stage;
-  size_t lds = lds_scan(m, a.Lcap, &stage);
+  size_t lds = lds_scan(m, a.Lcap, &stage, adj16 ? 16 : 0);
   if (lds > GG_LDS_LIMIT)
     return gg_fail(GG_ERR_UNSUPPORTED, "the resident-grid scan needs %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
   g.stage_tables = stage;
@@ -1490,7 +1498,6 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   // instead of 0.8).  Now the adjacency model's scan waits for the weight model's latest scan instead, and the weight model's
   // stream idles for a few microseconds behind its scan (k_delay): the adjacency model's grid assembles on the empty chip, the
   // pass then fills the room around it, and the weight model's next scan has the chip to itself.
-  const bool pair = pair_sched_on() && m->N >= pair_min_n() && !resume && ride_buf < 0 && !m->sharded;
   if (pair && m->is_adj && d->ev_wscan_set) GG_HIP(hipStreamWaitEvent(m->stream, d->ev_wscan, 0));
 #define SCN1(NTV, ADJV, SPV)                                                                                       \
   do {                                                                                                            \
@@ -1519,7 +1526,8 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     else if (stage != 1 && m->Kp == 64) SCN1(NTV, ADJV, 1);                                                       \
     else SCN1(NTV, ADJV, 0);                                                                                      \
   } while (0)
-  if (m->is_adj) SCN(2, true);
+  if (adj16) SCN1(2, true, 3);
+  else if (m->is_adj) SCN(2, true);
   else if (m->joint && m->B == 1) SCN(4, false);
   else if (m->joint) SCN(7, false);
   else if (m->B == 1) SCN(3, false);

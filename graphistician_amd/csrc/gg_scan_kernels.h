@@ -184,7 +184,11 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   // 33..64 blocks (MODE 1), NT <= 3: 8 nodes per group (adjacency) or 16 (one-dimensional weights), evaluated together on the
   // matrix cores (gg_lp_mfma, round 4; before: two passes of gg_lp_split4 over four nodes each - N=65536, K=64: 67 rounds of
   // 15.9 us of evaluation).
-  constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : (MODE == 1 ? GG_SCAN_SPLIT_P(NT) : 1);
+  // MODE 3 = MODE 1 with 16 nodes per group whatever NT: the adjacency model's scan under pair scheduling (gg_model.hip,
+  // launch_scan) - it is resident while the weight model's pass streams, never next to the weight model's scan, so its LDS need
+  // not leave room for that one, and half the bands and rounds halve the time it takes compute units away from the pass.
+  constexpr bool M13 = MODE == 1 || MODE == 3;
+  constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : (MODE == 3 ? 4 : (MODE == 1 ? GG_SCAN_SPLIT_P(NT) : 1));
   const int per = (256 / Kp) * PW;
   const int tid = threadIdx.x, b = blockIdx.x, G = a.G;
   const int ngroups = (N + per - 1) / per;
@@ -202,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   if (stage_tables == 1) off += (size_t)2 * ntab * sizeof(double);
   else if (stage_tables == 2) off += (size_t)K * RS * sizeof(double);
   double* s_acc = reinterpret_cast<double*>(s_raw + off);     // gg_lp_split4: where the chains of the four waves meet
-  constexpr bool split = MODE == 1;   // (the host: stage_tables != 1 && Kp == 64)
-  if (split) off += GG_SCAN_MEET_BYTES(NT);                   // (4 PW nodes at once: gg_lp_mfma leaves lp[node][64] here)
+  constexpr bool split = M13;         // (the host: stage_tables != 1 && Kp == 64)
+  if (split) off += MODE == 3 ? (size_t)16 * 64 * sizeof(double) : GG_SCAN_MEET_BYTES(NT);                   // (4 PW nodes at once: gg_lp_mfma leaves lp[node][64] here)
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
   int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);
@@ -216,6 +220,8 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   int* s_S = reinterpret_cast<int*>(s_raw + off); off += 256 * 3 * sizeof(int);      // its surprises, compacted: (node, from, to)
   int* s_cntn = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * K * sizeof(int);   // block sizes as node i of the group sees them
   int* s_misc = reinterpret_cast<int*>(s_raw + off); off += 16 * sizeof(int);
+  // (words 0..8 are scratch of the folds; an 8-byte aligned double inside words 10..13 holds 0.0 for gg_lp_mfma)
+  double* zero8 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_misc + 10) + 7) & ~(uintptr_t)7);
   unsigned short* s_H = reinterpret_cast<unsigned short*>(s_raw + off); off += (size_t)GG_SCAN_MAXWG * per * sizeof(short);   // [G per] hypothesis per node of the band: 0xffff none, else (old << 8 | new) (old != new: never 0xffff)
   off = (off + 3) & ~(size_t)3;
   unsigned* s_Hm = reinterpret_cast<unsigned*>(s_raw + off); off += (size_t)(GG_SCAN_MAXWG * per / 32 + 2) * sizeof(unsigned);   // one bit per node of the band: a hypothesis is in place
@@ -246,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     }
   }
   for (int k = tid; k < K; k += 256) s_cnt[k] = g.cnt[k];
+  if (tid == 0) *zero8 = 0.0;
   if (stage_tables == 1) {
     for (int idx = tid; idx < ntab; idx += 256) { s_T[idx] = x.Tout[idx]; s_T[ntab + idx] = x.Tin[idx]; }
   } else if (stage_tables == 2) {
@@ -382,13 +389,13 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     double u_bandp[PW];
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
-      const int nb = n0 + (MODE == 1 ? 4 * p + (tid >> 6) : (tid / Kp) * PW + p);
+      const int nb = n0 + (M13 ? 4 * p + (tid >> 6) : (tid / Kp) * PW + p);
       u_bandp[p] = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + ((has && nb < N) ? nb : N - 1)));
     }
     const double u_band = u_bandp[0];
     // gg_lp_mfma's lane layout: the self chains of this lane's (node, label) entries, once per band
     double self_mf[4] = {0.0, 0.0, 0.0, 0.0};
-    if (MODE == 1 && PW > 1 && !x.special) {
+    if (M13 && PW > 1 && !x.special) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int nb = n0 + 4 * r + ((tid >> 4) & 3);
@@ -420,8 +427,11 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     for (;;) {
       const long long c0 = g.dbg ? wall_clock64() : 0;
       // (the evaluation's first batch of coefficients is on its way while the statistics are converted)
-      double b0_mf[GG_MFMA_UB][2 * NT];
-      if (MODE == 1 && PW > 1) gg_lp_mfma_b<NT>(x, 0, b0_mf);
+      double b0_mf[GG_MFMA_RING][2 * NT];
+      if (M13 && PW > 1) {
+#pragma unroll
+        for (int u = 0; u < GG_MFMA_RING; ++u) gg_lp_mfma_b1<NT>(x, u, b0_mf[u]);
+      }
       __syncthreads();
       if (tid == 0) *s_min = GG_NO_CHANGE;
       if (has) {
@@ -505,11 +515,11 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
             s_dev[i] = dv;
           }
         }
-      } else if (MODE == 1 && PW > 1) {
+      } else if (M13 && PW > 1) {
         // the group's 4 PW nodes at once on the matrix cores (gg_lp_mfma: the chains of gg_block_lp as f64 MFMA steps, bit for
         // bit); wave w then draws for node 4 p + w, p = 0 .. PW - 1
         const int w4 = tid >> 6, k = tid & 63;
-        gg_lp_mfma<NT, ADJ, (PW > 1 ? 4 * PW : 8)>(x, s_st, s_acc, logm_mf, b0_mf, self_mf);   // (PW == 1: this branch is not taken)
+        gg_lp_mfma<NT, ADJ, (PW > 1 ? 4 * PW : 8)>(x, s_st, s_acc, logm_mf, b0_mf, self_mf, (int)(zero8 - s_st));   // (PW == 1: this branch is not taken)
         __syncthreads();
         if (g.dbg) cb = wall_clock64();
         double lpp[PW];
