@@ -806,12 +806,14 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   const int32_t* ctl = pipelined ? m->rs : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
+  // pair scheduling (launch_scan): the adjacency model's pass waits for the weight model's parameter step - it then streams under
+  // the weight model's scan (before the sampling events: the wait is not the pass)
+  const bool pair = pair_sched_on() && pair_pass_on() && m->N >= pair_min_n() && m->use_scan && !m->sharded && pipelined;   // (pipelined: a sweep's pass)
+  if (pair && m->is_adj && d->ev_wpass_set) GG_HIP(hipStreamWaitEvent(st, d->ev_wpass, 0));
   if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, st)); }
   const bulk_shape bs = bulk_shape_of(m, ndirs);
   dim3 grd(bs.strips, bs.nslots, ndirs);
   const int RW = bs.RW;
-  const bool pair = pair_sched_on() && pair_pass_on() && m->N >= pair_min_n() && m->use_scan && !m->sharded && pipelined;   // (pipelined: a sweep's pass)
-  if (pair && m->is_adj && d->ev_wpass_set) GG_HIP(hipStreamWaitEvent(st, d->ev_wpass, 0));
   if (m->is_adj) {
     if (bs.ntl)
       k_bulk_adj<true><<<grd, 256, 0, st>>>(d->AbT, d->Ab, Np, perm, lab_start, K, RW, gcnt(m, buf, 0), gcnt(m, buf, 1), dir0, ctl);
