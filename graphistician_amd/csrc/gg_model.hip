@@ -761,23 +761,11 @@ static bulk_shape bulk_shape_of(const gg_model* m, int ndirs) {
 }
 
 // BULK statistics under the current labels into buffer `buf`.  dirs: bit 0 = out (reads X^T), bit 1 = in (reads X).
-static int pair_sched_on() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("GG_PAIR_SCHED"); on = e ? atoi(e) : 1; }
-  return on;
-}
+static int pair_sched_on() { const char* e = getenv("GG_PAIR_SCHED"); return e ? atoi(e) : 1; }   // (read at every launch: the tests switch it)
 // the adjacency model's pass behind the weight model's pass as well (GG_PAIR_PASS, default 1): it then streams while the weight
 // model's scan - latency-bound, the memory system idle - runs, instead of sharing the pass's bandwidth
-static int pair_pass_on() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("GG_PAIR_PASS"); on = e ? atoi(e) : 1; }
-  return on;
-}
-static int pair_adj16_on() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("GG_PAIR_ADJ16"); on = e ? atoi(e) : 1; }
-  return on;
-}
+static int pair_pass_on() { const char* e = getenv("GG_PAIR_PASS"); return e ? atoi(e) : 1; }   // (read at every launch: the tests switch it)
+static int pair_adj16_on() { const char* e = getenv("GG_PAIR_ADJ16"); return e ? atoi(e) : 1; }   // (read at every launch: the tests switch it)
 static int pair_min_n() {
   static int n = -1;
   if (n < 0) { const char* e = getenv("GG_PAIR_MIN_N"); n = e ? atoi(e) : 16384; }

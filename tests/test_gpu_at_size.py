@@ -212,7 +212,8 @@ def test_cfg3_n65536_k64_full_size_properties(abi, monkeypatch):
     with no parity or property check").  The oracle cannot finish a sweep of it in a test's time, so the checks are the
     size-independent properties the sampler offers: the chain is a deterministic function of (seed, data) - run twice, bit
     for bit - and does not depend on the execution form: the same labels, block probabilities and Gaussians with the ahead
-    form switched off (GG_AHEAD=0) and with restart rounds in place of the resident-grid scan (GG_SCAN=0).  From a prior
+    form switched off (GG_AHEAD=0), with restart rounds in place of the resident-grid scan (GG_SCAN=0: vector fma chains in place
+    of the matrix cores' as well) and without the pair scheduling of the two models' scans (GG_PAIR_SCHED=0).  From a prior
     draw: the first sweeps relabel tens of thousands of nodes (change-list flushes, many hypothesis rounds), the later ones
     a few hundred.  The small shapes of this K are checked label for label against the oracle above (N=16384) and in
     tests/test_gpu_parity_sbm.py."""
@@ -221,7 +222,7 @@ def test_cfg3_n65536_k64_full_size_properties(abi, monkeypatch):
     data = abi.DeviceData.synthetic_sbm(N, t["c"], t["p"], t["p_self"], t["mu"], t["sigma"], 0.0, 1.0, seed=1234)
 
     def chain(env):
-        for k in ("GG_AHEAD", "GG_SCAN"):
+        for k in ("GG_AHEAD", "GG_SCAN", "GG_PAIR_SCHED", "GG_PAIR_ADJ16"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)          # (read when a model is created)
@@ -249,7 +250,10 @@ def test_cfg3_n65536_k64_full_size_properties(abi, monkeypatch):
     ref = chain({})
     assert ref["changes"].sum() > 50000                      # the chain did move: tens of thousands of relabelled nodes
     assert np.all(np.isfinite(ref["ll"])) and len(np.unique(ref["ca"])) > 1
-    for env in ({}, {"GG_AHEAD": "0"}, {"GG_SCAN": "0"}):
+    # (GG_SCAN=0 also swaps the evaluation: the restart rounds run gg_lp_split4's vector fma chains, the resident scan the same
+    # chains on the matrix cores - gg_lp_mfma; GG_PAIR_*: the two models' scans scheduled as a pair or not, the adjacency scan's
+    # group of 16 or 8 nodes)
+    for env in ({}, {"GG_AHEAD": "0"}, {"GG_SCAN": "0"}, {"GG_PAIR_SCHED": "0"}, {"GG_PAIR_ADJ16": "0"}):
         got = chain(env)
         for k in ref:
             assert np.array_equal(ref[k], got[k]), "N=65536, K=64: %s differs under %s" % (k, env or "a second run")
