@@ -952,6 +952,8 @@ def main():
                        "ms_per_step_min_max_over_blocks": [min(r["blocks"]) / args.steps * 1e3, max(r["blocks"]) / args.steps * 1e3],
                        "label_changes_per_sweep": r["changes"] / float(args.steps),
                        "scan_rounds_per_sweep": r["rounds"] / float(args.steps), "weight_model_sweep_forms": r["forms"],
+                       "adjacency_model_sweep_forms": r["forms_adj"],
+                       "us_per_step_by_block": [round(b / args.steps * 1e6, 1) for b in r["blocks"]],
                        "bulk_launch_ms": r["bulk"]["w_ms"] / max(r["bulk"]["w_n"], 1),
                        "bulk_launch_GBs": r["bulk"]["w_bytes"] / (r["bulk"]["w_ms"] * 1e-3) / 1e9 if r["bulk"]["w_ms"] > 0 else None})
         if rank == 0:

@@ -1947,9 +1947,28 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       // host round trips, the no-op launches behind it) = ~100 quiet sweeps.  So once a chain has surprised the
       // speculative form after a switch back, the resident form is held for 4 x the quiet run that preceded the surprise
       // (at least 64, at most 4096 sweeps); the first stall of all (burn-in) leaves the short initial hold alone.
+      // Round 4, re-measured: with the quiet chain's sweep fused into one launch (36-38 us) a quiet sweep costs ~18 us more in
+      // the resident form (the adjacency model beside a fused weight model: 56 us), a stall 300-600 us (bench blocks with one):
+      // break-even ~25 quiet sweeps, not 100 - and the old rule held a chain that had been quiet for q sweeps in the
+      // resident form for 4 q more (chains with one change in warm-up spent 80 of 140 timed sweeps there).  Now: a surprise
+      // after a SHORT quiet run (q < hold_q = 32: the chain changes labels every few sweeps) holds the resident form for
+      // hold_long = 32 clean sweeps; after a long one only hold_min = 16 (past the burst a change tends to start).
+      // Driver's seed mix (tools/scripts/hold_ab.sh): 16.7 k -> 18.6 k sweeps/s at 20-sweep calls, 17.6 -> 18.6 k at 200.
       if (!m->use_scan && m->since_revert < (1 << 29)) {
-        long long h = 4 * m->since_revert;
-        m->scan_hold = h < 64 ? 64 : (h > 4096 ? 4096 : h);
+        static int hold_q = -1, hold_long = -1, hold_min = -1, hold_old = -1;
+        if (hold_q < 0) {
+          const char* e;
+          hold_q = (e = getenv("GG_SCAN_HOLD_Q")) ? atoi(e) : 32;
+          hold_long = (e = getenv("GG_SCAN_HOLD_LONG")) ? atoi(e) : 32;
+          hold_min = (e = getenv("GG_SCAN_HOLD_MIN")) ? atoi(e) : 16;
+          hold_old = (e = getenv("GG_SCAN_HOLD_OLD")) ? atoi(e) : 0;
+        }
+        if (hold_old) {
+          long long h = 4 * m->since_revert;
+          m->scan_hold = h < 64 ? 64 : (h > 4096 ? 4096 : h);
+        } else {
+          m->scan_hold = m->since_revert < hold_q ? hold_long : hold_min;
+        }
       }
       m->use_scan = true; m->clean_run = 0; m->chg_seen = (long long)m->h_rs[2];
     }
