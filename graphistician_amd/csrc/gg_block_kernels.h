@@ -1190,8 +1190,10 @@ __device__ __forceinline__ double gg_node_self_acc(const gg_node_ctx& x, int n, 
 
 // Combination of the finished chains of node n, label k (the tail of gg_lp.h::gg_block_lp).
 template <int NT, bool ADJ>
+// self_pre: the self connection's chain when the caller has it already (it does not change during a band of a scan).
 __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n, int k, const double* acc_o,
-                                                    const double* acc_i, const double* logm_k = nullptr) {
+                                                    const double* acc_i, const double* logm_k = nullptr,
+                                                    const double* self_pre = nullptr) {
   if (k >= x.K) return -gg_inf();
   const int K = x.K;
   double lp = logm_k ? *logm_k : x.logm[k];
@@ -1199,7 +1201,7 @@ __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n,
   for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_o[t], lp);
 #pragma unroll
   for (int t = 0; t < NT; ++t) lp = gg_fma(x.beta, acc_i[t], lp);
-  if (!x.special) lp = gg_fma(x.beta, gg_node_self_acc<NT, ADJ>(x, n, k), lp);
+  if (!x.special) lp = gg_fma(x.beta, self_pre ? *self_pre : gg_node_self_acc<NT, ADJ>(x, n, k), lp);
   return lp;
 }
 
@@ -1208,7 +1210,7 @@ __device__ __forceinline__ double gg_node_lp_finish(const gg_node_ctx& x, int n,
 template <int NT, bool ADJ, int UJ_ = 0, class Loader>
 __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, int k, Loader ld,
                                                   const double* __restrict__ Tout, const double* __restrict__ Tin,
-                                                  const double* logm_k = nullptr) {
+                                                  const double* logm_k = nullptr, const double* self_pre = nullptr) {
   if (k >= x.K) return -gg_inf();
   const int K = x.K, Kp = x.Kp;
   double acc_o[NT], acc_i[NT];
@@ -1248,7 +1250,7 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
       acc_i[t] = gg_fma(Tin[((size_t)j * NT + t) * Kp + k], si[t], acc_i[t]);
     }
   }
-  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, logm_k);
+  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, logm_k, self_pre);
 }
 
 // The same with ONE copy of the table T[a][b][t] (rows padded to RS doubles, RS odd: lane k's reads of row k fall into
@@ -1256,7 +1258,8 @@ __device__ __forceinline__ double gg_node_lp_core(const gg_node_ctx& x, int n, i
 // = T[j][k][t].  Half the LDS of the two layouts: what lets K = 32..64 keep the table next to the statistics (k_scan).
 template <int NT, bool ADJ, class Loader>
 __device__ __forceinline__ double gg_node_lp_core_t1(const gg_node_ctx& x, int n, int k, Loader ld,
-                                                     const double* __restrict__ T1, int RS, const double* logm_k = nullptr) {
+                                                     const double* __restrict__ T1, int RS, const double* logm_k = nullptr,
+                                                     const double* self_pre = nullptr) {
   if (k >= x.K) return -gg_inf();
   const int K = x.K;
   double acc_o[NT], acc_i[NT];
@@ -1295,7 +1298,7 @@ __device__ __forceinline__ double gg_node_lp_core_t1(const gg_node_ctx& x, int n
       acc_i[t] = gg_fma(Ti[(size_t)j * RS + t], si[t], acc_i[t]);
     }
   }
-  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, logm_k);
+  return gg_node_lp_finish<NT, ADJ>(x, n, k, acc_o, acc_i, logm_k, self_pre);
 }
 
 // Where the spec-order doubles of (direction d, block j, node i of the workgroup) live in LDS: element t is at
@@ -1511,6 +1514,48 @@ __device__ __forceinline__ void gg_lp_mfma(const gg_node_ctx& x, const double* s
     if (!special) lp = gg_fma(beta, selfacc[r], lp);
     if (kk >= K) lp = -gg_inf();
     if (i < PER) s_lp[i * 64 + kk] = lp;
+  }
+}
+
+// The same for 9..32 blocks with the coefficient tables in LDS (k_scan, MODE 0, stage_tables == 1): a group is per = 256 / Kp
+// nodes (16 or 8) and Kp = 16 or 32 labels - one or two 16 x 16 tiles per chain.  The 2 NT x (Kp / 16) (chain, tile) items are
+// dealt out over the four waves; an item is ceil(K / 4) matrix instructions in a row (the chain of gg_block_lp, bit for bit:
+// tools/probe/mfma_f64_exact.hip), its statistics read from the normal layout [dir][j][node][NT], its coefficients from the
+// lane-major tables [j][t][Kp].  The finished chains meet in s_acc[chain][node][Kp]; after a barrier lane (node, k) of the
+// ordinary layout picks its 2 NT values up and finishes as gg_node_lp_core does.  Against the vector form (one fma, one
+// coefficient read and one broadcast statistic read per (j, t, direction) and lane): 1.78 against 1.70 us per round at K = 16 -
+// no gain (both are latency, not arithmetic); kept behind GG_MFMA_SMALL=1, off by default.
+template <int NT, bool ADJ>
+__device__ __forceinline__ void gg_lp_mfma_small(const gg_node_ctx& x, const double* s_st, const double* s_To, const double* s_Ti,
+                                                 double* s_acc, int per, int Kp, int zoff) {
+  constexpr int NCH = 2 * NT;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, K = x.K;
+  const int jr = l >> 4, c16 = l & 15;
+  const int ntile = Kp >> 4, S = (K + 3) >> 2;
+  const bool node_in = c16 < per;
+  for (int item = w; item < NCH * ntile; item += 4) {
+    const int c = item / ntile, tile = item - c * ntile;
+    const int d = c / NT, t = c - d * NT;
+    const double* Tb = (d == 0 ? s_To : s_Ti) + (size_t)t * Kp + 16 * tile + c16;
+    gg_d4 acc = gg_d4{0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < S; s0 += 4) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * (s0 + u) + jr;
+        const bool in = node_in && j < K;
+        av[u] = s_st[in ? ((d * K + j) * per + c16) * NT + t : zoff];
+        bv[u] = Tb[(size_t)(j < K ? j : K - 1) * NT * Kp];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < S) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);   // (uniform)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int node = 4 * r + jr;
+      if (node < per) s_acc[((size_t)c * per + node) * Kp + 16 * tile + c16] = acc[r];
+    }
   }
 }
 

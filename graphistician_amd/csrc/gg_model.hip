@@ -236,6 +236,14 @@ static int scan_nodes_per_wg(const gg_model* m) {
   return (256 / m->Kp) * (m->Kp > 64 ? GG_SCAN_WIDE_P(m->NT) : (m->Kp == 64 ? GG_SCAN_SPLIT_P(m->NT) : 1));
 }
 
+// 9..32 blocks: the resident scan's conditional on the matrix cores when the tables are staged - GG_MFMA_SMALL=1; off by default:
+// exact (tests) but no faster (N=4096, K=16: 1.78 against 1.70 us of a round's 8.6 - with the tables and the statistics both
+// in LDS the vector form's conditional is the latency of its LDS round trips, and the matrix form adds a barrier and a round
+// trip through the meeting place for the arithmetic it saves)
+static bool scan_mf_small(const gg_model* m) {
+  const char* e = getenv("GG_MFMA_SMALL");
+  return (m->Kp == 16 || m->Kp == 32) && e && atoi(e) != 0;
+}
 static size_t lds_scan(const gg_model* m, int lcap, int* stage_out, int per_override = 0) {
   const int K = m->K, per = per_override ? per_override : scan_nodes_per_wg(m);
   size_t lds = (size_t)2 * K * per * m->NT * sizeof(double) + (size_t)2 * K * per * sizeof(int) +
@@ -252,7 +260,10 @@ static size_t lds_scan(const gg_model* m, int lcap, int* stage_out, int per_over
   const size_t split_acc = m->Kp == 64 ? (per_override ? (size_t)per_override * 64 * sizeof(double) : GG_SCAN_MEET_BYTES(m->NT)) : 0;
   const size_t one_copy = (size_t)K * ((K * m->NT) | 1) * sizeof(double);
   int stage = 0;
-  if (lds + table_bytes(m) <= 64 * 1024) { stage = 1; lds += table_bytes(m); }
+  // (9..32 blocks with both table layouts in LDS: the conditional runs on the matrix cores - gg_lp_mfma_small - and its chains
+  // meet in 2 NT x 256 doubles more)
+  const size_t small_meet = scan_mf_small(m) ? (size_t)2 * m->NT * 256 * sizeof(double) : 0;
+  if (lds + small_meet + table_bytes(m) <= 64 * 1024) { stage = 1; lds += small_meet + table_bytes(m); }
   else if (lds + split_acc + one_copy <= 72 * 1024) { stage = 2; lds += split_acc + one_copy; }   // (two workgroups per CU)
   else lds += split_acc;
   if (stage_out) *stage_out = stage;
@@ -1469,6 +1480,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   if (lds > GG_LDS_LIMIT)
     return gg_fail(GG_ERR_UNSUPPORTED, "the resident-grid scan needs %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
   g.stage_tables = stage;
+  a.mf_small = (stage == 1 && scan_mf_small(m)) ? 1 : 0;
   int nr = 0, ntl = 0;
   double ride_bytes = 0.0;
   hipEvent_t e0 = nullptr, e1 = nullptr;

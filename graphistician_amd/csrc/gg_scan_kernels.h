@@ -48,6 +48,7 @@ struct gg_scan_args {
   int G;                      // workgroups in the grid
   int resume;                 // 1: finish a scan that k_resolve left stalled at rs[0] (G is exact for the current labels, L empty)
   int spin_limit;             // polls before an exchange gives up (GG_BAR_SPIN_LIMIT; GG_SCAN_SPIN overrides it for tests)
+  int mf_small;               // 9..32 blocks, tables in LDS: the conditional on the matrix cores (gg_lp_mfma_small; its meeting place is in the LDS request)
   // RIDE: the NEXT sweep's bulk pass rides behind the G scan workgroups, counting into the next statistics buffer under the
   // labels this scan STARTS with; the scan's change list (rs[GG_RS_CARRY] entries of g.L when it ends) then turns those
   // statistics into the ones under the labels it ends with (k_apply_L mode 3): integer moves, exact.
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   else if (stage_tables == 2) off += (size_t)K * RS * sizeof(double);
   double* s_acc = reinterpret_cast<double*>(s_raw + off);     // gg_lp_split4: where the chains of the four waves meet
   constexpr bool split = M13;         // (the host: stage_tables != 1 && Kp == 64)
-  if (split) off += MODE == 3 ? (size_t)16 * 64 * sizeof(double) : GG_SCAN_MEET_BYTES(NT);                   // (4 PW nodes at once: gg_lp_mfma leaves lp[node][64] here)
+  if (split) off += MODE == 3 ? (size_t)16 * 64 * sizeof(double) : GG_SCAN_MEET_BYTES(NT);
+  else if (a.mf_small) off += (size_t)2 * NT * 256 * sizeof(double);   // (gg_lp_mfma_small: [chain][node][Kp], per Kp = 256)                   // (4 PW nodes at once: gg_lp_mfma leaves lp[node][64] here)
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
   int* s_cnt = reinterpret_cast<int*>(s_raw + off); off += (size_t)K * sizeof(int);
@@ -393,6 +395,14 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
       u_bandp[p] = gg_uniform_at(g.seed, g.site, g.sweep, (uint32_t)(x.n0 + ((has && nb < N) ? nb : N - 1)));
     }
     const double u_band = u_bandp[0];
+    // the ordinary lane layout (node tid / Kp, label tid % Kp; MODE 0): the self connection's chain, once per band - its three
+    // dependent loads (diagonal entry, weight, pair (k, k)'s coefficients) were behind every round's chains
+    double self0 = 0.0;
+    if (MODE == 0 && !x.special) {
+      const int nb = n0 + tid / Kp, kb = tid % Kp;
+      self0 = gg_node_self_acc<NT, ADJ>(x, (has && nb < N) ? nb : N - 1, kb < K ? kb : 0);
+    }
+    const double* self0_p = (MODE == 0 && !x.special) ? &self0 : nullptr;
     // gg_lp_mfma's lane layout: the self chains of this lane's (node, label) entries, once per band
     double self_mf[4] = {0.0, 0.0, 0.0, 0.0};
     if (M13 && PW > 1 && !x.special) {
@@ -556,10 +566,20 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           for (int t = 0; t < NT; ++t) { so[t] = pa[t]; si[t] = pb[t]; }
         };
         double lp;
-        if (stage_tables == 1) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab, &logm_k);
+        if (MODE == 0 && a.mf_small) {
+          gg_lp_mfma_small<NT, ADJ>(x, s_st, s_T, s_T + ntab, s_acc, per, Kp, (int)(zero8 - s_st));
+          __syncthreads();
+          double ao[NT], ai[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            ao[t] = s_acc[((size_t)t * per + i) * Kp + k];
+            ai[t] = s_acc[((size_t)(NT + t) * per + i) * Kp + k];
+          }
+          lp = gg_node_lp_finish<NT, ADJ>(x, nn, k, ao, ai, &logm_k, self0_p);
+        } else if (stage_tables == 1) lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, s_T, s_T + ntab, &logm_k, self0_p);
         else if (split) lp = gg_lp_split4<NT, ADJ>(x, s_st, s_acc, nn, stage_tables == 2 ? s_T : nullptr, RS);
-        else if (stage_tables == 2) lp = gg_node_lp_core_t1<NT, ADJ>(x, nn, k, ld, s_T, RS, &logm_k);
-        else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin, &logm_k);
+        else if (stage_tables == 2) lp = gg_node_lp_core_t1<NT, ADJ>(x, nn, k, ld, s_T, RS, &logm_k, self0_p);
+        else lp = gg_node_lp_core<NT, ADJ>(x, nn, k, ld, x.Tout, x.Tin, &logm_k, self0_p);
         if (g.dbg) cb = wall_clock64();
         const int lab = gg_group_categorical(lp, k, K, Kp, u_band);
         if (k == 0) {

@@ -269,7 +269,8 @@ def test_ahead_form_is_the_same_chain(abi, monkeypatch, ahead, split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K,lcap,ride", [(300, 7, 0, 1), (1100, 64, 0, 1), (900, 32, 0, 1), (700, 40, 0, 1), (300, 7, 3, 0), (1100, 64, 5, 0),
+@pytest.mark.parametrize("N,K,lcap,ride", [(300, 7, 0, 1), (1100, 64, 0, 1), (900, 32, 0, 1), (700, 40, 0, 1), (800, 50, 0, 1), (700, 37, 4, 1),
+                                            (300, 7, 3, 0), (1100, 64, 5, 0),
                                             (700, 16, 2, 0), (300, 7, 0, 2), (1100, 64, 0, 2), (900, 32, 0, 2), (300, 7, 3, 2), (1100, 64, 5, 2),
                                             (700, 16, 2, 2), (2500, 16, 0, 2), (2500, 16, 40, 2)])
 def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, ride, monkeypatch):
@@ -280,7 +281,22 @@ def test_resident_grid_scan_is_the_same_chain(abi, N, K, lcap, ride, monkeypatch
     flush of the list runs many times per scan.  ride = 2 (GG_SCAN_RIDE=2): from the second sweep on the NEXT sweep's bulk
     pass rides in the scan's launch, counting under the labels the scan starts with, and the scan's change list - flushed
     into that buffer too whenever it overflows - moves those statistics to the labels it ends with (the default, 1, does
-    so only for chains that change few labels per sweep); 0: never."""
+    so only for chains that change few labels per sweep); 0: never.  K = 50, 37: block counts of the matrix-core conditional
+    (33..64 blocks, gg_lp_mfma) that are not multiples of four / whose steps do not fill the last ring of four."""
+    _resident_scan_case(abi, N, K, lcap, ride, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(700, 16), (900, 32), (500, 10), (600, 27)])
+def test_small_block_conditional_on_the_matrix_cores(abi, N, K, monkeypatch):
+    """GG_MFMA_SMALL=1 (off by default: measured no faster at K = 16): the resident scan's conditional for 9..32 blocks as f64
+    matrix instructions (gg_lp_mfma_small) - the chains of gg_block_lp bit for bit, block counts that are not multiples of four
+    (padding steps) included."""
+    monkeypatch.setenv("GG_MFMA_SMALL", "1")
+    _resident_scan_case(abi, N, K, 0, 0, monkeypatch)
+
+
+def _resident_scan_case(abi, N, K, lcap, ride, monkeypatch):
     monkeypatch.setenv("GG_SCAN", "1")
     monkeypatch.setenv("GG_SCAN_RIDE", str(ride))
     if lcap:
