@@ -158,11 +158,29 @@ struct gg_data {
   int refs, dead;
   unsigned long long uid;
   // Pair scheduling (gg_model.hip, launch_scan): the weight model on this network records an event behind each of its resident
-  // scans; the adjacency model's scan waits for the latest one - it then assembles on the empty chip just before the weight
+  // scans; the adjacency model's scan of the same sweep waits for it - it then assembles on the empty chip just before the weight
   // model's next pass instead of meeting the weight model's scan.  A scheduling hint only: no result depends on it.
-  mutable hipEvent_t ev_wscan = nullptr, ev_wpass = nullptr;
-  mutable int ev_wscan_set = 0, ev_wpass_set = 0;
+  // Events are kept per SWEEP INDEX (a ring of GG_PAIR_RING): the adjacency model's sweep s waits for the weight model's sweep s
+  // or for nothing - never for "the latest", which from a second host thread could be the weight model's last sweep of a long
+  // call (the whole adjacency chain would then run behind the whole weight chain).
+#define GG_PAIR_RING 256
+  struct pair_slot { hipEvent_t ev; uint32_t sweep; int set; };
+  mutable pair_slot wscan[GG_PAIR_RING] = {}, wpass[GG_PAIR_RING] = {};
 };
+// (record on `st` for sweep `sweep` / the event of exactly that sweep, or null)
+static inline int gg_pair_record(gg_data::pair_slot* ring, uint32_t sweep, hipStream_t st) {
+  gg_data::pair_slot& s = ring[sweep % GG_PAIR_RING];
+  s.set = 0;
+  if (!s.ev) GG_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  GG_HIP(hipEventRecord(s.ev, st));
+  s.sweep = sweep;
+  s.set = 1;
+  return GG_OK;
+}
+static inline hipEvent_t gg_pair_lookup(const gg_data::pair_slot* ring, uint32_t sweep) {
+  const gg_data::pair_slot& s = ring[sweep % GG_PAIR_RING];
+  return (s.set && s.sweep == sweep) ? s.ev : nullptr;
+}
 
 int gg_ensure_device(int device);
 void gg_data_retain(const gg_data* d);

@@ -662,8 +662,10 @@ static void data_free(gg_data* d) {
   if (d->WqT) hipFree(d->WqT);
   if (d->dWq) hipFree(d->dWq);
   if (d->stream) hipStreamDestroy(d->stream);
-  if (d->ev_wscan) hipEventDestroy(d->ev_wscan);
-  if (d->ev_wpass) hipEventDestroy(d->ev_wpass);
+  for (int i = 0; i < GG_PAIR_RING; ++i) {
+    if (d->wscan[i].ev) hipEventDestroy(d->wscan[i].ev);
+    if (d->wpass[i].ev) hipEventDestroy(d->wpass[i].ev);
+  }
   delete d;
 }
 

@@ -808,7 +808,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   // pair scheduling (launch_scan): the adjacency model's pass waits for the weight model's parameter step - it then streams under
   // the weight model's scan (before the sampling events: the wait is not the pass)
   const bool pair = pair_sched_on() && pair_pass_on() && m->N >= pair_min_n() && m->use_scan && !m->sharded && pipelined;   // (pipelined: a sweep's pass)
-  if (pair && m->is_adj && d->ev_wpass_set) GG_HIP(hipStreamWaitEvent(st, d->ev_wpass, 0));
+  if (pair && m->is_adj) { hipEvent_t ev = gg_pair_lookup(d->wpass, sweep); if (ev) GG_HIP(hipStreamWaitEvent(st, ev, 0)); }
   if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, st)); }
   const bulk_shape bs = bulk_shape_of(m, ndirs);
   dim3 grd(bs.strips, bs.nslots, ndirs);
@@ -1497,10 +1497,10 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   // GG_PAIR_SCHED=0 turns it off).  A resident grid cannot assemble while a pass keeps backfilling the compute units, so the
   // adjacency model's scan used to wait out the weight model's pass and then share the chip with the weight model's scan -
   // each grid's rounds then wait for workgroups that share a CU with the other's (N=65536, K=64: the weight model's scan 2.6 ms
-  // instead of 0.8).  Now the adjacency model's scan waits for the weight model's latest scan instead, and the weight model's
+  // instead of 0.8).  Now the adjacency model's scan waits for the weight model's scan of the same sweep instead, and the weight model's
   // stream idles for a few microseconds behind its scan (k_delay): the adjacency model's grid assembles on the empty chip, the
   // pass then fills the room around it, and the weight model's next scan has the chip to itself.
-  if (pair && m->is_adj && d->ev_wscan_set) GG_HIP(hipStreamWaitEvent(m->stream, d->ev_wscan, 0));
+  if (pair && m->is_adj) { hipEvent_t ev = gg_pair_lookup(d->wscan, sweep); if (ev) GG_HIP(hipStreamWaitEvent(m->stream, ev, 0)); }
 #define SCN1(NTV, ADJV, SPV)                                                                                       \
   do {                                                                                                            \
     static bool attr_set = false;                                                                                 \
@@ -1545,9 +1545,7 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
     m->zeroed[ride_buf] = false;
   }
   if (pair && !m->is_adj) {
-    if (!d->ev_wscan) GG_HIP(hipEventCreateWithFlags(&d->ev_wscan, hipEventDisableTiming));
-    GG_HIP(hipEventRecord(d->ev_wscan, m->stream));
-    d->ev_wscan_set = 1;
+    { const int rcp = gg_pair_record(d->wscan, sweep, m->stream); if (rcp) return rcp; }
     k_delay<<<1, 64, 0, m->stream>>>(pair_delay_ticks());
     GG_HIP(hipGetLastError());
   }
@@ -1702,9 +1700,7 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep, b
   if (scan && m->use_scan && !m->is_adj && !m->sharded && pair_sched_on() && pair_pass_on() && m->N >= pair_min_n()) {
     // (pair scheduling: the adjacency model's next pass waits for this point - it streams under the weight model's scan,
     // which leaves the memory system idle, not under its pass or its parameter step, which read at the memory system's rate)
-    if (!d->ev_wpass) GG_HIP(hipEventCreateWithFlags(&d->ev_wpass, hipEventDisableTiming));
-    GG_HIP(hipEventRecord(d->ev_wpass, m->stream));
-    d->ev_wpass_set = 1;
+    { const int rcp = gg_pair_record(d->wpass, sweep, m->stream); if (rcp) return rcp; }
   }
   if (scan) {
     if (pride) {
@@ -2206,7 +2202,13 @@ int gg_resample_many(gg_model** ms, const gg_data* const* ds, int32_t n, int32_t
   if (n == 0) return GG_OK;
   static int thr = -1;
   if (thr < 0) { const char* et = getenv("GG_MANY_INTERLEAVE"); thr = et ? atoi(et) : 32; }
-  if (n_sweeps <= thr) {
+  // (networks whose scans are scheduled as a pair - launch_scan - are always enqueued from this thread, sweep by sweep: the
+  // adjacency model's sweep s then finds the weight model's events of sweep s recorded; a sweep takes milliseconds there, what a
+  // second host thread would hide is nothing)
+  bool paired = false;
+  if (pair_sched_on())
+    for (int i = 0; i < n; ++i) paired = paired || (ms[i] && !ms[i]->eig && !ms[i]->ld && ms[i]->N >= pair_min_n());
+  if (n_sweeps <= thr || paired) {
     // short runs: enqueueing from this thread costs less than starting one per model - sweep by sweep, alternating
     // between the models, so that none of them waits for another's whole batch; completion is shared (gg_sync_many)
     // (the weight models first: theirs is the longer chain - every launch of it that waits behind an adjacency model's
