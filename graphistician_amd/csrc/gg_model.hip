@@ -807,7 +807,7 @@ static int enqueue_bulk(gg_model* m, const gg_data* d, int buf, int dirs, bool p
   const bool timed = m->timing > 0 && (sweep % (uint32_t)m->timing) == 0 && m->ev_used < 4096;
   // pair scheduling (launch_scan): the adjacency model's pass waits for the weight model's parameter step - it then streams under
   // the weight model's scan (before the sampling events: the wait is not the pass)
-  const bool pair = pair_sched_on() && pair_pass_on() && m->N >= pair_min_n() && m->use_scan && !m->sharded && pipelined;   // (pipelined: a sweep's pass)
+  const bool pair = pair_sched_on() && pair_pass_on() && m->N >= pair_min_n() && m->Kp == 64 && m->use_scan && !m->sharded && pipelined;   // (pipelined: a sweep's pass)
   if (pair && m->is_adj) { hipEvent_t ev = gg_pair_lookup(d->wpass, sweep); if (ev) GG_HIP(hipStreamWaitEvent(st, ev, 0)); }
   if (timed) { e0 = next_event(m); e1 = next_event(m); GG_HIP(hipEventRecord(e0, st)); }
   const bulk_shape bs = bulk_shape_of(m, ndirs);
@@ -1470,7 +1470,9 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   if (m->Kp == 64 && a.Lcap > 256) a.Lcap = 256;
   { const char* el = getenv("GG_SCAN_LCAP"); if (el && atoi(el) >= 2 && atoi(el) < a.Lcap) a.Lcap = atoi(el); }   // (tests: flush the list often)
   // (pair scheduling, below: the adjacency model's grid is never resident next to the weight model's - 16 nodes per group, MODE 3)
-  const bool pair = pair_sched_on() && m->N >= pair_min_n() && !resume && ride_buf < 0 && !m->sharded;
+  // (33..64 blocks only: there a scan is a millisecond of rounds; with 16 blocks it is a tenth of the pass and ordering the two
+  // chains costs more than their meeting - N=32768, K=16: 600 against 610 sweeps/s)
+  const bool pair = pair_sched_on() && m->N >= pair_min_n() && m->Kp == 64 && !resume && ride_buf < 0 && !m->sharded;
   const bool adj16 = pair && m->is_adj && m->Kp == 64 && pair_adj16_on();
   const int per = adj16 ? 16 : scan_nodes_per_wg(m);
   const int ngroups = (m->Nl + per - 1) / per;
@@ -1697,7 +1699,7 @@ static int enqueue_sweep_serial(gg_model* m, const gg_data* d, uint32_t sweep, b
     if ((rc = ensure_perm(m)) || (rc = ensure_zero(m, nxt))) return rc;
     if ((rc = enqueue_params(m, d, buf, true, true, true, c3, sweep, P, nxt, 2))) return rc;
   } else if ((rc = enqueue_params(m, d, buf, true, true, scan, nxt, sweep, P))) return rc;
-  if (scan && m->use_scan && !m->is_adj && !m->sharded && pair_sched_on() && pair_pass_on() && m->N >= pair_min_n()) {
+  if (scan && m->use_scan && !m->is_adj && !m->sharded && pair_sched_on() && pair_pass_on() && m->N >= pair_min_n() && m->Kp == 64) {
     // (pair scheduling: the adjacency model's next pass waits for this point - it streams under the weight model's scan,
     // which leaves the memory system idle, not under its pass or its parameter step, which read at the memory system's rate)
     { const int rcp = gg_pair_record(d->wpass, sweep, m->stream); if (rcp) return rcp; }
@@ -2207,7 +2209,7 @@ int gg_resample_many(gg_model** ms, const gg_data* const* ds, int32_t n, int32_t
   // second host thread would hide is nothing)
   bool paired = false;
   if (pair_sched_on())
-    for (int i = 0; i < n; ++i) paired = paired || (ms[i] && !ms[i]->eig && !ms[i]->ld && ms[i]->N >= pair_min_n());
+    for (int i = 0; i < n; ++i) paired = paired || (ms[i] && !ms[i]->eig && !ms[i]->ld && ms[i]->N >= pair_min_n() && ms[i]->Kp == 64);
   if (n_sweeps <= thr || paired) {
     // short runs: enqueueing from this thread costs less than starting one per model - sweep by sweep, alternating
     // between the models, so that none of them waits for another's whole batch; completion is shared (gg_sync_many)
