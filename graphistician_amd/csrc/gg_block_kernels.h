@@ -1461,30 +1461,37 @@ __device__ __forceinline__ void gg_lp_mfma_b1(const gg_node_ctx& x, int step, do
 // instructions, measured).
 template <int NT, bool ADJ, int PER>
 __device__ __forceinline__ void gg_lp_mfma(const gg_node_ctx& x, const double* s_st, double* s_lp, double logm_kk,
-                                           const double (&b0)[GG_MFMA_RING][2 * NT], const double (&selfacc)[4], int zoff) {
-  static_assert(PER == 8 || PER == 16, "one 16-row tile of nodes");
+                                           const double (&b0)[GG_MFMA_RING][2 * NT], const double (&selfacc)[4 * (PER > 16 ? PER / 16 : 1)],
+                                           int zoff) {
+  static_assert(PER == 8 || PER == 16 || PER == 32, "one or two 16-row tiles of nodes");
   constexpr int NCH = 2 * NT;
   constexpr int R = GG_MFMA_RING;
+  constexpr int NRT = PER > 16 ? PER / 16 : 1;     // row tiles: the coefficients of a step serve all of them
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, K = x.K;
   const int jr = l >> 4, c16 = l & 15;
   const int kk = 16 * w + c16;                // the label this lane's results belong to
-  const bool node_in = c16 < PER;
   const int S = (K + 3) >> 2;
-  gg_d4 acc[NCH];
+  gg_d4 acc[NRT][NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) acc[c] = gg_d4{0.0, 0.0, 0.0, 0.0};
-  double bq[R][NCH], av[2][NCH];
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[rt][c] = gg_d4{0.0, 0.0, 0.0, 0.0};
+  double bq[R][NCH], av[2][NRT][NCH];
 #pragma unroll
   for (int u = 0; u < R; ++u)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) bq[u][c] = b0[u][c];
-  auto load_a = [&](int step, double (&a)[NCH]) {
+  auto load_a = [&](int step, double (&a)[NRT][NCH]) {
     const int j = 4 * step + jr;
-    const bool in = node_in && j < K;
-    const int base = in ? j * NT * PER + c16 : zoff;
-    const int d1 = in ? K * NT * PER : 0, t1 = in ? PER : 0;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) a[c] = s_st[base + (c / NT) * d1 + (c % NT) * t1];
+    for (int rt = 0; rt < NRT; ++rt) {
+      const int node = 16 * rt + c16;
+      const bool in = node < PER && j < K;
+      const int base = in ? j * NT * PER + node : zoff;
+      const int d1 = in ? K * NT * PER : 0, t1 = in ? PER : 0;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) a[rt][c] = s_st[base + (c / NT) * d1 + (c % NT) * t1];
+    }
   };
   load_a(0, av[0]);
   for (int s0 = 0; s0 < S; s0 += R) {
@@ -1494,7 +1501,10 @@ __device__ __forceinline__ void gg_lp_mfma(const gg_node_ctx& x, const double* s
       load_a(step + 1, av[(i + 1) & 1]);      // (beyond the last step: zeros)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i & 1][c], bq[i][c], acc[c], 0, 0, 0);
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          acc[rt][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i & 1][rt][c], bq[i][c], acc[rt][c], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (step + R < S) gg_lp_mfma_b1<NT>(x, step + R, bq[i]);
       __builtin_amdgcn_sched_barrier(0);
@@ -1504,17 +1514,19 @@ __device__ __forceinline__ void gg_lp_mfma(const gg_node_ctx& x, const double* s
   const bool special = x.special != 0;
   const double beta = x.beta;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = 4 * r + jr;
-    double lp = logm_kk;
+  for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) lp = gg_fma(beta, acc[t][r], lp);
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * rt + 4 * r + jr;
+      double lp = logm_kk;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) lp = gg_fma(beta, acc[NT + t][r], lp);
-    if (!special) lp = gg_fma(beta, selfacc[r], lp);
-    if (kk >= K) lp = -gg_inf();
-    if (i < PER) s_lp[i * 64 + kk] = lp;
-  }
+      for (int t = 0; t < NT; ++t) lp = gg_fma(beta, acc[rt][t][r], lp);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) lp = gg_fma(beta, acc[rt][NT + t][r], lp);
+      if (!special) lp = gg_fma(beta, selfacc[4 * rt + r], lp);
+      if (kk >= K) lp = -gg_inf();
+      if (i < PER) s_lp[i * 64 + kk] = lp;
+    }
 }
 
 // The same for 9..32 blocks with the coefficient tables in LDS (k_scan, MODE 0, stage_tables == 1): a group is per = 256 / Kp
@@ -1799,6 +1811,11 @@ __device__ __forceinline__ void gg_spec_eval_split8(const gg_node_ctx& x, int n_
 #define GG_SCAN_SPLIT_P3 4
 #endif
 #define GG_SCAN_SPLIT_P(NT) ((NT) == 3 ? GG_SCAN_SPLIT_P3 : ((NT) < 3 ? 2 : 1))
+#ifndef GG_SCAN_ADJ_PW
+#define GG_SCAN_ADJ_PW 4      /* k_scan MODE 3 (the adjacency model's scan under pair scheduling): 4 x this many nodes per group.
+                                 8 (32 nodes, two row tiles per step of coefficients: gg_lp_mfma<.., 32>) is exact as well and measured
+                                 no faster - 27 rounds of 19 us instead of 46 of 11.5 alone, 6.9-7.2 against 6.9 ms per sweep of the pair */
+#endif
 // LDS where the evaluation's partial results meet (k_scan, MODE 1): lp[4 P][64] of gg_lp_mfma, or the split chains of gg_lp_split4
 #define GG_SCAN_MEET_BYTES(NT) ((size_t)(GG_SCAN_SPLIT_P(NT) > 1 ? 4 * GG_SCAN_SPLIT_P(NT) * 64 : 4 * 2 * (NT) * 64) * sizeof(double))
 template <int NT, bool ADJ, int P>

@@ -1474,11 +1474,11 @@ static int launch_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
   // chains costs more than their meeting - N=32768, K=16: 600 against 610 sweeps/s)
   const bool pair = pair_sched_on() && m->N >= pair_min_n() && m->Kp == 64 && !resume && ride_buf < 0 && !m->sharded;
   const bool adj16 = pair && m->is_adj && m->Kp == 64 && pair_adj16_on();
-  const int per = adj16 ? 16 : scan_nodes_per_wg(m);
+  const int per = adj16 ? 4 * GG_SCAN_ADJ_PW : scan_nodes_per_wg(m);
   const int ngroups = (m->Nl + per - 1) / per;
   a.G = ngroups < GG_SCAN_MAXWG ? ngroups : GG_SCAN_MAXWG;
   int stage;
-  size_t lds = lds_scan(m, a.Lcap, &stage, adj16 ? 16 : 0);
+  size_t lds = lds_scan(m, a.Lcap, &stage, adj16 ? 4 * GG_SCAN_ADJ_PW : 0);
   if (lds > GG_LDS_LIMIT)
     return gg_fail(GG_ERR_UNSUPPORTED, "the resident-grid scan needs %zu KB of LDS for K=%d, B=%d", lds / 1024, m->K, m->B);
   g.stage_tables = stage;

@@ -185,11 +185,12 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   // 33..64 blocks (MODE 1), NT <= 3: 8 nodes per group (adjacency) or 16 (one-dimensional weights), evaluated together on the
   // matrix cores (gg_lp_mfma, round 4; before: two passes of gg_lp_split4 over four nodes each - N=65536, K=64: 67 rounds of
   // 15.9 us of evaluation).
-  // MODE 3 = MODE 1 with 16 nodes per group whatever NT: the adjacency model's scan under pair scheduling (gg_model.hip,
-  // launch_scan) - it is resident while the weight model's pass streams, never next to the weight model's scan, so its LDS need
-  // not leave room for that one, and half the bands and rounds halve the time it takes compute units away from the pass.
+  // MODE 3 = MODE 1 with 4 GG_SCAN_ADJ_PW = 16 nodes per group whatever NT: the adjacency model's scan under pair scheduling
+  // (gg_model.hip, launch_scan) - it is resident while the weight model's pass streams, never next to the weight model's scan,
+  // so its LDS need not leave room for that one, and half the bands and rounds shorten the time it takes compute units away
+  // from the pass (32 nodes per group: measured no better).
   constexpr bool M13 = MODE == 1 || MODE == 3;
-  constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : (MODE == 3 ? 4 : (MODE == 1 ? GG_SCAN_SPLIT_P(NT) : 1));
+  constexpr int PW = WIDE ? GG_SCAN_WIDE_P(NT) : (MODE == 3 ? GG_SCAN_ADJ_PW : (MODE == 1 ? GG_SCAN_SPLIT_P(NT) : 1));
   const int per = (256 / Kp) * PW;
   const int tid = threadIdx.x, b = blockIdx.x, G = a.G;
   const int ngroups = (N + per - 1) / per;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   else if (stage_tables == 2) off += (size_t)K * RS * sizeof(double);
   double* s_acc = reinterpret_cast<double*>(s_raw + off);     // gg_lp_split4: where the chains of the four waves meet
   constexpr bool split = M13;         // (the host: stage_tables != 1 && Kp == 64)
-  if (split) off += MODE == 3 ? (size_t)16 * 64 * sizeof(double) : GG_SCAN_MEET_BYTES(NT);
+  if (split) off += MODE == 3 ? (size_t)4 * GG_SCAN_ADJ_PW * 64 * sizeof(double) : GG_SCAN_MEET_BYTES(NT);
   else if (a.mf_small) off += (size_t)2 * NT * 256 * sizeof(double);   // (gg_lp_mfma_small: [chain][node][Kp], per Kp = 256)                   // (4 PW nodes at once: gg_lp_mfma leaves lp[node][64] here)
   int* s_gc = reinterpret_cast<int*>(s_raw + off); off += (size_t)2 * K * per * sizeof(int);
   int* s_c = reinterpret_cast<int*>(s_raw + off); off += (size_t)per * sizeof(int);
@@ -404,12 +405,16 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     }
     const double* self0_p = (MODE == 0 && !x.special) ? &self0 : nullptr;
     // gg_lp_mfma's lane layout: the self chains of this lane's (node, label) entries, once per band
-    double self_mf[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int NRT_MF = PW > 4 ? PW / 4 : 1;   // (16-row tiles of the group)
+    double self_mf[4 * NRT_MF];
+#pragma unroll
+    for (int r = 0; r < 4 * NRT_MF; ++r) self_mf[r] = 0.0;
     if (M13 && PW > 1 && !x.special) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nb = n0 + 4 * r + ((tid >> 4) & 3);
-        self_mf[r] = gg_node_self_acc<NT, ADJ>(x, (has && 4 * r + ((tid >> 4) & 3) < per && nb < N) ? nb : N - 1, kk_mf < K ? kk_mf : 0);
+      for (int r = 0; r < 4 * NRT_MF; ++r) {
+        const int il = 16 * (r >> 2) + 4 * (r & 3) + ((tid >> 4) & 3);
+        const int nb = n0 + il;
+        self_mf[r] = gg_node_self_acc<NT, ADJ>(x, (has && il < per && nb < N) ? nb : N - 1, kk_mf < K ? kk_mf : 0);
       }
     }
     // ---- iterate until the band holds no further surprise
