@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_soak.txt
 echo "# tests/soak_parity.py N K sweeps (engine vs oracle_fast, compared along the way), final state of round 4" > $O
-for cfg in "512 8 8000" "4096 16 400" "1024 40 400" "1500 64 100" "8192 16 200" "2048 100 40" "1500 256 20"; do
+for cfg in "512 8 8000" "4096 16 400" "1024 40 400" "1500 64 100" "1200 50 200" "900 37 200" "8192 16 200" "2048 100 40" "1500 256 20"; do
   timeout -k 10 300 python tests/soak_parity.py $cfg 2>&1 | tail -1 >> $O || echo "FAILED: $cfg" >> $O
   tail -1 $O
 done
@@ -12,7 +12,7 @@ for cfg in "4096 16 300" "2048 32 100"; do
   tail -1 $O
 done
 i=41
-for env in "GG_X=1" "GG_SCAN=1" "GG_SCAN=0" "GG_AHEAD=0" "GG_SCAN=1 GG_SCAN_LCAP=3" "GG_PRIDE=1 GG_SCAN=1" "GG_PRIDE=1 GG_SCAN=1 GG_SCAN_LCAP=4" "GG_EPILOGUE=0"; do
+for env in "GG_X=1" "GG_SCAN=1" "GG_SCAN=0" "GG_AHEAD=0" "GG_SCAN=1 GG_SCAN_LCAP=3" "GG_PRIDE=1 GG_SCAN=1" "GG_PRIDE=1 GG_SCAN=1 GG_SCAN_LCAP=4" "GG_EPILOGUE=0" "GG_MFMA_SMALL=1 GG_SCAN=1"; do
   echo "fuzz $env FUZZ_EXTENDED=1 200 cases seed $i: $(env $env FUZZ_EXTENDED=1 timeout -k 10 600 python tests/fuzz_parity.py 200 $i 2>&1 | tail -1)" >> $O
   tail -1 $O
   i=$((i+1))
