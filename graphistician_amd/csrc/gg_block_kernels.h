@@ -574,6 +574,9 @@ struct gg_params_args {
   int n0, Nl;           // sharded chain: only nodes [n0, n0 + Nl) are stored locally (tables are then partial)
   int tables_from_tab;  // sharded chain: the all-reduced tables are already in `tab`
   unsigned long long* bar;   // k_scan's barrier counter + first-changer words, re-armed for the scan that follows
+  int32_t* ap;               // k_scan's per-node "entries of the change list already applied" (or null), zeroed with them: a resident
+  int ap_n;                  // grid whose workgroups are not all placed when it gives up (a device shared with another process)
+                             // has late workgroups that leave at once - they used to leave their groups' entries as they were
   int shared;                // SBMGaussianWeightSharedCov: draw the means given the shared covariance, leave the
                              // covariance draw and the coefficient tables to k_shared_cov
   double* csc;               // [K*K][B*B + 1] centred scatter and tempered count of every block pair's off-diagonal edges (shared-covariance kind)
@@ -633,6 +636,8 @@ __device__ __forceinline__ void gg_params_body(gg_params_args& g, const int bid,
     // k_scan's exchange slots (2 x 256, one per 128-byte line): tag 0 = never written
     if (g.do_prep && g.bar)
       for (unsigned sl = bid * blockDim.x + threadIdx.x; sl < 512u * 4u; sl += nfront * blockDim.x) g.bar[(size_t)(sl >> 2) * GG_SLOT_PAD + (sl & 3u)] = 0ull;   // (k_scan uses words 0..3 of a slot line)
+    if (g.do_prep && g.ap)
+      for (unsigned i = bid * blockDim.x + threadIdx.x; i < (unsigned)g.ap_n; i += nfront * blockDim.x) g.ap[i] = 0;
     if (g.zero_ptr) {
       size_t i = (size_t)bid * blockDim.x + threadIdx.x;
       size_t stride = (size_t)nfront * blockDim.x;
@@ -920,6 +925,8 @@ __device__ __forceinline__ void gg_params_body_w(gg_params_args& g, const int bi
   if (g.do_prep && bid == 0 && threadIdx.x == 0) { g.ctl[7] = 0; g.ctl[8] = 0; g.ctl[9] = 0; }
   if (g.do_prep && g.bar)
     for (unsigned sl = bid * blockDim.x + threadIdx.x; sl < 512u * 4u; sl += nfront * blockDim.x) g.bar[(size_t)(sl >> 2) * GG_SLOT_PAD + (sl & 3u)] = 0ull;
+  if (g.do_prep && g.ap)
+    for (unsigned i = bid * blockDim.x + threadIdx.x; i < (unsigned)g.ap_n; i += nfront * blockDim.x) g.ap[i] = 0;
   if (g.zero_ptr) {
     size_t i = (size_t)bid * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)nfront * blockDim.x;

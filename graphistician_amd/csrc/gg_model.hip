@@ -519,7 +519,10 @@ int gg_model_destroy(gg_model* m) {
   hipSetDevice(m->cfg.device);
   if (m->eig) { gg_eigen_destroy(m->eig); delete m; return GG_OK; }
   if (m->ld) { gg_latent_destroy(m->ld); delete m; return GG_OK; }
-  if (m->pend_data) { hipStreamSynchronize(m->stream); set_pend_data(m, nullptr); }
+  // (always: a call that ended on its epilogue's record may still have the pair scheduling's hand-over delay or a no-op
+  // launch behind it on the stream)
+  if (m->stream) hipStreamSynchronize(m->stream);
+  if (m->pend_data) set_pend_data(m, nullptr);
   void* ptrs[] = {m->c, m->cand, m->cnt, m->permb[0], m->permb[1], m->labb[0], m->labb[1], m->m, m->logm, m->pi, m->p, m->p_self, m->mu, m->sigma,
                   m->mu_self, m->sigma_self, m->T, m->Tout, m->Tin, m->Gbuf[0], m->Gbuf[1], m->Gbuf[2], m->tab,
                   m->rs, m->L, m->lp_out, m->ll_out, m->ap, m->dbg, m->bar, m->csc, m->swq_dbg, m->verdict, m->sh_buf, m->sh_trip, m->sh_all,
@@ -923,6 +926,8 @@ static gg_params_args fill_params_args(gg_model* m, const gg_data* d, int buf, b
   g.ctl = m->rs;
   g.verdict = m->verdict;
   g.bar = m->bar;
+  // (the serial form's parameter step in front of a resident scan: see gg_params_args::ap)
+  g.ap = (prep && m->use_scan && m->bar && !m->sharded) ? m->ap : nullptr; g.ap_n = m->N;
   g.pi = m->pi;
   g.beta = m->beta;
   g.sweep_from_ctl = 0;
@@ -1896,6 +1901,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
       m->ahead = false;
       m->pre = false;
       m->zeroed[0] = m->zeroed[1] = m->zeroed[2] = false;
+      (void)hipStreamSynchronize(m->stream);   // (what was enqueued behind the failed launch runs as no-ops: let it, before the caller tears anything down)
       set_pend_data(m, nullptr);
       if (st3 & 8) return gg_fail(GG_ERR_HIP, "k_sweep_q: the scan's verdict did not arrive (device hung?); set GG_AHEAD=0");
       if (st3 & 2) return gg_fail(GG_ERR_HIP, "k_scan: grid barrier timed out (the resident grid did not assemble); set GG_SCAN=0");
