@@ -1881,9 +1881,19 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
   if (!ctl_fresh && m->ev_call) GG_HIP(hipEventRecord(m->ev_call1, m->stream));
   bool enq_after_read = false;     // something was enqueued behind the last control-block read
   for (;;) {
-    bool abort0 = false;
+    bool abort0 = false, recount = false;
     if (ctl_fresh) ctl_fresh = false;
     else if ((rc = fetch_ctl(m))) return rc;
+    if ((m->h_rs[3] & 4) && !(m->h_rs[3] & ~6) && m->h_rs[4] && m->h_rs[0] != 0) {
+      // A k_scan exchange timed out AFTER the scan had flushed its change list (or inside the flush): labels, block sizes and
+      // position are a valid prefix of the scan, the statistics are not (k_scan's give-up path).  Count them again under the
+      // labels as they stand - one bulk pass, below - and let the restart rounds go on from the position with an empty list.
+      if ((rc = write_ctl_word(m, 3, 0))) return rc;
+      if (m->scan_pref != 0) fprintf(stderr, "graphgibbs: the resident-grid scan timed out at node %d after flushing its change list; statistics are counted again, this model continues with restart rounds for %llu sweeps\n", m->h_rs[0], (unsigned long long)m->scan_backoff);
+      scan_suspend(m);
+      m->h_rs[3] = 0;
+      recount = true;
+    }
     if (m->h_rs[3] == 2) {
       // A k_scan exchange timed out (the resident grid could not assemble - a device shared with other processes, say)
       // and left the scan as a stalled one at a consistent position: carry on with the launch-per-change form, for good.
@@ -2005,6 +2015,19 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
           if ((rc = launch_speculate(m, d, buf_s, 0, -1, m->sweep + (uint32_t)s_idx, true))) return rc;
           if ((rc = launch_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
         }
+      }
+      if (recount) {
+        // the sort of the labels as they stand into the slot the stalled sweep's pass used (it is not needed any more: the
+        // scan's tail writes the final sort into the other one), the buffer zeroed, one pass without the pipeline's gate
+        const int pcur_keep = m->pcur;
+        m->pcur = P_s;
+        m->perm_valid = false;
+        m->zeroed[buf_s] = false;
+        GG_HIP(hipMemsetAsync(m->ap, 0, (size_t)m->N * sizeof(int32_t), m->stream));
+        rc = enqueue_bulk(m, d, buf_s, 3, false);
+        m->pcur = pcur_keep;
+        m->perm_valid = false;
+        if (rc) return rc;
       }
       if ((rc = finish_scan(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
     } else {

@@ -824,7 +824,13 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
     // restarts the list), and the workgroups that gave up may stand one accepted change apart: there is no consistent
     // stalled scan to hand to the restart rounds.  Reported as an error instead of resuming from stale statistics
     // (needs > 1024 changes in one scan AND a grid that cannot assemble).
-    if (fatal || flushed) { if (tid == 0) atomicOr(&g.rs[3], 4); return; }
+    // Round 4: that case is recoverable after all - what workgroup 0 has recorded (labels, block sizes, position) is a valid
+    // prefix of the scan there too; only the statistics are not.  Status bit 4 beside the stalled state with an EMPTY list tells
+    // the host to count the statistics again under the labels as they stand (one bulk pass) before the restart rounds go on
+    // from the position (gg_model.hip, model_sync: "recount").
+    const bool recount = fatal || flushed;
+    if (recount && tid == 0) atomicOr(&g.rs[3], 4);
+    if (recount) nL = 0;
     __syncthreads();
     for (int k = tid; k < K; k += 256) g.cnt[k] = s_cnt[k];
     if (tid == 0) {

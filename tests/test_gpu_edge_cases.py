@@ -401,30 +401,26 @@ def test_more_than_64_blocks_fall_back_to_restart_rounds(abi, monkeypatch, capfd
 
 
 @pytest.mark.gpu
-def test_timeout_behind_a_flush_is_a_clean_error(abi, monkeypatch):
-    """VERDICT r2 "smaller" (ADVICE r1): a resident scan whose change list overflowed (flushed into the statistics chip-wide) and
-    whose grid then cannot assemble has no consistent stalled scan to hand to the restart rounds - the band that was in LDS at
-    the flush is not in G any more.  That is reported as an error (GG_ERR_HIP, "flush"), never resumed from stale statistics
-    and never a hang; the library stays usable.  Forced here with a 2-entry list and exchanges that give up after one poll;
-    when the workgroups do meet in time the chain must be the oracle's."""
+def test_timeout_behind_a_flush_recounts_and_continues(abi, monkeypatch, capfd):
+    """A resident scan whose change list overflowed (flushed into the statistics chip-wide) and whose grid then cannot assemble:
+    the band that was in LDS at the flush is not in G any more, so the stalled scan's statistics are not usable.  Rounds 2-3
+    reported that as an error (GG_ERR_HIP, "flush"); round 4 (two processes sharing one device ran into it during burn-in at
+    N=65536): labels, block sizes and position are a valid prefix of the scan, so the statistics are COUNTED AGAIN under the labels
+    as they stand and the restart rounds go on from the position - the chain stays the oracle's.  Forced here with a 2-entry list
+    and exchanges that give up after a few polls, from "never meets" to "mostly meets": timeouts at any point of a scan."""
     monkeypatch.setenv("GG_SCAN", "1")
     monkeypatch.setenv("GG_SCAN_LCAP", "2")
     N, K = 600, 8
     A, W, _ = planted_sbm(N, K, seed=29)
     d = abi.DeviceData(A, W)
     outcomes = []
-    for trial, spin in enumerate((1, 2, 3, 5, 8, 13, 21, 34)):      # (from "never meets" to "mostly meets": timeouts at any point of a scan)
+    for trial, spin in enumerate((1, 2, 3, 4, 5, 6, 8, 10, 13, 17, 21, 34)):      # (from "never meets" to "mostly meets": timeouts at any point of a scan)
         monkeypatch.setenv("GG_SCAN_SPIN", str(spin))
         sa = AdjState(N, K, seed=40 + trial)
         adj = abi.Model(kind=abi.SBM_ADJ, N=N, K=K, B=1, seed=90 + trial, tau1=1.0, tau0=1.0, allow_self_connections=1, special_case_self_conns=1)
         adj.set(abi.ST_C, sa.c, np.int32); adj.set(abi.ST_M, sa.m); adj.set(abi.ST_PI, sa.pi); adj.set(abi.ST_P, sa.p)
         adj.set(abi.ST_P_SELF, np.array([sa.p_self]))
-        try:
-            adj.resample(d, 2)
-        except abi.EngineError as exc:
-            assert "flush" in str(exc) or "timed out" in str(exc), str(exc)
-            outcomes.append("error")
-            continue
+        adj.resample(d, 2)       # (no error any more)
         ps = sa.p_self
         for s in range(2):
             ps = O.sbm_adj_sweep(A, sa.c, sa.m, sa.p, ps, sa.pi, 1.0, 1.0, 1, 90 + trial, s)
@@ -436,7 +432,11 @@ def test_timeout_behind_a_flush_is_a_clean_error(abi, monkeypatch):
         monkeypatch.delenv(k)
     sa = AdjState(N, K, seed=44)
     run_adj(abi, A, sa, 95, 2)      # (asserts the chain against the oracle itself)
-    assert outcomes and all(o in ("error", "exact") for o in outcomes)
+    assert outcomes and all(o == "exact" for o in outcomes)
+    err = capfd.readouterr().err
+    print("recounts:", err.count("counted again"), "plain timeouts:", err.count("timed out") - err.count("counted again"))
+    # (which trials give up behind a flush is a matter of timing - one of the eight in the round's runs; whichever path a trial
+    # takes, it must end in the oracle's chain, which is what is asserted above)
 
 
 @pytest.mark.gpu
