@@ -32,6 +32,9 @@
 #pragma once
 #include "gg_resolve_kernels.h"
 
+#ifndef GG_SCAN_MOVES_U
+#define GG_SCAN_MOVES_U 4   /* (8: band starts 3 % shorter at N=65536, every round's moves 0.4 us longer - N=4096 mixing chains 3 % slower) */
+#endif
 #define GG_SCAN_MAXWG 256
 #define GG_BAR_SPIN_LIMIT (1 << 19)   // about a quarter of a second of polling: far beyond any kernel the grid may have to wait behind
 #ifndef GG_SCAN_POLL_SLEEP
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   constexpr unsigned LMASK = (1u << LB) - 1u;
   constexpr int B = gg_tB(NT);
   constexpr int NSI = gg_tNSI(NT);
-  constexpr int U = 4;
+  constexpr int U = GG_SCAN_MOVES_U;   // (moves of a list in flight per thread: apply_moves)
   const gg_resolve_args& g = a.r;
   const gg_node_ctx& x = g.x;
   const long long t_kernel0 = g.dbg ? wall_clock64() : 0;
@@ -367,13 +370,34 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
           }
         }
       } else {
-        for (int idx = tid; idx < 2 * K * per; idx += 256) {
-          const int i = idx % per, j = (idx / per) % K, d = idx / (per * K);
-          const int n = (n0 + i < N) ? n0 + i : N - 1;
-          const size_t gi = d * dstride + (size_t)j * Np + n;
-          s_gc[idx] = a.Gc0[gi];
-          if (!ADJ)
-            for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = a.Gs0[gi * NSI + s];
+        // four entries per thread in flight together (2 K per = 2048 entries at K = 64 with 16 nodes per group: eight per
+        // thread, each a 4-byte and NSI 8-byte loads - one at a time they were eight memory round trips per band start)
+        constexpr int UL = 4;
+        for (int base = tid; base < 2 * K * per; base += 256 * UL) {
+          int gcv[UL];
+          long long gsv[UL][NSI > 0 ? NSI : 1];
+#pragma unroll
+          for (int u = 0; u < UL; ++u) {
+            const int idx = base + u * 256;
+            const int ii = idx < 2 * K * per ? idx : 0;
+            const int i = ii % per, j = (ii / per) % K, d = ii / (per * K);
+            const int n = (n0 + i < N) ? n0 + i : N - 1;
+            const size_t gi = d * dstride + (size_t)j * Np + n;
+            gcv[u] = a.Gc0[gi];
+            if (!ADJ)
+#pragma unroll
+              for (int s = 0; s < NSI; ++s) gsv[u][s] = a.Gs0[gi * NSI + s];
+          }
+#pragma unroll
+          for (int u = 0; u < UL; ++u) {
+            const int idx = base + u * 256;
+            if (idx < 2 * K * per) {
+              s_gc[idx] = gcv[u];
+              if (!ADJ)
+#pragma unroll
+                for (int s = 0; s < NSI; ++s) s_gs[(size_t)idx * NSI + s] = gsv[u][s];
+            }
+          }
         }
       }
       if (tid < per) s_c[tid] = (n0 + tid < N) ? g.c[n0 + tid] : 0;
