@@ -1591,6 +1591,25 @@ static void scan_maybe_resume(gg_model* m) {
 // batch of rounds is enqueued without host synchronisation; the host only checks between batches, and
 // flushes the change list into G chip-wide (k_apply_L) before a batch that could overflow it.
 // The round that completes the scan sorts the labels into perm buffer `pw`.
+// The statistics of a stalled sweep counted again under the labels as they stand (a resident scan gave up behind a flush of
+// its change list: k_scan's give-up path): the sort of the current labels into slot P_s - the one the stalled sweep's pass used,
+// not needed any more: the scan's tail writes the final sort into the other one -, the buffer zeroed, one pass without the
+// pipeline's gate; nothing of the (empty) list counts as applied.
+static int recount_stats(gg_model* m, const gg_data* d, int buf, int P_s) {
+  const int pcur_keep = m->pcur;
+  m->pcur = P_s;
+  m->perm_valid = false;
+  m->zeroed[buf] = false;
+  GG_HIP(hipMemsetAsync(m->ap, 0, (size_t)m->N * sizeof(int32_t), m->stream));
+  const int rc = enqueue_bulk(m, d, buf, 3, false);
+  m->pcur = pcur_keep;
+  m->perm_valid = false;
+  return rc;
+}
+static bool gave_up_behind_flush(const gg_model* m) {
+  return (m->h_rs[3] & 4) && !(m->h_rs[3] & ~6) && m->h_rs[4] && m->h_rs[0] != 0;
+}
+
 static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, bool tail_m, bool tail_sort, int pw) {
   int rc;
   if (m->scan_pref != 0 && !tail_m) {
@@ -1603,7 +1622,14 @@ static int finish_scan(gg_model* m, const gg_data* d, int buf, uint32_t sweep, b
       if ((rc = launch_scan(m, d, buf, sweep, tail_sort, pw, true))) return rc;   // (its rounds are counted on the device)
       if ((rc = read_ctl(m))) return rc;
     }
-    if (m->h_rs[3] == 2) {
+    if (gave_up_behind_flush(m)) {
+      // (the resumed resident scan gave up behind a flush: as in model_sync - count again, restart rounds from the position)
+      if ((rc = write_ctl_word(m, 3, 0))) return rc;
+      fprintf(stderr, "graphgibbs: the resident-grid scan timed out at node %d after flushing its change list; statistics are counted again, this model continues with restart rounds for %llu sweeps\n", m->h_rs[0], (unsigned long long)m->scan_backoff);
+      scan_suspend(m);
+      m->h_rs[3] = 0;
+      if ((rc = recount_stats(m, d, buf, 1 - pw))) return rc;
+    } else if (m->h_rs[3] == 2) {
       // the resident grid timed out and left a consistent stalled scan: restart rounds from here on (see model_sync)
       if ((rc = write_ctl_word(m, 3, 0))) return rc;
       fprintf(stderr, "graphgibbs: the resident-grid scan timed out; this model continues with restart rounds for %llu sweeps\n", (unsigned long long)m->scan_backoff);
@@ -1884,7 +1910,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
     bool abort0 = false, recount = false;
     if (ctl_fresh) ctl_fresh = false;
     else if ((rc = fetch_ctl(m))) return rc;
-    if ((m->h_rs[3] & 4) && !(m->h_rs[3] & ~6) && m->h_rs[4] && m->h_rs[0] != 0) {
+    if (gave_up_behind_flush(m)) {
       // A k_scan exchange timed out AFTER the scan had flushed its change list (or inside the flush): labels, block sizes and
       // position are a valid prefix of the scan, the statistics are not (k_scan's give-up path).  Count them again under the
       // labels as they stand - one bulk pass, below - and let the restart rounds go on from the position with an empty list.
@@ -2016,19 +2042,7 @@ static int model_sync(gg_model* m, bool ctl_fresh) {
           if ((rc = launch_resolve(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
         }
       }
-      if (recount) {
-        // the sort of the labels as they stand into the slot the stalled sweep's pass used (it is not needed any more: the
-        // scan's tail writes the final sort into the other one), the buffer zeroed, one pass without the pipeline's gate
-        const int pcur_keep = m->pcur;
-        m->pcur = P_s;
-        m->perm_valid = false;
-        m->zeroed[buf_s] = false;
-        GG_HIP(hipMemsetAsync(m->ap, 0, (size_t)m->N * sizeof(int32_t), m->stream));
-        rc = enqueue_bulk(m, d, buf_s, 3, false);
-        m->pcur = pcur_keep;
-        m->perm_valid = false;
-        if (rc) return rc;
-      }
+      if (recount && (rc = recount_stats(m, d, buf_s, P_s))) return rc;
       if ((rc = finish_scan(m, d, buf_s, m->sweep + (uint32_t)s_idx, false, true, 1 - P_s))) return rc;
     } else {
       if ((rc = write_ctl_word(m, 4, 0))) return rc;
