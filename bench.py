@@ -389,7 +389,7 @@ def extra_ais(abi, device, N=8192, R=3, B=100, steps_per_B=2):
 def extra_ais_eigen(abi, device, N=8192, D=8, B=12, steps_per_B=2):
     """BASELINE.json configs[4], the eigenmodel's chain: AIS with the tempered logistic eigenmodel (D = 8) at N = 8192 through
     the host class (examples/demo_ais.py:10-62; tempering build-defined: omega ~ PG(beta, psi)).  Few
-    temperatures: a tempered sweep draws 67 M PG(beta, psi) variates by the 64-term gamma series."""
+    temperatures: a tempered sweep draws 67 M PG(beta, psi) variates by the 16-term gamma series (spec/gg_pg.h)."""
     from graphistician_amd.eigenmodel import LogisticEigenmodel
     from graphistician_amd import ais as AIS
     rng = np.random.RandomState(4321)
@@ -417,7 +417,7 @@ def extra_ais_eigen(abi, device, N=8192, D=8, B=12, steps_per_B=2):
             "value": nsweeps / el, "unit": "sweeps/s (including the per-temperature log-likelihood)", "seconds_per_chain": el,
             "tempered_sweeps": nsweeps, "log_likelihood_evaluations": B - 1, "log_Z_one_chain": float(logZ),
             "ms_per_plain_sweep_beta_1": plain * 1e3,
-            "bound": "the PG(beta, psi) draws of a tempered sweep (64 gamma variates per pair); at beta = 1 the exact PG(1, psi) sampler "
+            "bound": "the PG(beta, psi) draws of a tempered sweep (16 gamma variates per pair; 64 until the end of round 4); at beta = 1 the exact PG(1, psi) sampler "
                      "and the sequential feature scan (DESIGN.md 7)"}
 
 

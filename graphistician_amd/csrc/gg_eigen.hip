@@ -150,7 +150,7 @@ __device__ __forceinline__ void eig_tile_pair(int b, int nt, int* I, int* J) {
 // eigenmodel.py:859-874: omega_ij ~ PG(1, psi_ij), psi = mu_0 + (F lambda) F^T, diag psi = mu_0 (:81-82).
 // gen: entries given as GG_A_MISSING are unobserved - no omega is drawn for them (their likelihood term is absent);
 // accumulate: a further graph of the list (its own Philox site), added to S / dO.
-// TEMP: the tempered draw PG(beta, psi), beta != 1 (its 64-term gamma sum would otherwise set the register count of the plain
+// TEMP: the tempered draw PG(beta, psi), beta != 1 (its gamma sum would otherwise set the register count of the plain
 // sweep's kernel, which runs at four waves per SIMD: 2.40 -> 1.96 ms at N=4096 against two).
 template <int DM, bool TEMP>
 __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, const double* __restrict__ F,
