@@ -75,7 +75,7 @@ def run(cases, seed0, verbose=False, extended=False):
     for case in range(cases):
         N = int(rng.choice([5, 17, 33, 64, 65, 100, 129, 200, 257, 300]))
         # (more than 64 blocks: every scan form since round 3, also under forced exchange timeouts)
-        ks = [2, 3, 4, 7, 16, 17, 33, 40, 64, 65, 100, 128, 200, 256]
+        ks = [2, 3, 4, 7, 10, 16, 17, 27, 33, 37, 40, 50, 57, 64, 65, 100, 128, 200, 256]   # (10, 27: padding steps of gg_lp_mfma_small; 37, 50, 57: of gg_lp_mfma)
         K = min(int(rng.choice(ks)), N)
         B = int(rng.choice([1, 1, 1, 2, 3, 4]))
         special = int(rng.rand() < 0.7)
