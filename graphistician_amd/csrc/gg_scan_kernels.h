@@ -307,6 +307,54 @@ __global__ __launch_bounds__(256, 2) void k_scan(gg_scan_args a) {
   // the moves (f: from -> to) of a list applied to the statistics of my group's nodes (first node n0); behind_only: only to
   // the nodes behind f - a node sees the changes at positions before its own - together with the block sizes they see
   auto apply_moves = [&](const int* list, int count, int n0, bool behind_only) {
+    if (ADJ && per <= 32 && (32 % per) == 0) {
+      // Adjacency: the group's per nodes are per consecutive bits of ONE word of row f of the bit matrix (groups start at
+      // multiples of per, per divides 32, rows are whole words): one load per (move, direction) instead of one per (move,
+      // direction, node) - the same word, per times over.  Two items per thread in flight.
+      const int nit = count * 2;
+      for (int base = tid; base < nit; base += 512) {
+        uint32_t wb[2];
+        int n2v[2], iav[2], ibv[2], dv[2];
+        bool okv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int it = base + u * 256;
+          okv[u] = it < nit;
+          const int e = okv[u] ? it >> 1 : 0;
+          dv[u] = it & 1;
+          n2v[u] = list[e * 3]; iav[u] = list[e * 3 + 1]; ibv[u] = list[e * 3 + 2];
+          const size_t at = (size_t)n2v[u] * Np + n0;
+          wb[u] = okv[u] ? (dv[u] == 0 ? g.XAT : g.XA)[at >> 5] >> (at & 31) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (!okv[u]) continue;
+          // nodes of the group that exist and (behind_only) lie behind the moved node
+          uint32_t live = per == 32 ? 0xffffffffu : ((1u << per) - 1u);
+          if (n0 + per > N) live &= (N - n0) > 0 ? ((1u << (N - n0)) - 1u) : 0u;
+          if (behind_only) {
+            const int first = n2v[u] + 1 - n0;                 // first node index behind f
+            if (first >= per) live = 0u;
+            else if (first > 0) live &= ~((1u << first) - 1u);
+          }
+          uint32_t edges = wb[u] & live;
+          while (edges) {
+            const int i = __ffs(edges) - 1;
+            edges &= edges - 1u;
+            move_edge(dv[u], i, iav[u], ibv[u], nullptr);
+          }
+          if (behind_only && dv[u] == 0) {
+            uint32_t lv = live;
+            while (lv) {
+              const int i = __ffs(lv) - 1;
+              lv &= lv - 1u;
+              atomicSub(&s_cntn[i * K + iav[u]], 1); atomicAdd(&s_cntn[i * K + ibv[u]], 1);
+            }
+          }
+        }
+      }
+      return;
+    }
     const int nitems = count * per * 2;
     for (int base = tid; base < nitems; base += 256 * U) {
       int ia[U], ib[U], ii[U], dd[U];
