@@ -822,8 +822,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--nodes", type=int, default=None, help="default: 4096 on one GPU (configs[1]), 65536 with --gpus G > 1 (configs[3])")
-    ap.add_argument("--blocks", type=int, default=None, help="default: 16 on one GPU, 64 with --gpus G > 1")
+    ap.add_argument("--nodes", type=int, default=None, help="default: 4096 (configs[1]); with --gpus G > 1 the legs of configs[3] run at 65536")
+    ap.add_argument("--blocks", type=int, default=None, help="default: 16 below 32768 nodes, 64 from there")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--burnin", type=int, default=None,
                     help="sweeps run as part of chain set-up, before the W warm-up steps: the chain starts from a prior draw "
@@ -883,8 +883,14 @@ def main():
         return
 
     from graphistician_amd import _abi as abi
+    # The headline workload is the SAME for every G - configs[1], the six-chain mix, one replica per GPU - so that the per-G
+    # values of the driver's 1 / 2 / 4 / 8 run are values of one workload (it computes the scaling efficiency from them).
+    # BASELINE.json's N=65536, K=64 at G > 1 comes in the same line as two legs: one replica of that chain per GPU
+    # (other_configs.sbm_n65536_k64_replicas) and ONE chain sharded over the G ranks (sharded_chain); at G = 1 it is
+    # other_configs.sbm_n65536_k64_one_gpu.  An explicit --nodes runs everything at that size (tests).
+    explicit_size = args.nodes is not None
     if args.nodes is None:
-        args.nodes = 4096 if (world == 1 or args.config != "sbm") else 65536
+        args.nodes = 4096
     if args.blocks is None:
         args.blocks = 16 if args.nodes < 32768 else 64
     if args.burnin is None:
@@ -1131,13 +1137,14 @@ def main():
         # reports how its set-up went, one failure skips the leg everywhere; (ii) a rank that fails or hangs INSIDE the
         # chain leaves the others in the library's collectives, so the leg runs under a deadline: when it passes, rank 0
         # prints the line it has (the replica result, `sharded_chain` = the timeout) and every rank leaves the process.
-        # GG_BENCH_NO_SHARD_LEG=1 switches the leg off, GG_BENCH_SHARD_LEG_SECONDS sets the deadline (default 240).
+        # GG_BENCH_NO_SHARD_LEG=1 switches the leg off, GG_BENCH_SHARD_LEG_SECONDS sets the deadline of the two configs[3] legs together (default 360).
         adj = w = r = data = None
         import gc
         import threading
         gc.collect()
-        if rank == 0:
-            _progress("sharded chain over %d ranks" % world)
+        # (GG_BENCH_BIG_NODES / GG_BENCH_BIG_BLOCKS: the legs at another size - the two-ranks-on-one-GPU test)
+        bigN, bigK = (N, K) if (explicit_size or args.config != "sbm") else (
+            int(os.environ.get("GG_BENCH_BIG_NODES", "65536")), int(os.environ.get("GG_BENCH_BIG_BLOCKS", "64")))
 
         def all_ok(flag):
             import torch
@@ -1145,14 +1152,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(int(t.item()))
 
-        deadline = float(os.environ.get("GG_BENCH_SHARD_LEG_SECONDS", "240"))
+        deadline = float(os.environ.get("GG_BENCH_SHARD_LEG_SECONDS", "360"))   # both configs[3] legs
         done = threading.Event()
 
         def watchdog():
             if done.wait(deadline):
                 return
             if rank == 0:
-                out["sharded_chain"] = {"error": "the sharded chain did not finish within %.0f s (a rank failed or hung inside it); "
+                out["sharded_chain"] = {"error": "the configs[3] legs did not finish within %.0f s (a rank failed or hung inside them); "
                                                  "the replica line above is complete" % deadline}
                 _emit(json.dumps(out))
             sys.stderr.write("[bench] rank %d: sharded leg timed out, leaving\n" % rank)
@@ -1161,8 +1168,48 @@ def main():
 
         wd = threading.Thread(target=watchdog, daemon=True)
         wd.start()
+        if (bigN, bigK) != (N, K):
+            # configs[3], one replica of the chain per GPU (weak scaling, no collective): the same leg as
+            # other_configs.sbm_n65536_k64_one_gpu of the G = 1 line, every timed block bracketed by the barrier, max over ranks.
+            # Collective discipline as for the sharded leg: all ranks agree that the network is resident before any of them
+            # enters a barrier-bracketed block.
+            if rank == 0:
+                _progress("configs[3] replicas: N=%d, K=%d on each of %d ranks" % (bigN, bigK, world))
+            bdata, err = None, None
+            try:
+                bt = planted_truth(bigN, bigK, seed=1234)
+                bdata = abi.DeviceData.synthetic_sbm(bigN, bt["c"], bt["p"], bt["p_self"], bt["mu"], bt["sigma"],
+                                                     bt["mu_self"], bt["sigma_self"], seed=1234, device=device)
+            except Exception as exc:
+                err = str(exc)
+            if all_ok(err is None):
+                bsteps = min(args.steps, 20)
+                try:
+                    br = run_chain(abi, bdata, bigN, bigK, 1, device, 12, min(args.warmup, 2), bsteps, 1, barrier,
+                                   repeats=3, max_over_ranks=max_over_ranks)
+                    bb = 2.0 * bigN * bigN * (0.125 + 4.0)
+                    big = {"workload": "Gaussian SBM Gibbs, N=%d, K=%d, B=1 (BASELINE.json configs[3]), one replica of the chain "
+                                       "per GPU, no collective" % (bigN, bigK),
+                           "value": world * bsteps / br["elapsed"], "unit": "sweeps/s (all replicas)", "n_gpus": world,
+                           "ms_per_step": br["elapsed"] / bsteps * 1e3, "steps": bsteps, "timed_blocks": 3,
+                           "ms_per_step_min_max_over_blocks": [min(br["blocks"]) / bsteps * 1e3, max(br["blocks"]) / bsteps * 1e3],
+                           "label_changes_per_sweep": br["changes"] / float(bsteps), "sweep_algorithmic_bytes": bb,
+                           "sweep_effective_GBs_per_gpu": bb * bsteps / br["elapsed"] / 1e9,
+                           "frac_of_hbm_peak_over_the_sweep": bb * bsteps / br["elapsed"] / 1e9 / HBM_PEAK_GBS,
+                           "compare_with": "other_configs.sbm_n65536_k64_one_gpu of the --gpus 1 line"}
+                    del br
+                except Exception as exc:     # (a rank failing INSIDE the chain leaves the others at the barrier: the deadline)
+                    big = {"error": str(exc)}
+            else:
+                big = {"skipped": "set-up failed on a rank" + ("" if err is None else ": " + err)}
+            bdata = None
+            gc.collect()
+            if rank == 0:
+                out.setdefault("other_configs", {})["sbm_n%d_k%d_replicas" % (bigN, bigK)] = big
+        if rank == 0:
+            _progress("sharded chain over %d ranks" % world)
         try:
-            line = run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, N, K, all_ok=all_ok,
+            line = run_sharded(args, abi, device, rank, world, barrier, max_over_ranks, bigN, bigK, all_ok=all_ok,
                                steps=min(args.steps, 20), warmup=min(args.warmup, 3))
         except Exception as exc:
             line = {"error": str(exc)}

@@ -56,3 +56,29 @@ def test_combined_replica_and_sharded_line_with_two_ranks():
     assert "error" not in sh, sh
     assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["value"] > 0
     assert sh["config"]["ranks"] == 2 and "labels_digest" in sh["config"] and sh["config"]["collectives_on_the_wire_in_run"] > 0
+
+
+@pytest.mark.gpu
+def test_default_two_rank_line_keeps_the_headline_workload_and_carries_the_configs3_legs():
+    """`bench.py --gpus 2` as the driver calls it (no --nodes): the headline stays configs[1] - the same workload as the
+    --gpus 1 line, so the per-G values the driver divides are values of one workload - and configs[3] comes as two legs of the
+    same line: one replica of the chain per GPU and ONE chain sharded over the ranks.  Two ranks on this box's one GPU (gloo),
+    the legs at N=8192, K=64 through GG_BENCH_BIG_NODES so that the test stays short."""
+    import json
+    env = dict(os.environ, GG_BENCH_BACKEND="gloo", GG_BENCH_SAME_DEVICE="1", GG_BENCH_BIG_NODES="8192", GG_BENCH_BIG_BLOCKS="64")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert "N=4096, K=16" in r["config"]["workload"] and len(r["config"]["chains"]) == 6
+    big = r["other_configs"]["sbm_n8192_k64_replicas"]
+    assert "error" not in big and "skipped" not in big, big
+    assert big["n_gpus"] == 2 and big["value"] > 0 and big["steps"] == 6
+    sh = r["sharded_chain"]
+    assert "error" not in sh, sh
+    assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["value"] > 0 and sh["config"]["ranks"] == 2
+    assert "N=8192" in sh["config"]["workload"] or sh["config"].get("nodes") == 8192, sh["config"]
