@@ -176,37 +176,90 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
   __syncthreads();
   eig_psi_tile_mfma<DM>(s_fi, s_fj, mu0, s_psi);
   __syncthreads();
-  for (int e = tid; e < 1024; e += 256) {
-    const int li = e >> 5, lj = e & 31;
-    const int gi = I * 32 + li, gj = J * 32 + lj;
-    double val = 0.0;
-    if (gi < N && gj < N) {
-      if (I == J && li == lj) {
-        double dv = 0.0;
-        if (!gen || dA[gi] != GG_A_MISSING) {
-          gg_stream s0;
-          gg_stream_init64(&s0, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gi);
-          // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
-          dv = TEMP ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
+  if (TEMP) {
+    for (int e = tid; e < 1024; e += 256) {
+      const int li = e >> 5, lj = e & 31;
+      const int gi = I * 32 + li, gj = J * 32 + lj;
+      double val = 0.0;
+      if (gi < N && gj < N) {
+        if (I == J && li == lj) {
+          double dv = 0.0;
+          if (!gen || dA[gi] != GG_A_MISSING) {
+            gg_stream s0;
+            gg_stream_init64(&s0, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gi);
+            // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
+            dv = TEMP ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
+          }
+          dO[gi] = accumulate ? dO[gi] + dv : dv;
+        } else if (I < J || li < lj) {
+          const double psi = s_psi[li][lj];
+          const size_t at = (size_t)gi * Np + gj;
+          const bool o1 = !gen || A[at] != GG_A_MISSING, o2 = !gen || AT[at] != GG_A_MISSING;   // i -> j, j -> i observed
+          gg_stream s1, s2;
+          gg_stream_init64(&s1, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gj);
+          gg_stream_init64(&s2, seed, site, sweep, (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
+          if (TEMP) {
+            if (beta > 0.0) val = (o1 ? gg_pg_frac(&s1, beta, psi) : 0.0) + (o2 ? gg_pg_frac(&s2, beta, psi) : 0.0);
+          } else {
+            // omega_ij and omega_ji see the same psi: the mixture mass is computed once for the pair
+            const double Zh = 0.5 * gg_fabs(psi), ptex = gg_pg_mass_texpon(Zh);
+            val = (o1 ? gg_pg1_pre(&s1, Zh, ptex) : 0.0) + (o2 ? gg_pg1_pre(&s2, Zh, ptex) : 0.0);
+          }
         }
-        dO[gi] = accumulate ? dO[gi] + dv : dv;
-      } else if (I < J || li < lj) {
-        const double psi = s_psi[li][lj];
-        const size_t at = (size_t)gi * Np + gj;
-        const bool o1 = !gen || A[at] != GG_A_MISSING, o2 = !gen || AT[at] != GG_A_MISSING;   // i -> j, j -> i observed
-        gg_stream s1, s2;
-        gg_stream_init64(&s1, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gj);
-        gg_stream_init64(&s2, seed, site, sweep, (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
-        if (TEMP) {
-          if (beta > 0.0) val = (o1 ? gg_pg_frac(&s1, beta, psi) : 0.0) + (o2 ? gg_pg_frac(&s2, beta, psi) : 0.0);
-        } else {
-          // omega_ij and omega_ji see the same psi: the mixture mass is computed once for the pair
-          const double Zh = 0.5 * gg_fabs(psi), ptex = gg_pg_mass_texpon(Zh);
-          val = (o1 ? gg_pg1_pre(&s1, Zh, ptex) : 0.0) + (o2 ? gg_pg1_pre(&s2, Zh, ptex) : 0.0);
+      }
+      if (I < J || li <= lj) s_t[li][lj] = val;
+    }
+  } else {
+    // PG(1, psi): the draws of a lane - its four tile entries, two directions each - as ONE loop over attempts
+    // (spec/gg_pg.h gg_pg1_attempt): a lane whose draw is accepted goes on to its next draw at once instead of waiting for
+    // the slowest lane of the wavefront at every draw (the nested rejection loops ran with a quarter of the lanes active:
+    // SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 15 of 64).  The mixture masses of the four pairs first, all lanes together.
+    __shared__ double s_p[32][33];
+    for (int e = tid; e < 1024; e += 256) {
+      const int li = e >> 5, lj = e & 31;
+      const int gi = I * 32 + li, gj = J * 32 + lj;
+      if (gi < N && gj < N) {
+        if (I == J && li == lj) {
+          double dv = 0.0;
+          if (!gen || dA[gi] != GG_A_MISSING) {
+            gg_stream s0;
+            gg_stream_init64(&s0, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gi);
+            dv = gg_pg1(&s0, mu0);
+          }
+          dO[gi] = accumulate ? dO[gi] + dv : dv;
+        } else if (I < J || li < lj) {
+          s_p[li][lj] = gg_pg_mass_texpon(0.5 * gg_fabs(s_psi[li][lj]));     // (own entry: no barrier needed before the loop)
         }
       }
     }
-    if (I < J || li <= lj) s_t[li][lj] = val;
+    gg_stream st;
+    int k = 0, tig = 0;
+    bool started = false;
+    double acc = 0.0;
+    while (k < 8) {
+      const int e = tid + 256 * (k >> 1), dir = k & 1;
+      const int li = e >> 5, lj = e & 31;
+      const int gi = I * 32 + li, gj = J * 32 + lj;
+      const bool pairv = gi < N && gj < N && (I < J || li < lj);
+      bool want = pairv;
+      if (want && gen) want = (dir == 0 ? A : AT)[(size_t)gi * Np + gj] != GG_A_MISSING;     // i -> j, j -> i observed
+      if (want) {
+        if (!started) {
+          gg_stream_init64(&st, seed, site, sweep, dir == 0 ? (uint64_t)gi * (uint64_t)N + (uint64_t)gj : (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
+          tig = 0;
+          started = true;
+        }
+        double om;
+        if (!gg_pg1_attempt(&st, 0.5 * gg_fabs(s_psi[li][lj]), s_p[li][lj], &tig, &om)) continue;
+        acc += om;
+      }
+      started = false;
+      if (dir == 1) {
+        if (I < J || li <= lj) s_t[li][lj] = acc;
+        acc = 0.0;
+      }
+      ++k;
+    }
   }
   __syncthreads();
   if (I == J) {
@@ -1086,7 +1139,8 @@ int gg_eigen_resample(gg_eigen* e, const gg_data* d, int parts) {
 // are unobserved and take part in nothing.  One fully observed graph is the plain sweep.
 int gg_eigen_resample_many(gg_eigen* e, const gg_data* const* ds, int nd, int parts) {
   if (!ds || nd < 1 || !ds[0]) return gg_fail(GG_ERR_INVALID, "null data handle");
-  if (nd > 31) return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: at most 31 graphs per model (the summed observations are kept as int8)");
+  // (a2 sums 2 A - 1 over the graphs and BOTH directions of a pair: |a2| <= 2 nd must fit int8, nob <= 2 nd uint8)
+  if (nd > 63) return gg_fail(GG_ERR_UNSUPPORTED, "eigenmodel: at most 63 graphs per model (the summed observations of a pair, two per graph, are kept as int8)");
   bool general = nd > 1;
   for (int g = 0; g < nd; ++g) {
     if (!ds[g]) return gg_fail(GG_ERR_INVALID, "null data handle");

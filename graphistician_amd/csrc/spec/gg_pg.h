@@ -45,18 +45,13 @@ GG_HD double gg_pg_a(int n, double x) {
   }
   return 0.0;
 }
-// The same with the logarithms that do not depend on n taken out of the series loop (lx = log x, lhp = log(pi / 2): the
-// caller computes them once per proposal): the same expression, the same value.
-GG_HD double gg_pg_a_pre(int n, double x, double lx, double lhp) {
-  const double K = ((double)n + 0.5) * GG_PI;
-  if (x > GG_PG_TRUNC) return K * GG_PG_EXP(-0.5 * K * K * x);
-  if (x > 0.0) {
-    double expnt = -1.5 * (lhp + lx) + GG_PG_LOG(K) - 2.0 * ((double)n + 0.5) * ((double)n + 0.5) / x;
-    return GG_PG_EXP(expnt);
-  }
-  return 0.0;
+// log((n + 1/2) pi) of the first terms as constants (round 4: nearly every series ends at n = 1, so the left branch paid two
+// logarithms per proposal for two numbers known in advance; the constants are the correctly rounded values, libm / ocml are
+// within an ulp of them - the same float-tolerance statement as for exp / log above).
+GG_HD double gg_pg_logK(int n, double K) {
+  return n == 0 ? 0.4515827052894548 : n == 1 ? 1.5501949939575645 : n == 2 ? 2.061020617723555 : n == 3 ? 2.397492854344768
+                                                                                                         : GG_PG_LOG(K);
 }
-
 // probability mass of the truncated-exponential component
 GG_HD double gg_pg_mass_texpon(double Z) {
   const double t = GG_PG_TRUNC;
@@ -70,58 +65,107 @@ GG_HD double gg_pg_mass_texpon(double Z) {
   return 1.0 / (1.0 + qdivp);
 }
 
-// inverse Gaussian(mu = 1/Z, lambda = 1) truncated to (0, t]
-GG_HD double gg_pg_rtigauss(gg_stream* s, double Z) {
+// One Philox block of a stream as two uniforms (the stream's pending half, if any, is dropped: the attempts below consume
+// whole blocks, so every lane of a wavefront calls the generator the same number of times per attempt).
+GG_HD void gg_stream_pair(gg_stream* s, double* u, double* v) {
+  gg_u32x4 r = gg_philox4x32_10(s->c0, s->c1, s->c2, s->c3, s->k0, s->k1);
+  s->c0 += 1u;
+  s->have = 0;
+  *u = gg_u53(r.v[0], r.v[1]);
+  *v = gg_u53(r.v[2], r.v[3]);
+}
+
+// a_n(x) with ONE exponential for both sides of the truncation point (the two sides differ in the argument and the factor in
+// front only): the same values as gg_pg_a_pre.
+GG_HD double gg_pg_a_sel(int n, double x, double lx) {
+  const double K = ((double)n + 0.5) * GG_PI, h = (double)n + 0.5;
+  const bool right = x > GG_PG_TRUNC;
+  const double arg = right ? -0.5 * K * K * x : -1.5 * (0.4515827052894548 + lx) + gg_pg_logK(n, K) - 2.0 * h * h / x;
+  const double v = (right ? K : 1.0) * GG_PG_EXP(arg);
+  return x > 0.0 ? v : 0.0;
+}
+
+// ONE ATTEMPT of the sampler (round 4, second part).  The textbook form nests three rejection loops (the series around the
+// truncated inverse Gaussian's acceptance around its proposal's); on a 64-wide wavefront every level waits for its slowest lane,
+// and the counters showed a quarter of the lanes active over the draws' kernel.  The same sampler as a sequence of independent
+// attempts, each a bounded, branch-poor piece of work:
+//   choose the component (unless a truncated inverse-Gaussian trial is pending from the last attempt: *tig);
+//   truncated exponential: X = t + E / fz - a proposal is at hand;
+//   truncated inverse Gaussian, Z < 1/t: ONE trial of Devroye's scheme - E1, E2 exponentials, fail unless E1^2 <= 2 E2 / t,
+//     X = t / (1 + t E1)^2, fail unless U <= exp(-Z^2 X / 2) (two acceptance tests in a row accept with the product of their
+//     probabilities: the law of the nested loops) - Z >= 1/t: one trial of the transformed-normal scheme (one polar candidate
+//     for the normal), fail unless X <= t;
+//     a failed trial leaves *tig set: the next attempt tries this component again (choosing anew would favour the other one);
+//   with a proposal at hand the series decides: accept (omega = X / 4) or reject - either way the component is chosen anew.
+// Variates per attempt: block 1 = (component, E1 | root flip), block 2 = (E2, U | polar candidate), block 3 = (series' Y,
+// unused) - whole Philox blocks.
+// A caller that carries several draws per lane moves a lane on to its next draw as soon as one is accepted (k_eig_omega);
+// gg_pg1_pre is the plain loop over attempts, and the oracle's form.
+GG_HD bool gg_pg1_attempt(gg_stream* s, double Z, double ptex, int* tig, double* omega) {
   const double t = GG_PG_TRUNC;
-  double X = t + 1.0;
-  if (1.0 / t > Z) {
-    double alpha = 0.0;
-    while (gg_stream_uniform(s) > alpha) {
-      double E1 = gg_expon(s), E2 = gg_expon(s);
-      while (E1 * E1 > 2.0 * E2 / t) { E1 = gg_expon(s); E2 = gg_expon(s); }
+  const double fz = 0.125 * GG_PI * GG_PI + 0.5 * Z * Z;
+  double u0, u1;
+  gg_stream_pair(s, &u0, &u1);
+  const double E1 = -GG_PG_LOG(u1 + (0.5 / 9007199254740992.0));
+  double X;
+  if (!*tig && u0 < ptex) {
+    X = t + E1 / fz;
+  } else {
+    // one trial of the truncated inverse Gaussian; both schemes take block 2 and ONE logarithm (of their own argument)
+    *tig = 1;
+    const bool small = 1.0 / t > Z;
+    double u2, u3;
+    gg_stream_pair(s, &u2, &u3);
+    const double pu = 2.0 * u2 - 1.0, pv = 2.0 * u3 - 1.0, r = pu * pu + pv * pv;     // polar method's candidate (Z >= 1/t)
+    const double L = GG_PG_LOG(small ? u2 + (0.5 / 9007199254740992.0) : r);
+    if (small) {
+      // Devroye's scheme: E1, E2 exponentials, E1^2 <= 2 E2 / t, then U <= exp(-Z^2 X / 2)
+      const double E2 = -L;
+      if (E1 * E1 > 2.0 * E2 / t) return false;
       X = 1.0 + E1 * t;
       X = t / (X * X);
-      alpha = GG_PG_EXP(-0.5 * Z * Z * X);
-    }
-  } else {
-    const double mu = 1.0 / Z;
-    while (X > t) {
-      double Y = gg_normal(s);
-      Y *= Y;
+      if (u3 > GG_PG_EXP(-0.5 * Z * Z * X)) return false;
+    } else {
+      // transformed normal (Michael, Schucany & Haas): Y = N(0,1)^2 from one polar trial - a candidate outside the unit disc
+      // fails the attempt like any other rejection -, the root flipped by block 1's second uniform (E1 is not used here)
+      if (!(r < 1.0 && r > 0.0)) return false;
+      const double mu = 1.0 / Z;
+      const double Y = pu * pu * (-2.0 * L / r);
       const double half_mu = 0.5 * mu;
       const double mu_Y = mu * Y;
       X = mu + half_mu * mu_Y - half_mu * gg_sqrt(4.0 * mu_Y + mu_Y * mu_Y);
-      if (gg_stream_uniform(s) > mu / (mu + X)) X = mu * mu / X;
+      if (u1 > mu / (mu + X)) X = mu * mu / X;
+      if (X > t) return false;
     }
   }
-  return X;
+  *tig = 0;
+  const double lx = GG_PG_LOG(X > GG_PG_TRUNC ? 1.0 : X);
+  double S = gg_pg_a_sel(0, X, lx);
+  double uy, un;
+  gg_stream_pair(s, &uy, &un);
+  const double Y = uy * S;
+  S -= gg_pg_a_sel(1, X, lx);
+  if (Y <= S) { *omega = 0.25 * X; return true; }
+  for (int n = 2;; ++n) {
+    if (n & 1) {
+      S -= gg_pg_a_sel(n, X, lx);
+      if (Y <= S) { *omega = 0.25 * X; return true; }
+    } else {
+      S += gg_pg_a_sel(n, X, lx);
+      if (Y > S) return false;
+    }
+    if (n > 200) { *omega = 0.25 * X; return true; }   // numerically converged series
+  }
 }
 
 // omega ~ PG(1, z) given Z = |z| / 2 and the mass of the truncated-exponential component (shared by the two
 // draws omega_ij, omega_ji of a pair: same psi)
 GG_HD double gg_pg1_pre(gg_stream* s, double Z, double ptex) {
-  const double fz = 0.125 * GG_PI * GG_PI + 0.5 * Z * Z;
-  for (;;) {
-    double X;
-    if (gg_stream_uniform(s) < ptex) X = GG_PG_TRUNC + gg_expon(s) / fz;
-    else X = gg_pg_rtigauss(s, Z);
-    // (log x and log(pi / 2) once per proposal, not once per term of the series: two of the three logarithms of a term)
-    const double lx = (X > 0.0 && !(X > GG_PG_TRUNC)) ? GG_PG_LOG(X) : 0.0, lhp = GG_PG_LOG(0.5 * GG_PI);
-    double S = gg_pg_a_pre(0, X, lx, lhp);
-    const double Y = gg_stream_uniform(s) * S;
-    int n = 0;
-    for (;;) {
-      ++n;
-      if (n & 1) {
-        S -= gg_pg_a_pre(n, X, lx, lhp);
-        if (Y <= S) return 0.25 * X;
-      } else {
-        S += gg_pg_a_pre(n, X, lx, lhp);
-        if (Y > S) break;
-      }
-      if (n > 200) return 0.25 * X;  // numerically converged series
-    }
-  }
+  int tig = 0;
+  double omega = 0.0;
+  s->have = 0;
+  while (!gg_pg1_attempt(s, Z, ptex, &tig, &omega)) {}
+  return omega;
 }
 
 // omega ~ PG(b, z) for a real shape 0 < b < 1: the tempered logistic likelihood sigma(psi)^(b a) (1 - sigma(psi))^(b (1 - a))
