@@ -232,33 +232,39 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
         }
       }
     }
+    // the tile's 2 x 1024 draws dealt out through a counter in LDS: a lane takes the next draw when its own is accepted, so the
+    // lanes of a wavefront end within an attempt or two of each other whatever their psi (dealt out statically, four entries a
+    // lane, the wavefront ran 20 attempts against a mean of 11: entries with |psi| > 3 need more of them).  The two
+    // directions of an entry may end up on different lanes: they are ADDED into the tile (0 + a + b in either order: the
+    // same double).
+    __shared__ int s_next;
+    if (tid == 0) s_next = 0;
+    for (int e = tid; e < 1024; e += 256) s_t[e >> 5][e & 31] = 0.0;
+    __syncthreads();
     gg_stream st;
-    int k = 0, tig = 0;
-    bool started = false;
-    double acc = 0.0;
-    while (k < 8) {
-      const int e = tid + 256 * (k >> 1), dir = k & 1;
-      const int li = e >> 5, lj = e & 31;
-      const int gi = I * 32 + li, gj = J * 32 + lj;
-      const bool pairv = gi < N && gj < N && (I < J || li < lj);
-      bool want = pairv;
-      if (want && gen) want = (dir == 0 ? A : AT)[(size_t)gi * Np + gj] != GG_A_MISSING;     // i -> j, j -> i observed
-      if (want) {
-        if (!started) {
-          gg_stream_init64(&st, seed, site, sweep, dir == 0 ? (uint64_t)gi * (uint64_t)N + (uint64_t)gj : (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
-          tig = 0;
-          started = true;
-        }
-        double om;
-        if (!gg_pg1_attempt(&st, 0.5 * gg_fabs(s_psi[li][lj]), s_p[li][lj], &tig, &om)) continue;
-        acc += om;
+    int tig = 0, li = 0, lj = 0;
+    double Zh = 0.0, ptex = 0.0;
+    bool busy = false;
+    for (;;) {
+      if (!busy) {
+        const int d = atomicAdd(&s_next, 1);
+        if (d >= 2048) break;
+        const int e = d >> 1, dir = d & 1;
+        li = e >> 5; lj = e & 31;
+        const int gi = I * 32 + li, gj = J * 32 + lj;
+        if (!(gi < N && gj < N && (I < J || li < lj))) continue;
+        if (gen && (dir == 0 ? A : AT)[(size_t)gi * Np + gj] == GG_A_MISSING) continue;     // i -> j, j -> i not observed
+        gg_stream_init64(&st, seed, site, sweep, dir == 0 ? (uint64_t)gi * (uint64_t)N + (uint64_t)gj : (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
+        tig = 0;
+        Zh = 0.5 * gg_fabs(s_psi[li][lj]);
+        ptex = s_p[li][lj];
+        busy = true;
       }
-      started = false;
-      if (dir == 1) {
-        if (I < J || li <= lj) s_t[li][lj] = acc;
-        acc = 0.0;
+      double om;
+      if (gg_pg1_attempt(&st, Zh, ptex, &tig, &om)) {
+        atomicAdd(&s_t[li][lj], om);
+        busy = false;
       }
-      ++k;
     }
   }
   __syncthreads();
