@@ -176,44 +176,11 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
   __syncthreads();
   eig_psi_tile_mfma<DM>(s_fi, s_fj, mu0, s_psi);
   __syncthreads();
-  if (TEMP) {
-    for (int e = tid; e < 1024; e += 256) {
-      const int li = e >> 5, lj = e & 31;
-      const int gi = I * 32 + li, gj = J * 32 + lj;
-      double val = 0.0;
-      if (gi < N && gj < N) {
-        if (I == J && li == lj) {
-          double dv = 0.0;
-          if (!gen || dA[gi] != GG_A_MISSING) {
-            gg_stream s0;
-            gg_stream_init64(&s0, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gi);
-            // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
-            dv = TEMP ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
-          }
-          dO[gi] = accumulate ? dO[gi] + dv : dv;
-        } else if (I < J || li < lj) {
-          const double psi = s_psi[li][lj];
-          const size_t at = (size_t)gi * Np + gj;
-          const bool o1 = !gen || A[at] != GG_A_MISSING, o2 = !gen || AT[at] != GG_A_MISSING;   // i -> j, j -> i observed
-          gg_stream s1, s2;
-          gg_stream_init64(&s1, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gj);
-          gg_stream_init64(&s2, seed, site, sweep, (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
-          if (TEMP) {
-            if (beta > 0.0) val = (o1 ? gg_pg_frac(&s1, beta, psi) : 0.0) + (o2 ? gg_pg_frac(&s2, beta, psi) : 0.0);
-          } else {
-            // omega_ij and omega_ji see the same psi: the mixture mass is computed once for the pair
-            const double Zh = 0.5 * gg_fabs(psi), ptex = gg_pg_mass_texpon(Zh);
-            val = (o1 ? gg_pg1_pre(&s1, Zh, ptex) : 0.0) + (o2 ? gg_pg1_pre(&s2, Zh, ptex) : 0.0);
-          }
-        }
-      }
-      if (I < J || li <= lj) s_t[li][lj] = val;
-    }
-  } else {
-    // PG(1, psi): the draws of a lane - its four tile entries, two directions each - as ONE loop over attempts
-    // (spec/gg_pg.h gg_pg1_attempt): a lane whose draw is accepted goes on to its next draw at once instead of waiting for
-    // the slowest lane of the wavefront at every draw (the nested rejection loops ran with a quarter of the lanes active:
-    // SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 15 of 64).  The mixture masses of the four pairs first, all lanes together.
+  {
+    // The draws of a lane as ONE loop over attempts (spec/gg_pg.h gg_pg1_attempt; tempered: gg_pg_frac_attempt, a trial of one
+    // term of the gamma sum): a lane whose draw is accepted goes on to its next draw at once instead of waiting for the slowest
+    // lane of the wavefront at every draw (the nested rejection loops ran with a quarter of the lanes active:
+    // SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 15 of 64).  PG(1, psi): the mixture masses first, all lanes together.
     __shared__ double s_p[32][33];
     for (int e = tid; e < 1024; e += 256) {
       const int li = e >> 5, lj = e & 31;
@@ -224,11 +191,12 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
           if (!gen || dA[gi] != GG_A_MISSING) {
             gg_stream s0;
             gg_stream_init64(&s0, seed, site, sweep, (uint64_t)gi * (uint64_t)N + (uint64_t)gi);
-            dv = gg_pg1(&s0, mu0);
+            // tempered likelihood (AIS; build-defined, spec/gg_pg.h gg_pg_frac): omega ~ PG(beta, psi), nothing at beta = 0
+            dv = TEMP ? (beta > 0.0 ? gg_pg_frac(&s0, beta, mu0) : 0.0) : gg_pg1(&s0, mu0);
           }
           dO[gi] = accumulate ? dO[gi] + dv : dv;
-        } else if (I < J || li < lj) {
-          s_p[li][lj] = gg_pg_mass_texpon(0.5 * gg_fabs(s_psi[li][lj]));     // (own entry: no barrier needed before the loop)
+        } else if (!TEMP && (I < J || li < lj)) {
+          s_p[li][lj] = gg_pg_mass_texpon(0.5 * gg_fabs(s_psi[li][lj]));
         }
       }
     }
@@ -242,10 +210,11 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
     for (int e = tid; e < 1024; e += 256) s_t[e >> 5][e & 31] = 0.0;
     __syncthreads();
     gg_stream st;
-    int tig = 0, li = 0, lj = 0;
-    double Zh = 0.0, ptex = 0.0;
+    int tig = 0, li = 0, lj = 0;       // (tig: PG(1, psi): a trial pending; PG(beta, psi): the term of the gamma sum)
+    double Zh = 0.0, ptex = 0.0;       // (PG(beta, psi): psi^2 / 4 pi^2 and the sum so far)
+    const bool none = TEMP && !(beta > 0.0);     // (beta = 0: no draws at all, the tile stays zero)
     bool busy = false;
-    for (;;) {
+    while (!none) {
       if (!busy) {
         const int d = atomicAdd(&s_next, 1);
         if (d >= 2048) break;
@@ -255,13 +224,20 @@ __global__ __launch_bounds__(256, 4) void k_eig_omega(int N, int Np, int D, cons
         if (!(gi < N && gj < N && (I < J || li < lj))) continue;
         if (gen && (dir == 0 ? A : AT)[(size_t)gi * Np + gj] == GG_A_MISSING) continue;     // i -> j, j -> i not observed
         gg_stream_init64(&st, seed, site, sweep, dir == 0 ? (uint64_t)gi * (uint64_t)N + (uint64_t)gj : (uint64_t)gj * (uint64_t)N + (uint64_t)gi);
-        tig = 0;
-        Zh = 0.5 * gg_fabs(s_psi[li][lj]);
-        ptex = s_p[li][lj];
+        if (TEMP) {
+          const double psi = s_psi[li][lj];
+          tig = 1;
+          Zh = psi * psi / (4.0 * GG_PI * GG_PI);
+          ptex = 0.0;
+        } else {
+          tig = 0;
+          Zh = 0.5 * gg_fabs(s_psi[li][lj]);
+          ptex = s_p[li][lj];
+        }
         busy = true;
       }
       double om;
-      if (gg_pg1_attempt(&st, Zh, ptex, &tig, &om)) {
+      if (TEMP ? gg_pg_frac_attempt(&st, beta, Zh, &tig, &ptex, &om) : gg_pg1_attempt(&st, Zh, ptex, &tig, &om)) {
         atomicAdd(&s_t[li][lj], om);
         busy = false;
       }

@@ -178,17 +178,48 @@ GG_HD double gg_pg1_pre(gg_stream* s, double Z, double ptex) {
 // test of the law can see; rounds 2-3 summed 64 terms - 3e-9 b - at four times the gamma draws, 67 M x 64 per tempered sweep at
 // N = 8192).  APPROXIMATE by construction and labelled so.
 #define GG_PG_TRUNC_TERMS 16
-GG_HD double gg_pg_frac(gg_stream* s, double b, double z) {
-  const double c = z * z / (4.0 * GG_PI * GG_PI);
-  double acc = 0.0;
-  for (int k = 1; k <= GG_PG_TRUNC_TERMS; ++k) {
-    const double h = (double)k - 0.5;
-    acc += gg_gamma(s, b) / (h * h + c);
-  }
+// One trial of g ~ Gamma(b, 1), 0 < b < 1: Marsaglia & Tsang's scheme for the shape b + 1 with ONE polar candidate for its
+// normal, times U^(1/b) - in whole Philox blocks like gg_pg1_attempt (block 1 = the polar candidate, block 2 = the test's
+// uniform and the boost's), a rejection anywhere fails the trial (independent trials: the law of the nested loops of
+// gg_gamma).  The scheme's squeeze is left out: it only spares a logarithm that a wavefront computes anyway.
+GG_HD bool gg_gamma_frac_trial(gg_stream* s, double b, double* g) {
+  const double d = b + 1.0 - 1.0 / 3.0, c = 1.0 / gg_sqrt(9.0 * d);
+  double p, q;
+  gg_stream_pair(s, &p, &q);
+  const double pu = 2.0 * p - 1.0, pv = 2.0 * q - 1.0, r = pu * pu + pv * pv;
+  if (!(r < 1.0 && r > 0.0)) return false;
+  const double x = pu * gg_sqrt(-2.0 * GG_PG_LOG(r) / r);
+  double v = 1.0 + c * x;
+  if (v <= 0.0) return false;
+  v = v * v * v;
+  double ut, ub;
+  gg_stream_pair(s, &ut, &ub);
+  ut += 0.5 / 9007199254740992.0;
+  ub += 0.5 / 9007199254740992.0;
+  if (!(GG_PG_LOG(ut) < 0.5 * x * x + d * (1.0 - v + GG_PG_LOG(v)))) return false;
+  *g = GG_PG_EXP(GG_PG_LOG(ub) / b) * d * v;
+  return true;
+}
+// One attempt of omega ~ PG(b, z): a trial of the term *k (1 .. GG_PG_TRUNC_TERMS; start: *k = 1, *acc = 0) of the gamma sum;
+// true with the draw once the last term is in.  c = z^2 / (4 pi^2).
+GG_HD bool gg_pg_frac_attempt(gg_stream* s, double b, double c, int* k, double* acc, double* omega) {
+  double g;
+  if (!gg_gamma_frac_trial(s, b, &g)) return false;
+  const double h = (double)*k - 0.5;
+  *acc += g / (h * h + c);
+  if (++*k <= GG_PG_TRUNC_TERMS) return false;
   const double K = (double)GG_PG_TRUNC_TERMS;
   const double sc = gg_sqrt(c);
   const double tail = c > 1e-12 ? atan2(sc, K) / sc : 1.0 / K;     // int_K^inf dx / (x^2 + c)
-  return (acc + b * tail) / (2.0 * GG_PI * GG_PI);
+  *omega = (*acc + b * tail) / (2.0 * GG_PI * GG_PI);
+  return true;
+}
+GG_HD double gg_pg_frac(gg_stream* s, double b, double z) {
+  const double c = z * z / (4.0 * GG_PI * GG_PI);
+  int k = 1;
+  double acc = 0.0, omega = 0.0;
+  while (!gg_pg_frac_attempt(s, b, c, &k, &acc, &omega)) {}
+  return omega;
 }
 
 // omega ~ PG(1, z)
