@@ -10,6 +10,8 @@
 //   X ~ J*(1, z/2) by rejection from a mixture of a truncated inverse-Gaussian
 //   (left of t) and a truncated exponential (right of t), accepted with the
 //   alternating series S_n = sum (-1)^i a_i(X);  PG(1, z) = X / 4.
+// Round 4: the same sampler written as a sequence of independent, bounded ATTEMPTS (gg_pg1_attempt below) instead of three
+// nested rejection loops - the form a 64-wide wavefront can run with most of its lanes active; the law is the same.
 // Only anchor inside the reference: E[omega] = tanh(z/2)/(2z) (eigenmodel.py:1062-1063);
 // tests/ add the variance and a KS test against a series representation.
 //
