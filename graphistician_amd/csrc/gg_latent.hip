@@ -13,7 +13,7 @@
 #include "spec/gg_latent.h"
 #include "spec/gg_ldw.h"
 
-#define LD_MAXDIM 4
+#define LD_MAXDIM 8
 #define LD_NSTEPS 10
 
 // device scalars
@@ -555,7 +555,11 @@ int gg_latent_get_state(gg_latent* e, int id, void* buf, size_t nbytes) {
       case 1: { CALL(1); } break;    \
       case 2: { CALL(2); } break;    \
       case 3: { CALL(3); } break;    \
-      default: { CALL(4); } break;   \
+      case 4: { CALL(4); } break;    \
+      case 5: { CALL(5); } break;    \
+      case 6: { CALL(6); } break;    \
+      case 7: { CALL(7); } break;    \
+      default: { CALL(8); } break;   \
     }                                \
   } while (0)
 

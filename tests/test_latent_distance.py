@@ -86,7 +86,7 @@ def test_oracle_hmc_leaves_the_prior_invariant():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,dim,beta", [(40, 2, 1.0), (130, 3, 1.0), (97, 1, 0.4), (200, 4, 1.0)])
+@pytest.mark.parametrize("N,dim,beta", [(40, 2, 1.0), (130, 3, 1.0), (97, 1, 0.4), (200, 4, 1.0), (90, 6, 1.0), (120, 8, 0.7)])
 def test_engine_parts_match_oracle(N, dim, beta):
     from graphistician_amd import _abi as abi
     sigma = 2.0

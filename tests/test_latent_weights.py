@@ -107,7 +107,7 @@ def test_oracle_hmc_leaves_the_prior_invariant():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,dim,beta,density", [(40, 2, 1.0, 0.5), (130, 3, 1.0, 0.2), (97, 1, 0.4, 0.7), (260, 4, 1.0, 0.05)])
+@pytest.mark.parametrize("N,dim,beta,density", [(40, 2, 1.0, 0.5), (130, 3, 1.0, 0.2), (97, 1, 0.4, 0.7), (260, 4, 1.0, 0.05), (90, 6, 1.0, 0.3), (120, 8, 0.7, 0.2)])
 def test_engine_parts_match_oracle(N, dim, beta, density):
     from graphistician_amd import _abi as abi
     A, W, q, shift, L = make_case(N, dim, N, density)
