@@ -792,28 +792,44 @@ __global__ __launch_bounds__(256) void k_eig_global(int N, int Np, int D, const 
   double acc[NGM];
 #pragma unroll
   for (int e = 0; e < NGM; ++e) acc[e] = 0.0;
-  for (int i = blockIdx.x; i < N; i += gridDim.x) {   // a few rows per workgroup: <= 512 partials to sum afterwards
-  double fi[DM];
-#pragma unroll
-  for (int d = 0; d < DM; ++d) fi[d] = d < D ? F[(size_t)i * D + d] : 0.0;
-  for (int j = i + 1 + threadIdx.x; j < N; j += 256) {
-    double s, a;
-    eig_pair(ob, probit, ka, S[(size_t)i * Np + j], (size_t)i * Np + j, &s, &a);
-    double g[DM];
-#pragma unroll
-    for (int d = 0; d < DM; ++d) g[d] = d < D ? fi[d] * F[(size_t)j * D + d] : 0.0;
-    acc[0] += s;
-    acc[1] += a;
-    int e = 2 + 2 * DM;
-#pragma unroll
-    for (int a1 = 0; a1 < DM; ++a1) {
-      const double sg = s * g[a1];
-      acc[2 + a1] += sg;
-      acc[2 + DM + a1] += a * g[a1];
-#pragma unroll
-      for (int b1 = a1; b1 < DM; ++b1) acc[e++] += sg * g[b1];
+  // A few rows per workgroup (<= 512 partials to sum afterwards), EIGHT at a time with a lane's F[j] held in registers across
+  // them: per pair the pass then reads its entry of S and of the observations only - read row by row, F[j] came from L2 once per
+  // PAIR (620 MB per launch at N=4096, the bound of the pass: 138 us).
+  constexpr int RB = 8;
+  __shared__ double s_fi[RB][DM];
+  for (int r0 = blockIdx.x; r0 < N; r0 += RB * gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < RB * DM) {
+      const int r = threadIdx.x / DM, d = threadIdx.x % DM, i = r0 + r * gridDim.x;
+      s_fi[r][d] = (i < N && d < D) ? F[(size_t)i * D + d] : 0.0;
     }
-  }
+    __syncthreads();
+    for (int j = r0 + 1 + threadIdx.x; j < N; j += 256) {
+      double fj[DM];
+#pragma unroll
+      for (int d = 0; d < DM; ++d) fj[d] = d < D ? F[(size_t)j * D + d] : 0.0;
+#pragma unroll 2
+      for (int r = 0; r < RB; ++r) {
+        const int i = r0 + r * gridDim.x;          // (ascending in r: past the first row that is not above j, none is)
+        if (i >= N || i >= j) break;
+        double s, a;
+        eig_pair(ob, probit, ka, S[(size_t)i * Np + j], (size_t)i * Np + j, &s, &a);
+        double g[DM];
+#pragma unroll
+        for (int d = 0; d < DM; ++d) g[d] = s_fi[r][d] * fj[d];
+        acc[0] += s;
+        acc[1] += a;
+        int e = 2 + 2 * DM;
+#pragma unroll
+        for (int a1 = 0; a1 < DM; ++a1) {
+          const double sg = s * g[a1];
+          acc[2 + a1] += sg;
+          acc[2 + DM + a1] += a * g[a1];
+#pragma unroll
+          for (int b1 = a1; b1 < DM; ++b1) acc[e++] += sg * g[b1];
+        }
+      }
+    }
   }
   __shared__ double s_red[4][NGM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
